@@ -1,0 +1,64 @@
+#!/bin/bash
+# ORACLE — TEST INFRASTRUCTURE ONLY.
+# Builds the *real* reference decoder from the sources where they lie under /root/reference
+# (never copied) into oracle/_ref/:
+#   libnfcref.so   reference lab::NfcDecoder + oracle/ref_capi.cpp C wrapper (parity checker, CPU baseline)
+#   test-sdr-ref   the reference's own golden-vector harness (src/nfc-test/test-sdr)
+# Flags are the reference's Release flags (CMakeLists.txt:22-23,26-27,36-40) minus -march=native
+# (the .so travels to a different host CPU) — SURVEY.md shows goldens are invariant to codegen
+# (18/18 PASS with -O0, -O3 -mfma, clang -ffp-contract=off); -mno-avx keeps FMA contraction off.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${NFC_REFERENCE_ROOT:-/root/reference}"
+OUT="$HERE/_ref"
+R="$REF/src/nfc-lib"
+
+if [ ! -d "$R" ]; then
+  echo "reference tree not present at $REF; keeping prebuilt oracle/_ref" >&2
+  exit 0
+fi
+
+mkdir -p "$OUT/obj"
+
+CXXFLAGS="-std=c++17 -O3 -fno-math-errno -falign-functions=32 -falign-loops=32 -msse -msse3 -mno-avx -pthread -fPIC -w"
+INC="-I$R/lib-rt/rt-lang/src/main/include -I$R/lib-hw/hw-dev/src/main/include -I$R/lib-lab/lab-data/src/main/include \
+ -I$R/lib-lab/lab-radio/src/main/include -I$R/lib-lab/lab-radio/src/main/cpp -I$R/lib-ext/nlohmann/src/main/cpp"
+
+SRCS="
+$R/lib-rt/rt-lang/src/main/cpp/Logger.cpp
+$R/lib-rt/rt-lang/src/main/cpp/FileSystem.cpp
+$R/lib-rt/rt-lang/src/main/cpp/Format.cpp
+$R/lib-rt/rt-lang/src/main/cpp/Tokenizer.cpp
+$R/lib-rt/rt-lang/src/main/cpp/Map.cpp
+$R/lib-hw/hw-dev/src/main/cpp/hw/RecordDevice.cpp
+$R/lib-hw/hw-dev/src/main/cpp/hw/SignalBuffer.cpp
+$R/lib-lab/lab-data/src/main/cpp/Crc.cpp
+$R/lib-lab/lab-data/src/main/cpp/RawFrame.cpp
+$R/lib-lab/lab-radio/src/main/cpp/NfcDecoder.cpp
+$R/lib-lab/lab-radio/src/main/cpp/NfcTech.cpp
+$R/lib-lab/lab-radio/src/main/cpp/tech/NfcA.cpp
+$R/lib-lab/lab-radio/src/main/cpp/tech/NfcB.cpp
+$R/lib-lab/lab-radio/src/main/cpp/tech/NfcF.cpp
+$R/lib-lab/lab-radio/src/main/cpp/tech/NfcV.cpp
+"
+
+OBJS=""
+pids=""
+for s in $SRCS; do
+  o="$OUT/obj/$(basename "${s%.cpp}").o"
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ]; then
+    g++ $CXXFLAGS $INC -c "$s" -o "$o" &
+    pids="$pids $!"
+  fi
+done
+for p in $pids; do wait $p; done
+
+# reference objects that do not contain NfcDecoder (reused to host the GPU drop-in shim)
+ar rcs "$OUT/libnfcref_support.a" $(echo $OBJS | tr ' ' '\n' | grep -v -e NfcDecoder.o -e NfcTech.o -e NfcA.o -e NfcB.o -e NfcF.o -e NfcV.o)
+
+g++ $CXXFLAGS $INC -c "$HERE/ref_capi.cpp" -o "$OUT/obj/ref_capi.o"
+g++ -shared -o "$OUT/libnfcref.so" "$OUT/obj/ref_capi.o" $OBJS -pthread
+
+g++ $CXXFLAGS $INC "$REF/src/nfc-test/test-sdr/src/main/cpp/main.cpp" $OBJS -o "$OUT/test-sdr-ref" -pthread
+echo "built $OUT/libnfcref.so $OUT/test-sdr-ref"

@@ -1,0 +1,164 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin C-ABI wrapper around the *unmodified* reference decoder lab::NfcDecoder
+ * (/root/reference/src/nfc-lib/lib-lab/lab-radio/src/main/cpp/NfcDecoder.cpp:374-467),
+ * compiled in place from the reference sources by oracle/build_ref.sh into
+ * oracle/_ref/libnfcref.so. Nothing in the product path (nfc-laboratory_amd/, include/)
+ * may link or call this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / the timed CPU baseline.
+ *
+ * The harness feeds float magnitude samples to the reference exactly the way
+ * src/nfc-test/test-sdr/src/main/cpp/main.cpp:141-180 does (SignalBuffer of
+ * `chunk` samples, type SIGNAL_TYPE_RADIO_SAMPLES, stride 1) and flattens the
+ * resulting std::list<lab::RawFrame> into PODs with the same layout as
+ * include/nfcgpu.h's nfcgpu_frame.
+ */
+#include <cstdint>
+#include <cstring>
+#include <chrono>
+#include <list>
+
+#include <hw/SignalType.h>
+#include <hw/SignalBuffer.h>
+#include <lab/data/RawFrame.h>
+#include <lab/nfc/NfcDecoder.h>
+
+extern "C" {
+
+struct nfcref_frame
+{
+   uint32_t stream_id;
+   uint32_t tech_type;
+   uint32_t frame_type;
+   uint32_t frame_flags;
+   uint32_t frame_phase;
+   uint32_t frame_rate;
+   uint32_t length;
+   uint32_t reserved;
+   uint64_t sample_start;
+   uint64_t sample_end;
+   uint64_t sample_rate;
+   uint8_t data[512];
+};
+
+struct nfcref_params
+{
+   uint32_t tech_mask;          // bit0 A, bit1 B, bit2 F, bit3 V
+   float power_level_threshold; // NaN => keep reference default
+   float corr_threshold[4];     // NaN => keep default
+   float min_depth[4];          // NaN => keep default
+   float max_depth[4];          // NaN => keep default
+};
+
+/* returns number of frames produced (may exceed cap; only cap are stored), <0 on error */
+long nfcref_decode(const float *samples, uint64_t count, uint32_t sample_rate, uint32_t chunk,
+                   const nfcref_params *params, int keep_carrier, int send_eof,
+                   nfcref_frame *out, uint32_t cap, double *seconds)
+{
+   if (!chunk)
+      chunk = 65536;
+
+   lab::NfcDecoder decoder;
+
+   uint32_t mask = params ? params->tech_mask : 0xF;
+
+   decoder.setEnableNfcA(mask & 1);
+   decoder.setEnableNfcB(mask & 2);
+   decoder.setEnableNfcF(mask & 4);
+   decoder.setEnableNfcV(mask & 8);
+
+   if (params)
+   {
+      if (params->power_level_threshold == params->power_level_threshold)
+         decoder.setPowerLevelThreshold(params->power_level_threshold);
+
+      decoder.setCorrelationThresholdNfcA(params->corr_threshold[0]);
+      decoder.setCorrelationThresholdNfcB(params->corr_threshold[1]);
+      decoder.setCorrelationThresholdNfcF(params->corr_threshold[2]);
+      decoder.setCorrelationThresholdNfcV(params->corr_threshold[3]);
+      decoder.setModulationThresholdNfcA(params->min_depth[0], params->max_depth[0]);
+      decoder.setModulationThresholdNfcB(params->min_depth[1], params->max_depth[1]);
+      decoder.setModulationThresholdNfcF(params->min_depth[2], params->max_depth[2]);
+      decoder.setModulationThresholdNfcV(params->min_depth[3], params->max_depth[3]);
+   }
+
+   long total = 0;
+   double elapsed = 0;
+
+   auto emit = [&](const std::list<lab::RawFrame> &frames) {
+      for (const lab::RawFrame &frame: frames)
+      {
+         bool data = frame.frameType() == lab::FrameType::NfcPollFrame || frame.frameType() == lab::FrameType::NfcListenFrame;
+
+         if (!data && !keep_carrier)
+            continue;
+
+         if (total < cap && out)
+         {
+            nfcref_frame &f = out[total];
+            std::memset(&f, 0, sizeof(f));
+            f.tech_type = frame.techType();
+            f.frame_type = frame.frameType();
+            f.frame_flags = frame.frameFlags();
+            f.frame_phase = frame.framePhase();
+            f.frame_rate = frame.frameRate();
+            f.sample_start = frame.sampleStart();
+            f.sample_end = frame.sampleEnd();
+            f.sample_rate = frame.sampleRate();
+            f.length = frame.limit();
+            if (f.length > 512)
+               f.length = 512;
+            for (uint32_t i = 0; i < f.length; i++)
+               f.data[i] = frame[i];
+         }
+
+         total++;
+      }
+   };
+
+   for (uint64_t pos = 0; pos < count; pos += chunk)
+   {
+      uint32_t n = (count - pos) < chunk ? (uint32_t)(count - pos) : chunk;
+
+      // same construction as test-sdr main.cpp:163 (one channel)
+      hw::SignalBuffer buffer(n, 1, 1, sample_rate, 0, 0, hw::SignalType::SIGNAL_TYPE_RADIO_SAMPLES, 0);
+      buffer.put(samples + pos, n).flip();
+
+      auto t0 = std::chrono::steady_clock::now();
+      std::list<lab::RawFrame> frames = decoder.nextFrames(buffer);
+      auto t1 = std::chrono::steady_clock::now();
+      elapsed += std::chrono::duration<double>(t1 - t0).count();
+
+      emit(frames);
+   }
+
+   if (send_eof)
+   {
+      hw::SignalBuffer invalid;
+      emit(decoder.nextFrames(invalid));
+   }
+
+   if (seconds)
+      *seconds = elapsed;
+
+   return total;
+}
+
+/* reference scalar IQ -> magnitude (RadioDeviceTask.cpp:626-642 scalar branch): sqrtf(I*I + Q*Q), no FMA */
+void nfcref_magnitude(const float *iq, uint64_t count, float *out)
+{
+   for (uint64_t i = 0; i < count; i++)
+   {
+      volatile float ii = iq[2 * i] * iq[2 * i];
+      volatile float qq = iq[2 * i + 1] * iq[2 * i + 1];
+      out[i] = __builtin_sqrtf(ii + qq);
+   }
+}
+
+unsigned int nfcref_frame_size()
+{
+   return sizeof(nfcref_frame);
+}
+
+}
