@@ -1,0 +1,471 @@
+/*
+ * nfc_core.hpp — the demodulator as a per-sample step machine, one lane per capture stream.
+ *
+ * This header is device code: kernels.hip includes it with NFC_DEV = `__device__ __forceinline__`.
+ * (tests/hostsim compiles the same text with NFC_DEV = `static inline` to unit-test the state
+ * machine on a CPU-only box; that build is test infrastructure and is never linked into the
+ * product library.)
+ *
+ * Behavioural contract: identical frames to the reference CPU decoder
+ *   lab::NfcDecoder::nextFrames            src/nfc-lib/lib-lab/lab-radio/src/main/cpp/NfcDecoder.cpp:374-467
+ *   NfcDecoderStatus::nextSample           .../cpp/NfcTech.cpp:28-105
+ *   NfcA / NfcB / NfcF / NfcV              .../cpp/tech/Nfc{A,B,F,V}.cpp
+ * The reference runs nested loops (frame -> symbol -> sample) that return when the buffer is
+ * exhausted and recompute their indices from signalClock on re-entry; every sample is therefore
+ * handled by exactly one "mode" after the front end. Here that is made explicit: nfc_step()
+ * advances one sample: front end, then either the search bank (all enabled detectors, first lock
+ * wins) or the locked technology's symbol machine, whose symbols feed bit/byte/frame assembly.
+ * All arithmetic is fp32 without contraction (compile with -ffp-contract=off) and unsigned 32-bit
+ * sample clocks, matching the reference's Release build (-msse3 -mno-avx: no FMA).
+ */
+#ifndef NFC_AMD_CORE_HPP
+#define NFC_AMD_CORE_HPP
+
+#include "nfc_types.h"
+
+#ifndef NFC_DEV
+#error "define NFC_DEV before including nfc_core.hpp"
+#endif
+
+/* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
+struct NfcLaneMem
+{
+   float *x;       /* samplingValue  [NFC_HIST][64] */
+   float *filt;    /* filteredValue  [NFC_HIST][64] */
+   float *mdev;    /* meanDeviation  [NFC_HIST][64] */
+   float *depth;   /* modulateDepth  [NFC_HIST][64] */
+   float *prod;    /* listen-mode product ring [NFC_PROD][64] */
+   float *corr;    /* correlation rings [corrTotal][64] */
+   uint8_t *bytes; /* frame assembly buffer, NFC_STREAM_BYTES contiguous */
+   uint32_t *arena;
+   uint32_t arenaWords;
+};
+
+#define NFC_AT(ptr, slot) ((ptr)[(uint32_t)(slot) * NFC_LANES])
+#define NFC_HMASK (NFC_HIST - 1u)
+#define NFC_PMASK (NFC_PROD - 1u)
+
+/* symbol patterns (private numbering; 0 = nothing yet, 1 = give up / timeout) */
+enum
+{
+   SYM_NONE = 0,
+   SYM_TIMEOUT = 1,
+   /* NFC-A */
+   A_X = 2, A_Y = 3, A_Z = 4, A_D = 5, A_E = 6, A_F = 7, A_M = 8, A_N = 9, A_S = 10, A_O = 11,
+   /* NFC-B */
+   B_L = 2, B_H = 3, B_S = 4, B_M = 5, B_N = 6, B_O = 7,
+   /* NFC-F */
+   F_L = 2, F_H = 3, F_S = 4, F_E = 5,
+   /* NFC-V */
+   V_0 = 2, V_1 = 3, V_2 = 4, V_8 = 5, V_S = 6, V_E = 7
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+NFC_DEV float nfc_abs(float v)
+{
+   return __builtin_fabsf(v);
+}
+
+/* samples for a duration given in 1/fc units: static_cast<int>(sampleTimeUnit * units) */
+NFC_DEV uint32_t nfc_tu(const NfcConfig &c, int units)
+{
+   return (uint32_t)(int)(c.stu * (double)units);
+}
+
+NFC_DEV void nfc_mod_clear(NfcMod &m)
+{
+   m.stage = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0; m.pulses = 0;
+   m.thr = 0; m.phaseThr = 0; m.lastPhase = 0; m.lastValue = 0; m.syncValue = 0;
+   m.cD = 0; m.c0 = 0; m.c1 = 0;
+   m.symStart = 0; m.symEnd = 0; m.symRise = 0;
+   m.acc = 0; m.phaseAcc = 0; m.peak = 0; m.aux = 0;
+   m.peakTime = 0; m.auxTime = 0;
+}
+
+NFC_DEV void nfc_zero_ring(float *ring, uint32_t from, uint32_t count)
+{
+   for (uint32_t i = 0; i < count; i++)
+      NFC_AT(ring, from + i) = 0.0f;
+}
+
+/* what the reference does to the locked modulation at the end of every poll frame
+ * ("clear modulation status for receiving card response", e.g. NfcA.cpp:491-511) */
+NFC_DEV void nfc_poll_end_clear(const NfcLaneMem &mem, NfcMod &m, uint32_t corrFrom, uint32_t corrCount)
+{
+   m.symStart = 0; m.symEnd = 0; m.acc = 0; m.phaseAcc = 0; m.stage = 0;
+   m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+   m.lastValue = 0; m.lastPhase = 0; m.thr = 0; m.phaseThr = 0; m.peak = 0;
+   nfc_zero_ring(mem.prod, 0, NFC_PROD);
+   nfc_zero_ring(mem.corr, corrFrom, corrCount);
+}
+
+NFC_DEV void nfc_clear_assembly(NfcStreamState &s)
+{
+   s.bsPrevious = 0; s.bsPattern = 0; s.bsBits = 0; s.bsSkip = 0;
+   s.bsData = 0; s.bsFlags = 0; s.bsParity = 0; s.bsBytes = 0;
+}
+
+NFC_DEV void nfc_clear_symbol(NfcStreamState &s)
+{
+   s.symPattern = 0; s.symValue = 0; s.symStart = 0; s.symEnd = 0; s.symEdge = 0; s.symLength = 0;
+}
+
+NFC_DEV void nfc_push_byte(const NfcLaneMem &mem, NfcStreamState &s, uint32_t value)
+{
+   /* the reference's buffer is 512 bytes (NfcTech.h:288); beyond that it would overrun, we drop */
+   if (s.bsBytes < NFC_STREAM_BYTES)
+      mem.bytes[s.bsBytes] = (uint8_t)value;
+   s.bsBytes++;
+}
+
+NFC_DEV uint32_t nfc_byte(const uint8_t *data, uint32_t len, uint32_t i)
+{
+   return i < len ? data[i] : 0u;
+}
+
+/* CRC-16/CCITT as lab::Crc::ccitt16 (lab-data Crc.cpp:96-113), computed bitwise */
+NFC_DEV uint32_t nfc_crc16(const uint8_t *data, uint32_t count, uint32_t init, bool reflected)
+{
+   if (count == 0)
+      return (~init) & 0xFFFFu;
+
+   uint32_t crc = init & 0xFFFFu;
+
+   if (reflected)
+   {
+      for (uint32_t i = 0; i < count; i++)
+      {
+         crc ^= data[i];
+         for (int k = 0; k < 8; k++)
+            crc = (crc & 1u) ? (crc >> 1) ^ 0x8408u : (crc >> 1);
+      }
+   }
+   else
+   {
+      for (uint32_t i = 0; i < count; i++)
+      {
+         crc ^= ((uint32_t)data[i]) << 8;
+         for (int k = 0; k < 8; k++)
+            crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x1021u) & 0xFFFFu : (crc << 1) & 0xFFFFu;
+      }
+   }
+
+   return crc;
+}
+
+/* append one frame to the stream's arena */
+NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, uint32_t type, uint32_t flags,
+                      uint32_t phase, uint32_t rate, uint32_t start, uint32_t end, const uint8_t *data, uint32_t len)
+{
+   if (len > NFC_STREAM_BYTES)
+      len = NFC_STREAM_BYTES;
+
+   uint32_t words = NFC_FRAME_HEADER_WORDS + ((len + 3u) >> 2);
+
+   if (s.arenaUsed + words > mem.arenaWords)
+   {
+      s.arenaOverflow++;
+      return;
+   }
+
+   uint32_t *w = mem.arena + s.arenaUsed;
+
+   w[0] = tech; w[1] = type; w[2] = flags; w[3] = phase;
+   w[4] = rate; w[5] = start; w[6] = end; w[7] = len;
+
+   for (uint32_t i = 0; i < len; i += 4)
+   {
+      uint32_t v = 0;
+      for (uint32_t k = 0; k < 4 && i + k < len; k++)
+         v |= ((uint32_t)data[i + k]) << (8 * k);
+      w[NFC_FRAME_HEADER_WORDS + (i >> 2)] = v;
+   }
+
+   s.arenaUsed += words;
+   s.framesOut++;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* front end: NfcDecoderStatus::nextSample, NfcTech.cpp:28-105                                */
+/* ------------------------------------------------------------------------------------------ */
+
+NFC_DEV void nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+{
+   ++s.clock;
+   ++s.pulseFilter;
+
+   float env = s.env;
+   float diff = nfc_abs(value - env) / env;
+
+   if (diff < 0.05f || s.pulseFilter > (uint32_t)(c.etu * 10))
+   {
+      s.pulseFilter = 0;
+      env = env * c.envW0 + value * c.envW1;
+   }
+   else if (s.clock < (uint32_t)c.etu)
+   {
+      env = value;
+   }
+
+   s.env = env;
+
+   float n0 = value + s.n1 * c.iirA;
+   float filtered = n0 - s.n1;
+   s.n1 = n0;
+
+   s.mdev = s.mdev * c.mdevW0 + nfc_abs(filtered) * c.mdevW1;
+   s.avg = s.avg * c.meanW0 + value * c.meanW1;
+
+   float clamped = (value < 0.0f) ? 0.0f : ((env < value) ? env : value);
+
+   uint32_t slot = s.clock & NFC_HMASK;
+
+   NFC_AT(mem.x, slot) = value;
+   NFC_AT(mem.filt, slot) = filtered;
+   NFC_AT(mem.mdev, slot) = s.mdev;
+   NFC_AT(mem.depth, slot) = (env - clamped) / env;
+
+   float rectified = nfc_abs(filtered);
+
+   if (rectified > c.highThreshold)
+   {
+      if (rectified > s.edgePeak)
+      {
+         s.edgePeak = rectified;
+         s.edgeTime = s.clock;
+      }
+   }
+   else if (rectified < c.lowThreshold)
+   {
+      s.edgePeak = 0;
+   }
+}
+
+/* ring positions idx % period for the six correlators (idx = 1024 - delay + clock, as the
+ * reference's offsetSignalIndex + signalClock). Incremental, except in a window around the
+ * 32-bit clock wrap and at stream start where the exact modulo is taken. */
+NFC_DEV bool nfc_exact_zone(uint32_t clock)
+{
+   return (uint32_t)(clock + 1024u) < 2048u;
+}
+
+NFC_DEV uint32_t nfc_bump(uint32_t pos, uint32_t period)
+{
+   ++pos;
+   return pos >= period ? 0u : pos;
+}
+
+NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s)
+{
+   if (nfc_exact_zone(s.clock))
+   {
+      for (int r = 0; r < 3; r++)
+         s.posA[r] = (uint32_t)(1024u - c.a[r].delay + s.clock) % c.a[r].p1;
+      for (int r = 1; r < 3; r++)
+         s.posF[r] = (uint32_t)(1024u - c.f[r].delay + s.clock) % c.f[r].p1;
+      s.posV1 = (uint32_t)(1024u - c.v.delay + s.clock) % c.v.p1;
+      s.posV0 = (uint32_t)(1024u - c.v.delay + s.clock) % c.v.p0;
+   }
+   else
+   {
+      for (int r = 0; r < 3; r++)
+         s.posA[r] = nfc_bump(s.posA[r], c.a[r].p1);
+      for (int r = 1; r < 3; r++)
+         s.posF[r] = nfc_bump(s.posF[r], c.f[r].p1);
+      s.posV1 = nfc_bump(s.posV1, c.v.p1);
+      s.posV0 = nfc_bump(s.posV0, c.v.p0);
+   }
+}
+
+/* (idx + add) % period given pos = idx % period; exact modulo near the clock wrap */
+NFC_DEV uint32_t nfc_point(uint32_t clock, uint32_t delay, uint32_t pos, uint32_t add, uint32_t period)
+{
+   if (nfc_exact_zone(clock))
+      return (uint32_t)(1024u - delay + clock + add) % period;
+
+   uint32_t p = pos + add;
+   return p >= period ? p - period : p;
+}
+
+/* carrier presence, NfcDecoder.cpp:472-523 */
+NFC_DEV void nfc_detect_carrier(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   if (s.avg > c.highThreshold)
+   {
+      if (!s.carrierOn)
+      {
+         s.carrierOn = s.edgeTime ? s.edgeTime : s.clock;
+         nfc_emit(mem, s, NFC_TECH_ANY, NFC_FRAME_CARRIER_ON, 0, NFC_PHASE_CARRIER, 0, s.carrierOn, s.carrierOn, nullptr, 0);
+         s.carrierOff = 0;
+         s.edgeTime = 0;
+      }
+   }
+   else if (s.avg < c.lowThreshold)
+   {
+      if (!s.carrierOff)
+      {
+         s.carrierOff = s.edgeTime ? s.edgeTime : s.clock;
+         nfc_emit(mem, s, NFC_TECH_ANY, NFC_FRAME_CARRIER_OFF, 0, NFC_PHASE_CARRIER, 0, s.carrierOff, s.carrierOff, nullptr, 0);
+         s.carrierOn = 0;
+         s.edgeTime = 0;
+      }
+   }
+}
+
+/* the shared sliding correlator: box sum of width p2 over the delayed raw signal,
+ * kept in a p1-deep ring; S0/S1 are differences of ring entries. */
+struct NfcCorr
+{
+   float s0, s1;
+};
+
+NFC_DEV NfcCorr nfc_correlate_raw(const NfcLaneMem &mem, NfcStreamState &s, NfcMod &m, const NfcRate &rt,
+                                  uint32_t ringBase, uint32_t pos)
+{
+   uint32_t cur = (s.clock - rt.delay) & NFC_HMASK;
+   uint32_t old = (s.clock - rt.delay - rt.p2) & NFC_HMASK;
+
+   m.acc += NFC_AT(mem.x, cur);
+   m.acc -= NFC_AT(mem.x, old);
+
+   uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
+   uint32_t f3 = nfc_point(s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1);
+
+   NFC_AT(mem.corr, ringBase + pos) = m.acc;
+
+   float a = m.acc;
+   float b = NFC_AT(mem.corr, ringBase + f2);
+   float d = NFC_AT(mem.corr, ringBase + f3);
+
+   NfcCorr r;
+   r.s0 = a - b;
+   r.s1 = b - d;
+   return r;
+}
+
+/* same correlator over 10*filtered^2 (listen ASK, NfcA.cpp:1115-1131) */
+NFC_DEV NfcCorr nfc_correlate_power(const NfcLaneMem &mem, NfcStreamState &s, NfcMod &m, const NfcRate &rt,
+                                    uint32_t ringBase, uint32_t pos)
+{
+   uint32_t cur = (s.clock - rt.delay);
+   float v = NFC_AT(mem.filt, cur & NFC_HMASK);
+   float sq = v * v * 10.0f;
+
+   NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
+
+   m.acc += sq;
+   m.acc -= NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
+
+   uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
+   uint32_t f3 = nfc_point(s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1);
+
+   NFC_AT(mem.corr, ringBase + pos) = m.acc;
+
+   float a = m.acc;
+   float b = NFC_AT(mem.corr, ringBase + f2);
+   float d = NFC_AT(mem.corr, ringBase + f3);
+
+   NfcCorr r;
+   r.s0 = a - b;
+   r.s1 = b - d;
+   return r;
+}
+
+/* delayed self product for BPSK listen frames (NfcA.cpp:1236-1244, NfcB.cpp:785-796) */
+NFC_DEV float nfc_phase_product(const NfcLaneMem &mem, const NfcStreamState &s, const NfcRate &rt)
+{
+   uint32_t cur = (s.clock - rt.delay);
+   float a = NFC_AT(mem.filt, cur & NFC_HMASK);
+   float b = NFC_AT(mem.filt, (cur - rt.p1) & NFC_HMASK);
+   float p = a * b * 10.0f;
+   NFC_AT(mem.prod, cur & NFC_PMASK) = p;
+   return p;
+}
+
+NFC_DEV void nfc_phase_integrate(const NfcLaneMem &mem, const NfcStreamState &s, NfcMod &m, const NfcRate &rt, float p)
+{
+   uint32_t cur = (s.clock - rt.delay);
+   m.phaseAcc += p;
+   m.phaseAcc -= NFC_AT(mem.prod, (cur - rt.p4) & NFC_PMASK);
+}
+
+#include "nfc_tech_a.hpp"
+#include "nfc_tech_b.hpp"
+#include "nfc_tech_f.hpp"
+#include "nfc_tech_v.hpp"
+
+/* ------------------------------------------------------------------------------------------ */
+/* one sample                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+NFC_DEV void nfc_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+{
+   nfc_front_end(c, s, mem, value);
+   nfc_advance_positions(c, s);
+
+   switch (s.lockTech)
+   {
+      case NFC_TECH_A:
+         nfca_decode(c, s, mem);
+         break;
+      case NFC_TECH_B:
+         nfcb_decode(c, s, mem);
+         break;
+      case NFC_TECH_F:
+         nfcf_decode(c, s, mem);
+         break;
+      case NFC_TECH_V:
+         nfcv_decode(c, s, mem);
+         break;
+      default:
+      {
+         /* search bank, NfcDecoder.cpp:394-418: first detector that locks wins, later ones skip this sample */
+         nfc_detect_carrier(c, s, mem);
+
+         if ((c.enabled & 1u) && nfca_detect(c, s, mem))
+            break;
+         if ((c.enabled & 2u) && nfcb_detect(c, s, mem))
+            break;
+         if ((c.enabled & 4u) && nfcf_detect(c, s, mem))
+            break;
+         if ((c.enabled & 8u) && nfcv_detect(c, s, mem))
+            break;
+      }
+   }
+}
+
+/* state of a freshly initialised decoder; `keep` carries over what the reference's initialize()
+ * leaves untouched (envelope / IIR / EMA scalars, carrier bookkeeping): NfcDecoder.cpp:295-360 */
+NFC_DEV void nfc_state_init(const NfcConfig &c, NfcStreamState &s, bool keepFrontEnd)
+{
+   float env = s.env, n1 = s.n1, mdev = s.mdev, avg = s.avg, edgePeak = s.edgePeak;
+   uint32_t pulse = s.pulseFilter, edgeTime = s.edgeTime, off = s.carrierOff, on = s.carrierOn;
+
+   uint32_t *w = (uint32_t *)&s;
+   for (uint32_t i = 0; i < sizeof(NfcStreamState) / 4; i++)
+      w[i] = 0;
+
+   if (keepFrontEnd)
+   {
+      s.env = env; s.n1 = n1; s.mdev = mdev; s.avg = avg; s.edgePeak = edgePeak;
+      s.pulseFilter = pulse; s.edgeTime = edgeTime; s.carrierOff = off; s.carrierOn = on;
+   }
+
+   s.clock = 0xFFFFFFFFu;
+
+   nfca_protocol_defaults(c, s);
+   nfcb_protocol_defaults(c, s);
+   nfcf_protocol_defaults(c, s);
+   nfcv_protocol_defaults(c, s);
+
+   for (int t = 0; t < 4; t++)
+   {
+      s.tim[t].guardTime = s.tim[t].protoGuardTime;
+      s.tim[t].waitingTime = s.tim[t].protoWaitingTime;
+   }
+}
+
+#endif

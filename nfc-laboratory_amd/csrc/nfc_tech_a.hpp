@@ -1,0 +1,1001 @@
+/*
+ * nfc_tech_a.hpp — ISO14443-A / NFC-A: modified-Miller ASK poll frames at 106/212/424 kbps,
+ * Manchester-OOK (106k) and BPSK (212k/424k) listen frames.
+ *
+ * Reference behaviour being matched: src/nfc-lib/lib-lab/lab-radio/src/main/cpp/tech/NfcA.cpp
+ *   detectModulation 217-411, decodePollFrame 432-563, decodeListenFrame 568-803,
+ *   symbol decoders 812-1421, resetFrameSearch/resetModulation 1426-1475, process* 1480-1973,
+ *   checkCrc/checkParity 1978-2005.
+ * Included by nfc_core.hpp (device code).
+ */
+#ifndef NFC_AMD_TECH_A_HPP
+#define NFC_AMD_TECH_A_HPP
+
+NFC_DEV void nfca_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+{
+   NfcTiming &t = s.tim[0];
+   t.maxFrameSize = 256;
+   t.protoGuardTime = nfc_tu(c, 1024);             /* NFCA_FGT_DEF */
+   t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);  /* NFCA_FWT_DEF */
+}
+
+/* resetModulation, NfcA.cpp:1451-1475 */
+NFC_DEV void nfca_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   for (int r = 0; r < 3; r++)
+   {
+      nfc_mod_clear(s.modA[r]);
+      nfc_zero_ring(mem.corr, c.corrOffset[r], c.a[r].p1);
+   }
+
+   nfc_clear_assembly(s);
+   nfc_clear_symbol(s);
+
+   s.frameType = 0;
+   s.frameStart = 0;
+   s.frameEnd = 0;
+   s.lockTech = 0;
+}
+
+/* resetFrameSearch, NfcA.cpp:1426-1446 */
+NFC_DEV void nfca_reset_search(NfcStreamState &s, NfcMod &m)
+{
+   m.symStart = 0; m.symEnd = 0; m.symRise = 0;
+   m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+   m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+   s.frameStart = 0;
+}
+
+NFC_DEV bool nfca_crc_ok(const uint8_t *data, uint32_t len)
+{
+   if (len < 2)
+      return true;
+
+   uint32_t crc = nfc_crc16(data, len - 2, 0x6363u, true);
+   uint32_t res = (uint32_t)data[len - 2] | ((uint32_t)data[len - 1] << 8);
+   return res == crc;
+}
+
+/* odd parity check as NfcA.cpp:1994-2005: returns the parity bit xor-ed with every set data bit */
+NFC_DEV uint32_t nfca_parity(uint32_t value, uint32_t parity)
+{
+   for (uint32_t i = 0; i < 8; i++)
+      if (value & (1u << i))
+         parity ^= 1u;
+   return parity;
+}
+
+NFC_DEV void nfca_default_timing(const NfcConfig &c, NfcTiming &t)
+{
+   t.maxFrameSize = 256;
+   t.protoGuardTime = nfc_tu(c, 1024);
+   t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
+}
+
+/* frame classification + protocol timing feedback, NfcA.cpp:1480-1973 */
+NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t type,
+                          const uint8_t *data, uint32_t len, uint32_t &flags, uint32_t &phase)
+{
+   NfcTiming &t = s.tim[0];
+   const bool poll = (type == NFC_FRAME_POLL);
+   const uint32_t b0 = nfc_byte(data, len, 0);
+
+   if (poll)
+   {
+      t.guardTime = t.protoGuardTime;
+      t.waitingTime = t.protoWaitingTime;
+   }
+   else
+   {
+      t.guardTime = t.protoGuardTime;
+   }
+
+   bool done = false;
+
+   /* REQA / WUPA */
+   if (poll)
+   {
+      if ((b0 == 0x26 || b0 == 0x52) && len == 1)
+      {
+         phase = NFC_PHASE_SELECTION;
+         t.lastCommand = b0;
+         nfca_default_timing(c, t);
+         t.guardTime = nfc_tu(c, 1024);     /* NFCA_FGT_DEF  */
+         t.waitingTime = nfc_tu(c, 128 * 18); /* NFCA_FWT_ATQA */
+         s.chainedA = 0;
+         done = true;
+      }
+   }
+   else if (t.lastCommand == 0x26 || t.lastCommand == 0x52)
+   {
+      phase = NFC_PHASE_SELECTION;
+      done = true;
+   }
+
+   /* HLTA */
+   if (!done && poll && b0 == 0x50 && len == 4 && !(flags & NFC_FLAG_CRC))
+   {
+      phase = NFC_PHASE_SELECTION;
+      if (!nfca_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+      t.lastCommand = b0;
+      nfca_default_timing(c, t);
+      s.chainedA = 0;
+      nfca_reset(c, s, mem);
+      done = true;
+   }
+
+   if (!done)
+   {
+      if (!(s.chainedA & NFC_FLAG_ENCRYPTED))
+      {
+         const uint32_t last = t.lastCommand;
+
+         /* SEL1/2/3 */
+         if (poll ? (b0 == 0x93 || b0 == 0x95 || b0 == 0x97) : (last == 0x93 || last == 0x95 || last == 0x97))
+         {
+            phase = NFC_PHASE_SELECTION;
+            if (poll)
+            {
+               t.lastCommand = b0;
+               t.guardTime = nfc_tu(c, 1024);
+               t.waitingTime = nfc_tu(c, 128 * 18);
+            }
+         }
+         /* RATS */
+         else if (poll ? (b0 == 0xE0) : (last == 0xE0))
+         {
+            if (poll)
+            {
+               static const uint16_t fsd[16] = {16, 24, 32, 40, 48, 64, 96, 128, 256, 512, 1024, 2048, 4096, 0, 0, 0};
+               uint32_t fsdi = (nfc_byte(data, len, 1) >> 4) & 0x0F;
+               t.lastCommand = b0;
+               t.maxFrameSize = fsd[fsdi];
+               t.waitingTime = nfc_tu(c, 71680); /* NFC_FWT_ACTIVATION */
+            }
+            else
+            {
+               uint32_t offset = 0;
+               uint32_t tl = nfc_byte(data, len, offset++);
+
+               if (tl > 0)
+               {
+                  uint32_t t0 = nfc_byte(data, len, offset++);
+
+                  if (t0 & 0x10)
+                     offset++;
+
+                  if (t0 & 0x20)
+                  {
+                     uint32_t tb = nfc_byte(data, len, offset++);
+                     uint32_t fwi = (tb >> 4) & 0x0f;
+
+                     if (fwi == 15)
+                        fwi = 4;
+
+                     t.protoWaitingTime = nfc_tu(c, 4096 << fwi); /* NFC_FWT_TABLE[fwi] */
+                  }
+                  else
+                  {
+                     t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
+                  }
+               }
+            }
+
+            phase = NFC_PHASE_SELECTION;
+            if (!nfca_crc_ok(data, len))
+               flags |= NFC_FLAG_CRC;
+         }
+         /* PPS */
+         else if (poll ? ((b0 & 0xF0) == 0xD0) : (last == 0xD0))
+         {
+            if (poll)
+               t.lastCommand = b0 & 0xF0;
+            phase = NFC_PHASE_SELECTION;
+            if (!nfca_crc_ok(data, len))
+               flags |= NFC_FLAG_CRC;
+         }
+         /* Mifare AUTH */
+         else if (poll ? (b0 == 0x60 || b0 == 0x61) : (last == 0x60 || last == 0x61))
+         {
+            phase = NFC_PHASE_APPLICATION;
+            if (poll)
+            {
+               t.lastCommand = b0;
+               if (!nfca_crc_ok(data, len))
+                  flags |= NFC_FLAG_CRC;
+            }
+            else
+            {
+               s.chainedA = NFC_FLAG_ENCRYPTED;
+            }
+         }
+         /* I-Block */
+         else if (poll ? ((b0 & 0xE2) == 0x02 && len > 4) : (last == 0x02))
+         {
+            if (poll)
+               t.lastCommand = b0 & 0xE2;
+            phase = NFC_PHASE_APPLICATION;
+            if (!nfca_crc_ok(data, len))
+               flags |= NFC_FLAG_CRC;
+         }
+         /* R-Block */
+         else if (poll ? ((b0 & 0xE6) == 0xA2 && len == 3) : (last == 0xA2))
+         {
+            if (poll)
+               t.lastCommand = b0 & 0xE6;
+            phase = NFC_PHASE_APPLICATION;
+            if (!nfca_crc_ok(data, len))
+               flags |= NFC_FLAG_CRC;
+         }
+         /* S-Block */
+         else if (poll ? ((b0 & 0xC7) == 0xC0 && len == 4) : (last == 0xC0))
+         {
+            if (poll)
+               t.lastCommand = b0 & 0xC7;
+            phase = NFC_PHASE_APPLICATION;
+            if (!nfca_crc_ok(data, len))
+               flags |= NFC_FLAG_CRC;
+         }
+         else
+         {
+            phase = NFC_PHASE_APPLICATION;
+            if (!nfca_crc_ok(data, len))
+               flags |= NFC_FLAG_CRC;
+         }
+      }
+      else
+      {
+         /* everything after AUTH is ciphered: parity is meaningless, frame is application level */
+         flags &= ~(uint32_t)NFC_FLAG_PARITY;
+         phase = NFC_PHASE_APPLICATION;
+      }
+   }
+
+   flags |= s.chainedA;
+
+   const bool locked = (s.lockTech == NFC_TECH_A);
+   const uint32_t delay = locked ? c.a[s.lockRate].delay : 0u;
+
+   if (poll)
+   {
+      if (locked)
+      {
+         t.guardEnd = s.frameEnd + t.guardTime + delay;
+         t.waitingEnd = s.frameEnd + t.waitingTime + delay;
+         s.frameType = NFC_FRAME_LISTEN;
+      }
+   }
+   else
+   {
+      if (locked)
+         t.guardEnd = s.frameEnd + t.guardTime + delay;
+
+      s.frameType = 0;
+      t.lastCommand = 0;
+   }
+
+   s.frameStart = 0;
+   s.frameEnd = 0;
+}
+
+/* ---- search: SOF of a poll frame = one modified-Miller pause, NfcA.cpp:217-411 ---- */
+NFC_DEV bool nfca_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   if (s.clock < 1024u)
+      return false;
+
+   if (s.env < c.powerThreshold)
+      return false;
+
+   const float minimumCorrelation = s.env * c.corrThreshold[0];
+   const float minimumDepth = c.minDepth[0];
+
+   for (int r = 0; r < 3; r++)
+   {
+      const NfcRate &rt = c.a[r];
+      NfcMod &m = s.modA[r];
+
+      NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[r], s.posA[r]);
+      float sd = (k.s0 - k.s1) / (float)rt.p2;
+
+      if (m.peakTime && s.clock > m.peakTime + rt.p1)
+      {
+         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+         m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+      }
+
+      if (s.clock < m.winStart)
+         continue;
+
+      if (!m.symStart)
+      {
+         if (sd < -minimumCorrelation)
+         {
+            float deep = NFC_AT(mem.depth, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+
+            if (sd < m.peak)
+            {
+               m.peak = sd;
+               m.peakTime = s.clock;
+               m.winEnd = s.clock + rt.p4;
+            }
+
+            if (deep > m.aux)
+            {
+               m.aux = deep;
+               m.auxTime = s.clock;
+            }
+         }
+      }
+      else if (sd > minimumCorrelation)
+      {
+         if (sd > m.peak)
+         {
+            m.peak = sd;
+            m.peakTime = s.clock;
+         }
+      }
+
+      if (s.clock != m.winEnd)
+         continue;
+
+      if (!m.symStart)
+      {
+         if (m.aux < minimumDepth)
+         {
+            m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+            m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+            continue;
+         }
+
+         m.sync = m.peakTime + rt.p2;
+         m.winStart = m.sync - rt.p8;
+         m.winEnd = m.sync + rt.p8;
+         m.symStart = m.peakTime - rt.p2;
+         m.peakTime = 0;
+         m.peak = 0;
+         continue;
+      }
+
+      m.symEnd = m.peakTime;
+      m.pulses = m.symEnd - m.symStart;
+
+      const uint32_t minimumWidth = rt.p1 - rt.p4;
+      const uint32_t maximumWidth = rt.p1 + rt.p4;
+
+      if (m.peakTime == 0 || m.aux < minimumDepth || m.pulses < minimumWidth || m.pulses > maximumWidth)
+      {
+         m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+         m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+         continue;
+      }
+
+      m.sync = m.symEnd + rt.p1;
+      m.winStart = m.sync - rt.p8;
+      m.winEnd = m.sync + rt.p8;
+      m.thr = m.peak / 2;
+      m.c0 = 0;
+      m.c1 = 0;
+      m.peakTime = 0;
+      m.peak = 0;
+
+      s.frameType = NFC_FRAME_POLL;
+      s.frameRate = rt.symbolsPerSecond;
+      s.frameStart = m.symStart - rt.delay;
+      s.frameEnd = 0;
+
+      s.symValue = 0;
+      s.symStart = m.symStart - rt.delay;
+      s.symEnd = m.symEnd - rt.delay;
+      s.symLength = s.symEnd - s.symStart;
+      s.symPattern = A_Z;
+
+      s.lockTech = NFC_TECH_A;
+      s.lockRate = (uint32_t)r;
+      return true;
+   }
+
+   return false;
+}
+
+/* ---- poll frame symbols (modified Miller), NfcA.cpp:812-934 ---- */
+NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t r = s.lockRate;
+   const NfcRate &rt = c.a[r];
+   NfcMod &m = s.modA[r];
+
+   NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[r], s.posA[r]);
+   float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (sd > m.peak && sd > m.thr)
+   {
+      m.peak = sd;
+      m.peakTime = s.clock;
+   }
+
+   if (s.clock == m.sync)
+   {
+      m.cD = sd;
+      m.c0 = k.s0;
+      m.c1 = k.s1;
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   if (m.cD < m.thr)
+   {
+      m.symStart = m.symEnd;
+      m.symEnd = m.sync;
+      m.symRise = m.symStart;
+      s.symValue = 1;
+      s.symPattern = A_Y;
+   }
+   else if (m.c0 > m.c1)
+   {
+      m.symStart = m.symEnd;
+      m.symEnd = m.peakTime;
+      m.symRise = m.peakTime - rt.p2;
+      s.symValue = 0;
+      s.symPattern = A_Z;
+   }
+   else
+   {
+      m.symStart = m.symEnd;
+      m.symEnd = m.peakTime;
+      m.symRise = m.peakTime;
+      s.symValue = 1;
+      s.symPattern = A_X;
+   }
+
+   m.sync = m.symEnd + rt.p1;
+   m.winStart = m.sync - rt.p8;
+   m.winEnd = m.sync + rt.p8;
+   m.cD = 0; m.c0 = 0; m.c1 = 0;
+   m.peakTime = 0;
+   m.peak = 0;
+
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symEdge = m.symRise - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+
+   return s.symPattern;
+}
+
+/* ---- poll frame assembly, NfcA.cpp:432-563 ---- */
+NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t pattern)
+{
+   NfcTiming &t = s.tim[0];
+   bool frameEnd = false, truncated = false;
+
+   s.bsPattern = pattern;
+
+   if (pattern == A_Y && (s.bsPrevious == A_Y || s.bsPrevious == A_Z))
+      frameEnd = true;
+   else if (s.bsBytes == t.maxFrameSize)
+      truncated = true;
+
+   if (frameEnd || truncated)
+   {
+      if (s.bsBytes > 0 || s.bsBits == 7)
+      {
+         if (s.bsBits >= 7)
+            nfc_push_byte(mem, s, s.bsData);
+
+         uint32_t flags = 0, phase = 0;
+
+         if (s.bsFlags & NFC_FLAG_PARITY)
+            flags |= NFC_FLAG_PARITY;
+         if (truncated)
+            flags |= NFC_FLAG_TRUNCATED;
+         if (s.bsBytes == 1 && s.bsBits == 7)
+            flags |= NFC_FLAG_SHORT;
+
+         const uint32_t start = s.frameStart, end = s.frameEnd, rate = s.frameRate, len = s.bsBytes;
+         const uint32_t lockedRate = s.lockRate;
+
+         nfca_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
+         nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
+
+         nfc_clear_assembly(s);
+
+         if (s.lockTech == NFC_TECH_A)
+            nfc_poll_end_clear(mem, s.modA[lockedRate], c.corrOffset[lockedRate], c.a[lockedRate].p1);
+
+         return;
+      }
+
+      nfca_reset(c, s, mem);
+      return;
+   }
+
+   if (s.symEdge)
+      s.frameEnd = s.symEdge;
+
+   if (s.bsPrevious)
+   {
+      uint32_t value = (s.bsPrevious == A_X) ? 1u : 0u;
+
+      if (s.bsBits < 8)
+      {
+         s.bsData |= value << s.bsBits++;
+      }
+      else if (s.bsBytes < t.maxFrameSize)
+      {
+         nfc_push_byte(mem, s, s.bsData);
+         if (!nfca_parity(s.bsData, value))
+            s.bsFlags |= NFC_FLAG_PARITY;
+         s.bsData = 0;
+         s.bsBits = 0;
+      }
+      else
+      {
+         nfca_reset(c, s, mem);
+         return;
+      }
+   }
+
+   s.bsPrevious = s.bsPattern;
+}
+
+/* ---- listen SOF, 106k OOK subcarrier, NfcA.cpp:939-1090 ---- */
+NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t r = s.lockRate;
+   const NfcRate &rt = c.a[r];
+   NfcMod &m = s.modA[r];
+   NfcTiming &t = s.tim[0];
+
+   /* this stage only forms S0 (NfcA.cpp:962-975): same ring, no S1 */
+   const uint32_t cur = s.clock - rt.delay;
+   float v = NFC_AT(mem.filt, cur & NFC_HMASK);
+   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
+   float sq = v * v * 10.0f;
+
+   NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
+   m.acc += sq;
+   m.acc -= NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
+
+   const uint32_t pos = s.posA[r];
+   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
+   NFC_AT(mem.corr, c.corrOffset[r] + pos) = m.acc;
+   float s0 = m.acc - NFC_AT(mem.corr, c.corrOffset[r] + f2);
+
+   if (s.clock < t.guardEnd)
+      return SYM_NONE;
+
+   if (s.clock == t.guardEnd)
+      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK) * (float)rt.p8;
+
+   if (s.clock > t.waitingEnd)
+      return SYM_TIMEOUT;
+
+   if (deep > c.minDepth[0])
+      return SYM_TIMEOUT;
+
+   if (!m.symStart)
+   {
+      if (s0 > m.thr && s0 > m.peak)
+      {
+         m.peak = s0;
+         m.peakTime = s.clock;
+         m.winEnd = s.clock + rt.p4;
+      }
+   }
+   else if (s0 < -m.thr && s0 < m.peak)
+   {
+      m.peak = s0;
+      m.peakTime = s.clock;
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   if (!m.symStart)
+   {
+      m.sync = m.peakTime + rt.p2;
+      m.winEnd = m.winEnd + rt.p2;
+      m.symStart = m.peakTime - rt.p2;
+      m.peakTime = 0;
+      m.peak = 0;
+      return SYM_NONE;
+   }
+
+   m.symEnd = m.peakTime;
+   m.pulses = m.symEnd - m.symStart;
+
+   const uint32_t minimumWidth = rt.p1 - rt.p8;
+   const uint32_t maximumWidth = rt.p1 + rt.p8;
+
+   if (m.peakTime == 0 || m.pulses < minimumWidth || m.pulses > maximumWidth)
+   {
+      m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      return SYM_NONE;
+   }
+
+   m.sync = m.symEnd + rt.p1;
+   m.winStart = m.sync - rt.p8;
+   m.winEnd = m.sync + rt.p8;
+   m.thr = nfc_abs(m.peak * 0.25f);
+   m.c0 = 0;
+   m.c1 = 0;
+   m.peakTime = 0;
+   m.peak = 0;
+
+   s.symValue = 1;
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+   s.symPattern = A_D;
+
+   return A_D;
+}
+
+/* ---- listen symbols, 106k Manchester, NfcA.cpp:1095-1214 ---- */
+NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t r = s.lockRate;
+   const NfcRate &rt = c.a[r];
+   NfcMod &m = s.modA[r];
+
+   NfcCorr k = nfc_correlate_power(mem, s, m, rt, c.corrOffset[r], s.posA[r]);
+   float sd = nfc_abs(k.s0 - k.s1);
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (sd > m.peak)
+   {
+      m.peak = sd;
+      m.peakTime = s.clock;
+   }
+
+   if (s.clock == m.sync)
+   {
+      m.cD = sd;
+      m.c0 = k.s0;
+      m.c1 = k.s1;
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   if (m.cD > m.thr)
+   {
+      m.symStart = m.symEnd;
+      m.symEnd = m.peakTime;
+      m.thr = m.peak * 0.25f;
+
+      if (m.c0 > m.c1)
+      {
+         m.symRise = m.sync;
+         s.symValue = 0;
+         s.symPattern = A_E;
+      }
+      else
+      {
+         m.symRise = m.sync - rt.p2;
+         s.symValue = 1;
+         s.symPattern = A_D;
+      }
+   }
+   else
+   {
+      m.symStart = m.symEnd;
+      m.symEnd = m.sync;
+      m.symRise = 0;
+      s.symPattern = A_F;
+   }
+
+   m.sync = m.symEnd + rt.p1;
+   m.winStart = m.sync - rt.p8;
+   m.winEnd = m.sync + rt.p8;
+   m.peakTime = 0;
+   m.peak = 0;
+
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symEdge = m.symRise - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+
+   return s.symPattern;
+}
+
+/* ---- listen SOF, BPSK (212k/424k), NfcA.cpp:1220-1329 ---- */
+NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t r = s.lockRate;
+   const NfcRate &rt = c.a[r];
+   NfcMod &m = s.modA[r];
+   NfcTiming &t = s.tim[0];
+
+   const uint32_t cur = s.clock - rt.delay;
+   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
+   float p = nfc_phase_product(mem, s, rt);
+
+   if (s.clock < t.guardEnd)
+      return SYM_NONE;
+
+   if (s.clock == t.guardEnd)
+      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK);
+
+   if (s.clock > t.waitingEnd)
+      return SYM_TIMEOUT;
+
+   if (deep > c.minDepth[0])
+      return SYM_TIMEOUT;
+
+   nfc_phase_integrate(mem, s, m, rt, p);
+
+   if (m.phaseAcc > m.thr)
+   {
+      if (!m.symStart)
+         m.symStart = s.clock;
+
+      m.winEnd = s.clock + rt.p2;
+   }
+
+   if (!m.symEnd && (m.phaseAcc < 0 || s.clock == m.winEnd))
+   {
+      int preamble = (int)(s.clock - m.symStart);
+
+      if (preamble < c.etu * 3 || preamble > c.etu * 4)
+      {
+         m.symStart = 0;
+         m.symEnd = 0;
+         m.winEnd = 0;
+         return SYM_NONE;
+      }
+
+      m.symEnd = m.winEnd + rt.p2;
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   m.sync = m.symEnd + rt.p2;
+   m.lastPhase = m.phaseAcc;
+   m.phaseThr = nfc_abs(m.phaseAcc * 0.25f);
+   m.auxTime = 0;
+
+   s.symValue = 0;
+   s.symStart = m.symStart - rt.p1 - rt.delay;
+   s.symEnd = m.symEnd - rt.p1 - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+   s.symPattern = A_S;
+
+   return A_S;
+}
+
+/* ---- listen symbols, BPSK, NfcA.cpp:1334-1421 ---- */
+NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t r = s.lockRate;
+   const NfcRate &rt = c.a[r];
+   NfcMod &m = s.modA[r];
+
+   float p = nfc_phase_product(mem, s, rt);
+   nfc_phase_integrate(mem, s, m, rt, p);
+
+   if (!m.auxTime)
+   {
+      if ((m.phaseAcc > 0 && m.lastPhase < 0) || (m.phaseAcc < 0 && m.lastPhase > 0))
+      {
+         m.auxTime = s.clock;
+         m.sync = s.clock + rt.p2;
+         m.lastPhase = m.phaseAcc;
+      }
+   }
+
+   if (s.clock != m.sync)
+      return SYM_NONE;
+
+   if (nfc_abs(m.phaseAcc) < nfc_abs(m.phaseThr))
+      return A_O;
+
+   m.symStart = m.symEnd;
+   m.symEnd = m.sync + rt.p2;
+   m.sync = m.sync + rt.p1;
+   m.lastPhase = m.phaseAcc;
+   m.auxTime = 0;
+
+   if (m.phaseAcc < -m.phaseThr)
+   {
+      s.symValue = !s.symValue;
+      s.symPattern = (s.symPattern == A_M) ? A_N : A_M;
+   }
+   else
+   {
+      m.phaseThr = m.phaseAcc * 0.25f;
+   }
+
+   s.symStart = m.symStart - rt.p1 - rt.delay;
+   s.symEnd = m.symEnd - rt.p1 - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+
+   return s.symPattern;
+}
+
+/* emit a listen frame and fall back to search, shared by ASK and BPSK paths */
+NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t flags)
+{
+   uint32_t phase = 0;
+   const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes;
+   const uint32_t rate = c.a[s.lockRate].symbolsPerSecond;
+
+   nfca_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
+   nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
+   nfca_reset(c, s, mem);
+}
+
+/* ---- one sample in locked NFC-A mode: decodeFrame, NfcA.cpp:416-803 ---- */
+NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   NfcTiming &t = s.tim[0];
+
+   if (s.frameType == NFC_FRAME_POLL)
+   {
+      uint32_t pattern = nfca_poll_symbol(c, s, mem);
+
+      if (pattern > SYM_TIMEOUT)
+         nfca_poll_frame(c, s, mem, pattern);
+
+      return;
+   }
+
+   if (s.frameType != NFC_FRAME_LISTEN)
+      return;
+
+   if (s.lockRate == 0)
+   {
+      if (!s.frameStart)
+      {
+         uint32_t pattern = nfca_listen_ask_start(c, s, mem);
+
+         if (pattern == A_D)
+            s.frameStart = s.symStart;
+         else if (pattern == SYM_TIMEOUT)
+            nfca_reset(c, s, mem);
+
+         return;
+      }
+
+      uint32_t pattern = nfca_listen_ask_symbol(c, s, mem);
+
+      if (pattern <= SYM_TIMEOUT)
+         return;
+
+      bool frameEnd = false, truncated = false;
+
+      if (pattern == A_F)
+         frameEnd = true;
+      else if (s.bsBytes == t.maxFrameSize)
+         truncated = true;
+
+      if (frameEnd || truncated)
+      {
+         if (s.bsBytes > 0 || s.bsBits == 4)
+         {
+            if (s.bsBits == 4)
+               nfc_push_byte(mem, s, s.bsData);
+
+            uint32_t flags = 0;
+            if (s.bsFlags & NFC_FLAG_PARITY)
+               flags |= NFC_FLAG_PARITY;
+            if (truncated)
+               flags |= NFC_FLAG_TRUNCATED;
+            if (s.bsBytes == 1 && s.bsBits == 4)
+               flags |= NFC_FLAG_SHORT;
+
+            nfca_finish_listen(c, s, mem, flags);
+            return;
+         }
+
+         nfca_reset_search(s, s.modA[s.lockRate]);
+         return;
+      }
+
+      if (s.symEdge)
+         s.frameEnd = s.symEdge;
+
+      if (s.bsBits < 8)
+      {
+         s.bsData |= (s.symValue << s.bsBits++);
+      }
+      else if (s.bsBytes < t.maxFrameSize)
+      {
+         nfc_push_byte(mem, s, s.bsData);
+         if (!nfca_parity(s.bsData, s.symValue))
+            s.bsFlags |= NFC_FLAG_PARITY;
+         s.bsData = 0;
+         s.bsBits = 0;
+      }
+      else
+      {
+         nfca_reset(c, s, mem);
+      }
+
+      return;
+   }
+
+   /* 212k / 424k: BPSK */
+   if (!s.frameStart)
+   {
+      uint32_t pattern = nfca_listen_bpsk_start(c, s, mem);
+
+      if (pattern == A_S)
+         s.frameStart = s.symStart;
+      else if (pattern == SYM_TIMEOUT)
+         nfca_reset(c, s, mem);
+
+      return;
+   }
+
+   uint32_t pattern = nfca_listen_bpsk_symbol(c, s, mem);
+
+   if (pattern <= SYM_TIMEOUT)
+      return;
+
+   bool frameEnd = false, truncated = false;
+
+   if (pattern == A_O)
+      frameEnd = true;
+   else if (s.bsBytes == t.maxFrameSize)
+      truncated = true;
+
+   if (frameEnd || truncated)
+   {
+      if (s.bsBits == 9)
+      {
+         nfc_push_byte(mem, s, s.bsData);
+
+         if (nfca_parity(s.bsData, s.bsParity))
+            s.bsFlags |= NFC_FLAG_PARITY;
+      }
+
+      if (s.bsBytes > 0)
+      {
+         s.frameEnd = s.symEnd;
+
+         uint32_t flags = 0;
+         if (s.bsFlags & NFC_FLAG_PARITY)
+            flags |= NFC_FLAG_PARITY;
+         if (truncated)
+            flags |= NFC_FLAG_TRUNCATED;
+
+         nfca_finish_listen(c, s, mem, flags);
+         return;
+      }
+
+      nfca_reset(c, s, mem);
+      return;
+   }
+
+   if (s.bsBits < 8)
+   {
+      s.bsData |= (s.symValue << s.bsBits);
+   }
+   else if (s.bsBits < 9)
+   {
+      s.bsParity = s.symValue;
+   }
+   else
+   {
+      nfc_push_byte(mem, s, s.bsData);
+      if (!nfca_parity(s.bsData, s.bsParity))
+         s.bsFlags |= NFC_FLAG_PARITY;
+      s.bsData = s.symValue;
+      s.bsBits = 0;
+   }
+
+   s.bsBits++;
+}
+
+#endif

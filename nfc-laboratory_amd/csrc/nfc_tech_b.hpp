@@ -1,0 +1,615 @@
+/*
+ * nfc_tech_b.hpp — ISO14443-B / NFC-B: NRZ-L ASK (10 %) poll frames, BPSK listen frames.
+ *
+ * Reference behaviour being matched: src/nfc-lib/lib-lab/lab-radio/src/main/cpp/tech/NfcB.cpp
+ *   detectModulation 238-432 (edge detector on the DC-removed signal, rates 106k/212k),
+ *   decodePollFrame 453-567, decodeListenFrame 572-679, decodePollFrameSymbolAsk 684-762,
+ *   decodeListenFrameStartBpsk 767-949, decodeListenFrameSymbolBpsk 954-1040,
+ *   resetModulation 1045-1069, process* 1074-1267, checkCrc 1272-1283.
+ * Included by nfc_core.hpp (device code).
+ */
+#ifndef NFC_AMD_TECH_B_HPP
+#define NFC_AMD_TECH_B_HPP
+
+NFC_DEV void nfcb_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+{
+   NfcTiming &t = s.tim[1];
+   t.maxFrameSize = 256;
+   t.protoGuardTime = nfc_tu(c, 1024);            /* NFCB_FGT_DEF = TR0min */
+   t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16); /* NFCB_FWT_DEF */
+}
+
+NFC_DEV void nfcb_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   for (int r = 0; r < 3; r++)
+      nfc_mod_clear(s.modB[r]);
+
+   nfc_clear_assembly(s);
+   nfc_clear_symbol(s);
+
+   s.frameType = 0;
+   s.frameStart = 0;
+   s.frameEnd = 0;
+   s.lockTech = 0;
+}
+
+/* ISO/IEC 13239 CRC_B */
+NFC_DEV bool nfcb_crc_ok(const uint8_t *data, uint32_t len)
+{
+   if (len < 3)
+      return false;
+
+   uint32_t crc = (~nfc_crc16(data, len - 2, 0xFFFFu, true)) & 0xFFFFu;
+   uint32_t res = (uint32_t)data[len - 2] | ((uint32_t)data[len - 1] << 8);
+   return res == crc;
+}
+
+NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, const uint8_t *data, uint32_t len,
+                          uint32_t &flags, uint32_t &phase)
+{
+   static const uint16_t fsd[16] = {16, 24, 32, 40, 48, 64, 96, 128, 256, 512, 1024, 2048, 4096, 0, 0, 0};
+
+   NfcTiming &t = s.tim[1];
+   const bool poll = (type == NFC_FRAME_POLL);
+   const uint32_t b0 = nfc_byte(data, len, 0);
+
+   t.guardTime = t.protoGuardTime;
+   if (poll)
+      t.waitingTime = t.protoWaitingTime;
+
+   /* REQB / WUPB and its ATQB */
+   if (poll && b0 == 0x05 && len == 5)
+   {
+      t.lastCommand = b0;
+      t.maxFrameSize = 256;
+      t.protoGuardTime = nfc_tu(c, 1024);
+      t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
+      t.guardTime = nfc_tu(c, 1024);   /* NFCB_TR0_MIN  */
+      t.waitingTime = nfc_tu(c, 7680); /* NFCB_FWT_ATQB */
+      phase = NFC_PHASE_SELECTION;
+      if (!nfcb_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+   }
+   else if (!poll && t.lastCommand == 0x05)
+   {
+      uint32_t fsdi = (nfc_byte(data, len, 10) >> 4) & 0x0f;
+      uint32_t fwi = (nfc_byte(data, len, 11) >> 4) & 0x0f;
+
+      t.maxFrameSize = fsd[fsdi];
+      t.protoWaitingTime = nfc_tu(c, 4096 << fwi);
+
+      phase = NFC_PHASE_SELECTION;
+      if (!nfcb_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+   }
+   /* ATTRIB */
+   else if (poll && b0 == 0x1d && len > 10)
+   {
+      static const uint16_t tr0min[4] = {0, 48 * 16, 16 * 16, 0};
+
+      t.lastCommand = b0;
+
+      uint32_t param1 = nfc_byte(data, len, 5);
+      uint32_t param2 = nfc_byte(data, len, 6);
+      uint32_t tr0i = (param1 >> 6) & 0x3;
+      uint32_t fsdi = param2 & 0xf;
+
+      t.maxFrameSize = fsd[fsdi];
+
+      if (!tr0i)
+         t.protoGuardTime = nfc_tu(c, 1024);
+      else
+         t.protoGuardTime = nfc_tu(c, tr0min[tr0i]);
+
+      t.waitingTime = nfc_tu(c, 71680); /* NFC_FWT_ACTIVATION */
+
+      phase = NFC_PHASE_SELECTION;
+      if (!nfcb_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+   }
+   else if (!poll && t.lastCommand == 0x1d)
+   {
+      phase = NFC_PHASE_SELECTION;
+   }
+   else
+   {
+      phase = NFC_PHASE_APPLICATION;
+      if (!nfcb_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+   }
+
+   /* chained flags are always zero for NFC-B */
+
+   const bool locked = (s.lockTech == NFC_TECH_B);
+   const uint32_t delay = locked ? c.b[s.lockRate].delay : 0u;
+
+   if (poll)
+   {
+      if (locked)
+      {
+         t.guardEnd = s.frameEnd + t.guardTime + delay;
+         t.waitingEnd = s.frameEnd + t.waitingTime + delay;
+         s.frameType = NFC_FRAME_LISTEN;
+      }
+   }
+   else
+   {
+      if (locked)
+         t.guardEnd = s.frameEnd + t.guardTime + delay;
+
+      s.frameType = 0;
+      t.lastCommand = 0;
+   }
+
+   s.frameStart = 0;
+   s.frameEnd = 0;
+}
+
+/* ---- search: SOF = falling edge, 10-11 etu low, rising edge, 2-3 etu high, falling edge ---- */
+NFC_DEV bool nfcb_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   if (s.clock < 1024u)
+      return false;
+
+   if (s.env < c.powerThreshold)
+      return false;
+
+   for (int r = 0; r < 2; r++)
+   {
+      const NfcRate &rt = c.b[r];
+      NfcMod &m = s.modB[r];
+
+      const uint32_t slot = (s.clock - rt.delay) & NFC_HMASK;
+      float edge = NFC_AT(mem.filt, slot);
+      float deep = NFC_AT(mem.depth, slot);
+
+      if (deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1))
+      {
+         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+         m.auxTime = 0; m.aux = 0;
+      }
+
+      if (!m.symStart)
+      {
+         m.thr = s.env * c.minDepth[1];
+
+         if (edge < -m.thr && edge < m.aux)
+         {
+            m.aux = edge;
+            m.auxTime = s.clock;
+            m.winEnd = s.clock + rt.p4;
+         }
+
+         if (s.clock != m.winEnd)
+            continue;
+
+         m.symStart = m.auxTime - rt.p8;
+         m.winStart = m.symStart + (10 * rt.p1) - rt.p2;
+         m.winEnd = m.symStart + (11 * rt.p1) + rt.p2;
+         m.thr = nfc_abs(m.aux * 0.5f);
+         m.aux = 0;
+         m.auxTime = 0;
+         continue;
+      }
+
+      if (!m.symEnd)
+      {
+         if (s.clock < m.winStart)
+         {
+            if (edge > m.thr)
+            {
+               m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+               m.auxTime = 0; m.aux = 0;
+            }
+            continue;
+         }
+
+         if (edge > m.thr && edge > m.aux)
+         {
+            m.aux = edge;
+            m.auxTime = s.clock;
+            m.winEnd = s.clock + rt.p4;
+         }
+
+         if (s.clock != m.winEnd)
+            continue;
+
+         if (!m.auxTime)
+         {
+            m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.aux = 0;
+            continue;
+         }
+
+         m.symEnd = m.auxTime;
+         m.winStart = m.auxTime + (2 * rt.p1) - rt.p2;
+         m.winEnd = m.auxTime + (3 * rt.p1) + rt.p2;
+         m.thr = nfc_abs(m.aux) / 2;
+         m.aux = 0;
+         m.auxTime = 0;
+         continue;
+      }
+
+      if (s.clock < m.winStart)
+      {
+         if (edge < -m.thr)
+         {
+            m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+            m.auxTime = 0; m.aux = 0;
+         }
+         continue;
+      }
+
+      if (edge < -m.thr && m.aux > edge)
+      {
+         m.aux = edge;
+         m.auxTime = s.clock;
+         m.winEnd = s.clock + rt.p4;
+      }
+
+      if (s.clock != m.winEnd)
+         continue;
+
+      if (!m.auxTime)
+      {
+         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+         m.auxTime = 0; m.aux = 0;
+         break; /* the reference leaves the rate loop here (NfcB.cpp:396) */
+      }
+
+      m.symEnd = m.auxTime;
+      m.sync = m.symEnd + rt.p2;
+      m.winStart = 0;
+      m.winEnd = 0;
+      m.thr = nfc_abs(m.aux * 0.5f);
+      m.auxTime = 0;
+      m.aux = 0;
+
+      s.frameType = NFC_FRAME_POLL;
+      s.frameRate = rt.symbolsPerSecond;
+      s.frameStart = m.symStart - rt.delay;
+      s.frameEnd = 0;
+
+      s.lockTech = NFC_TECH_B;
+      s.lockRate = (uint32_t)r;
+      return true;
+   }
+
+   return false;
+}
+
+/* ---- poll symbols: sample modulation depth at bit centres, resync on edges ---- */
+NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const NfcRate &rt = c.b[s.lockRate];
+   NfcMod &m = s.modB[s.lockRate];
+
+   const uint32_t slot = (s.clock - rt.delay) & NFC_HMASK;
+   float edge = NFC_AT(mem.filt, slot);
+   float deep = NFC_AT(mem.depth, slot);
+
+   if (s.clock > m.winStart && s.clock < m.winEnd)
+   {
+      edge = nfc_abs(edge);
+
+      if (edge > m.thr && m.aux < edge)
+      {
+         m.aux = edge;
+         m.sync = s.clock + rt.p2;
+      }
+   }
+
+   if (s.clock != m.sync)
+      return SYM_NONE;
+
+   m.symStart = m.symEnd;
+   m.symEnd = m.sync + rt.p2;
+   m.winStart = m.sync + rt.p4;
+   m.winEnd = m.winStart + rt.p2;
+   m.sync = m.sync + rt.p1;
+   m.aux = 0;
+
+   if (deep > c.minDepth[1])
+   {
+      s.symValue = 0;
+      s.symPattern = B_L;
+   }
+   else
+   {
+      s.symValue = 1;
+      s.symPattern = B_H;
+   }
+
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+
+   return s.symPattern;
+}
+
+/* ---- listen SOF: TR1 subcarrier, then two phase changes (S1, S2) ---- */
+NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const NfcRate &rt = c.b[s.lockRate];
+   NfcMod &m = s.modB[s.lockRate];
+   NfcTiming &t = s.tim[1];
+
+   const uint32_t cur = s.clock - rt.delay;
+   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
+   float p = nfc_phase_product(mem, s, rt);
+
+   nfc_phase_integrate(mem, s, m, rt, p);
+
+   if (s.clock < t.guardEnd)
+      return SYM_NONE;
+
+   if (s.clock == t.guardEnd)
+      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK);
+
+   if (s.clock > t.waitingEnd)
+      return SYM_TIMEOUT;
+
+   if (deep > c.maxDepth[1])
+      return SYM_TIMEOUT;
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (m.phaseAcc > m.thr)
+   {
+      if (!m.symStart)
+         m.symStart = s.clock;
+
+      m.winEnd = s.clock + rt.p2;
+   }
+
+   if (s.clock != m.winEnd && m.phaseAcc > 0)
+      return SYM_NONE;
+
+   /* durations are compared unsigned against the protocol limits (int vs unsigned int in the reference) */
+   const uint32_t tr1Min = nfc_tu(c, 1024), tr1Max = nfc_tu(c, 3200);
+   const uint32_t s1Min = nfc_tu(c, 1272), s1Max = nfc_tu(c, 1416);
+   const uint32_t s2Min = nfc_tu(c, 248), s2Max = nfc_tu(c, 392);
+
+   if (m.stage == 0)
+   {
+      uint32_t length = s.clock - m.symStart;
+
+      if (length < tr1Min || length > tr1Max)
+      {
+         m.stage = 0; m.winStart = 0; m.winEnd = 0; m.symStart = 0; m.symEnd = 0;
+         return SYM_NONE;
+      }
+
+      m.symEnd = s.clock;
+      m.stage = 1;
+      m.winStart = s.clock + rt.p1 + rt.p4;
+      m.winEnd = 0;
+      return SYM_NONE;
+   }
+
+   if (m.stage == 1)
+   {
+      uint32_t length = s.clock - m.symEnd;
+
+      if (length < s1Min || length > s1Max)
+      {
+         m.stage = 0; m.winStart = 0; m.winEnd = 0; m.symStart = 0; m.symEnd = 0;
+         return SYM_NONE;
+      }
+
+      m.symEnd = s.clock;
+      m.stage = 2;
+      m.winStart = s.clock + rt.p1 + rt.p4;
+      m.winEnd = 0;
+      return SYM_NONE;
+   }
+
+   if (m.stage == 2)
+   {
+      uint32_t length = s.clock - m.symEnd;
+
+      if (length < s2Min || length > s2Max)
+      {
+         m.stage = 0; m.winStart = 0; m.winEnd = 0; m.symStart = 0; m.symEnd = 0;
+         return SYM_NONE;
+      }
+
+      m.symEnd = s.clock;
+      m.sync = s.clock + rt.p2;
+      m.lastPhase = m.phaseAcc;
+      m.phaseThr = nfc_abs(m.aux * 0.25f);
+      m.winStart = 0;
+      m.winEnd = 0;
+      m.aux = 0;
+
+      s.symValue = 1;
+      s.symStart = m.symStart - rt.p1 - rt.delay;
+      s.symEnd = m.symEnd - rt.p1 - rt.delay;
+      s.symLength = s.symEnd - s.symStart;
+      s.symPattern = B_S;
+
+      return B_S;
+   }
+
+   /* any other stage value: the reference's switch has no case and simply keeps consuming samples */
+   return SYM_NONE;
+}
+
+/* ---- listen symbols: BPSK phase at bit centres ---- */
+NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const NfcRate &rt = c.b[s.lockRate];
+   NfcMod &m = s.modB[s.lockRate];
+
+   float p = nfc_phase_product(mem, s, rt);
+   nfc_phase_integrate(mem, s, m, rt, p);
+
+   if (!m.auxTime)
+   {
+      if ((m.phaseAcc > 0 && m.lastPhase < 0) || (m.phaseAcc < 0 && m.lastPhase > 0))
+      {
+         m.auxTime = s.clock;
+         m.sync = s.clock + rt.p2;
+         m.lastPhase = m.phaseAcc;
+      }
+   }
+
+   if (s.clock != m.sync)
+      return SYM_NONE;
+
+   if (nfc_abs(m.phaseAcc) < nfc_abs(m.phaseThr))
+      return B_O;
+
+   m.symStart = m.symEnd;
+   m.symEnd = m.sync + rt.p2;
+   m.sync = m.sync + rt.p1;
+   m.lastPhase = m.phaseAcc;
+   m.auxTime = 0;
+
+   if (m.phaseAcc < -m.phaseThr)
+   {
+      s.symValue = !s.symValue;
+      s.symPattern = (s.symPattern == B_M) ? B_N : B_M;
+   }
+   else
+   {
+      m.phaseThr = m.phaseAcc * 0.25f;
+   }
+
+   s.symStart = m.symStart - rt.p1 - rt.delay;
+   s.symEnd = m.symEnd - rt.p1 - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+
+   return s.symPattern;
+}
+
+/* ---- one sample in locked NFC-B mode ---- */
+NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   NfcTiming &t = s.tim[1];
+
+   if (s.frameType == NFC_FRAME_POLL)
+   {
+      uint32_t pattern = nfcb_poll_symbol(c, s, mem);
+
+      if (pattern <= SYM_TIMEOUT)
+         return;
+
+      bool frameEnd = false, truncated = false, streamError = false;
+
+      if (s.bsBits == 9 && !s.bsData && pattern == B_L)
+         frameEnd = true;
+      else if (s.bsBits == 9 && pattern == B_L)
+         streamError = true;
+      else if (s.bsBits == 0 && pattern == B_H && s.bsSkip == 6)
+         streamError = true;
+      else if (s.bsBytes == t.maxFrameSize)
+         truncated = true;
+      else if ((s.bsBits == 0 && pattern == B_H) && ++s.bsSkip)
+         return; /* extra guard time between characters */
+
+      if (frameEnd || streamError || truncated)
+      {
+         if (s.bsBytes > 2)
+         {
+            s.frameEnd = s.symEnd;
+
+            uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
+            const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = c.b[s.lockRate].symbolsPerSecond;
+            const uint32_t lockedRate = s.lockRate;
+
+            nfcb_process(c, s, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
+            nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
+
+            nfc_clear_assembly(s);
+
+            if (s.lockTech == NFC_TECH_B)
+               nfc_poll_end_clear(mem, s.modB[lockedRate], 0, 0);
+
+            return;
+         }
+
+         nfcb_reset(c, s, mem);
+         return;
+      }
+
+      if (s.bsBits < 9)
+      {
+         if (s.bsBits > 0)
+            s.bsData |= (s.symValue << (s.bsBits - 1));
+
+         s.bsBits++;
+      }
+      else
+      {
+         nfc_push_byte(mem, s, s.bsData);
+         s.bsData = 0;
+         s.bsBits = 0;
+         s.bsSkip = 0;
+      }
+
+      return;
+   }
+
+   if (s.frameType != NFC_FRAME_LISTEN)
+      return;
+
+   if (!s.frameStart)
+   {
+      uint32_t pattern = nfcb_listen_start(c, s, mem);
+
+      if (pattern == B_S)
+         s.frameStart = s.symStart;
+      else if (pattern == SYM_TIMEOUT)
+         nfcb_reset(c, s, mem);
+
+      return;
+   }
+
+   uint32_t pattern = nfcb_listen_symbol(c, s, mem);
+
+   if (pattern <= SYM_TIMEOUT)
+      return;
+
+   bool frameEnd = false, truncated = false, streamError = false;
+
+   if (s.bsBits == 9 && !s.bsData && pattern == B_M)
+      frameEnd = true;
+   else if ((s.bsBits == 0 && pattern == B_N) || (s.bsBits == 9 && pattern == B_M))
+      streamError = true;
+   else if (s.bsBytes == t.maxFrameSize)
+      truncated = true;
+
+   if (frameEnd || streamError || truncated)
+   {
+      if (s.bsBytes > 0)
+      {
+         s.frameEnd = s.symEnd + nfc_tu(c, 352); /* EOS is not tracked to its end */
+
+         uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
+         const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = c.b[s.lockRate].symbolsPerSecond;
+
+         nfcb_process(c, s, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
+         nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
+      }
+
+      nfcb_reset(c, s, mem);
+      return;
+   }
+
+   if (s.bsBits < 9)
+   {
+      if (s.bsBits > 0)
+         s.bsData |= (s.symValue << (s.bsBits - 1));
+
+      s.bsBits++;
+   }
+   else
+   {
+      nfc_push_byte(mem, s, s.bsData);
+      s.bsData = 0;
+      s.bsBits = 0;
+   }
+}
+
+#endif

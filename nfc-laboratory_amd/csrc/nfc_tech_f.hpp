@@ -1,0 +1,443 @@
+/*
+ * nfc_tech_f.hpp — JIS X 6319-4 / NFC-F (FeliCa): Manchester ASK at 212/424 kbps, both directions.
+ *
+ * Reference behaviour being matched: src/nfc-lib/lib-lab/lab-radio/src/main/cpp/tech/NfcF.cpp
+ *   detectModulation 206-408 (>= 94 preamble pulses, 48-symbol preamble length, polarity),
+ *   decodePollFrame 428-529, decodeListenFrame 534-636, decodePollFrameSymbolAsk 641-744,
+ *   decodeListenFrameStartAsk 749-936, decodeListenFrameSymbolAsk 941-1042,
+ *   resetModulation 1047-1071, process/processREQC/processOther 1076-1210, checkCrc 1215-1226.
+ * Included by nfc_core.hpp (device code).
+ */
+#ifndef NFC_AMD_TECH_F_HPP
+#define NFC_AMD_TECH_F_HPP
+
+NFC_DEV void nfcf_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+{
+   NfcTiming &t = s.tim[2];
+   t.maxFrameSize = 256;
+   t.protoGuardTime = nfc_tu(c, 1024);            /* NFCF_FGT_DEF */
+   t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16); /* NFCF_FWT_DEF */
+}
+
+NFC_DEV void nfcf_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   for (int r = 1; r < 3; r++)
+   {
+      nfc_mod_clear(s.modF[r]);
+      nfc_zero_ring(mem.corr, c.corrOffset[2 + r], c.f[r].p1);
+   }
+
+   nfc_clear_assembly(s);
+   nfc_clear_symbol(s);
+
+   s.frameType = 0;
+   s.frameStart = 0;
+   s.frameEnd = 0;
+   s.lockTech = 0;
+}
+
+/* CRC-16/XMODEM, big-endian on the wire */
+NFC_DEV bool nfcf_crc_ok(const uint8_t *data, uint32_t len)
+{
+   if (len < 2)
+      return false;
+
+   uint32_t crc = nfc_crc16(data, len - 2, 0x0000u, false);
+   uint32_t res = ((uint32_t)data[len - 2] << 8) | (uint32_t)data[len - 1];
+   return res == crc;
+}
+
+NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, const uint8_t *data, uint32_t len,
+                          uint32_t &flags, uint32_t &phase)
+{
+   NfcTiming &t = s.tim[2];
+   const bool poll = (type == NFC_FRAME_POLL);
+
+   t.guardTime = t.protoGuardTime;
+   if (poll)
+      t.waitingTime = t.protoWaitingTime;
+
+   /* REQC (command code 0x00 in the second byte) and its responses */
+   if (poll && nfc_byte(data, len, 1) == 0x00)
+   {
+      t.lastCommand = 0x00;
+
+      int tsn = (int)nfc_byte(data, len, 5);
+
+      t.maxFrameSize = 256;
+      t.protoGuardTime = nfc_tu(c, 1024);
+      t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
+      t.guardTime = nfc_tu(c, 1024);
+      t.waitingTime = (uint32_t)(c.stu * (double)(512 * 64 + (tsn + 1) * 256 * 64)); /* FDT_ATQC + slots */
+
+      phase = NFC_PHASE_SELECTION;
+      if (!nfcf_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+   }
+   else if (!poll && t.lastCommand == 0x00)
+   {
+      phase = NFC_PHASE_SELECTION;
+      if (!nfcf_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+   }
+   else
+   {
+      phase = NFC_PHASE_APPLICATION;
+      if (!nfcf_crc_ok(data, len))
+         flags |= NFC_FLAG_CRC;
+   }
+
+   const bool locked = (s.lockTech == NFC_TECH_F);
+   const uint32_t delay = locked ? c.f[s.lockRate].delay : 0u;
+
+   if (poll)
+   {
+      if (locked)
+      {
+         t.guardEnd = s.frameEnd + t.guardTime + delay;
+         t.waitingEnd = s.frameEnd + t.waitingTime + delay;
+         s.frameType = NFC_FRAME_LISTEN;
+      }
+   }
+   else
+   {
+      if (locked)
+         t.guardEnd = s.frameEnd + t.guardTime + delay;
+
+      s.frameType = 0;
+      t.lastCommand = 0;
+   }
+
+   s.frameStart = 0;
+   s.frameEnd = 0;
+}
+
+/* the preamble tracker shared by search (NfcF.cpp:267-405) and listen-SOF (NfcF.cpp:815-933);
+ * returns true when a complete, length-checked preamble has just ended */
+NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, NfcMod &m, const NfcRate &rt, float sd, float s0, bool above)
+{
+   if (above)
+   {
+      if (sd > m.peak)
+      {
+         m.peak = sd;
+         m.peakTime = s.clock;
+
+         if (!m.sync)
+         {
+            m.syncValue = sd;
+            m.c0 = s0;
+            m.winEnd = s.clock + rt.p8;
+         }
+      }
+   }
+
+   if (s.clock == m.sync)
+   {
+      m.syncValue = sd;
+      m.lastValue = s0;
+   }
+
+   if (s.clock != m.winEnd)
+      return false;
+
+   if (m.pulses++ < 94)
+   {
+      if (m.peakTime == 0 || m.syncValue < m.thr)
+      {
+         m.symStart = 0; m.symEnd = 0; m.sync = 0; m.syncValue = 0; m.winStart = 0; m.winEnd = 0;
+         m.pulses = 0; m.thr = 0; m.peak = 0; m.peakTime = 0;
+         return false;
+      }
+   }
+
+   if (m.syncValue > m.thr)
+   {
+      if (!m.symStart)
+         m.symStart = m.peakTime - rt.p2;
+
+      m.symEnd = m.peakTime;
+      m.sync = m.symEnd + rt.p2;
+      m.winStart = m.sync - rt.p8;
+      m.winEnd = m.sync + rt.p8;
+      m.thr = m.peak / 2;
+      m.lastPhase = m.lastValue;
+      m.peakTime = 0;
+      m.peak = 0;
+      return false;
+   }
+
+   if ((m.lastPhase < 0 && m.c0 < 0) || (m.lastPhase > 0 && m.c0 > 0))
+      m.symStart -= rt.p2;
+
+   int length = (int)(m.symEnd - m.symStart);
+   int minimum = (int)(rt.preamble - rt.p4);
+   int maximum = (int)(rt.preamble + rt.p4);
+
+   if (length < minimum || length > maximum)
+   {
+      m.symStart = 0; m.symEnd = 0; m.sync = 0; m.syncValue = 0; m.winStart = 0; m.winEnd = 0;
+      m.pulses = 0; m.thr = 0; m.peak = 0; m.peakTime = 0;
+      return false;
+   }
+
+   m.stage = m.lastPhase > 0 ? 0u : 1u; /* observed / reversed polarity */
+   m.sync = m.sync + rt.p2;
+   m.winStart = m.sync - rt.p4;
+   m.winEnd = m.sync + rt.p4;
+   m.peakTime = 0;
+   m.peak = 0;
+
+   return true;
+}
+
+NFC_DEV bool nfcf_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   if (s.clock < 1024u)
+      return false;
+
+   if (s.env < c.powerThreshold)
+      return false;
+
+   const float minimumCorrelation = s.env * c.corrThreshold[2];
+
+   for (int r = 1; r < 3; r++)
+   {
+      const NfcRate &rt = c.f[r];
+      NfcMod &m = s.modF[r];
+
+      float deep = NFC_AT(mem.depth, (s.clock - rt.delay) & NFC_HMASK);
+
+      NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[2 + r], s.posF[r]);
+      float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
+
+      if (deep > c.maxDepth[2] || (m.peakTime && s.clock > m.peakTime + rt.p1))
+      {
+         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+         m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+      }
+
+      if (s.clock < m.winStart)
+         continue;
+
+      if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation))
+         continue;
+
+      s.symStart = m.symStart;
+      s.symEnd = m.symEnd;
+      s.symLength = s.symEnd - s.symStart;
+      s.symPattern = F_S;
+
+      s.frameType = NFC_FRAME_POLL;
+      s.frameRate = rt.symbolsPerSecond;
+      s.frameStart = s.symStart;
+      s.frameEnd = 0;
+
+      s.lockTech = NFC_TECH_F;
+      s.lockRate = (uint32_t)r;
+      return true;
+   }
+
+   return false;
+}
+
+/* Manchester data symbols, identical for both directions (NfcF.cpp:641-744 and 941-1042) */
+NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t r = s.lockRate;
+   const NfcRate &rt = c.f[r];
+   NfcMod &m = s.modF[r];
+
+   NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[2 + r], s.posF[r]);
+   float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (sd > m.thr && sd > m.peak)
+   {
+      m.peak = sd;
+      m.peakTime = s.clock;
+   }
+
+   if (s.clock == m.sync)
+   {
+      m.c0 = k.s0;
+      m.c1 = k.s1;
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   if (!m.peakTime)
+      return F_E;
+
+   m.symStart = m.symEnd;
+   m.symEnd = m.peakTime;
+   m.sync = m.symEnd + rt.p1;
+   m.winStart = m.sync - rt.p4;
+   m.winEnd = m.sync + rt.p4;
+   m.thr = m.peak / 2;
+   m.peakTime = 0;
+   m.peak = 0;
+
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+
+   if ((m.stage == 0 && m.c0 > m.c1) || (m.stage == 1 && m.c0 < m.c1))
+   {
+      s.symValue = 0;
+      s.symPattern = F_L;
+   }
+   else
+   {
+      s.symValue = 1;
+      s.symPattern = F_H;
+   }
+
+   return s.symPattern;
+}
+
+NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t r = s.lockRate;
+   const NfcRate &rt = c.f[r];
+   NfcMod &m = s.modF[r];
+   NfcTiming &t = s.tim[2];
+
+   const uint32_t cur = s.clock - rt.delay;
+
+   /* the box sum runs from the end of the poll frame, the ring only from one symbol before the guard */
+   m.acc += NFC_AT(mem.x, cur & NFC_HMASK);
+   m.acc -= NFC_AT(mem.x, (cur - rt.p2) & NFC_HMASK);
+
+   if (s.clock < (uint32_t)(t.guardEnd - rt.p1))
+      return SYM_NONE;
+
+   const uint32_t base = c.corrOffset[2 + r];
+   const uint32_t pos = s.posF[r];
+   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
+   const uint32_t f3 = nfc_point(s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1);
+
+   NFC_AT(mem.corr, base + pos) = m.acc;
+
+   float a = m.acc;
+   float b = NFC_AT(mem.corr, base + f2);
+   float d = NFC_AT(mem.corr, base + f3);
+   float s0 = a - b;
+   float s1 = b - d;
+   float sd = nfc_abs(s0 - s1) / (float)rt.p2;
+
+   if (s.clock < t.guardEnd)
+      return SYM_NONE;
+
+   if (s.clock == t.guardEnd)
+      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK) * 10.0f;
+
+   if (s.clock > t.waitingEnd)
+      return SYM_TIMEOUT;
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd >= m.thr))
+      return SYM_NONE;
+
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+   s.symPattern = F_S;
+
+   return F_S;
+}
+
+/* bits are MSB first, no parity; frame = 2 sync bytes + payload */
+NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t pattern, uint32_t type)
+{
+   NfcTiming &t = s.tim[2];
+   bool frameEnd = false, truncated = false;
+
+   if (pattern == F_E)
+      frameEnd = true;
+   else if (s.bsBytes == t.maxFrameSize)
+      truncated = true;
+
+   if (frameEnd || truncated)
+   {
+      if (s.bsBytes > 2)
+      {
+         s.frameEnd = s.symEnd;
+
+         uint32_t flags = truncated ? NFC_FLAG_TRUNCATED : 0, phase = 0;
+
+         if (mem.bytes[0] != 0xB2 || mem.bytes[1] != 0x4D)
+            flags |= NFC_FLAG_SYNC;
+
+         uint32_t total = s.bsBytes > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : s.bsBytes;
+         const uint32_t start = s.frameStart, end = s.frameEnd, len = total - 2;
+         const uint32_t rate = c.f[s.lockRate].symbolsPerSecond;
+         const uint32_t lockedRate = s.lockRate;
+
+         nfcf_process(c, s, type, mem.bytes + 2, len, flags, phase);
+         nfc_emit(mem, s, NFC_TECH_F, type, flags, phase, rate, start, end, mem.bytes + 2, len);
+
+         if (type == NFC_FRAME_POLL)
+         {
+            nfc_clear_assembly(s);
+
+            if (s.lockTech == NFC_TECH_F)
+               nfc_poll_end_clear(mem, s.modF[lockedRate], c.corrOffset[2 + lockedRate], c.f[lockedRate].p1);
+
+            return;
+         }
+      }
+
+      nfcf_reset(c, s, mem);
+      return;
+   }
+
+   s.bsData = (s.bsData << 1) | s.symValue;
+
+   if (++s.bsBits == 8)
+   {
+      nfc_push_byte(mem, s, s.bsData);
+      s.bsData = 0;
+      s.bsBits = 0;
+   }
+}
+
+NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   if (s.frameType == NFC_FRAME_POLL)
+   {
+      uint32_t pattern = nfcf_data_symbol(c, s, mem);
+
+      if (pattern > SYM_TIMEOUT)
+         nfcf_frame(c, s, mem, pattern, NFC_FRAME_POLL);
+
+      return;
+   }
+
+   if (s.frameType != NFC_FRAME_LISTEN)
+      return;
+
+   if (!s.frameStart)
+   {
+      uint32_t pattern = nfcf_listen_start(c, s, mem);
+
+      if (pattern == F_S)
+         s.frameStart = s.symStart;
+      else if (pattern == SYM_TIMEOUT)
+         nfcf_reset(c, s, mem);
+
+      return;
+   }
+
+   uint32_t pattern = nfcf_data_symbol(c, s, mem);
+
+   if (pattern > SYM_TIMEOUT)
+      nfcf_frame(c, s, mem, pattern, NFC_FRAME_LISTEN);
+}
+
+#endif

@@ -1,0 +1,565 @@
+/*
+ * nfc_tech_v.hpp — ISO15693 / NFC-V: pulse-position (1 of 4 / 1 of 256) poll frames,
+ * single-subcarrier Manchester listen frames.
+ *
+ * Reference behaviour being matched: src/nfc-lib/lib-lab/lab-radio/src/main/cpp/tech/NfcV.cpp
+ *   configurePulse 220-234, detectModulation 236-435, decodePollFrame 450-556,
+ *   decodeListenFrame 561-667, decodePollFrameSymbolPpm 672-795, decodeListenFrameStartAsk 800-980,
+ *   decodeListenFrameSymbolAsk 985-1074, resetModulation 1079-1103, process 1108-1183, checkCrc 1193-1205.
+ * Included by nfc_core.hpp (device code).
+ */
+#ifndef NFC_AMD_TECH_V_HPP
+#define NFC_AMD_TECH_V_HPP
+
+NFC_DEV void nfcv_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+{
+   NfcTiming &t = s.tim[3];
+   t.maxFrameSize = 256;
+   t.protoGuardTime = nfc_tu(c, 1024);            /* NFCV_FGT_DEF */
+   t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16); /* NFCV_FWT_DEF */
+}
+
+NFC_DEV void nfcv_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   nfc_clear_assembly(s);
+   nfc_clear_symbol(s);
+   nfc_mod_clear(s.modV);
+   nfc_zero_ring(mem.corr, c.corrOffset[5], c.v.p0);
+
+   s.frameType = 0;
+   s.frameStart = 0;
+   s.frameEnd = 0;
+   s.pulseCode = 0;
+   s.lockTech = 0;
+}
+
+NFC_DEV bool nfcv_crc_ok(const uint8_t *data, uint32_t len)
+{
+   if (len < 3)
+      return false;
+
+   uint32_t crc = (~nfc_crc16(data, len - 2, 0xFFFFu, true)) & 0xFFFFu;
+   uint32_t res = (uint32_t)data[len - 2] | ((uint32_t)data[len - 1] << 8);
+   return res == crc;
+}
+
+NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, const uint8_t *data, uint32_t len,
+                          uint32_t &flags, uint32_t &phase)
+{
+   NfcTiming &t = s.tim[3];
+   const bool poll = (type == NFC_FRAME_POLL);
+
+   t.guardTime = t.protoGuardTime;
+   if (poll)
+      t.waitingTime = t.protoWaitingTime;
+
+   phase = NFC_PHASE_APPLICATION;
+   if (!nfcv_crc_ok(data, len))
+      flags |= NFC_FLAG_CRC;
+
+   const bool locked = (s.lockTech == NFC_TECH_V);
+
+   if (poll)
+   {
+      if (locked)
+      {
+         /* note the sign: the poll side runs on the delayed signal (NfcV.cpp:1145-1148) */
+         t.guardEnd = s.frameEnd + t.guardTime - c.v.delay;
+         t.waitingEnd = s.frameEnd + t.waitingTime - c.v.delay;
+         s.frameType = NFC_FRAME_LISTEN;
+      }
+   }
+   else
+   {
+      if (locked)
+         t.guardEnd = s.frameEnd + t.guardTime + c.v.delay;
+
+      s.frameType = 0;
+      t.lastCommand = 0;
+   }
+
+   s.frameStart = 0;
+   s.frameEnd = 0;
+}
+
+/* box sum over p2 of the raw signal delayed by two symbols; S0 compares it with half a symbol before */
+NFC_DEV float nfcv_pulse_correlation(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m)
+{
+   const NfcRate &rt = c.v;
+   const uint32_t cur = s.clock - rt.delay;
+
+   m.acc += NFC_AT(mem.x, cur & NFC_HMASK);
+   m.acc -= NFC_AT(mem.x, (cur - rt.p2) & NFC_HMASK);
+
+   const uint32_t base = c.corrOffset[5];
+   const uint32_t pos = s.posV1;
+   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
+
+   NFC_AT(mem.corr, base + pos) = m.acc;
+
+   return (NFC_AT(mem.corr, base + f2) - m.acc) / (float)rt.p2;
+}
+
+NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   if (s.clock < 1024u)
+      return false;
+
+   if (s.env < c.powerThreshold)
+      return false;
+
+   const NfcRate &rt = c.v;
+   NfcMod &m = s.modV;
+
+   const float minimumCorrelation = s.env * c.corrThreshold[3];
+   const float raw = NFC_AT(mem.x, (s.clock - rt.delay) & NFC_HMASK);
+
+   float s0 = nfcv_pulse_correlation(c, s, mem, m);
+
+   if (m.peakTime && s.clock > m.peakTime + rt.p0)
+   {
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+      m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+   }
+
+   if (s.clock < m.winStart)
+      return false;
+
+   if (s0 > minimumCorrelation)
+   {
+      if (s0 > m.peak)
+      {
+         m.peak = s0;
+         m.peakTime = s.clock;
+         m.winEnd = s.clock + rt.p4;
+      }
+
+      float deep = NFC_AT(mem.depth, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+
+      if (deep > m.aux)
+      {
+         m.aux = deep;
+         m.auxTime = s.clock;
+      }
+   }
+
+   if (s.clock != m.winEnd)
+      return false;
+
+   if (raw < minimumCorrelation || m.peakTime == 0 || m.aux < c.minDepth[3])
+   {
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      return false;
+   }
+
+   if (!m.symStart)
+   {
+      m.symStart = m.peakTime - rt.p2;
+      m.winStart = m.symStart + (2 * rt.p1);
+      m.winEnd = m.symStart + (4 * rt.p1);
+      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      return false;
+   }
+
+   if (m.peakTime > (m.symStart + 3 * rt.p1 - rt.p8) && m.peakTime < (m.symStart + 3 * rt.p1 + rt.p8))
+   {
+      m.symEnd = m.peakTime + rt.p1;
+      m.sync = m.symEnd;
+      m.winStart = m.sync;
+      m.winEnd = m.sync + (uint32_t)c.vLen2;
+      s.frameRate = rt.symbolsPerSecond / 2;
+      s.pulseCode = 0;
+   }
+   else if (m.peakTime > (m.symStart + 4 * rt.p1 - rt.p8) && m.peakTime < (m.symStart + 4 * rt.p1 + rt.p8))
+   {
+      m.symEnd = m.peakTime;
+      m.sync = m.symEnd;
+      m.winStart = m.sync;
+      m.winEnd = m.sync + (uint32_t)c.vLen8;
+      s.frameRate = rt.symbolsPerSecond / 32;
+      s.pulseCode = 1;
+   }
+   else
+   {
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      return false;
+   }
+
+   s.frameType = NFC_FRAME_POLL;
+   s.frameStart = m.symStart - rt.delay;
+   s.frameEnd = 0;
+
+   m.peakTime = 0;
+   m.peak = 0;
+   m.thr = minimumCorrelation;
+
+   s.lockTech = NFC_TECH_V;
+   s.lockRate = 0;
+   return true;
+}
+
+/* one pulse-position symbol (2 or 8 bits), NfcV.cpp:672-795 */
+NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const NfcRate &rt = c.v;
+   NfcMod &m = s.modV;
+
+   float s0 = nfcv_pulse_correlation(c, s, mem, m);
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (s0 > m.thr)
+   {
+      if (s0 > m.peak)
+      {
+         m.peak = s0;
+         m.peakTime = s.clock;
+         m.winEnd = s.clock + rt.p4;
+      }
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   /* a pulse in the first half of the second slot is the EOF marker */
+   if (m.peakTime > (m.winStart + 1 * rt.p1 + rt.p4) && m.peakTime < (m.winStart + 2 * rt.p1 - rt.p4))
+   {
+      m.symEnd = m.peakTime + rt.p2;
+
+      s.symValue = 0;
+      s.symStart = m.symStart - rt.delay;
+      s.symEnd = m.symEnd - rt.delay;
+      s.symLength = s.symEnd - s.symStart;
+      s.symPattern = V_S;
+      return V_S;
+   }
+
+   s.symValue = 0;
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+   s.symPattern = V_E;
+
+   const int periods = s.pulseCode ? 256 : 4;
+   const int length = s.pulseCode ? c.vLen8 : c.vLen2;
+   const int32_t *ends = s.pulseCode ? c.vSlotEnd8 : c.vSlotEnd2;
+
+   for (int i = 0; i < periods; i++)
+   {
+      const uint32_t slotEnd = (uint32_t)ends[i];
+
+      if (m.peakTime > (m.winStart + slotEnd - rt.p4) && m.peakTime < (m.winStart + slotEnd + rt.p4))
+      {
+         m.symStart = m.peakTime - slotEnd;
+         m.symEnd = m.symStart + (uint32_t)length;
+         m.sync = m.symEnd;
+         m.winStart = m.sync;
+         m.winEnd = m.sync + (uint32_t)length;
+         m.peakTime = 0;
+         m.peak = 0;
+
+         s.symValue = (uint32_t)i;
+         s.symStart = m.symStart - rt.delay;
+         s.symEnd = m.symEnd - rt.delay;
+         s.symLength = s.symEnd - s.symStart;
+         s.symPattern = s.pulseCode ? V_8 : V_2;
+         return s.symPattern;
+      }
+   }
+
+   return V_E;
+}
+
+/* subcarrier power integrated over one symbol half (p1), ring of two symbols (p0) */
+NFC_DEV float nfcv_burst_correlation(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m)
+{
+   const NfcRate &rt = c.v;
+   const uint32_t cur = s.clock - rt.delay;
+
+   float v = NFC_AT(mem.filt, cur & NFC_HMASK);
+   float sq = v * v * 10.0f;
+
+   NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
+
+   m.acc += sq;
+   m.acc -= NFC_AT(mem.prod, (cur - rt.p1) & NFC_PMASK);
+
+   const uint32_t base = c.corrOffset[5];
+   const uint32_t pos = s.posV0;
+   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p1, rt.p0);
+
+   NFC_AT(mem.corr, base + pos) = m.acc;
+
+   return NFC_AT(mem.corr, base + f2) - m.acc;
+}
+
+NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const NfcRate &rt = c.v;
+   NfcMod &m = s.modV;
+   NfcTiming &t = s.tim[3];
+
+   const uint32_t cur = s.clock - rt.delay;
+   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
+   float s0 = nfcv_burst_correlation(c, s, mem, m);
+
+   if (s.clock < t.guardEnd)
+      return SYM_NONE;
+
+   if (s.clock == t.guardEnd)
+      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK);
+
+   if (s.clock > t.waitingEnd)
+      return SYM_TIMEOUT;
+
+   if (deep > c.maxDepth[3])
+      return SYM_TIMEOUT;
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (s0 < -m.thr && s0 < m.peak)
+   {
+      m.peak = s0;
+      m.peakTime = s.clock;
+      m.winEnd = s.clock + rt.p8;
+   }
+
+   if (s0 > m.thr && s0 > m.peak)
+   {
+      m.peak = s0;
+      m.peakTime = s.clock;
+      m.winEnd = s.clock + rt.p8;
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   /* durations compare unsigned against the limits (int vs unsigned int in the reference) */
+   if (m.stage == 0)
+   {
+      if (!m.symStart)
+      {
+         m.symStart = m.peakTime - rt.p1;
+         m.winStart = m.peakTime + rt.p0;
+         m.winEnd = m.winStart + rt.p1;
+         m.peak = 0;
+         m.peakTime = 0;
+         return SYM_NONE;
+      }
+
+      m.symEnd = m.peakTime;
+
+      uint32_t length = m.symEnd - m.symStart - rt.p1;
+
+      if (m.peakTime == 0 || length < nfc_tu(c, 768 - 32) || length > nfc_tu(c, 768 + 32))
+      {
+         m.stage = 0; m.winStart = 0; m.winEnd = 0; m.symStart = 0; m.symEnd = 0;
+         return SYM_NONE;
+      }
+
+      m.stage = 1;
+      m.winStart = m.peakTime + rt.p1 - rt.p2;
+      m.winEnd = m.winStart + rt.p1;
+      m.peak = 0;
+      m.peakTime = 0;
+      return SYM_NONE;
+   }
+
+   if (m.stage == 1)
+   {
+      uint32_t length = m.peakTime - m.symEnd;
+
+      if (m.peakTime == 0 || length < nfc_tu(c, 256 - 32) || length > nfc_tu(c, 256 + 32))
+      {
+         m.stage = 0; m.winStart = 0; m.winEnd = 0; m.symStart = 0; m.symEnd = 0;
+         return SYM_NONE;
+      }
+
+      m.symEnd = m.peakTime;
+      m.sync = m.symEnd + rt.p0;
+      m.winStart = m.sync - rt.p4;
+      m.winEnd = m.sync + rt.p4;
+      m.thr = m.peak * 0.25f;
+      m.c0 = 0;
+      m.c1 = 0;
+      m.peakTime = 0;
+      m.peak = 0;
+
+      s.symValue = 0;
+      s.symStart = m.symStart - rt.delay;
+      s.symEnd = m.symEnd - rt.delay;
+      s.symLength = s.symEnd - s.symStart;
+      s.symPattern = V_S;
+      return V_S;
+   }
+
+   return SYM_NONE;
+}
+
+NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const NfcRate &rt = c.v;
+   NfcMod &m = s.modV;
+
+   float s0 = nfcv_burst_correlation(c, s, mem, m);
+   float sd = nfc_abs(s0);
+
+   if (s.clock < m.winStart)
+      return SYM_NONE;
+
+   if (sd > m.thr && sd > m.peak)
+   {
+      m.c0 = s0;
+      m.c1 = -s0;
+      m.peak = sd;
+      m.symEnd = s.clock;
+   }
+
+   if (s.clock != m.winEnd)
+      return SYM_NONE;
+
+   if (m.peak < m.thr)
+      return V_S;
+
+   m.symStart = m.symEnd;
+   m.symEnd = m.symStart + rt.p0;
+   m.sync = m.symEnd;
+   m.winStart = m.sync - rt.p4;
+   m.winEnd = m.sync + rt.p4;
+   m.thr = m.peak * 0.25f;
+   m.peakTime = 0;
+   m.peak = 0;
+
+   s.symValue = m.c0 > m.c1 ? 0u : 1u;
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+   s.symPattern = s.symValue ? V_1 : V_0;
+
+   return s.symPattern;
+}
+
+NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   NfcTiming &t = s.tim[3];
+
+   if (s.frameType == NFC_FRAME_POLL)
+   {
+      uint32_t pattern = nfcv_poll_symbol(c, s, mem);
+
+      if (pattern <= SYM_TIMEOUT)
+         return;
+
+      bool frameEnd = false, truncated = false, streamError = false;
+
+      if (pattern == V_S)
+         frameEnd = true;
+      else if (pattern == V_E)
+         streamError = true;
+      else if (s.bsBytes == t.maxFrameSize)
+         truncated = true;
+
+      if (frameEnd || streamError || truncated)
+      {
+         if (s.bsBytes > 0)
+         {
+            if (s.bsBits == 8)
+               nfc_push_byte(mem, s, s.bsData);
+
+            s.frameEnd = s.symEnd;
+
+            uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
+            const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.frameRate;
+
+            nfcv_process(c, s, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
+            nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
+
+            nfc_clear_assembly(s);
+
+            if (s.lockTech == NFC_TECH_V)
+               nfc_poll_end_clear(mem, s.modV, c.corrOffset[5], c.v.p0);
+
+            return;
+         }
+
+         nfcv_reset(c, s, mem);
+         return;
+      }
+
+      if (s.bsBits == 8)
+      {
+         nfc_push_byte(mem, s, s.bsData);
+         s.bsData = 0;
+         s.bsBits = 0;
+      }
+
+      s.bsData |= (s.symValue << s.bsBits);
+      s.bsBits += s.pulseCode ? 8u : 2u;
+      return;
+   }
+
+   if (s.frameType != NFC_FRAME_LISTEN)
+      return;
+
+   if (!s.frameStart)
+   {
+      uint32_t pattern = nfcv_listen_start(c, s, mem);
+
+      if (pattern == V_S)
+         s.frameStart = s.symStart;
+      else if (pattern == SYM_TIMEOUT)
+         nfcv_reset(c, s, mem);
+
+      return;
+   }
+
+   uint32_t pattern = nfcv_listen_symbol(c, s, mem);
+
+   if (pattern <= SYM_TIMEOUT)
+      return;
+
+   bool frameEnd = false, truncated = false, streamError = false;
+
+   if (pattern == V_S)
+      frameEnd = true;
+   else if (pattern == V_E)
+      streamError = true;
+   else if (s.bsBytes == t.maxFrameSize)
+      truncated = true;
+
+   if (frameEnd || streamError || truncated)
+   {
+      if (s.bsBytes > 0)
+      {
+         if (s.bsBits == 8)
+            nfc_push_byte(mem, s, s.bsData);
+
+         s.frameEnd = s.symEnd;
+
+         uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
+         const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.frameRate;
+
+         nfcv_process(c, s, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
+         nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
+      }
+
+      nfcv_reset(c, s, mem);
+      return;
+   }
+
+   if (s.bsBits == 8)
+   {
+      nfc_push_byte(mem, s, s.bsData);
+      s.bsData = 0;
+      s.bsBits = 0;
+   }
+
+   s.bsData |= (s.symValue << s.bsBits);
+   s.bsBits++;
+}
+
+#endif

@@ -1,0 +1,203 @@
+/*
+ * nfc_types.h — plain-old-data layouts shared by the host runtime (C-ABI side) and the HIP kernels.
+ *
+ * Layout philosophy (MI355X): one wavefront = 64 independent capture streams, one lane per stream.
+ *   - scalar decoder state: one StreamState record per stream (AoS, touched once per launch),
+ *   - history rings: "stream block" storage, [slot][64 lanes] floats, so that a wave whose 64 streams
+ *     share the same sample clock touches one contiguous 256-byte row per ring access,
+ *   - frames: per-stream append-only arena of 32-bit words (FrameRecord header + payload).
+ *
+ * What the state represents follows the reference decoder's data model
+ * (src/nfc-lib/lib-lab/lab-radio/src/main/cpp/NfcTech.h:151-393) but only keeps what is ever read:
+ * 512-deep sample history instead of 1024 (deepest look-back is NFC-V: 378+94 samples), one shared
+ * 256-deep product ring (the reference zeroes integrationData before every listen window), and
+ * period-sized correlation rings.
+ */
+#ifndef NFC_AMD_TYPES_H
+#define NFC_AMD_TYPES_H
+
+#include <stdint.h>
+
+#define NFC_LANES 64u          /* streams per stream-block == wavefront width            */
+#define NFC_HIST 512u          /* sample history depth (power of two, > 472)             */
+#define NFC_PROD 256u          /* product ring depth for listen-mode integrators (> 189) */
+#define NFC_STREAM_BYTES 512u  /* frame assembly buffer, NfcTech.h:288                   */
+
+/* tech / frame enums: values are the reference's wire values (lab-data RawFrame.h:29-84) */
+enum
+{
+   NFC_TECH_NONE = 0,
+   NFC_TECH_ANY = 0x0100,
+   NFC_TECH_A = 0x0101,
+   NFC_TECH_B = 0x0102,
+   NFC_TECH_F = 0x0103,
+   NFC_TECH_V = 0x0104
+};
+
+enum
+{
+   NFC_FRAME_CARRIER_OFF = 0x0100,
+   NFC_FRAME_CARRIER_ON = 0x0101,
+   NFC_FRAME_POLL = 0x0102,
+   NFC_FRAME_LISTEN = 0x0103
+};
+
+enum
+{
+   NFC_PHASE_CARRIER = 0x0101,
+   NFC_PHASE_SELECTION = 0x0102,
+   NFC_PHASE_APPLICATION = 0x0103
+};
+
+enum
+{
+   NFC_FLAG_SHORT = 0x01,
+   NFC_FLAG_ENCRYPTED = 0x02,
+   NFC_FLAG_TRUNCATED = 0x08,
+   NFC_FLAG_PARITY = 0x10,
+   NFC_FLAG_CRC = 0x20,
+   NFC_FLAG_SYNC = 0x40
+};
+
+/* symbol timing of one bitrate, in samples (NfcTech.h:168-194) */
+struct NfcRate
+{
+   uint32_t symbolsPerSecond;
+   uint32_t p0; /* two symbols  */
+   uint32_t p1; /* one symbol   */
+   uint32_t p2; /* 1/2 symbol   */
+   uint32_t p4; /* 1/4 symbol   */
+   uint32_t p8; /* 1/8 symbol   */
+   uint32_t delay;    /* symbolDelayDetect */
+   uint32_t preamble; /* NFC-F preamble length */
+};
+
+/* per-configuration constants, derived on the host exactly like the reference's initialize() chain
+ * (NfcDecoder.cpp:295-360, NfcA.cpp:115-212, NfcB.cpp:124-233, NfcF.cpp:108-204, NfcV.cpp:126-234) */
+struct NfcConfig
+{
+   uint32_t sampleRate;
+   uint32_t enabled; /* bit0 A, bit1 B, bit2 F, bit3 V */
+   double stu;       /* sampleTimeUnit = fs / fc */
+   int32_t etu;      /* elementaryTimeUnit */
+   float iirA;
+   float envW0, envW1;
+   float mdevW0, mdevW1;
+   float meanW0, meanW1;
+   float powerThreshold;
+   float lowThreshold, highThreshold;
+   float corrThreshold[4]; /* A B F V */
+   float minDepth[4];
+   float maxDepth[4];
+   NfcRate a[3];
+   NfcRate b[3];
+   NfcRate f[3]; /* index by rate type, [0] unused */
+   NfcRate v;
+   int32_t vLen2;
+   int32_t vLen8;
+   int32_t vSlotEnd2[4];
+   int32_t vSlotEnd8[256];
+   uint32_t corrOffset[6]; /* word offsets of the six correlation rings inside the block ring */
+   uint32_t corrTotal;     /* total correlation ring slots */
+   uint32_t reserved;
+};
+
+/* demodulator state of one (tech, bitrate): the reference's NfcModulationStatus minus its buffers */
+struct NfcMod
+{
+   uint32_t stage;     /* searchModeState    */
+   uint32_t winStart;  /* searchStartTime    */
+   uint32_t winEnd;    /* searchEndTime      */
+   uint32_t sync;      /* searchSyncTime     */
+   uint32_t pulses;    /* searchPulseWidth   */
+   float thr;          /* searchValueThreshold */
+   float phaseThr;     /* searchPhaseThreshold */
+   float lastPhase;    /* searchLastPhase    */
+   float lastValue;    /* searchLastValue    */
+   float syncValue;    /* searchSyncValue    */
+   float cD, c0, c1;   /* searchCorrD/0/1Value */
+   uint32_t symStart;  /* symbolStartTime    */
+   uint32_t symEnd;    /* symbolEndTime      */
+   uint32_t symRise;   /* symbolRiseTime     */
+   float acc;          /* filterIntegrate    */
+   float phaseAcc;     /* phaseIntegrate     */
+   float peak;         /* correlatedPeakValue */
+   float aux;          /* detectorPeakValue  */
+   uint32_t peakTime;  /* correlatedPeakTime */
+   uint32_t auxTime;   /* detectorPeakTime   */
+};
+
+struct NfcTiming
+{
+   uint32_t lastCommand;
+   uint32_t guardTime;   /* frameStatus.frameGuardTime   */
+   uint32_t waitingTime; /* frameStatus.frameWaitingTime */
+   uint32_t guardEnd;
+   uint32_t waitingEnd;
+   /* protocolStatus */
+   uint32_t maxFrameSize;
+   uint32_t protoGuardTime;
+   uint32_t protoWaitingTime;
+};
+
+struct NfcStreamState
+{
+   /* ---- front end (NfcTech.h:317-393) ---- */
+   uint32_t clock;       /* signalClock, starts at 0xFFFFFFFF */
+   uint32_t pulseFilter;
+   float env;            /* signalEnvelope */
+   float n1;             /* signalFilterN1 */
+   float mdev;           /* signalDeviation */
+   float avg;            /* signalAverage */
+   float edgePeak;
+   uint32_t edgeTime;
+   uint32_t carrierOff;
+   uint32_t carrierOn;
+
+   /* ---- lock ---- */
+   uint32_t lockTech;  /* NFC_TECH_* or 0 */
+   uint32_t lockRate;  /* rate type 0..2 */
+   uint32_t pulseCode; /* NFC-V: 0 -> 1 of 4, 1 -> 1 of 256 */
+
+   /* ---- shared symbol / bit stream / frame assembly ---- */
+   uint32_t symPattern, symValue, symStart, symEnd, symEdge, symLength;
+   uint32_t bsPrevious, bsPattern, bsBits, bsSkip, bsData, bsFlags, bsParity, bsBytes;
+   uint32_t frameType, frameRate, frameStart, frameEnd;
+   uint32_t chainedA;
+
+   /* ---- ring positions (idx % period), kept for every correlator ---- */
+   uint32_t posA[3];
+   uint32_t posF[3];
+   uint32_t posV1; /* mod p1 */
+   uint32_t posV0; /* mod p0 */
+
+   NfcTiming tim[4]; /* A B F V */
+
+   NfcMod modA[3];
+   NfcMod modB[3];
+   NfcMod modF[3]; /* [0] unused */
+   NfcMod modV;
+
+   /* ---- output arena bookkeeping ---- */
+   uint32_t arenaUsed; /* words */
+   uint32_t arenaOverflow;
+   uint32_t framesOut;
+   uint32_t reserved;
+};
+
+/* header of one frame in the per-stream arena, followed by (length+3)/4 payload words */
+struct NfcFrameRecord
+{
+   uint32_t tech;
+   uint32_t type;
+   uint32_t flags;
+   uint32_t phase;
+   uint32_t rate;
+   uint32_t start;
+   uint32_t end;
+   uint32_t length;
+};
+
+#define NFC_FRAME_HEADER_WORDS 8u
+
+#endif

@@ -1,0 +1,152 @@
+"""Shared helpers for the parity tests (fixtures, oracle binding, frame comparison)."""
+import ctypes
+import json
+import lzma
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+class Frame(ctypes.Structure):
+    """Same layout as include/nfcgpu.h nfcgpu_frame, oracle/ref_capi.cpp nfcref_frame."""
+    _fields_ = [
+        ("stream_id", ctypes.c_uint32),
+        ("tech_type", ctypes.c_uint32),
+        ("frame_type", ctypes.c_uint32),
+        ("frame_flags", ctypes.c_uint32),
+        ("frame_phase", ctypes.c_uint32),
+        ("frame_rate", ctypes.c_uint32),
+        ("length", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+        ("sample_start", ctypes.c_uint64),
+        ("sample_end", ctypes.c_uint64),
+        ("sample_rate", ctypes.c_uint64),
+        ("data", ctypes.c_uint8 * 512),
+    ]
+
+
+def frame_tuple(f):
+    """The eight fields RawFrame::operator== compares (lab-data RawFrame.cpp:82-98) + payload."""
+    return (f.tech_type, f.frame_type, f.frame_flags, f.frame_phase, f.frame_rate,
+            f.sample_start, f.sample_end, f.sample_rate, bytes(f.data[:f.length]))
+
+
+def frames_to_tuples(arr, n, keep_carrier=False):
+    out = []
+    for i in range(n):
+        t = frame_tuple(arr[i])
+        if keep_carrier or t[1] in (0x0102, 0x0103):
+            out.append(t)
+    return out
+
+
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def fixture_names():
+    return sorted(manifest().keys())
+
+
+def load_fixture_i16(name):
+    with open(os.path.join(GOLDEN, "wav", name + ".i16.xz"), "rb") as f:
+        raw = lzma.decompress(f.read())
+    return np.frombuffer(raw, dtype="<i2")
+
+
+def load_fixture(name):
+    """float32 magnitude exactly as hw::RecordDevice reads it: int16 / 32768.0f."""
+    return (load_fixture_i16(name).astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+def load_golden(name):
+    """Golden frames as tuples in frame_tuple() order (test-sdr main.cpp:47-93)."""
+    with open(os.path.join(GOLDEN, "wav", name + ".json")) as f:
+        data = json.load(f)
+    out = []
+    for e in data["frames"]:
+        payload = bytes(int(x, 16) for x in e["frameData"].split(":")) if e["frameData"] else b""
+        out.append((e["techType"], e["frameType"], e["frameFlags"], e["framePhase"], e["frameRate"],
+                    e["sampleStart"], e["sampleEnd"], e["sampleRate"], payload))
+    return out
+
+
+class RefParams(ctypes.Structure):
+    _fields_ = [
+        ("tech_mask", ctypes.c_uint32),
+        ("power_level_threshold", ctypes.c_float),
+        ("corr_threshold", ctypes.c_float * 4),
+        ("min_depth", ctypes.c_float * 4),
+        ("max_depth", ctypes.c_float * 4),
+    ]
+
+
+_ref = None
+
+
+def reference_lib():
+    """oracle/_ref/libnfcref.so: the real reference decoder (test infrastructure)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libnfcref.so")
+        if not os.path.exists(path):
+            return None
+        lib = ctypes.CDLL(path)
+        lib.nfcref_decode.restype = ctypes.c_long
+        lib.nfcref_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
+        lib.nfcref_magnitude.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        _ref = lib
+    return _ref
+
+
+def reference_decode(samples, sample_rate=10000000, chunk=65536, tech_mask=0xF, keep_carrier=False, send_eof=False,
+                     cap=4096, params=None):
+    lib = reference_lib()
+    samples = np.ascontiguousarray(samples, dtype=np.float32)
+    out = (Frame * cap)()
+    secs = ctypes.c_double(0)
+    nan = float("nan")
+    p = params or RefParams(tech_mask, nan, (ctypes.c_float * 4)(nan, nan, nan, nan),
+                            (ctypes.c_float * 4)(nan, nan, nan, nan), (ctypes.c_float * 4)(nan, nan, nan, nan))
+    n = lib.nfcref_decode(samples.ctypes.data, len(samples), sample_rate, chunk, ctypes.byref(p),
+                          int(keep_carrier), int(send_eof), ctypes.byref(out), cap, ctypes.byref(secs))
+    assert 0 <= n <= cap, n
+    return frames_to_tuples(out, n, keep_carrier=True), secs.value
+
+
+_sim = None
+
+
+def hostsim_lib():
+    global _sim
+    if _sim is None:
+        path = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
+        lib = ctypes.CDLL(path)
+        lib.hostsim_decode.restype = ctypes.c_long
+        lib.hostsim_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_uint32]
+        _sim = lib
+    return _sim
+
+
+def hostsim_decode(samples, sample_rate=10000000, lane=0, tech_mask=0xF, stride=1, cap=4096, keep_carrier=False):
+    lib = hostsim_lib()
+    samples = np.ascontiguousarray(samples, dtype=np.float32)
+    out = (Frame * cap)()
+    count = len(samples) // stride
+    n = lib.hostsim_decode(samples.ctypes.data, count, stride, sample_rate, lane, tech_mask, float("nan"),
+                           None, None, None, ctypes.byref(out), cap)
+    assert 0 <= n <= cap, n
+    return frames_to_tuples(out, n, keep_carrier=keep_carrier)
+
+
+def describe(t):
+    return "tech=%x type=%x flags=%x phase=%x rate=%d start=%d end=%d data=%s" % (
+        t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[8].hex(":"))
