@@ -1,0 +1,162 @@
+/*
+ * nfcgpu.h — C ABI of libnfcgpu.so, the MI355X (gfx950) implementation of nfc-laboratory's radio
+ * demodulation hot path. This is the drop-in boundary: everything above it (lab::NfcDecoder shim,
+ * RadioDecoderTask, the Qt app, nfc-rx, test-sdr) is host C++ from the reference, unchanged.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference/src/nfc-lib):
+ *
+ *   nfcgpu_init / nfcgpu_shutdown      process-wide decoder resources; the reference has none
+ *                                      (lab::NfcDecoder::NfcDecoder(), lib-lab/lab-radio/src/main/cpp/NfcDecoder.cpp:75-77,288-290)
+ *   nfcgpu_stream_open                 one `lab::NfcDecoder` instance == one stream
+ *                                      (lib-lab/lab-radio/src/main/include/lab/nfc/NfcDecoder.h:33-122)
+ *   nfcgpu_stream_configure            NfcDecoder::setEnableNfcA/B/F/V, setPowerLevelThreshold,
+ *                                      setModulationThresholdNfcX, setCorrelationThresholdNfcX, setSampleRate,
+ *                                      setStreamTime (NfcDecoder.cpp:96-286), as driven by
+ *                                      RadioDecoderTask::configDecoder (lib-lab/lab-tasks/src/main/cpp/tasks/RadioDecoderTask.cpp:207-366)
+ *   nfcgpu_stream_reset                NfcDecoder::initialize() (NfcDecoder.cpp:295-360)
+ *   nfcgpu_submit                      NfcDecoder::nextFrames(hw::SignalBuffer) for a valid buffer
+ *                                      (NfcDecoder.cpp:374-447); stride 1 = SIGNAL_TYPE_RADIO_SAMPLES magnitude,
+ *                                      stride 2 = SIGNAL_TYPE_RADIO_IQ with the IQ->magnitude step of
+ *                                      RadioDeviceTask::processQueue (lab-tasks/.../RadioDeviceTask.cpp:547-656) fused in
+ *   nfcgpu_submit_batch / _uniform     the same call for many independent streams at once (the reference would run one
+ *                                      NfcDecoder per stream on one thread each); inputs may already be resident in HBM
+ *   nfcgpu_flush                       NfcDecoder::nextFrames(invalid buffer) -> one carrier-state frame (NfcDecoder.cpp:449-463)
+ *   nfcgpu_poll                        the returned std::list<lab::RawFrame> (lab-data/src/main/cpp/RawFrame.cpp:26-98)
+ *   nfcgpu_stream_close                ~NfcDecoder
+ *
+ * Conventions: every function returns 0 on success or a negative NFCGPU_E* code; no exceptions cross the ABI;
+ * outputs are caller-allocated; input buffers are never retained past the call that received them unless they are
+ * device-resident (then they must stay valid until nfcgpu_sync / nfcgpu_poll returns). One thread per context.
+ * There is no CPU fallback: without a usable gfx950 device nfcgpu_init fails with NFCGPU_ENODEV.
+ */
+#ifndef NFCGPU_H
+#define NFCGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFCGPU_OK 0
+#define NFCGPU_EINVAL (-1)    /* bad argument */
+#define NFCGPU_ENODEV (-2)    /* no usable HIP device / kernel image */
+#define NFCGPU_ENOMEM (-3)    /* device or host allocation failed */
+#define NFCGPU_ESTREAM (-4)   /* unknown or closed stream id */
+#define NFCGPU_ERATE (-5)     /* sample rate not decodable (history depth) */
+#define NFCGPU_EOVERFLOW (-6) /* frame sink overflowed, frames were dropped */
+#define NFCGPU_EHIP (-7)      /* HIP runtime error, see nfcgpu_last_error */
+#define NFCGPU_EFULL (-8)     /* no free stream slot */
+
+#define NFCGPU_TECH_A 0x1u
+#define NFCGPU_TECH_B 0x2u
+#define NFCGPU_TECH_F 0x4u
+#define NFCGPU_TECH_V 0x8u
+
+#define NFCGPU_LOC_HOST 0u
+#define NFCGPU_LOC_DEVICE 1u
+
+typedef struct nfcgpu_ctx nfcgpu_ctx;
+
+/* decoder configuration of one stream; defaults (nfcgpu_default_params) are the reference's
+ * (NfcTech.h:347, NfcA.cpp:94-100, NfcB.cpp:103-109, NfcF.cpp:88-94, NfcV.cpp:101-107) */
+typedef struct nfcgpu_params
+{
+   uint32_t sample_rate;          /* Hz; 0 = take it from the first submitted buffer */
+   uint32_t tech_mask;            /* NFCGPU_TECH_* */
+   int64_t stream_time;           /* reference time added to frame dateTime (NfcDecoder::setStreamTime) */
+   float power_level_threshold;
+   float corr_threshold[4];       /* A B F V */
+   float min_modulation_depth[4]; /* A B F V */
+   float max_modulation_depth[4]; /* A B F V */
+} nfcgpu_params;
+
+/* one decoded frame == the compared fields of lab::RawFrame plus payload (RawFrame.cpp:82-98) */
+typedef struct nfcgpu_frame
+{
+   uint32_t stream_id;
+   uint32_t tech_type;   /* lab::FrameTech  */
+   uint32_t frame_type;  /* lab::FrameType  */
+   uint32_t frame_flags; /* lab::FrameFlags */
+   uint32_t frame_phase; /* lab::FramePhase */
+   uint32_t frame_rate;
+   uint32_t length;
+   uint32_t reserved;
+   uint64_t sample_start;
+   uint64_t sample_end;
+   uint64_t sample_rate;
+   uint8_t data[512];
+} nfcgpu_frame;
+
+typedef struct nfcgpu_options
+{
+   uint32_t max_streams;     /* stream slots reserved in HBM (rounded up to 64); default 1024 */
+   uint32_t reserved;
+   uint64_t frame_sink_bytes; /* device frame sink per sync interval; default 64 MiB */
+} nfcgpu_options;
+
+/* many streams, one call. data[i] points to n_samples[i]*stride floats of stream stream_ids[i] */
+typedef struct nfcgpu_batch
+{
+   uint32_t n_streams;
+   uint32_t stride;      /* 1 magnitude, 2 interleaved IQ */
+   uint32_t location;    /* NFCGPU_LOC_* of every data[i] */
+   uint32_t sample_rate; /* Hz */
+   const uint32_t *stream_ids;
+   const void *const *data;
+   const uint32_t *n_samples;
+} nfcgpu_batch;
+
+/* accumulated since nfcgpu_stats_reset; kernel_ms is HIP-event time of the demodulation kernel on the context's stream */
+typedef struct nfcgpu_stats
+{
+   uint64_t launches;
+   uint64_t samples;
+   uint64_t frames;
+   uint64_t dropped_frames;
+   double kernel_ms;
+} nfcgpu_stats;
+
+void nfcgpu_default_params(nfcgpu_params *params);
+
+int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **ctx);
+int nfcgpu_shutdown(nfcgpu_ctx *ctx);
+
+int nfcgpu_stream_open(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32_t *stream_id);
+int nfcgpu_stream_open_many(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32_t count, uint32_t *first_stream_id);
+int nfcgpu_stream_configure(nfcgpu_ctx *ctx, uint32_t stream_id, const nfcgpu_params *params);
+int nfcgpu_stream_reset(nfcgpu_ctx *ctx, uint32_t stream_id);
+int nfcgpu_stream_close(nfcgpu_ctx *ctx, uint32_t stream_id);
+
+int nfcgpu_submit(nfcgpu_ctx *ctx, uint32_t stream_id, const float *data, uint32_t n_samples, uint32_t stride, uint32_t sample_rate);
+int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *batch);
+/* streams first..first+count-1; stream i reads n_samples*stride floats at base + i*pitch_bytes */
+int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first_stream_id, uint32_t count, const void *base, uint64_t pitch_bytes,
+                          uint32_t n_samples, uint32_t stride, uint32_t location, uint32_t sample_rate);
+
+int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t stream_id);
+int nfcgpu_sync(nfcgpu_ctx *ctx);
+int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t stream_id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count);
+int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t stream_id, uint32_t *count);
+
+/* device-resident view of the frames produced since the last sync: packed records of 32-bit words
+ * [stream_id, tech, type, flags, phase, rate, start, end, length, payload...]; used for RCCL frame gathers */
+int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cursor_words, uint64_t *capacity_words);
+/* when enabled, nfcgpu_sync leaves the sink untouched (no host drain) until nfcgpu_sink_rewind */
+int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold);
+int nfcgpu_sink_rewind(nfcgpu_ctx *ctx);
+
+int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats);
+int nfcgpu_stats_reset(nfcgpu_ctx *ctx);
+int nfcgpu_profile(nfcgpu_ctx *ctx, int enable);
+
+void *nfcgpu_hip_stream(nfcgpu_ctx *ctx);
+const char *nfcgpu_strerror(int code);
+const char *nfcgpu_last_error(nfcgpu_ctx *ctx);
+const char *nfcgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -26,6 +26,9 @@
 #ifndef NFC_DEV
 #error "define NFC_DEV before including nfc_core.hpp"
 #endif
+#ifndef NFC_ATOMIC_ADD
+#error "define NFC_ATOMIC_ADD(ptr, value) (returns the old value) before including nfc_core.hpp"
+#endif
 
 /* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
 struct NfcLaneMem
@@ -37,8 +40,11 @@ struct NfcLaneMem
    float *prod;    /* listen-mode product ring [NFC_PROD][64] */
    float *corr;    /* correlation rings [corrTotal][64] */
    uint8_t *bytes; /* frame assembly buffer, NFC_STREAM_BYTES contiguous */
-   uint32_t *arena;
-   uint32_t arenaWords;
+   uint32_t *sink;       /* frame sink shared by every stream of the launch (packed records) */
+   uint32_t *sinkCursor; /* words used, advanced atomically */
+   uint32_t *sinkDropped;
+   uint32_t sinkWords;
+   uint32_t streamId;
 };
 
 #define NFC_AT(ptr, slot) ((ptr)[(uint32_t)(slot) * NFC_LANES])
@@ -156,25 +162,31 @@ NFC_DEV uint32_t nfc_crc16(const uint8_t *data, uint32_t count, uint32_t init, b
    return crc;
 }
 
-/* append one frame to the stream's arena */
+/* append one frame to the launch's frame sink: [stream, tech, type, flags, phase, rate, start, end, length, payload...] */
 NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, uint32_t type, uint32_t flags,
                       uint32_t phase, uint32_t rate, uint32_t start, uint32_t end, const uint8_t *data, uint32_t len)
 {
    if (len > NFC_STREAM_BYTES)
       len = NFC_STREAM_BYTES;
 
-   uint32_t words = NFC_FRAME_HEADER_WORDS + ((len + 3u) >> 2);
+   const uint32_t words = NFC_FRAME_HEADER_WORDS + ((len + 3u) >> 2);
+   const uint32_t at = NFC_ATOMIC_ADD(mem.sinkCursor, words);
 
-   if (s.arenaUsed + words > mem.arenaWords)
+   s.framesOut++;
+
+   /* a record is only written when a maximum-size record would still fit: everything that starts at or
+    * below sinkWords - NFC_FRAME_MAX_WORDS is valid, everything above was dropped (no holes to guess) */
+   if (at + NFC_FRAME_MAX_WORDS > mem.sinkWords)
    {
-      s.arenaOverflow++;
+      NFC_ATOMIC_ADD(mem.sinkDropped, 1u);
       return;
    }
 
-   uint32_t *w = mem.arena + s.arenaUsed;
+   uint32_t *w = mem.sink + at;
 
-   w[0] = tech; w[1] = type; w[2] = flags; w[3] = phase;
-   w[4] = rate; w[5] = start; w[6] = end; w[7] = len;
+   w[0] = mem.streamId;
+   w[1] = tech; w[2] = type; w[3] = flags; w[4] = phase;
+   w[5] = rate; w[6] = start; w[7] = end; w[8] = len;
 
    for (uint32_t i = 0; i < len; i += 4)
    {
@@ -183,9 +195,6 @@ NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, u
          v |= ((uint32_t)data[i + k]) << (8 * k);
       w[NFC_FRAME_HEADER_WORDS + (i >> 2)] = v;
    }
-
-   s.arenaUsed += words;
-   s.framesOut++;
 }
 
 /* ------------------------------------------------------------------------------------------ */

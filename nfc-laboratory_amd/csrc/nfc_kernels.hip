@@ -1,0 +1,164 @@
+/*
+ * nfc_kernels.hip — gfx950 kernels of the demodulation path.
+ *
+ *   nfc_demod_kernel   one wavefront = one stream block (64 capture streams, one lane each).
+ *                      Per 64-sample tile: the wave loads 64 rows (one per stream) of IQ/magnitude with
+ *                      fully coalesced 512 B / 256 B row reads, turns IQ into magnitude on the fly
+ *                      (the reference's RadioDeviceTask.cpp:626-642 scalar formula, no contraction) and parks
+ *                      the tile transposed in LDS (pitch 65 -> conflict-free column reads); then every lane
+ *                      walks its own row through nfc_step(). History rings live in HBM as [slot][64 lanes]
+ *                      so a clock-aligned wave touches one 256 B row per ring access.
+ *   nfc_init_kernel    (re)initialise stream slots: decoder state + rings.
+ *
+ * Bound: HBM. Algorithmic traffic is 8 B (IQ) or 4 B (magnitude) read per sample plus frame bytes written;
+ * MFMA is not applicable (1-D sliding correlation + sequential state machine, no GEMM shape).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NFC_DEV __device__ __forceinline__
+#define NFC_ATOMIC_ADD(ptr, value) atomicAdd((ptr), (value))
+
+#include "nfc_core.hpp"
+#include "nfc_launch.h"
+
+#define TILE 64
+#define TILE_PITCH 65
+
+__global__ __launch_bounds__(64) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+{
+   __shared__ float tile[TILE * TILE_PITCH];
+   __shared__ NfcWork work[NFC_LANES];
+
+   const uint32_t lane = threadIdx.x;
+   const uint32_t block = L.firstBlock + blockIdx.x;
+   const uint32_t slot = block * NFC_LANES + lane;
+
+   NfcWork mine;
+   mine.data = nullptr;
+   mine.count = 0;
+   mine.stride = 1;
+
+   if (slot >= L.firstSlot && slot < L.firstSlot + L.slotCount)
+   {
+      if (L.works)
+      {
+         mine = L.works[slot];
+      }
+      else
+      {
+         mine.data = L.uniformBase + (uint64_t)(slot - L.firstSlot) * L.uniformPitch;
+         mine.count = L.uniformCount;
+         mine.stride = L.uniformStride;
+      }
+   }
+
+   work[lane] = mine;
+
+   /* longest row of the block (wave-wide max) */
+   uint32_t longest = mine.count;
+   for (int off = 32; off > 0; off >>= 1)
+   {
+      uint32_t other = __shfl_xor(longest, off, 64);
+      longest = other > longest ? other : longest;
+   }
+
+   __syncthreads();
+
+   if (longest == 0)
+      return;
+
+   const NfcConfig &cfg = *cfgPtr;
+
+   NfcStreamState s = L.states[slot];
+
+   float *ring = L.rings + (uint64_t)block * L.ringBlockFloats + lane;
+
+   NfcLaneMem mem;
+   mem.x = ring;
+   mem.filt = ring + 1 * NFC_HIST * NFC_LANES;
+   mem.mdev = ring + 2 * NFC_HIST * NFC_LANES;
+   mem.depth = ring + 3 * NFC_HIST * NFC_LANES;
+   mem.prod = ring + 4 * NFC_HIST * NFC_LANES;
+   mem.corr = ring + (4 * NFC_HIST + NFC_PROD) * NFC_LANES;
+   mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
+   mem.sink = L.sink;
+   mem.sinkCursor = L.sinkCtl;
+   mem.sinkDropped = L.sinkCtl + 1;
+   mem.sinkWords = L.sinkWords;
+   mem.streamId = slot;
+
+   for (uint32_t base = 0; base < longest; base += TILE)
+   {
+      /* stage: row r = stream r of the block, column = lane */
+      const uint32_t idx = base + lane;
+
+      for (uint32_t r = 0; r < NFC_LANES; r++)
+      {
+         const NfcWork w = work[r];
+
+         if (base >= w.count)
+            continue;
+
+         float v = 0.0f;
+
+         if (idx < w.count)
+         {
+            if (w.stride == 2)
+            {
+               const float2 iq = reinterpret_cast<const float2 *>(w.data)[idx];
+               v = __fsqrt_rn(__fadd_rn(__fmul_rn(iq.x, iq.x), __fmul_rn(iq.y, iq.y)));
+            }
+            else
+            {
+               v = reinterpret_cast<const float *>(w.data)[idx];
+            }
+         }
+
+         tile[r * TILE_PITCH + lane] = v;
+      }
+
+      __syncthreads();
+
+      if (base < mine.count)
+      {
+         const uint32_t left = mine.count - base;
+         const uint32_t n = left < TILE ? left : TILE;
+
+         for (uint32_t k = 0; k < n; k++)
+            nfc_step(cfg, s, mem, tile[lane * TILE_PITCH + k]);
+      }
+
+      __syncthreads();
+   }
+
+   if (mine.count)
+      L.states[slot] = s;
+}
+
+__global__ __launch_bounds__(64) void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd)
+{
+   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (idx >= L.slotCount)
+      return;
+
+   const uint32_t slot = L.firstSlot + idx;
+   const uint32_t block = slot / NFC_LANES;
+   const uint32_t lane = slot % NFC_LANES;
+
+   const NfcConfig &cfg = *cfgPtr;
+
+   NfcStreamState s = L.states[slot];
+   nfc_state_init(cfg, s, keepFrontEnd != 0);
+   L.states[slot] = s;
+
+   float *ring = L.rings + (uint64_t)block * L.ringBlockFloats + lane;
+
+   /* the reference's initialize() leaves the sample history alone and clears every modulation buffer */
+   const uint32_t from = keepFrontEnd ? 4 * NFC_HIST : 0;
+   const uint32_t total = L.ringBlockFloats / NFC_LANES;
+
+   for (uint32_t i = from; i < total; i++)
+      ring[i * NFC_LANES] = 0.0f;
+}

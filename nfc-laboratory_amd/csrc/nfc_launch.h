@@ -1,0 +1,39 @@
+/*
+ * nfc_launch.h — launch descriptors shared by nfc_kernels.hip and the host runtime (nfcgpu.hip).
+ */
+#ifndef NFC_AMD_LAUNCH_H
+#define NFC_AMD_LAUNCH_H
+
+#include <stdint.h>
+
+#include "nfc_types.h"
+
+/* input of one stream slot for one launch */
+struct NfcWork
+{
+   const uint8_t *data; /* device pointer: count*stride floats */
+   uint32_t count;      /* samples */
+   uint32_t stride;     /* 1 magnitude, 2 interleaved IQ */
+};
+
+struct NfcLaunch
+{
+   NfcStreamState *states; /* [maxStreams] */
+   float *rings;           /* [blocks][ringBlockFloats] */
+   uint8_t *bytes;         /* [maxStreams][NFC_STREAM_BYTES] */
+   uint32_t *sink;         /* packed frame records */
+   uint32_t *sinkCtl;      /* [0] cursor (words), [1] dropped frames */
+   const NfcWork *works;   /* per slot table, or null for the uniform layout below */
+   const uint8_t *uniformBase;
+   uint64_t uniformPitch;
+   uint32_t uniformCount;
+   uint32_t uniformStride;
+   uint32_t sinkWords;
+   uint32_t firstBlock;
+   uint32_t firstSlot;
+   uint32_t slotCount;
+   uint32_t ringBlockFloats;
+   uint32_t reserved;
+};
+
+#endif

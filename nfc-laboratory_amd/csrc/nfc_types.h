@@ -5,7 +5,8 @@
  *   - scalar decoder state: one StreamState record per stream (AoS, touched once per launch),
  *   - history rings: "stream block" storage, [slot][64 lanes] floats, so that a wave whose 64 streams
  *     share the same sample clock touches one contiguous 256-byte row per ring access,
- *   - frames: per-stream append-only arena of 32-bit words (FrameRecord header + payload).
+ *   - frames: one packed sink of 32-bit words per context (NfcFrameRecord header + payload), appended
+ *     with one atomic per frame; frames of one stream stay in order because one lane emits them.
  *
  * What the state represents follows the reference decoder's data model
  * (src/nfc-lib/lib-lab/lab-radio/src/main/cpp/NfcTech.h:151-393) but only keeps what is ever read:
@@ -178,16 +179,15 @@ struct NfcStreamState
    NfcMod modF[3]; /* [0] unused */
    NfcMod modV;
 
-   /* ---- output arena bookkeeping ---- */
-   uint32_t arenaUsed; /* words */
-   uint32_t arenaOverflow;
-   uint32_t framesOut;
-   uint32_t reserved;
+   /* ---- bookkeeping ---- */
+   uint32_t framesOut; /* frames emitted by this stream since it was opened */
+   uint32_t reserved[3];
 };
 
-/* header of one frame in the per-stream arena, followed by (length+3)/4 payload words */
+/* header of one frame in the frame sink, followed by (length+3)/4 payload words */
 struct NfcFrameRecord
 {
+   uint32_t stream;
    uint32_t tech;
    uint32_t type;
    uint32_t flags;
@@ -198,6 +198,7 @@ struct NfcFrameRecord
    uint32_t length;
 };
 
-#define NFC_FRAME_HEADER_WORDS 8u
+#define NFC_FRAME_HEADER_WORDS 9u
+#define NFC_FRAME_MAX_WORDS (NFC_FRAME_HEADER_WORDS + NFC_STREAM_BYTES / 4u)
 
 #endif

@@ -1,0 +1,1042 @@
+/*
+ * nfcgpu.hip — host runtime behind the C ABI of include/nfcgpu.h.
+ *
+ * Owns, per context: one HIP stream, the HBM-resident stream slots (state records, history rings,
+ * frame assembly buffers), the device frame sink and the per-stream host frame queues. Streams are
+ * grouped into stream blocks of 64 (one wavefront). There is deliberately no CPU decoding path here:
+ * if HIP or the gfx950 code object is unavailable every entry point fails with NFCGPU_ENODEV/EHIP.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/nfcgpu.h"
+#include "nfc_config.hpp"
+#include "nfc_launch.h"
+
+__global__ void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd);
+
+namespace {
+
+constexpr uint32_t kMaxConfigs = 64;
+constexpr uint32_t kRingBlockFloats = (4 * NFC_HIST + NFC_PROD + NFC_CORR_MAX) * NFC_LANES;
+
+struct StreamInfo
+{
+   bool open = false;
+   bool initialized = false; /* device state valid */
+   bool needInit = true;
+   nfcgpu_params params {};
+   float powerAtInit = 0.01f; /* carrier thresholds are derived when the decoder (re)initialises */
+   uint32_t config = 0;
+   std::deque<nfcgpu_frame> queue;
+};
+
+struct ProfiledLaunch
+{
+   hipEvent_t start;
+   hipEvent_t stop;
+};
+
+}
+
+struct nfcgpu_ctx
+{
+   int device = 0;
+   hipStream_t stream = nullptr;
+   uint32_t maxStreams = 0;
+   uint32_t blocks = 0;
+
+   NfcStreamState *dStates = nullptr;
+   float *dRings = nullptr;
+   uint8_t *dBytes = nullptr;
+   uint32_t *dSink = nullptr;
+   uint32_t *dSinkCtl = nullptr;
+   uint64_t sinkWords = 0;
+   NfcWork *dWorks = nullptr;
+   NfcConfig *dConfigs = nullptr;
+   uint8_t *dStage = nullptr;
+   size_t stageBytes = 0;
+
+   std::vector<NfcConfig> configs;
+   std::vector<StreamInfo> streams;
+   std::vector<NfcWork> hWorks;
+   std::vector<uint32_t> hSink;
+
+   bool hold = false;
+   bool profile = false;
+   bool dirty = false; /* work submitted since last sync */
+   std::vector<ProfiledLaunch> timed;
+   std::vector<hipEvent_t> eventPool;
+   nfcgpu_stats stats {};
+   std::string lastError;
+};
+
+namespace {
+
+int fail(nfcgpu_ctx *ctx, int code, const char *what, hipError_t err = hipSuccess)
+{
+   if (ctx)
+   {
+      ctx->lastError = what;
+      if (err != hipSuccess)
+      {
+         ctx->lastError += ": ";
+         ctx->lastError += hipGetErrorString(err);
+      }
+   }
+   return code;
+}
+
+#define HIP_TRY(ctx, call)                                   \
+   do                                                        \
+   {                                                         \
+      hipError_t err__ = (call);                             \
+      if (err__ != hipSuccess)                               \
+         return fail((ctx), NFCGPU_EHIP, #call, err__);      \
+   } while (0)
+
+NfcLaunch base_launch(nfcgpu_ctx *ctx)
+{
+   NfcLaunch L;
+   std::memset(&L, 0, sizeof(L));
+   L.states = ctx->dStates;
+   L.rings = ctx->dRings;
+   L.bytes = ctx->dBytes;
+   L.sink = ctx->dSink;
+   L.sinkCtl = ctx->dSinkCtl;
+   L.sinkWords = (uint32_t)ctx->sinkWords;
+   L.ringBlockFloats = kRingBlockFloats;
+   return L;
+}
+
+/* find or create the device-side NfcConfig for a stream's parameters */
+int resolve_config(nfcgpu_ctx *ctx, StreamInfo &si)
+{
+   NfcHostParams hp;
+   hp.sampleRate = si.params.sample_rate;
+   hp.enabled = si.params.tech_mask & 0xF;
+   hp.powerLevelThreshold = si.params.power_level_threshold;
+   for (int t = 0; t < 4; t++)
+   {
+      hp.corrThreshold[t] = si.params.corr_threshold[t];
+      hp.minDepth[t] = si.params.min_modulation_depth[t];
+      hp.maxDepth[t] = si.params.max_modulation_depth[t];
+   }
+
+   NfcConfig cfg;
+   if (!nfc_build_config(hp, cfg))
+      return fail(ctx, NFCGPU_ERATE, "sample rate not decodable with the fixed history depth");
+
+   /* signalLow/HighThreshold are only recomputed by initialize() (NfcDecoder.cpp:327-329) */
+   cfg.lowThreshold = si.powerAtInit / 1.25f;
+   cfg.highThreshold = si.powerAtInit * 1.25f;
+
+   for (uint32_t i = 0; i < ctx->configs.size(); i++)
+   {
+      if (std::memcmp(&ctx->configs[i], &cfg, sizeof(cfg)) == 0)
+      {
+         si.config = i;
+         return NFCGPU_OK;
+      }
+   }
+
+   if (ctx->configs.size() >= kMaxConfigs)
+      return fail(ctx, NFCGPU_ENOMEM, "too many distinct decoder configurations");
+
+   ctx->configs.push_back(cfg);
+   si.config = (uint32_t)ctx->configs.size() - 1;
+
+   HIP_TRY(ctx, hipMemcpyAsync(ctx->dConfigs + si.config, &cfg, sizeof(cfg), hipMemcpyHostToDevice, ctx->stream));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* cfg is a stack object */
+
+   return NFCGPU_OK;
+}
+
+/* apply a new sample rate the way NfcDecoder::nextFrames does (NfcDecoder.cpp:383-388) */
+int adopt_sample_rate(nfcgpu_ctx *ctx, StreamInfo &si, uint32_t sampleRate)
+{
+   if (sampleRate == 0)
+      return fail(ctx, NFCGPU_EINVAL, "sample rate must be non-zero");
+
+   if (si.params.sample_rate != sampleRate || !si.initialized)
+   {
+      si.params.sample_rate = sampleRate;
+      si.needInit = true;
+   }
+
+   if (si.needInit)
+   {
+      si.powerAtInit = si.params.power_level_threshold;
+      return resolve_config(ctx, si);
+   }
+
+   return NFCGPU_OK;
+}
+
+/* run nfc_init_kernel for every stream in [first, first+count) that needs it; contiguous runs with equal
+ * (config, keep) share one launch */
+int initialize_pending(nfcgpu_ctx *ctx, uint32_t first, uint32_t count)
+{
+   uint32_t i = first;
+   const uint32_t end = first + count;
+
+   while (i < end)
+   {
+      StreamInfo &si = ctx->streams[i];
+
+      if (!si.open || !si.needInit)
+      {
+         i++;
+         continue;
+      }
+
+      const uint32_t cfg = si.config;
+      const bool keep = si.initialized;
+      uint32_t j = i;
+
+      while (j < end && ctx->streams[j].open && ctx->streams[j].needInit && ctx->streams[j].config == cfg &&
+             ctx->streams[j].initialized == keep)
+         j++;
+
+      NfcLaunch L = base_launch(ctx);
+      L.firstSlot = i;
+      L.slotCount = j - i;
+
+      const uint32_t threads = 64;
+      const uint32_t grid = (L.slotCount + threads - 1) / threads;
+
+      hipLaunchKernelGGL(nfc_init_kernel, dim3(grid), dim3(threads), 0, ctx->stream, ctx->dConfigs + cfg, L, keep ? 1u : 0u);
+      HIP_TRY(ctx, hipGetLastError());
+
+      for (uint32_t k = i; k < j; k++)
+      {
+         ctx->streams[k].needInit = false;
+         ctx->streams[k].initialized = true;
+      }
+
+      i = j;
+   }
+
+   return NFCGPU_OK;
+}
+
+hipEvent_t take_event(nfcgpu_ctx *ctx)
+{
+   if (!ctx->eventPool.empty())
+   {
+      hipEvent_t e = ctx->eventPool.back();
+      ctx->eventPool.pop_back();
+      return e;
+   }
+   hipEvent_t e = nullptr;
+   (void)hipEventCreate(&e);
+   return e;
+}
+
+int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t samples)
+{
+   const uint32_t firstBlock = L.firstSlot / NFC_LANES;
+   const uint32_t lastBlock = (L.firstSlot + L.slotCount - 1) / NFC_LANES;
+
+   L.firstBlock = firstBlock;
+
+   ProfiledLaunch pl {nullptr, nullptr};
+
+   if (ctx->profile)
+   {
+      pl.start = take_event(ctx);
+      pl.stop = take_event(ctx);
+      HIP_TRY(ctx, hipEventRecord(pl.start, ctx->stream));
+   }
+
+   hipLaunchKernelGGL(nfc_demod_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0, ctx->stream,
+                      ctx->dConfigs + config, L);
+   HIP_TRY(ctx, hipGetLastError());
+
+   if (ctx->profile)
+   {
+      HIP_TRY(ctx, hipEventRecord(pl.stop, ctx->stream));
+      ctx->timed.push_back(pl);
+   }
+
+   ctx->stats.launches++;
+   ctx->stats.samples += samples;
+   ctx->dirty = true;
+
+   return NFCGPU_OK;
+}
+
+int ensure_stage(nfcgpu_ctx *ctx, size_t bytes)
+{
+   if (bytes <= ctx->stageBytes)
+      return NFCGPU_OK;
+
+   /* the previous staging buffer may still be read by an in-flight launch */
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   if (ctx->dStage)
+      (void)hipFree(ctx->dStage);
+
+   ctx->dStage = nullptr;
+   ctx->stageBytes = 0;
+
+   size_t want = bytes + bytes / 2;
+   if (hipMalloc((void **)&ctx->dStage, want) != hipSuccess)
+      return fail(ctx, NFCGPU_ENOMEM, "staging buffer allocation failed");
+
+   ctx->stageBytes = want;
+   return NFCGPU_OK;
+}
+
+void drain_sink(nfcgpu_ctx *ctx, uint64_t cursor)
+{
+   const uint64_t valid = cursor < ctx->sinkWords ? cursor : ctx->sinkWords;
+   uint64_t pos = 0;
+
+   while (pos < valid && pos + NFC_FRAME_MAX_WORDS <= ctx->sinkWords)
+   {
+      const uint32_t *w = ctx->hSink.data() + pos;
+      const uint32_t len = w[8] > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : w[8];
+      const uint32_t id = w[0];
+
+      if (id < ctx->streams.size())
+      {
+         StreamInfo &si = ctx->streams[id];
+
+         nfcgpu_frame f;
+         std::memset(&f, 0, sizeof(f));
+         f.stream_id = id;
+         f.tech_type = w[1];
+         f.frame_type = w[2];
+         f.frame_flags = w[3];
+         f.frame_phase = w[4];
+         f.frame_rate = w[5];
+         f.sample_start = w[6];
+         f.sample_end = w[7];
+         f.sample_rate = si.params.sample_rate;
+         f.length = len;
+         std::memcpy(f.data, w + NFC_FRAME_HEADER_WORDS, len);
+
+         if (si.open)
+            si.queue.push_back(f);
+
+         ctx->stats.frames++;
+      }
+
+      pos += NFC_FRAME_HEADER_WORDS + ((len + 3) >> 2);
+   }
+}
+
+}
+
+extern "C" {
+
+void nfcgpu_default_params(nfcgpu_params *p)
+{
+   if (!p)
+      return;
+
+   std::memset(p, 0, sizeof(*p));
+   p->sample_rate = 0;
+   p->tech_mask = NFCGPU_TECH_A | NFCGPU_TECH_B | NFCGPU_TECH_F | NFCGPU_TECH_V;
+   p->power_level_threshold = 0.01f;
+
+   const float corr[4] = {0.75f, 0.50f, 0.50f, 0.50f};
+   const float lo[4] = {0.90f, 0.10f, 0.10f, 0.90f};
+   const float hi[4] = {1.00f, 0.90f, 0.90f, 1.00f};
+
+   for (int t = 0; t < 4; t++)
+   {
+      p->corr_threshold[t] = corr[t];
+      p->min_modulation_depth[t] = lo[t];
+      p->max_modulation_depth[t] = hi[t];
+   }
+}
+
+int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
+{
+   if (!out)
+      return NFCGPU_EINVAL;
+
+   *out = nullptr;
+
+   int count = 0;
+   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+      return NFCGPU_ENODEV;
+
+   if (hipSetDevice(device) != hipSuccess)
+      return NFCGPU_ENODEV;
+
+   nfcgpu_ctx *ctx = new (std::nothrow) nfcgpu_ctx();
+   if (!ctx)
+      return NFCGPU_ENOMEM;
+
+   ctx->device = device;
+
+   uint32_t maxStreams = options && options->max_streams ? options->max_streams : 1024;
+   uint64_t sinkBytes = options && options->frame_sink_bytes ? options->frame_sink_bytes : (64ull << 20);
+
+   maxStreams = (maxStreams + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
+
+   if (sinkBytes < 4ull * 4 * NFC_FRAME_MAX_WORDS)
+      sinkBytes = 4ull * 4 * NFC_FRAME_MAX_WORDS;
+   if (sinkBytes > (0xFFFFFFF0ull * 4ull))
+      sinkBytes = 0xFFFFFFF0ull * 4ull;
+
+   ctx->maxStreams = maxStreams;
+   ctx->blocks = maxStreams / NFC_LANES;
+   ctx->sinkWords = sinkBytes / 4;
+
+   bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+
+   ok = ok && hipMalloc((void **)&ctx->dStates, sizeof(NfcStreamState) * (size_t)maxStreams) == hipSuccess;
+   ok = ok && hipMalloc((void **)&ctx->dRings, sizeof(float) * (size_t)kRingBlockFloats * ctx->blocks) == hipSuccess;
+   ok = ok && hipMalloc((void **)&ctx->dBytes, (size_t)NFC_STREAM_BYTES * maxStreams) == hipSuccess;
+   ok = ok && hipMalloc((void **)&ctx->dSink, ctx->sinkWords * 4) == hipSuccess;
+   ok = ok && hipMalloc((void **)&ctx->dSinkCtl, 16) == hipSuccess;
+   ok = ok && hipMalloc((void **)&ctx->dWorks, sizeof(NfcWork) * (size_t)maxStreams) == hipSuccess;
+   ok = ok && hipMalloc((void **)&ctx->dConfigs, sizeof(NfcConfig) * kMaxConfigs) == hipSuccess;
+
+   if (ok)
+   {
+      ok = ok && hipMemsetAsync(ctx->dStates, 0, sizeof(NfcStreamState) * (size_t)maxStreams, ctx->stream) == hipSuccess;
+      ok = ok && hipMemsetAsync(ctx->dRings, 0, sizeof(float) * (size_t)kRingBlockFloats * ctx->blocks, ctx->stream) == hipSuccess;
+      ok = ok && hipMemsetAsync(ctx->dBytes, 0, (size_t)NFC_STREAM_BYTES * maxStreams, ctx->stream) == hipSuccess;
+      ok = ok && hipMemsetAsync(ctx->dSinkCtl, 0, 16, ctx->stream) == hipSuccess;
+      ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+   }
+
+   if (!ok)
+   {
+      nfcgpu_shutdown(ctx);
+      return NFCGPU_ENOMEM;
+   }
+
+   ctx->streams.resize(maxStreams);
+   ctx->hWorks.resize(maxStreams);
+   for (auto &w: ctx->hWorks)
+   {
+      w.data = nullptr;
+      w.count = 0;
+      w.stride = 1;
+   }
+
+   *out = ctx;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_shutdown(nfcgpu_ctx *ctx)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+
+   (void)hipSetDevice(ctx->device);
+
+   if (ctx->stream)
+      (void)hipStreamSynchronize(ctx->stream);
+
+   for (auto &pl: ctx->timed)
+   {
+      (void)hipEventDestroy(pl.start);
+      (void)hipEventDestroy(pl.stop);
+   }
+   for (auto e: ctx->eventPool)
+      (void)hipEventDestroy(e);
+
+   (void)hipFree(ctx->dStates);
+   (void)hipFree(ctx->dRings);
+   (void)hipFree(ctx->dBytes);
+   (void)hipFree(ctx->dSink);
+   (void)hipFree(ctx->dSinkCtl);
+   (void)hipFree(ctx->dWorks);
+   (void)hipFree(ctx->dConfigs);
+   (void)hipFree(ctx->dStage);
+
+   if (ctx->stream)
+      (void)hipStreamDestroy(ctx->stream);
+
+   delete ctx;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_stream_open_many(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32_t count, uint32_t *first)
+{
+   if (!ctx || !first || count == 0)
+      return NFCGPU_EINVAL;
+
+   /* first fit of `count` contiguous free slots */
+   uint32_t run = 0, start = 0;
+   bool found = false;
+
+   for (uint32_t i = 0; i < ctx->maxStreams; i++)
+   {
+      if (ctx->streams[i].open)
+      {
+         run = 0;
+         continue;
+      }
+      if (run == 0)
+         start = i;
+      if (++run == count)
+      {
+         found = true;
+         break;
+      }
+   }
+
+   if (!found)
+      return fail(ctx, NFCGPU_EFULL, "no free stream slots (raise nfcgpu_options.max_streams)");
+
+   nfcgpu_params p;
+   if (params)
+      p = *params;
+   else
+      nfcgpu_default_params(&p);
+
+   for (uint32_t i = start; i < start + count; i++)
+   {
+      StreamInfo &si = ctx->streams[i];
+      si = StreamInfo();
+      si.open = true;
+      si.params = p;
+      si.powerAtInit = p.power_level_threshold;
+   }
+
+   *first = start;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_stream_open(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32_t *id)
+{
+   return nfcgpu_stream_open_many(ctx, params, 1, id);
+}
+
+int nfcgpu_stream_configure(nfcgpu_ctx *ctx, uint32_t id, const nfcgpu_params *params)
+{
+   if (!ctx || !params)
+      return NFCGPU_EINVAL;
+   if (id >= ctx->maxStreams || !ctx->streams[id].open)
+      return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
+
+   StreamInfo &si = ctx->streams[id];
+   const uint32_t oldRate = si.params.sample_rate;
+
+   si.params = *params;
+
+   /* setSampleRate() only stores the value; the decoder re-initialises when a buffer arrives whose rate differs
+    * from it. Keeping the old rate here until then reproduces that. */
+   if (params->sample_rate == 0)
+      si.params.sample_rate = oldRate;
+
+   if (si.initialized && !si.needInit && si.params.sample_rate == oldRate)
+      return resolve_config(ctx, si); /* thresholds take effect immediately */
+
+   if (si.params.sample_rate != oldRate)
+      si.needInit = true;
+
+   return NFCGPU_OK;
+}
+
+int nfcgpu_stream_reset(nfcgpu_ctx *ctx, uint32_t id)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   if (id >= ctx->maxStreams || !ctx->streams[id].open)
+      return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
+
+   ctx->streams[id].needInit = true;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_stream_close(nfcgpu_ctx *ctx, uint32_t id)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   if (id >= ctx->maxStreams || !ctx->streams[id].open)
+      return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
+
+   int rc = nfcgpu_sync(ctx);
+
+   ctx->streams[id] = StreamInfo();
+   return rc;
+}
+
+int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
+{
+   if (!ctx || !b || !b->stream_ids || !b->data || !b->n_samples || (b->stride != 1 && b->stride != 2))
+      return NFCGPU_EINVAL;
+   if (b->n_streams == 0)
+      return NFCGPU_OK;
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+   /* validate + adopt rate */
+   size_t hostBytes = 0;
+   uint32_t lo = 0xFFFFFFFFu, hi = 0;
+
+   for (uint32_t i = 0; i < b->n_streams; i++)
+   {
+      const uint32_t id = b->stream_ids[i];
+
+      if (id >= ctx->maxStreams || !ctx->streams[id].open)
+         return fail(ctx, NFCGPU_ESTREAM, "unknown stream in batch");
+      if (ctx->hWorks[id].count)
+         return fail(ctx, NFCGPU_EINVAL, "stream listed twice in one batch");
+      if (b->n_samples[i] && !b->data[i])
+         return fail(ctx, NFCGPU_EINVAL, "null data pointer in batch");
+
+      int rc = adopt_sample_rate(ctx, ctx->streams[id], b->sample_rate);
+      if (rc)
+         return rc;
+
+      ctx->hWorks[id].count = b->n_samples[i]; /* also marks the slot as taken for the duplicate check */
+      hostBytes += (size_t)b->n_samples[i] * b->stride * 4;
+      lo = id < lo ? id : lo;
+      hi = id > hi ? id : hi;
+   }
+
+   auto clearWorks = [&]() {
+      for (uint32_t i = 0; i < b->n_streams; i++)
+      {
+         NfcWork &w = ctx->hWorks[b->stream_ids[i]];
+         w.data = nullptr;
+         w.count = 0;
+         w.stride = 1;
+      }
+   };
+
+   int rc = NFCGPU_OK;
+
+   if (b->location == NFCGPU_LOC_HOST)
+   {
+      rc = ensure_stage(ctx, hostBytes + 256 * (size_t)b->n_streams);
+      if (rc)
+      {
+         clearWorks();
+         return rc;
+      }
+   }
+
+   rc = initialize_pending(ctx, lo, hi - lo + 1);
+   if (rc)
+   {
+      clearWorks();
+      return rc;
+   }
+
+   size_t stageAt = 0;
+   uint64_t samples = 0;
+
+   for (uint32_t i = 0; i < b->n_streams; i++)
+   {
+      const uint32_t id = b->stream_ids[i];
+      NfcWork &w = ctx->hWorks[id];
+      const size_t bytes = (size_t)b->n_samples[i] * b->stride * 4;
+
+      w.stride = b->stride;
+      samples += b->n_samples[i];
+
+      if (b->location == NFCGPU_LOC_HOST)
+      {
+         w.data = ctx->dStage + stageAt;
+         if (bytes)
+         {
+            hipError_t err = hipMemcpyAsync(ctx->dStage + stageAt, b->data[i], bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (err != hipSuccess)
+            {
+               clearWorks();
+               return fail(ctx, NFCGPU_EHIP, "hipMemcpyAsync(H2D samples)", err);
+            }
+         }
+         stageAt += (bytes + 255) & ~(size_t)255;
+      }
+      else
+      {
+         w.data = (const uint8_t *)b->data[i];
+      }
+   }
+
+   /* one launch per decoder configuration present in the batch */
+   std::vector<uint32_t> cfgs;
+   for (uint32_t i = 0; i < b->n_streams; i++)
+   {
+      uint32_t c = ctx->streams[b->stream_ids[i]].config;
+      bool seen = false;
+      for (uint32_t k: cfgs)
+         seen = seen || k == c;
+      if (!seen)
+         cfgs.push_back(c);
+   }
+
+   std::vector<NfcWork> table;
+
+   for (uint32_t c: cfgs)
+   {
+      uint32_t first = 0xFFFFFFFFu, last = 0;
+      uint64_t groupSamples = 0;
+
+      for (uint32_t i = 0; i < b->n_streams; i++)
+      {
+         const uint32_t id = b->stream_ids[i];
+         if (ctx->streams[id].config != c)
+            continue;
+         first = id < first ? id : first;
+         last = id > last ? id : last;
+         groupSamples += b->n_samples[i];
+      }
+
+      /* slots of other configurations inside [first,last] must stay idle in this launch */
+      table.assign(ctx->hWorks.begin() + first, ctx->hWorks.begin() + last + 1);
+      for (uint32_t id = first; id <= last; id++)
+      {
+         if (!ctx->streams[id].open || ctx->streams[id].config != c)
+         {
+            table[id - first].data = nullptr;
+            table[id - first].count = 0;
+            table[id - first].stride = 1;
+         }
+      }
+
+      hipError_t err = hipMemcpyAsync(ctx->dWorks + first, table.data(), sizeof(NfcWork) * table.size(), hipMemcpyHostToDevice, ctx->stream);
+      if (err == hipSuccess && cfgs.size() > 1)
+         err = hipStreamSynchronize(ctx->stream); /* `table` is reused by the next group */
+      if (err != hipSuccess)
+      {
+         clearWorks();
+         return fail(ctx, NFCGPU_EHIP, "hipMemcpyAsync(work table)", err);
+      }
+
+      NfcLaunch L = base_launch(ctx);
+      L.works = ctx->dWorks;
+      L.firstSlot = first;
+      L.slotCount = last - first + 1;
+
+      rc = launch_demod(ctx, c, L, groupSamples);
+      if (rc)
+      {
+         clearWorks();
+         return rc;
+      }
+   }
+
+   /* pageable H2D copies above are complete on return (HIP stages them), but `table` is not: wait */
+   if (cfgs.size() == 1)
+   {
+      hipError_t err = hipStreamSynchronize(ctx->stream);
+      if (err != hipSuccess)
+      {
+         clearWorks();
+         return fail(ctx, NFCGPU_EHIP, "hipStreamSynchronize", err);
+      }
+   }
+
+   clearWorks();
+   return NFCGPU_OK;
+}
+
+int nfcgpu_submit(nfcgpu_ctx *ctx, uint32_t id, const float *data, uint32_t n, uint32_t stride, uint32_t sampleRate)
+{
+   const void *ptr = data;
+   nfcgpu_batch b;
+   std::memset(&b, 0, sizeof(b));
+   b.n_streams = 1;
+   b.stride = stride;
+   b.location = NFCGPU_LOC_HOST;
+   b.sample_rate = sampleRate;
+   b.stream_ids = &id;
+   b.data = &ptr;
+   b.n_samples = &n;
+   return nfcgpu_submit_batch(ctx, &b);
+}
+
+int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const void *base, uint64_t pitch, uint32_t n,
+                          uint32_t stride, uint32_t location, uint32_t sampleRate)
+{
+   if (!ctx || !base || (stride != 1 && stride != 2) || count == 0)
+      return NFCGPU_EINVAL;
+   if ((uint64_t)first + count > ctx->maxStreams)
+      return fail(ctx, NFCGPU_ESTREAM, "stream range out of bounds");
+   if (n == 0)
+      return NFCGPU_OK;
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+   for (uint32_t i = first; i < first + count; i++)
+   {
+      if (!ctx->streams[i].open)
+         return fail(ctx, NFCGPU_ESTREAM, "closed stream inside uniform range");
+
+      int rc = adopt_sample_rate(ctx, ctx->streams[i], sampleRate);
+      if (rc)
+         return rc;
+   }
+
+   const uint8_t *devBase = (const uint8_t *)base;
+   uint64_t devPitch = pitch;
+
+   if (location == NFCGPU_LOC_HOST)
+   {
+      const size_t row = (size_t)n * stride * 4;
+      devPitch = (row + 255) & ~(size_t)255;
+
+      int rc = ensure_stage(ctx, devPitch * count);
+      if (rc)
+         return rc;
+
+      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->dStage, devPitch, base, pitch, row, count, hipMemcpyHostToDevice, ctx->stream));
+      devBase = ctx->dStage;
+   }
+
+   int rc = initialize_pending(ctx, first, count);
+   if (rc)
+      return rc;
+
+   /* contiguous runs of one configuration -> one launch each (normally exactly one) */
+   uint32_t i = first;
+
+   while (i < first + count)
+   {
+      const uint32_t c = ctx->streams[i].config;
+      uint32_t j = i;
+
+      while (j < first + count && ctx->streams[j].config == c)
+         j++;
+
+      NfcLaunch L = base_launch(ctx);
+      L.works = nullptr;
+      L.uniformBase = devBase + (uint64_t)(i - first) * devPitch;
+      L.uniformPitch = devPitch;
+      L.uniformCount = n;
+      L.uniformStride = stride;
+      L.firstSlot = i;
+      L.slotCount = j - i;
+
+      rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i));
+      if (rc)
+         return rc;
+
+      i = j;
+   }
+
+   /* host buffers are never retained past the call */
+   if (location == NFCGPU_LOC_HOST)
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   return NFCGPU_OK;
+}
+
+int nfcgpu_sync(nfcgpu_ctx *ctx)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   for (auto &pl: ctx->timed)
+   {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
+         ctx->stats.kernel_ms += ms;
+      ctx->eventPool.push_back(pl.start);
+      ctx->eventPool.push_back(pl.stop);
+   }
+   ctx->timed.clear();
+
+   if (!ctx->dirty || ctx->hold)
+      return NFCGPU_OK;
+
+   uint32_t ctl[2] = {0, 0};
+   HIP_TRY(ctx, hipMemcpy(ctl, ctx->dSinkCtl, sizeof(ctl), hipMemcpyDeviceToHost));
+
+   const uint64_t used = ctl[0] < ctx->sinkWords ? ctl[0] : ctx->sinkWords;
+
+   if (used)
+   {
+      ctx->hSink.resize(used);
+      HIP_TRY(ctx, hipMemcpy(ctx->hSink.data(), ctx->dSink, used * 4, hipMemcpyDeviceToHost));
+      drain_sink(ctx, ctl[0]);
+   }
+
+   ctx->stats.dropped_frames += ctl[1];
+
+   HIP_TRY(ctx, hipMemsetAsync(ctx->dSinkCtl, 0, 16, ctx->stream));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   ctx->dirty = false;
+
+   if (ctl[1])
+      return fail(ctx, NFCGPU_EOVERFLOW, "frame sink overflow: frames were dropped (raise frame_sink_bytes or sync more often)");
+
+   return NFCGPU_OK;
+}
+
+int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t id)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   if (id >= ctx->maxStreams || !ctx->streams[id].open)
+      return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
+
+   int rc = nfcgpu_sync(ctx);
+   if (rc && rc != NFCGPU_EOVERFLOW)
+      return rc;
+
+   StreamInfo &si = ctx->streams[id];
+
+   uint32_t clock = 0xFFFFFFFFu, carrierOn = 0;
+
+   if (si.initialized)
+   {
+      NfcStreamState s;
+      HIP_TRY(ctx, hipMemcpy(&s, ctx->dStates + id, sizeof(s), hipMemcpyDeviceToHost));
+      clock = s.clock;
+      carrierOn = s.carrierOn;
+   }
+
+   nfcgpu_frame f;
+   std::memset(&f, 0, sizeof(f));
+   f.stream_id = id;
+   f.tech_type = NFC_TECH_ANY;
+   f.frame_type = carrierOn ? NFC_FRAME_CARRIER_ON : NFC_FRAME_CARRIER_OFF;
+   f.frame_phase = NFC_PHASE_CARRIER;
+   f.sample_start = clock;
+   f.sample_end = clock;
+   f.sample_rate = si.params.sample_rate;
+
+   si.queue.push_back(f);
+   return rc;
+}
+
+int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count)
+{
+   if (!ctx || !count || (capacity && !out))
+      return NFCGPU_EINVAL;
+   if (id >= ctx->maxStreams || !ctx->streams[id].open)
+      return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
+
+   int rc = nfcgpu_sync(ctx);
+   if (rc && rc != NFCGPU_EOVERFLOW)
+      return rc;
+
+   StreamInfo &si = ctx->streams[id];
+   uint32_t n = 0;
+
+   while (n < capacity && !si.queue.empty())
+   {
+      out[n++] = si.queue.front();
+      si.queue.pop_front();
+   }
+
+   *count = n;
+   return rc;
+}
+
+int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t id, uint32_t *count)
+{
+   if (!ctx || !count)
+      return NFCGPU_EINVAL;
+   if (id >= ctx->maxStreams || !ctx->streams[id].open)
+      return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
+
+   int rc = nfcgpu_sync(ctx);
+   *count = (uint32_t)ctx->streams[id].queue.size();
+   return rc;
+}
+
+int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cursor, uint64_t *capacity)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   if (words)
+      *words = ctx->dSink;
+   if (cursor)
+      *cursor = ctx->dSinkCtl;
+   if (capacity)
+      *capacity = ctx->sinkWords;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   ctx->hold = hold != 0;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_sink_rewind(nfcgpu_ctx *ctx)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+   HIP_TRY(ctx, hipMemsetAsync(ctx->dSinkCtl, 0, 16, ctx->stream));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+   ctx->dirty = false;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats)
+{
+   if (!ctx || !stats)
+      return NFCGPU_EINVAL;
+   *stats = ctx->stats;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_stats_reset(nfcgpu_ctx *ctx)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   ctx->stats = nfcgpu_stats();
+   return NFCGPU_OK;
+}
+
+int nfcgpu_profile(nfcgpu_ctx *ctx, int enable)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+   ctx->profile = enable != 0;
+   return NFCGPU_OK;
+}
+
+void *nfcgpu_hip_stream(nfcgpu_ctx *ctx)
+{
+   return ctx ? (void *)ctx->stream : nullptr;
+}
+
+const char *nfcgpu_strerror(int code)
+{
+   switch (code)
+   {
+      case NFCGPU_OK: return "ok";
+      case NFCGPU_EINVAL: return "invalid argument";
+      case NFCGPU_ENODEV: return "no usable HIP device (this library has no CPU fallback)";
+      case NFCGPU_ENOMEM: return "out of memory";
+      case NFCGPU_ESTREAM: return "unknown or closed stream";
+      case NFCGPU_ERATE: return "sample rate not decodable";
+      case NFCGPU_EOVERFLOW: return "frame sink overflow, frames dropped";
+      case NFCGPU_EHIP: return "HIP runtime error";
+      case NFCGPU_EFULL: return "no free stream slot";
+      default: return "unknown error";
+   }
+}
+
+const char *nfcgpu_last_error(nfcgpu_ctx *ctx)
+{
+   return ctx ? ctx->lastError.c_str() : "";
+}
+
+const char *nfcgpu_version(void)
+{
+   return "nfcgpu 0.1 (gfx950)";
+}
+
+}

@@ -1,0 +1,237 @@
+"""ctypes binding of libnfcgpu.so (include/nfcgpu.h) for the tests and bench.py.
+
+This is plumbing only: the product is the C-ABI library; the reference's host language is C++ and
+its drop-in host side lives in nfc-laboratory_amd/host/. Nothing here decodes on the CPU: if the
+library or a GPU is missing, NfcGpu() raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnfcgpu.so")
+
+TECH_A, TECH_B, TECH_F, TECH_V = 1, 2, 4, 8
+LOC_HOST, LOC_DEVICE = 0, 1
+
+FRAME_CARRIER_OFF, FRAME_CARRIER_ON, FRAME_POLL, FRAME_LISTEN = 0x100, 0x101, 0x102, 0x103
+
+
+class Params(ctypes.Structure):
+    _fields_ = [
+        ("sample_rate", ctypes.c_uint32),
+        ("tech_mask", ctypes.c_uint32),
+        ("stream_time", ctypes.c_int64),
+        ("power_level_threshold", ctypes.c_float),
+        ("corr_threshold", ctypes.c_float * 4),
+        ("min_modulation_depth", ctypes.c_float * 4),
+        ("max_modulation_depth", ctypes.c_float * 4),
+    ]
+
+
+class Frame(ctypes.Structure):
+    _fields_ = [
+        ("stream_id", ctypes.c_uint32),
+        ("tech_type", ctypes.c_uint32),
+        ("frame_type", ctypes.c_uint32),
+        ("frame_flags", ctypes.c_uint32),
+        ("frame_phase", ctypes.c_uint32),
+        ("frame_rate", ctypes.c_uint32),
+        ("length", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+        ("sample_start", ctypes.c_uint64),
+        ("sample_end", ctypes.c_uint64),
+        ("sample_rate", ctypes.c_uint64),
+        ("data", ctypes.c_uint8 * 512),
+    ]
+
+    def as_tuple(self):
+        return (self.tech_type, self.frame_type, self.frame_flags, self.frame_phase, self.frame_rate,
+                self.sample_start, self.sample_end, self.sample_rate, bytes(self.data[:self.length]))
+
+
+class Options(ctypes.Structure):
+    _fields_ = [
+        ("max_streams", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+        ("frame_sink_bytes", ctypes.c_uint64),
+    ]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [
+        ("n_streams", ctypes.c_uint32),
+        ("stride", ctypes.c_uint32),
+        ("location", ctypes.c_uint32),
+        ("sample_rate", ctypes.c_uint32),
+        ("stream_ids", ctypes.POINTER(ctypes.c_uint32)),
+        ("data", ctypes.POINTER(ctypes.c_void_p)),
+        ("n_samples", ctypes.POINTER(ctypes.c_uint32)),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("launches", ctypes.c_uint64),
+        ("samples", ctypes.c_uint64),
+        ("frames", ctypes.c_uint64),
+        ("dropped_frames", ctypes.c_uint64),
+        ("kernel_ms", ctypes.c_double),
+    ]
+
+
+class NfcGpuError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("nfcgpu error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load libnfcgpu.so and declare prototypes. Raises OSError if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    lib = ctypes.CDLL(path)
+    vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    P = ctypes.POINTER
+    lib.nfcgpu_default_params.argtypes = [P(Params)]
+    lib.nfcgpu_default_params.restype = None
+    lib.nfcgpu_init.argtypes = [i32, P(Options), P(vp)]
+    lib.nfcgpu_shutdown.argtypes = [vp]
+    lib.nfcgpu_stream_open.argtypes = [vp, P(Params), P(u32)]
+    lib.nfcgpu_stream_open_many.argtypes = [vp, P(Params), u32, P(u32)]
+    lib.nfcgpu_stream_configure.argtypes = [vp, u32, P(Params)]
+    lib.nfcgpu_stream_reset.argtypes = [vp, u32]
+    lib.nfcgpu_stream_close.argtypes = [vp, u32]
+    lib.nfcgpu_submit.argtypes = [vp, u32, vp, u32, u32, u32]
+    lib.nfcgpu_submit_batch.argtypes = [vp, P(Batch)]
+    lib.nfcgpu_submit_uniform.argtypes = [vp, u32, u32, vp, u64, u32, u32, u32, u32]
+    lib.nfcgpu_flush.argtypes = [vp, u32]
+    lib.nfcgpu_sync.argtypes = [vp]
+    lib.nfcgpu_poll.argtypes = [vp, u32, P(Frame), u32, P(u32)]
+    lib.nfcgpu_pending.argtypes = [vp, u32, P(u32)]
+    lib.nfcgpu_sink_device_view.argtypes = [vp, P(vp), P(vp), P(u64)]
+    lib.nfcgpu_sink_hold.argtypes = [vp, i32]
+    lib.nfcgpu_sink_rewind.argtypes = [vp]
+    lib.nfcgpu_stats_get.argtypes = [vp, P(Stats)]
+    lib.nfcgpu_stats_reset.argtypes = [vp]
+    lib.nfcgpu_profile.argtypes = [vp, i32]
+    lib.nfcgpu_hip_stream.argtypes = [vp]
+    lib.nfcgpu_hip_stream.restype = vp
+    lib.nfcgpu_strerror.argtypes = [i32]
+    lib.nfcgpu_strerror.restype = ctypes.c_char_p
+    lib.nfcgpu_last_error.argtypes = [vp]
+    lib.nfcgpu_last_error.restype = ctypes.c_char_p
+    lib.nfcgpu_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def default_params(sample_rate=0, tech_mask=0xF):
+    p = Params()
+    load_library().nfcgpu_default_params(ctypes.byref(p))
+    p.sample_rate = sample_rate
+    p.tech_mask = tech_mask
+    return p
+
+
+class NfcGpu:
+    """One nfcgpu context (one GPU, one HIP stream)."""
+
+    def __init__(self, device=0, max_streams=1024, frame_sink_bytes=64 << 20):
+        self.lib = load_library()
+        self.ctx = ctypes.c_void_p()
+        opts = Options(max_streams, 0, frame_sink_bytes)
+        rc = self.lib.nfcgpu_init(device, ctypes.byref(opts), ctypes.byref(self.ctx))
+        if rc != 0:
+            self.ctx = None
+            raise NfcGpuError(rc, self.lib.nfcgpu_strerror(rc).decode())
+
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            msg = self.lib.nfcgpu_strerror(rc).decode()
+            detail = self.lib.nfcgpu_last_error(self.ctx).decode()
+            raise NfcGpuError(rc, "%s (%s)" % (msg, detail))
+        return rc
+
+    def close(self):
+        if self.ctx:
+            self.lib.nfcgpu_shutdown(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def open(self, params=None, count=1):
+        first = ctypes.c_uint32()
+        p = params or default_params()
+        self._check(self.lib.nfcgpu_stream_open_many(self.ctx, ctypes.byref(p), count, ctypes.byref(first)))
+        return first.value
+
+    def configure(self, stream, params):
+        self._check(self.lib.nfcgpu_stream_configure(self.ctx, stream, ctypes.byref(params)))
+
+    def reset(self, stream):
+        self._check(self.lib.nfcgpu_stream_reset(self.ctx, stream))
+
+    def close_stream(self, stream):
+        self._check(self.lib.nfcgpu_stream_close(self.ctx, stream))
+
+    def submit(self, stream, samples, sample_rate, stride=1):
+        """samples: contiguous float32 numpy array (host)."""
+        n = samples.size // stride
+        self._check(self.lib.nfcgpu_submit(self.ctx, stream, samples.ctypes.data, n, stride, sample_rate))
+
+    def submit_batch(self, stream_ids, pointers, counts, sample_rate, stride=1, location=LOC_HOST):
+        n = len(stream_ids)
+        ids = (ctypes.c_uint32 * n)(*stream_ids)
+        ptrs = (ctypes.c_void_p * n)(*pointers)
+        cnts = (ctypes.c_uint32 * n)(*counts)
+        b = Batch(n, stride, location, sample_rate, ids, ptrs, cnts)
+        self._check(self.lib.nfcgpu_submit_batch(self.ctx, ctypes.byref(b)))
+
+    def submit_uniform(self, first, count, base_ptr, pitch_bytes, n_samples, sample_rate, stride=1, location=LOC_DEVICE):
+        self._check(self.lib.nfcgpu_submit_uniform(self.ctx, first, count, base_ptr, pitch_bytes, n_samples, stride,
+                                                   location, sample_rate))
+
+    def flush(self, stream):
+        self._check(self.lib.nfcgpu_flush(self.ctx, stream))
+
+    def sync(self):
+        self._check(self.lib.nfcgpu_sync(self.ctx))
+
+    def poll(self, stream, capacity=4096):
+        out = (Frame * capacity)()
+        n = ctypes.c_uint32()
+        self._check(self.lib.nfcgpu_poll(self.ctx, stream, out, capacity, ctypes.byref(n)))
+        return [out[i].as_tuple() for i in range(n.value)]
+
+    def sink_view(self):
+        words, cursor, cap = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        self._check(self.lib.nfcgpu_sink_device_view(self.ctx, ctypes.byref(words), ctypes.byref(cursor), ctypes.byref(cap)))
+        return words.value, cursor.value, cap.value
+
+    def sink_hold(self, hold):
+        self._check(self.lib.nfcgpu_sink_hold(self.ctx, int(hold)))
+
+    def sink_rewind(self):
+        self._check(self.lib.nfcgpu_sink_rewind(self.ctx))
+
+    def profile(self, enable):
+        self._check(self.lib.nfcgpu_profile(self.ctx, int(enable)))
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.nfcgpu_stats_get(self.ctx, ctypes.byref(s)))
+        return s
+
+    def stats_reset(self):
+        self._check(self.lib.nfcgpu_stats_reset(self.ctx))
+
+    def hip_stream(self):
+        return self.lib.nfcgpu_hip_stream(self.ctx)

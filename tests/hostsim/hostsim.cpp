@@ -9,6 +9,8 @@
 #include <vector>
 
 #define NFC_DEV static inline
+static inline uint32_t hostsim_add(uint32_t *p, uint32_t v) { uint32_t old = *p; *p += v; return old; }
+#define NFC_ATOMIC_ADD(ptr, value) hostsim_add((ptr), (value))
 #include "../../nfc-laboratory_amd/csrc/nfc_core.hpp"
 #include "../../nfc-laboratory_amd/csrc/nfc_config.hpp"
 
@@ -55,8 +57,12 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
    mem.prod = base + 4 * NFC_HIST * NFC_LANES;
    mem.corr = base + (4 * NFC_HIST + NFC_PROD) * NFC_LANES;
    mem.bytes = bytes.data();
-   mem.arena = arena.data();
-   mem.arenaWords = (uint32_t)arena.size();
+   uint32_t ctl[2] = {0, 0};
+   mem.sink = arena.data();
+   mem.sinkCursor = &ctl[0];
+   mem.sinkDropped = &ctl[1];
+   mem.sinkWords = (uint32_t)arena.size();
+   mem.streamId = lane;
 
    NfcStreamState s;
    std::memset(&s, 0, sizeof(s));
@@ -79,9 +85,12 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
 
    long n = 0;
    uint32_t pos = 0;
-   while (pos < s.arenaUsed)
+   if (ctl[1])
+      return -2;
+
+   while (pos < ctl[0])
    {
-      const uint32_t *w = arena.data() + pos;
+      const uint32_t *w = arena.data() + pos + 1;
       uint32_t len = w[7];
       if (n < cap)
       {
@@ -93,7 +102,7 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
          std::memcpy(f.data, w + 8, len);
       }
       n++;
-      pos += 8 + ((len + 3) >> 2);
+      pos += NFC_FRAME_HEADER_WORDS + ((len + 3) >> 2);
    }
    return n;
 }

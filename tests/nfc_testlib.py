@@ -150,3 +150,47 @@ def hostsim_decode(samples, sample_rate=10000000, lane=0, tech_mask=0xF, stride=
 def describe(t):
     return "tech=%x type=%x flags=%x phase=%x rate=%d start=%d end=%d data=%s" % (
         t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[8].hex(":"))
+
+
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def magnitude_to_iq(mag, seed=0, period=4096):
+    """Interleaved IQ whose magnitude is exactly `mag`: the sample is put on +I, +Q, -I or -Q, the axis
+    advancing every `period` samples (SURVEY.md 8(d) set S1). sqrtf(m*m + 0) == |m| exactly in fp32."""
+    mag = np.ascontiguousarray(mag, dtype=np.float32)
+    n = mag.size
+    phase = ((np.arange(n) // period) + (splitmix64(seed) & 3)) & 3
+    iq = np.zeros(2 * n, dtype=np.float32)
+    i = np.where(phase == 0, mag, np.where(phase == 2, -mag, 0)).astype(np.float32)
+    q = np.where(phase == 1, mag, np.where(phase == 3, -mag, 0)).astype(np.float32)
+    iq[0::2] = i
+    iq[1::2] = q
+    return iq
+
+
+def synthetic_stream_i16(stream, length, names=None):
+    """Deterministic synthetic capture: fixtures (seeded choice, circular shift) tiled to `length` samples
+    with an integer gain of 3/4 or 1 on the int16 grid; values stay exact multiples of 2^-15."""
+    names = names or fixture_names()
+    state = splitmix64(0x9E3779B97F4A7C15 * (stream + 1) & 0xFFFFFFFFFFFFFFFF)
+    out = np.empty(length, dtype=np.int16)
+    pos = 0
+    while pos < length:
+        state = splitmix64(state)
+        src = load_fixture_i16(names[state % len(names)])
+        state = splitmix64(state)
+        shift = state % src.size
+        state = splitmix64(state)
+        piece = np.roll(src, -int(shift))
+        if state & 1:
+            piece = ((piece.astype(np.int32) * 3) // 4).astype(np.int16)
+        n = min(length - pos, piece.size)
+        out[pos:pos + n] = piece[:n]
+        pos += n
+    return out
