@@ -142,6 +142,10 @@ int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t stream_id, uint32_t *count);
 /* device-resident view of the frames produced since the last sync: packed records of 32-bit words
  * [stream_id, tech, type, flags, phase, rate, start, end, length, payload...]; used for RCCL frame gathers */
 int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cursor_words, uint64_t *capacity_words);
+/* use caller-owned device memory as the frame sink (e.g. a torch tensor that RCCL can gather directly):
+ * `words` holds capacity_words 32-bit words, `ctl` holds 4 words ([0] cursor in words, [1] dropped frames).
+ * Pass words == NULL to return to the context's own sink. Implies a sync + rewind. */
+int nfcgpu_sink_attach(nfcgpu_ctx *ctx, void *words, uint64_t capacity_words, void *ctl);
 /* when enabled, nfcgpu_sync leaves the sink untouched (no host drain) until nfcgpu_sink_rewind */
 int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold);
 int nfcgpu_sink_rewind(nfcgpu_ctx *ctx);

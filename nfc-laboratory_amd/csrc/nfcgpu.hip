@@ -59,6 +59,9 @@ struct nfcgpu_ctx
    uint32_t *dSink = nullptr;
    uint32_t *dSinkCtl = nullptr;
    uint64_t sinkWords = 0;
+   uint32_t *ownSink = nullptr; /* the context's own sink, kept while a caller-provided one is attached */
+   uint32_t *ownSinkCtl = nullptr;
+   uint64_t ownSinkWords = 0;
    NfcWork *dWorks = nullptr;
    NfcConfig *dConfigs = nullptr;
    uint8_t *dStage = nullptr;
@@ -419,6 +422,10 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
       return NFCGPU_ENOMEM;
    }
 
+   ctx->ownSink = ctx->dSink;
+   ctx->ownSinkCtl = ctx->dSinkCtl;
+   ctx->ownSinkWords = ctx->sinkWords;
+
    ctx->streams.resize(maxStreams);
    ctx->hWorks.resize(maxStreams);
    for (auto &w: ctx->hWorks)
@@ -453,8 +460,8 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    (void)hipFree(ctx->dStates);
    (void)hipFree(ctx->dRings);
    (void)hipFree(ctx->dBytes);
-   (void)hipFree(ctx->dSink);
-   (void)hipFree(ctx->dSinkCtl);
+   (void)hipFree(ctx->ownSink ? ctx->ownSink : ctx->dSink);
+   (void)hipFree(ctx->ownSinkCtl ? ctx->ownSinkCtl : ctx->dSinkCtl);
    (void)hipFree(ctx->dWorks);
    (void)hipFree(ctx->dConfigs);
    (void)hipFree(ctx->dStage);
@@ -962,6 +969,35 @@ int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cu
    if (capacity)
       *capacity = ctx->sinkWords;
    return NFCGPU_OK;
+}
+
+int nfcgpu_sink_attach(nfcgpu_ctx *ctx, void *words, uint64_t capacityWords, void *ctl)
+{
+   if (!ctx || (words && (!ctl || capacityWords < 4ull * NFC_FRAME_MAX_WORDS || capacityWords > 0xFFFFFFF0ull)))
+      return NFCGPU_EINVAL;
+
+   const bool wasHeld = ctx->hold;
+   ctx->hold = false;
+   int rc = nfcgpu_sync(ctx); /* drain what the current sink holds */
+   ctx->hold = wasHeld;
+
+   if (rc && rc != NFCGPU_EOVERFLOW)
+      return rc;
+
+   if (words)
+   {
+      ctx->dSink = (uint32_t *)words;
+      ctx->dSinkCtl = (uint32_t *)ctl;
+      ctx->sinkWords = capacityWords;
+   }
+   else
+   {
+      ctx->dSink = ctx->ownSink;
+      ctx->dSinkCtl = ctx->ownSinkCtl;
+      ctx->sinkWords = ctx->ownSinkWords;
+   }
+
+   return nfcgpu_sink_rewind(ctx);
 }
 
 int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold)

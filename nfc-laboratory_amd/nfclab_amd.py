@@ -93,6 +93,13 @@ def load_library(path=LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own ROCm runtime (same SONAMEs as /opt/rocm). Whichever copy is loaded first serves the
+    # whole process, and torch only finds the GPU through its own copy: load torch first when it is installed.
+    if os.environ.get("NFCGPU_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = ctypes.CDLL(path)
     vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
     P = ctypes.POINTER
@@ -113,6 +120,7 @@ def load_library(path=LIB_PATH):
     lib.nfcgpu_poll.argtypes = [vp, u32, P(Frame), u32, P(u32)]
     lib.nfcgpu_pending.argtypes = [vp, u32, P(u32)]
     lib.nfcgpu_sink_device_view.argtypes = [vp, P(vp), P(vp), P(u64)]
+    lib.nfcgpu_sink_attach.argtypes = [vp, vp, u64, vp]
     lib.nfcgpu_sink_hold.argtypes = [vp, i32]
     lib.nfcgpu_sink_rewind.argtypes = [vp]
     lib.nfcgpu_stats_get.argtypes = [vp, P(Stats)]
@@ -215,6 +223,9 @@ class NfcGpu:
         words, cursor, cap = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
         self._check(self.lib.nfcgpu_sink_device_view(self.ctx, ctypes.byref(words), ctypes.byref(cursor), ctypes.byref(cap)))
         return words.value, cursor.value, cap.value
+
+    def sink_attach(self, words_ptr, capacity_words, ctl_ptr):
+        self._check(self.lib.nfcgpu_sink_attach(self.ctx, words_ptr, capacity_words, ctl_ptr))
 
     def sink_hold(self, hold):
         self._check(self.lib.nfcgpu_sink_hold(self.ctx, int(hold)))
