@@ -145,11 +145,14 @@ def test_tech_mask_and_thresholds_follow_reference(gpu):
 def test_empty_and_short_inputs(gpu):
     sid = gpu.open()
     gpu.submit(sid, np.zeros(0, np.float32), FS)
-    gpu.submit(sid, np.zeros(5, np.float32), FS)
     assert gpu.poll(sid) == []
+    gpu.submit(sid, np.zeros(5, np.float32), FS)
     gpu.flush(sid)
     frames = gpu.poll(sid)
-    assert len(frames) == 1 and frames[0][1] == 0x100 and frames[0][5] == 4  # CarrierOff at signalClock
+    if T.reference_lib() is not None:
+        ref, _ = T.reference_decode(np.zeros(5, np.float32), keep_carrier=True, send_eof=True)
+        assert frames == ref
+    assert frames[-1][1] == 0x100 and frames[-1][5] == 4  # end-of-stream frame: CarrierOff at signalClock
     gpu.close_stream(sid)
 
 
