@@ -201,11 +201,18 @@ NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, u
 /* front end: NfcDecoderStatus::nextSample, NfcTech.cpp:28-105                                */
 /* ------------------------------------------------------------------------------------------ */
 
-NFC_DEV void nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+/* what the front end derives from the current sample (the reference reads these back from its ring) */
+struct NfcNow
 {
-   ++s.clock;
-   ++s.pulseFilter;
+   float x;     /* samplingValue  */
+   float filt;  /* filteredValue  */
+   float mdev;  /* meanDeviation  */
+   float depth; /* modulateDepth  */
+};
 
+/* the caller has already advanced s.clock and s.pulseFilter for this sample */
+NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+{
    float env = s.env;
    float diff = nfc_abs(value - env) / env;
 
@@ -230,12 +237,18 @@ NFC_DEV void nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneM
 
    float clamped = (value < 0.0f) ? 0.0f : ((env < value) ? env : value);
 
-   uint32_t slot = s.clock & NFC_HMASK;
+   NfcNow now;
+   now.x = value;
+   now.filt = filtered;
+   now.mdev = s.mdev;
+   now.depth = (env - clamped) / env;
 
-   NFC_AT(mem.x, slot) = value;
-   NFC_AT(mem.filt, slot) = filtered;
-   NFC_AT(mem.mdev, slot) = s.mdev;
-   NFC_AT(mem.depth, slot) = (env - clamped) / env;
+   const uint32_t slot = s.clock & NFC_HMASK;
+
+   NFC_AT(mem.x, slot) = now.x;
+   NFC_AT(mem.filt, slot) = now.filt;
+   NFC_AT(mem.mdev, slot) = now.mdev;
+   NFC_AT(mem.depth, slot) = now.depth;
 
    float rectified = nfc_abs(filtered);
 
@@ -251,11 +264,13 @@ NFC_DEV void nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneM
    {
       s.edgePeak = 0;
    }
+
+   return now;
 }
 
-/* ring positions idx % period for the six correlators (idx = 1024 - delay + clock, as the
- * reference's offsetSignalIndex + signalClock). Incremental, except in a window around the
- * 32-bit clock wrap and at stream start where the exact modulo is taken. */
+/* ring positions idx % period for the correlators (idx = 1024 - delay + clock, as the reference's
+ * offsetSignalIndex + signalClock). Incremental, except in a window around the 32-bit clock wrap and at
+ * stream start where the exact modulo is taken. */
 NFC_DEV bool nfc_exact_zone(uint32_t clock)
 {
    return (uint32_t)(clock + 1024u) < 2048u;
@@ -267,26 +282,38 @@ NFC_DEV uint32_t nfc_bump(uint32_t pos, uint32_t period)
    return pos >= period ? 0u : pos;
 }
 
+NFC_DEV uint32_t nfc_next_pos(uint32_t clock, bool exact, uint32_t pos, const NfcRate &rt, uint32_t period)
+{
+   return exact ? (uint32_t)(1024u - rt.delay + clock) % period : nfc_bump(pos, period);
+}
+
 NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s)
 {
+   const bool exact = nfc_exact_zone(s.clock);
+
+   /* written out per correlator: every state field keeps a compile-time address, so the record stays in VGPRs */
+   s.posA[0] = nfc_next_pos(s.clock, exact, s.posA[0], c.a[0], c.a[0].p1);
+   s.posA[1] = nfc_next_pos(s.clock, exact, s.posA[1], c.a[1], c.a[1].p1);
+   s.posA[2] = nfc_next_pos(s.clock, exact, s.posA[2], c.a[2], c.a[2].p1);
+   s.posF[1] = nfc_next_pos(s.clock, exact, s.posF[1], c.f[1], c.f[1].p1);
+   s.posF[2] = nfc_next_pos(s.clock, exact, s.posF[2], c.f[2], c.f[2].p1);
+   s.posV1 = nfc_next_pos(s.clock, exact, s.posV1, c.v, c.v.p1);
+   s.posV0 = nfc_next_pos(s.clock, exact, s.posV0, c.v, c.v.p0);
+}
+
+/* ring position of the locked correlator: a private copy taken at lock time and advanced alongside the others
+ * (selecting among posA/posF by index would put the whole state record back into scratch memory) */
+NFC_DEV void nfc_advance_lock_pos(NfcStreamState &s)
+{
    if (nfc_exact_zone(s.clock))
-   {
-      for (int r = 0; r < 3; r++)
-         s.posA[r] = (uint32_t)(1024u - c.a[r].delay + s.clock) % c.a[r].p1;
-      for (int r = 1; r < 3; r++)
-         s.posF[r] = (uint32_t)(1024u - c.f[r].delay + s.clock) % c.f[r].p1;
-      s.posV1 = (uint32_t)(1024u - c.v.delay + s.clock) % c.v.p1;
-      s.posV0 = (uint32_t)(1024u - c.v.delay + s.clock) % c.v.p0;
-   }
+      s.lockPos = (uint32_t)(1024u - s.rt.delay + s.clock) % s.rt.p1;
    else
-   {
-      for (int r = 0; r < 3; r++)
-         s.posA[r] = nfc_bump(s.posA[r], c.a[r].p1);
-      for (int r = 1; r < 3; r++)
-         s.posF[r] = nfc_bump(s.posF[r], c.f[r].p1);
-      s.posV1 = nfc_bump(s.posV1, c.v.p1);
-      s.posV0 = nfc_bump(s.posV0, c.v.p0);
-   }
+      s.lockPos = nfc_bump(s.lockPos, s.rt.p1);
+}
+
+NFC_DEV uint32_t nfc_lock_pos(const NfcStreamState &s)
+{
+   return s.lockPos;
 }
 
 /* (idx + add) % period given pos = idx % period; exact modulo near the clock wrap */
@@ -324,81 +351,110 @@ NFC_DEV void nfc_detect_carrier(const NfcConfig &c, NfcStreamState &s, const Nfc
    }
 }
 
-/* the shared sliding correlator: box sum of width p2 over the delayed raw signal,
- * kept in a p1-deep ring; S0/S1 are differences of ring entries. */
+/* ------------------------------------------------------------------------------------------ */
+/* the shared sliding correlator: box sum of width p2 over the delayed signal, kept  */
+/* in a p1-deep ring; S0/S1 are differences of ring entries. Memory reads ("taps") are split from  */
+/* the arithmetic so that a step can issue all of its reads first and pay one memory latency.     */
+/* ------------------------------------------------------------------------------------------ */
+
+struct NfcTap
+{
+   float in;   /* value entering the window */
+   float out;  /* value leaving the window  */
+   float c2;   /* ring[(idx + p2) % p1]     */
+   float c3;   /* ring[(idx - 1) % p1]      */
+};
+
 struct NfcCorr
 {
    float s0, s1;
 };
 
-NFC_DEV NfcCorr nfc_correlate_raw(const NfcLaneMem &mem, NfcStreamState &s, NfcMod &m, const NfcRate &rt,
-                                  uint32_t ringBase, uint32_t pos)
+/* taps of the raw-signal correlator; `fresh` = the entering value is the current sample (delay 0) */
+NFC_DEV NfcTap nfc_tap_raw(const NfcLaneMem &mem, uint32_t clock, const NfcRate &rt, uint32_t base, uint32_t pos, bool needC3)
 {
-   uint32_t cur = (s.clock - rt.delay) & NFC_HMASK;
-   uint32_t old = (s.clock - rt.delay - rt.p2) & NFC_HMASK;
+   NfcTap t;
+   const uint32_t cur = clock - rt.delay;
+   t.in = NFC_AT(mem.x, cur & NFC_HMASK);
+   t.out = NFC_AT(mem.x, (cur - rt.p2) & NFC_HMASK);
+   t.c2 = NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p2, rt.p1));
+   t.c3 = needC3 ? NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p1 - 1u, rt.p1)) : 0.0f;
+   return t;
+}
 
-   m.acc += NFC_AT(mem.x, cur);
-   m.acc -= NFC_AT(mem.x, old);
+NFC_DEV NfcCorr nfc_corr_apply(const NfcLaneMem &mem, NfcMod &m, const NfcTap &t, uint32_t base, uint32_t pos)
+{
+   m.acc += t.in;
+   m.acc -= t.out;
 
-   uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
-   uint32_t f3 = nfc_point(s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1);
-
-   NFC_AT(mem.corr, ringBase + pos) = m.acc;
-
-   float a = m.acc;
-   float b = NFC_AT(mem.corr, ringBase + f2);
-   float d = NFC_AT(mem.corr, ringBase + f3);
+   NFC_AT(mem.corr, base + pos) = m.acc;
 
    NfcCorr r;
-   r.s0 = a - b;
-   r.s1 = b - d;
+   r.s0 = m.acc - t.c2;
+   r.s1 = t.c2 - t.c3;
    return r;
 }
 
-/* same correlator over 10*filtered^2 (listen ASK, NfcA.cpp:1115-1131) */
-NFC_DEV NfcCorr nfc_correlate_power(const NfcLaneMem &mem, NfcStreamState &s, NfcMod &m, const NfcRate &rt,
-                                    uint32_t ringBase, uint32_t pos)
+/* same correlator over 10*filtered^2 (listen ASK, NfcA.cpp:1115-1131); window w = p2 (NFC-A) */
+NFC_DEV NfcCorr nfc_correlate_power(const NfcLaneMem &mem, uint32_t clock, NfcMod &m, const NfcRate &rt, uint32_t base, uint32_t pos)
 {
-   uint32_t cur = (s.clock - rt.delay);
-   float v = NFC_AT(mem.filt, cur & NFC_HMASK);
-   float sq = v * v * 10.0f;
+   const uint32_t cur = clock - rt.delay;
+
+   const float v = NFC_AT(mem.filt, cur & NFC_HMASK);
+   const float old = NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
+   const float c2 = NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p2, rt.p1));
+   const float c3 = NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
+
+   const float sq = v * v * 10.0f;
 
    NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
 
    m.acc += sq;
-   m.acc -= NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
+   m.acc -= old;
 
-   uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
-   uint32_t f3 = nfc_point(s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1);
-
-   NFC_AT(mem.corr, ringBase + pos) = m.acc;
-
-   float a = m.acc;
-   float b = NFC_AT(mem.corr, ringBase + f2);
-   float d = NFC_AT(mem.corr, ringBase + f3);
+   NFC_AT(mem.corr, base + pos) = m.acc;
 
    NfcCorr r;
-   r.s0 = a - b;
-   r.s1 = b - d;
+   r.s0 = m.acc - c2;
+   r.s1 = c2 - c3;
    return r;
 }
 
-/* delayed self product for BPSK listen frames (NfcA.cpp:1236-1244, NfcB.cpp:785-796) */
-NFC_DEV float nfc_phase_product(const NfcLaneMem &mem, const NfcStreamState &s, const NfcRate &rt)
+/* delayed self product for BPSK listen frames (NfcA.cpp:1236-1244, NfcB.cpp:785-796); returns the product and
+ * the product leaving the p4 window */
+struct NfcPhase
 {
-   uint32_t cur = (s.clock - rt.delay);
-   float a = NFC_AT(mem.filt, cur & NFC_HMASK);
-   float b = NFC_AT(mem.filt, (cur - rt.p1) & NFC_HMASK);
-   float p = a * b * 10.0f;
-   NFC_AT(mem.prod, cur & NFC_PMASK) = p;
+   float in, out;
+};
+
+NFC_DEV NfcPhase nfc_phase_product(const NfcLaneMem &mem, uint32_t clock, const NfcRate &rt)
+{
+   const uint32_t cur = clock - rt.delay;
+   const float a = NFC_AT(mem.filt, cur & NFC_HMASK);
+   const float b = NFC_AT(mem.filt, (cur - rt.p1) & NFC_HMASK);
+   NfcPhase p;
+   p.out = NFC_AT(mem.prod, (cur - rt.p4) & NFC_PMASK);
+   p.in = a * b * 10.0f;
+   NFC_AT(mem.prod, cur & NFC_PMASK) = p.in;
    return p;
 }
 
-NFC_DEV void nfc_phase_integrate(const NfcLaneMem &mem, const NfcStreamState &s, NfcMod &m, const NfcRate &rt, float p)
+NFC_DEV void nfc_phase_integrate(NfcMod &m, const NfcPhase &p)
 {
-   uint32_t cur = (s.clock - rt.delay);
-   m.phaseAcc += p;
-   m.phaseAcc -= NFC_AT(mem.prod, (cur - rt.p4) & NFC_PMASK);
+   m.phaseAcc += p.in;
+   m.phaseAcc -= p.out;
+}
+
+/* take the working copy of a modulation at lock time */
+NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcMod &m, const NfcRate &rt, uint32_t tech, uint32_t rate,
+                           uint32_t base, uint32_t pos)
+{
+   s.lock = m;
+   s.rt = rt;
+   s.lockBase = base;
+   s.lockPos = pos;
+   s.lockTech = tech;
+   s.lockRate = rate;
 }
 
 #include "nfc_tech_a.hpp"
@@ -412,37 +468,66 @@ NFC_DEV void nfc_phase_integrate(const NfcLaneMem &mem, const NfcStreamState &s,
 
 NFC_DEV void nfc_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
 {
-   nfc_front_end(c, s, mem, value);
+   ++s.clock;
+   ++s.pulseFilter;
+
    nfc_advance_positions(c, s);
+
+   if (s.lockTech == 0)
+   {
+      /* search bank, NfcDecoder.cpp:394-418. All history reads of the eight detectors are issued before the
+       * front end stores this sample (none of them can alias the slot being written: their delays are > 0). */
+      NfcTapsA ta = {};
+      NfcTapsB tb = {};
+      NfcTapsF tf = {};
+      NfcTapsV tv = {};
+
+      const bool armed = s.clock >= 1024u;
+
+      if (armed && (c.enabled & 1u))
+         nfca_load_taps(c, s, mem, ta);
+      if (armed && (c.enabled & 2u))
+         nfcb_load_taps(c, s, mem, tb);
+      if (armed && (c.enabled & 4u))
+         nfcf_load_taps(c, s, mem, tf);
+      if (armed && (c.enabled & 8u))
+         nfcv_load_taps(c, s, mem, tv);
+
+      const NfcNow now = nfc_front_end(c, s, mem, value);
+
+      nfc_detect_carrier(c, s, mem);
+
+      /* first detector that locks wins, later ones skip this sample */
+      if ((c.enabled & 1u) && nfca_detect(c, s, mem, ta, now))
+         return;
+      if ((c.enabled & 2u) && nfcb_detect(c, s, mem, tb, now))
+         return;
+      if ((c.enabled & 4u) && nfcf_detect(c, s, mem, tf, now))
+         return;
+      if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
+         return;
+
+      return;
+   }
+
+   nfc_advance_lock_pos(s);
+
+   const NfcNow now = nfc_front_end(c, s, mem, value);
 
    switch (s.lockTech)
    {
       case NFC_TECH_A:
-         nfca_decode(c, s, mem);
+         nfca_decode(c, s, mem, now);
          break;
       case NFC_TECH_B:
-         nfcb_decode(c, s, mem);
+         nfcb_decode(c, s, mem, now);
          break;
       case NFC_TECH_F:
-         nfcf_decode(c, s, mem);
-         break;
-      case NFC_TECH_V:
-         nfcv_decode(c, s, mem);
+         nfcf_decode(c, s, mem, now);
          break;
       default:
-      {
-         /* search bank, NfcDecoder.cpp:394-418: first detector that locks wins, later ones skip this sample */
-         nfc_detect_carrier(c, s, mem);
-
-         if ((c.enabled & 1u) && nfca_detect(c, s, mem))
-            break;
-         if ((c.enabled & 2u) && nfcb_detect(c, s, mem))
-            break;
-         if ((c.enabled & 4u) && nfcf_detect(c, s, mem))
-            break;
-         if ((c.enabled & 8u) && nfcv_detect(c, s, mem))
-            break;
-      }
+         nfcv_decode(c, s, mem, now);
+         break;
    }
 }
 

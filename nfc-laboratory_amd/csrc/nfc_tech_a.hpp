@@ -22,11 +22,13 @@ NFC_DEV void nfca_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
 /* resetModulation, NfcA.cpp:1451-1475 */
 NFC_DEV void nfca_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   for (int r = 0; r < 3; r++)
-   {
-      nfc_mod_clear(s.modA[r]);
-      nfc_zero_ring(mem.corr, c.corrOffset[r], c.a[r].p1);
-   }
+   nfc_mod_clear(s.modA[0]);
+   nfc_mod_clear(s.modA[1]);
+   nfc_mod_clear(s.modA[2]);
+   nfc_mod_clear(s.lock);
+
+   /* the three rings are adjacent */
+   nfc_zero_ring(mem.corr, c.corrOffset[0], c.a[0].p1 + c.a[1].p1 + c.a[2].p1);
 
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
@@ -255,7 +257,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    flags |= s.chainedA;
 
    const bool locked = (s.lockTech == NFC_TECH_A);
-   const uint32_t delay = locked ? c.a[s.lockRate].delay : 0u;
+   const uint32_t delay = locked ? s.rt.delay : 0u;
 
    if (poll)
    {
@@ -279,8 +281,140 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    s.frameEnd = 0;
 }
 
+/* history reads of the three poll-SOF correlators, issued before the front end stores the new sample */
+struct NfcTapsA
+{
+   NfcTap t[3];
+   float deep[3];
+};
+
+template <int R>
+NFC_DEV void nfca_load_taps_rate(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsA &taps)
+{
+   const NfcRate &rt = c.a[R];
+   taps.t[R] = nfc_tap_raw(mem, s.clock, rt, c.corrOffset[R], s.posA[R], true);
+   taps.deep[R] = NFC_AT(mem.depth, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+}
+
+NFC_DEV void nfca_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsA &taps)
+{
+   nfca_load_taps_rate<0>(c, s, mem, taps);
+   nfca_load_taps_rate<1>(c, s, mem, taps);
+   nfca_load_taps_rate<2>(c, s, mem, taps);
+}
+
 /* ---- search: SOF of a poll frame = one modified-Miller pause, NfcA.cpp:217-411 ---- */
-NFC_DEV bool nfca_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+template <int R>
+NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsA &taps, const NfcNow &now,
+                              float minimumCorrelation, float minimumDepth)
+{
+   const NfcRate &rt = c.a[R];
+   NfcMod &m = s.modA[R];
+
+   NfcTap tap = taps.t[R];
+   if (rt.delay == 0)
+      tap.in = now.x; /* the newest sample is not in memory yet when the taps are read */
+
+   NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[R], s.posA[R]);
+   float sd = (k.s0 - k.s1) / (float)rt.p2;
+
+   if (m.peakTime && s.clock > m.peakTime + rt.p1)
+   {
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+      m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+   }
+
+   if (s.clock < m.winStart)
+      return false;
+
+   if (!m.symStart)
+   {
+      if (sd < -minimumCorrelation)
+      {
+         float deep = taps.deep[R];
+
+         if (sd < m.peak)
+         {
+            m.peak = sd;
+            m.peakTime = s.clock;
+            m.winEnd = s.clock + rt.p4;
+         }
+
+         if (deep > m.aux)
+         {
+            m.aux = deep;
+            m.auxTime = s.clock;
+         }
+      }
+   }
+   else if (sd > minimumCorrelation)
+   {
+      if (sd > m.peak)
+      {
+         m.peak = sd;
+         m.peakTime = s.clock;
+      }
+   }
+
+   if (s.clock != m.winEnd)
+      return false;
+
+   if (!m.symStart)
+   {
+      if (m.aux < minimumDepth)
+      {
+         m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+         m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+         return false;
+      }
+
+      m.sync = m.peakTime + rt.p2;
+      m.winStart = m.sync - rt.p8;
+      m.winEnd = m.sync + rt.p8;
+      m.symStart = m.peakTime - rt.p2;
+      m.peakTime = 0;
+      m.peak = 0;
+      return false;
+   }
+
+   m.symEnd = m.peakTime;
+   m.pulses = m.symEnd - m.symStart;
+
+   const uint32_t minimumWidth = rt.p1 - rt.p4;
+   const uint32_t maximumWidth = rt.p1 + rt.p4;
+
+   if (m.peakTime == 0 || m.aux < minimumDepth || m.pulses < minimumWidth || m.pulses > maximumWidth)
+   {
+      m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      return false;
+   }
+
+   m.sync = m.symEnd + rt.p1;
+   m.winStart = m.sync - rt.p8;
+   m.winEnd = m.sync + rt.p8;
+   m.thr = m.peak / 2;
+   m.c0 = 0;
+   m.c1 = 0;
+   m.peakTime = 0;
+   m.peak = 0;
+
+   s.frameType = NFC_FRAME_POLL;
+   s.frameRate = rt.symbolsPerSecond;
+   s.frameStart = m.symStart - rt.delay;
+   s.frameEnd = 0;
+
+   s.symValue = 0;
+   s.symStart = m.symStart - rt.delay;
+   s.symEnd = m.symEnd - rt.delay;
+   s.symLength = s.symEnd - s.symStart;
+   s.symPattern = A_Z;
+
+   nfc_take_lock(s, m, rt, NFC_TECH_A, (uint32_t)R, c.corrOffset[R], s.posA[R]);
+   return true;
+}
+
+NFC_DEV bool nfca_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsA &taps, const NfcNow &now)
 {
    if (s.clock < 1024u)
       return false;
@@ -291,110 +425,12 @@ NFC_DEV bool nfca_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    const float minimumCorrelation = s.env * c.corrThreshold[0];
    const float minimumDepth = c.minDepth[0];
 
-   for (int r = 0; r < 3; r++)
-   {
-      const NfcRate &rt = c.a[r];
-      NfcMod &m = s.modA[r];
-
-      NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[r], s.posA[r]);
-      float sd = (k.s0 - k.s1) / (float)rt.p2;
-
-      if (m.peakTime && s.clock > m.peakTime + rt.p1)
-      {
-         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
-         m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
-      }
-
-      if (s.clock < m.winStart)
-         continue;
-
-      if (!m.symStart)
-      {
-         if (sd < -minimumCorrelation)
-         {
-            float deep = NFC_AT(mem.depth, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
-
-            if (sd < m.peak)
-            {
-               m.peak = sd;
-               m.peakTime = s.clock;
-               m.winEnd = s.clock + rt.p4;
-            }
-
-            if (deep > m.aux)
-            {
-               m.aux = deep;
-               m.auxTime = s.clock;
-            }
-         }
-      }
-      else if (sd > minimumCorrelation)
-      {
-         if (sd > m.peak)
-         {
-            m.peak = sd;
-            m.peakTime = s.clock;
-         }
-      }
-
-      if (s.clock != m.winEnd)
-         continue;
-
-      if (!m.symStart)
-      {
-         if (m.aux < minimumDepth)
-         {
-            m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
-            m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
-            continue;
-         }
-
-         m.sync = m.peakTime + rt.p2;
-         m.winStart = m.sync - rt.p8;
-         m.winEnd = m.sync + rt.p8;
-         m.symStart = m.peakTime - rt.p2;
-         m.peakTime = 0;
-         m.peak = 0;
-         continue;
-      }
-
-      m.symEnd = m.peakTime;
-      m.pulses = m.symEnd - m.symStart;
-
-      const uint32_t minimumWidth = rt.p1 - rt.p4;
-      const uint32_t maximumWidth = rt.p1 + rt.p4;
-
-      if (m.peakTime == 0 || m.aux < minimumDepth || m.pulses < minimumWidth || m.pulses > maximumWidth)
-      {
-         m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
-         m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
-         continue;
-      }
-
-      m.sync = m.symEnd + rt.p1;
-      m.winStart = m.sync - rt.p8;
-      m.winEnd = m.sync + rt.p8;
-      m.thr = m.peak / 2;
-      m.c0 = 0;
-      m.c1 = 0;
-      m.peakTime = 0;
-      m.peak = 0;
-
-      s.frameType = NFC_FRAME_POLL;
-      s.frameRate = rt.symbolsPerSecond;
-      s.frameStart = m.symStart - rt.delay;
-      s.frameEnd = 0;
-
-      s.symValue = 0;
-      s.symStart = m.symStart - rt.delay;
-      s.symEnd = m.symEnd - rt.delay;
-      s.symLength = s.symEnd - s.symStart;
-      s.symPattern = A_Z;
-
-      s.lockTech = NFC_TECH_A;
-      s.lockRate = (uint32_t)r;
+   if (nfca_detect_rate<0>(c, s, mem, taps, now, minimumCorrelation, minimumDepth))
       return true;
-   }
+   if (nfca_detect_rate<1>(c, s, mem, taps, now, minimumCorrelation, minimumDepth))
+      return true;
+   if (nfca_detect_rate<2>(c, s, mem, taps, now, minimumCorrelation, minimumDepth))
+      return true;
 
    return false;
 }
@@ -402,11 +438,12 @@ NFC_DEV bool nfca_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 /* ---- poll frame symbols (modified Miller), NfcA.cpp:812-934 ---- */
 NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const uint32_t r = s.lockRate;
-   const NfcRate &rt = c.a[r];
-   NfcMod &m = s.modA[r];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
-   NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[r], s.posA[r]);
+   const uint32_t pos = nfc_lock_pos(s);
+   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.lockBase, pos, true);
+   NfcCorr k = nfc_corr_apply(mem, m, tap, s.lockBase, pos);
    float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
 
    if (s.clock < m.winStart)
@@ -498,7 +535,6 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
             flags |= NFC_FLAG_SHORT;
 
          const uint32_t start = s.frameStart, end = s.frameEnd, rate = s.frameRate, len = s.bsBytes;
-         const uint32_t lockedRate = s.lockRate;
 
          nfca_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
@@ -506,7 +542,7 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
          nfc_clear_assembly(s);
 
          if (s.lockTech == NFC_TECH_A)
-            nfc_poll_end_clear(mem, s.modA[lockedRate], c.corrOffset[lockedRate], c.a[lockedRate].p1);
+            nfc_poll_end_clear(mem, s.lock, s.lockBase, s.rt.p1);
 
          return;
       }
@@ -545,33 +581,35 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
 }
 
 /* ---- listen SOF, 106k OOK subcarrier, NfcA.cpp:939-1090 ---- */
-NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const uint32_t r = s.lockRate;
-   const NfcRate &rt = c.a[r];
-   NfcMod &m = s.modA[r];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
    NfcTiming &t = s.tim[0];
 
    /* this stage only forms S0 (NfcA.cpp:962-975): same ring, no S1 */
    const uint32_t cur = s.clock - rt.delay;
-   float v = NFC_AT(mem.filt, cur & NFC_HMASK);
-   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
-   float sq = v * v * 10.0f;
+   const uint32_t pos = nfc_lock_pos(s);
+
+   const float v = NFC_AT(mem.filt, cur & NFC_HMASK);
+   const float old = NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
+   const float c2 = NFC_AT(mem.corr, s.lockBase + nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1));
+   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const float deep = now.depth;
+   const float sq = v * v * 10.0f;
 
    NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
    m.acc += sq;
-   m.acc -= NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
+   m.acc -= old;
 
-   const uint32_t pos = s.posA[r];
-   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
-   NFC_AT(mem.corr, c.corrOffset[r] + pos) = m.acc;
-   float s0 = m.acc - NFC_AT(mem.corr, c.corrOffset[r] + f2);
+   NFC_AT(mem.corr, s.lockBase + pos) = m.acc;
+   float s0 = m.acc - c2;
 
    if (s.clock < t.guardEnd)
       return SYM_NONE;
 
    if (s.clock == t.guardEnd)
-      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK) * (float)rt.p8;
+      m.thr = guardDev * (float)rt.p8;
 
    if (s.clock > t.waitingEnd)
       return SYM_TIMEOUT;
@@ -641,11 +679,10 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
 /* ---- listen symbols, 106k Manchester, NfcA.cpp:1095-1214 ---- */
 NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const uint32_t r = s.lockRate;
-   const NfcRate &rt = c.a[r];
-   NfcMod &m = s.modA[r];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
-   NfcCorr k = nfc_correlate_power(mem, s, m, rt, c.corrOffset[r], s.posA[r]);
+   NfcCorr k = nfc_correlate_power(mem, s.clock, m, rt, s.lockBase, nfc_lock_pos(s));
    float sd = nfc_abs(k.s0 - k.s1);
 
    if (s.clock < m.winStart)
@@ -709,22 +746,22 @@ NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, c
 }
 
 /* ---- listen SOF, BPSK (212k/424k), NfcA.cpp:1220-1329 ---- */
-NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const uint32_t r = s.lockRate;
-   const NfcRate &rt = c.a[r];
-   NfcMod &m = s.modA[r];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
    NfcTiming &t = s.tim[0];
 
    const uint32_t cur = s.clock - rt.delay;
-   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
-   float p = nfc_phase_product(mem, s, rt);
+   const float deep = now.depth;
+   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
 
    if (s.clock < t.guardEnd)
       return SYM_NONE;
 
    if (s.clock == t.guardEnd)
-      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK);
+      m.thr = guardDev;
 
    if (s.clock > t.waitingEnd)
       return SYM_TIMEOUT;
@@ -732,7 +769,7 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
    if (deep > c.minDepth[0])
       return SYM_TIMEOUT;
 
-   nfc_phase_integrate(mem, s, m, rt, p);
+   nfc_phase_integrate(m, p);
 
    if (m.phaseAcc > m.thr)
    {
@@ -777,12 +814,11 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
 /* ---- listen symbols, BPSK, NfcA.cpp:1334-1421 ---- */
 NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const uint32_t r = s.lockRate;
-   const NfcRate &rt = c.a[r];
-   NfcMod &m = s.modA[r];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
-   float p = nfc_phase_product(mem, s, rt);
-   nfc_phase_integrate(mem, s, m, rt, p);
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
+   nfc_phase_integrate(m, p);
 
    if (!m.auxTime)
    {
@@ -828,7 +864,7 @@ NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const Nfc
 {
    uint32_t phase = 0;
    const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes;
-   const uint32_t rate = c.a[s.lockRate].symbolsPerSecond;
+   const uint32_t rate = s.rt.symbolsPerSecond;
 
    nfca_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
    nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
@@ -836,7 +872,7 @@ NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const Nfc
 }
 
 /* ---- one sample in locked NFC-A mode: decodeFrame, NfcA.cpp:416-803 ---- */
-NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
    NfcTiming &t = s.tim[0];
 
@@ -857,7 +893,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    {
       if (!s.frameStart)
       {
-         uint32_t pattern = nfca_listen_ask_start(c, s, mem);
+         uint32_t pattern = nfca_listen_ask_start(c, s, mem, now);
 
          if (pattern == A_D)
             s.frameStart = s.symStart;
@@ -898,7 +934,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             return;
          }
 
-         nfca_reset_search(s, s.modA[s.lockRate]);
+         nfca_reset_search(s, s.lock);
          return;
       }
 
@@ -928,7 +964,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    /* 212k / 424k: BPSK */
    if (!s.frameStart)
    {
-      uint32_t pattern = nfca_listen_bpsk_start(c, s, mem);
+      uint32_t pattern = nfca_listen_bpsk_start(c, s, mem, now);
 
       if (pattern == A_S)
          s.frameStart = s.symStart;

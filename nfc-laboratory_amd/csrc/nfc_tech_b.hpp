@@ -21,9 +21,10 @@ NFC_DEV void nfcb_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
 
 NFC_DEV void nfcb_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   for (int r = 0; r < 3; r++)
-      nfc_mod_clear(s.modB[r]);
-
+   nfc_mod_clear(s.modB[0]);
+   nfc_mod_clear(s.modB[1]);
+   nfc_mod_clear(s.modB[2]);
+   nfc_mod_clear(s.lock);
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
 
@@ -121,7 +122,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
    /* chained flags are always zero for NFC-B */
 
    const bool locked = (s.lockTech == NFC_TECH_B);
-   const uint32_t delay = locked ? c.b[s.lockRate].delay : 0u;
+   const uint32_t delay = locked ? s.rt.delay : 0u;
 
    if (poll)
    {
@@ -145,101 +146,46 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
    s.frameEnd = 0;
 }
 
-/* ---- search: SOF = falling edge, 10-11 etu low, rising edge, 2-3 etu high, falling edge ---- */
-NFC_DEV bool nfcb_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+/* history reads of the edge detectors (rate 0 looks at the current sample, rate 1 one 106k symbol back) */
+struct NfcTapsB
 {
-   if (s.clock < 1024u)
-      return false;
+   float edge[2];
+   float deep[2];
+};
 
-   if (s.env < c.powerThreshold)
-      return false;
+NFC_DEV void nfcb_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsB &taps)
+{
+   const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_HMASK;
+   const uint32_t slot1 = (s.clock - c.b[1].delay) & NFC_HMASK;
+   taps.edge[0] = NFC_AT(mem.filt, slot0);
+   taps.deep[0] = NFC_AT(mem.depth, slot0);
+   taps.edge[1] = NFC_AT(mem.filt, slot1);
+   taps.deep[1] = NFC_AT(mem.depth, slot1);
+}
 
-   for (int r = 0; r < 2; r++)
+/* ---- search: SOF = falling edge, 10-11 etu low, rising edge, 2-3 etu high, falling edge ----
+ * returns 0 = keep searching, 1 = locked, 2 = abandon this sample for the remaining rates */
+template <int R>
+NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsB &taps, const NfcNow &now)
+{
+   const NfcRate &rt = c.b[R];
+   NfcMod &m = s.modB[R];
+
+   /* with no delay the sample of interest is the one the front end has just produced */
+   float edge = rt.delay ? taps.edge[R] : now.filt;
+   float deep = rt.delay ? taps.deep[R] : now.depth;
+
+   if (deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1))
    {
-      const NfcRate &rt = c.b[r];
-      NfcMod &m = s.modB[r];
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+      m.auxTime = 0; m.aux = 0;
+   }
 
-      const uint32_t slot = (s.clock - rt.delay) & NFC_HMASK;
-      float edge = NFC_AT(mem.filt, slot);
-      float deep = NFC_AT(mem.depth, slot);
+   if (!m.symStart)
+   {
+      m.thr = s.env * c.minDepth[1];
 
-      if (deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1))
-      {
-         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
-         m.auxTime = 0; m.aux = 0;
-      }
-
-      if (!m.symStart)
-      {
-         m.thr = s.env * c.minDepth[1];
-
-         if (edge < -m.thr && edge < m.aux)
-         {
-            m.aux = edge;
-            m.auxTime = s.clock;
-            m.winEnd = s.clock + rt.p4;
-         }
-
-         if (s.clock != m.winEnd)
-            continue;
-
-         m.symStart = m.auxTime - rt.p8;
-         m.winStart = m.symStart + (10 * rt.p1) - rt.p2;
-         m.winEnd = m.symStart + (11 * rt.p1) + rt.p2;
-         m.thr = nfc_abs(m.aux * 0.5f);
-         m.aux = 0;
-         m.auxTime = 0;
-         continue;
-      }
-
-      if (!m.symEnd)
-      {
-         if (s.clock < m.winStart)
-         {
-            if (edge > m.thr)
-            {
-               m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
-               m.auxTime = 0; m.aux = 0;
-            }
-            continue;
-         }
-
-         if (edge > m.thr && edge > m.aux)
-         {
-            m.aux = edge;
-            m.auxTime = s.clock;
-            m.winEnd = s.clock + rt.p4;
-         }
-
-         if (s.clock != m.winEnd)
-            continue;
-
-         if (!m.auxTime)
-         {
-            m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.aux = 0;
-            continue;
-         }
-
-         m.symEnd = m.auxTime;
-         m.winStart = m.auxTime + (2 * rt.p1) - rt.p2;
-         m.winEnd = m.auxTime + (3 * rt.p1) + rt.p2;
-         m.thr = nfc_abs(m.aux) / 2;
-         m.aux = 0;
-         m.auxTime = 0;
-         continue;
-      }
-
-      if (s.clock < m.winStart)
-      {
-         if (edge < -m.thr)
-         {
-            m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
-            m.auxTime = 0; m.aux = 0;
-         }
-         continue;
-      }
-
-      if (edge < -m.thr && m.aux > edge)
+      if (edge < -m.thr && edge < m.aux)
       {
          m.aux = edge;
          m.auxTime = s.clock;
@@ -247,41 +193,118 @@ NFC_DEV bool nfcb_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       }
 
       if (s.clock != m.winEnd)
-         continue;
+         return 0;
+
+      m.symStart = m.auxTime - rt.p8;
+      m.winStart = m.symStart + (10 * rt.p1) - rt.p2;
+      m.winEnd = m.symStart + (11 * rt.p1) + rt.p2;
+      m.thr = nfc_abs(m.aux * 0.5f);
+      m.aux = 0;
+      m.auxTime = 0;
+      return 0;
+   }
+
+   if (!m.symEnd)
+   {
+      if (s.clock < m.winStart)
+      {
+         if (edge > m.thr)
+         {
+            m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+            m.auxTime = 0; m.aux = 0;
+         }
+         return 0;
+      }
+
+      if (edge > m.thr && edge > m.aux)
+      {
+         m.aux = edge;
+         m.auxTime = s.clock;
+         m.winEnd = s.clock + rt.p4;
+      }
+
+      if (s.clock != m.winEnd)
+         return 0;
 
       if (!m.auxTime)
       {
-         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
-         m.auxTime = 0; m.aux = 0;
-         break; /* the reference leaves the rate loop here (NfcB.cpp:396) */
+         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.aux = 0;
+         return 0;
       }
 
       m.symEnd = m.auxTime;
-      m.sync = m.symEnd + rt.p2;
-      m.winStart = 0;
-      m.winEnd = 0;
-      m.thr = nfc_abs(m.aux * 0.5f);
-      m.auxTime = 0;
+      m.winStart = m.auxTime + (2 * rt.p1) - rt.p2;
+      m.winEnd = m.auxTime + (3 * rt.p1) + rt.p2;
+      m.thr = nfc_abs(m.aux) / 2;
       m.aux = 0;
-
-      s.frameType = NFC_FRAME_POLL;
-      s.frameRate = rt.symbolsPerSecond;
-      s.frameStart = m.symStart - rt.delay;
-      s.frameEnd = 0;
-
-      s.lockTech = NFC_TECH_B;
-      s.lockRate = (uint32_t)r;
-      return true;
+      m.auxTime = 0;
+      return 0;
    }
 
-   return false;
+   if (s.clock < m.winStart)
+   {
+      if (edge < -m.thr)
+      {
+         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+         m.auxTime = 0; m.aux = 0;
+      }
+      return 0;
+   }
+
+   if (edge < -m.thr && m.aux > edge)
+   {
+      m.aux = edge;
+      m.auxTime = s.clock;
+      m.winEnd = s.clock + rt.p4;
+   }
+
+   if (s.clock != m.winEnd)
+      return 0;
+
+   if (!m.auxTime)
+   {
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
+      m.auxTime = 0; m.aux = 0;
+      return 2; /* the reference leaves the rate loop here (NfcB.cpp:396) */
+   }
+
+   m.symEnd = m.auxTime;
+   m.sync = m.symEnd + rt.p2;
+   m.winStart = 0;
+   m.winEnd = 0;
+   m.thr = nfc_abs(m.aux * 0.5f);
+   m.auxTime = 0;
+   m.aux = 0;
+
+   s.frameType = NFC_FRAME_POLL;
+   s.frameRate = rt.symbolsPerSecond;
+   s.frameStart = m.symStart - rt.delay;
+   s.frameEnd = 0;
+
+   nfc_take_lock(s, m, rt, NFC_TECH_B, (uint32_t)R, 0, 0);
+   return 1;
+}
+
+NFC_DEV bool nfcb_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsB &taps, const NfcNow &now)
+{
+   if (s.clock < 1024u)
+      return false;
+
+   if (s.env < c.powerThreshold)
+      return false;
+
+   int r0 = nfcb_detect_rate<0>(c, s, mem, taps, now);
+   if (r0)
+      return r0 == 1;
+
+   return nfcb_detect_rate<1>(c, s, mem, taps, now) == 1;
 }
 
 /* ---- poll symbols: sample modulation depth at bit centres, resync on edges ---- */
 NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = c.b[s.lockRate];
-   NfcMod &m = s.modB[s.lockRate];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
    const uint32_t slot = (s.clock - rt.delay) & NFC_HMASK;
    float edge = NFC_AT(mem.filt, slot);
@@ -327,23 +350,24 @@ NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 }
 
 /* ---- listen SOF: TR1 subcarrier, then two phase changes (S1, S2) ---- */
-NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const NfcRate &rt = c.b[s.lockRate];
-   NfcMod &m = s.modB[s.lockRate];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
    NfcTiming &t = s.tim[1];
 
    const uint32_t cur = s.clock - rt.delay;
-   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
-   float p = nfc_phase_product(mem, s, rt);
+   const float deep = now.depth;
+   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
 
-   nfc_phase_integrate(mem, s, m, rt, p);
+   nfc_phase_integrate(m, p);
 
    if (s.clock < t.guardEnd)
       return SYM_NONE;
 
    if (s.clock == t.guardEnd)
-      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK);
+      m.thr = guardDev;
 
    if (s.clock > t.waitingEnd)
       return SYM_TIMEOUT;
@@ -438,11 +462,11 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 /* ---- listen symbols: BPSK phase at bit centres ---- */
 NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = c.b[s.lockRate];
-   NfcMod &m = s.modB[s.lockRate];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
-   float p = nfc_phase_product(mem, s, rt);
-   nfc_phase_integrate(mem, s, m, rt, p);
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
+   nfc_phase_integrate(m, p);
 
    if (!m.auxTime)
    {
@@ -484,7 +508,7 @@ NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 }
 
 /* ---- one sample in locked NFC-B mode ---- */
-NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
    NfcTiming &t = s.tim[1];
 
@@ -515,8 +539,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             s.frameEnd = s.symEnd;
 
             uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-            const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = c.b[s.lockRate].symbolsPerSecond;
-            const uint32_t lockedRate = s.lockRate;
+            const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.rt.symbolsPerSecond;
 
             nfcb_process(c, s, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
             nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
@@ -524,7 +547,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             nfc_clear_assembly(s);
 
             if (s.lockTech == NFC_TECH_B)
-               nfc_poll_end_clear(mem, s.modB[lockedRate], 0, 0);
+               nfc_poll_end_clear(mem, s.lock, 0, 0);
 
             return;
          }
@@ -556,7 +579,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (!s.frameStart)
    {
-      uint32_t pattern = nfcb_listen_start(c, s, mem);
+      uint32_t pattern = nfcb_listen_start(c, s, mem, now);
 
       if (pattern == B_S)
          s.frameStart = s.symStart;
@@ -587,7 +610,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          s.frameEnd = s.symEnd + nfc_tu(c, 352); /* EOS is not tracked to its end */
 
          uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-         const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = c.b[s.lockRate].symbolsPerSecond;
+         const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.rt.symbolsPerSecond;
 
          nfcb_process(c, s, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);

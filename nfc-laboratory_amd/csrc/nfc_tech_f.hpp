@@ -21,11 +21,12 @@ NFC_DEV void nfcf_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
 
 NFC_DEV void nfcf_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   for (int r = 1; r < 3; r++)
-   {
-      nfc_mod_clear(s.modF[r]);
-      nfc_zero_ring(mem.corr, c.corrOffset[2 + r], c.f[r].p1);
-   }
+   nfc_mod_clear(s.modF[1]);
+   nfc_mod_clear(s.modF[2]);
+   nfc_mod_clear(s.lock);
+
+   /* the two rings are adjacent */
+   nfc_zero_ring(mem.corr, c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
 
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
@@ -88,7 +89,7 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
    }
 
    const bool locked = (s.lockTech == NFC_TECH_F);
-   const uint32_t delay = locked ? c.f[s.lockRate].delay : 0u;
+   const uint32_t delay = locked ? s.rt.delay : 0u;
 
    if (poll)
    {
@@ -191,7 +192,60 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, NfcMod &m, const NfcRate &rt
    return true;
 }
 
-NFC_DEV bool nfcf_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+/* history reads of the two preamble correlators */
+struct NfcTapsF
+{
+   NfcTap t[3];
+};
+
+NFC_DEV void nfcf_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsF &taps)
+{
+   taps.t[1] = nfc_tap_raw(mem, s.clock, c.f[1], c.corrOffset[3], s.posF[1], true);
+   taps.t[2] = nfc_tap_raw(mem, s.clock, c.f[2], c.corrOffset[4], s.posF[2], true);
+}
+
+template <int R>
+NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsF &taps, const NfcNow &now,
+                              float minimumCorrelation)
+{
+   const NfcRate &rt = c.f[R];
+   NfcMod &m = s.modF[R];
+
+   /* NFC-F correlates the undelayed signal: the entering sample and its depth are the current ones */
+   NfcTap tap = taps.t[R];
+   tap.in = now.x;
+   const float deep = now.depth;
+
+   NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[2 + R], s.posF[R]);
+   float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
+
+   if (deep > c.maxDepth[2] || (m.peakTime && s.clock > m.peakTime + rt.p1))
+   {
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+      m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+   }
+
+   if (s.clock < m.winStart)
+      return false;
+
+   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation))
+      return false;
+
+   s.symStart = m.symStart;
+   s.symEnd = m.symEnd;
+   s.symLength = s.symEnd - s.symStart;
+   s.symPattern = F_S;
+
+   s.frameType = NFC_FRAME_POLL;
+   s.frameRate = rt.symbolsPerSecond;
+   s.frameStart = s.symStart;
+   s.frameEnd = 0;
+
+   nfc_take_lock(s, m, rt, NFC_TECH_F, (uint32_t)R, c.corrOffset[2 + R], s.posF[R]);
+   return true;
+}
+
+NFC_DEV bool nfcf_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsF &taps, const NfcNow &now)
 {
    if (s.clock < 1024u)
       return false;
@@ -201,54 +255,21 @@ NFC_DEV bool nfcf_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    const float minimumCorrelation = s.env * c.corrThreshold[2];
 
-   for (int r = 1; r < 3; r++)
-   {
-      const NfcRate &rt = c.f[r];
-      NfcMod &m = s.modF[r];
-
-      float deep = NFC_AT(mem.depth, (s.clock - rt.delay) & NFC_HMASK);
-
-      NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[2 + r], s.posF[r]);
-      float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
-
-      if (deep > c.maxDepth[2] || (m.peakTime && s.clock > m.peakTime + rt.p1))
-      {
-         m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
-         m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
-      }
-
-      if (s.clock < m.winStart)
-         continue;
-
-      if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation))
-         continue;
-
-      s.symStart = m.symStart;
-      s.symEnd = m.symEnd;
-      s.symLength = s.symEnd - s.symStart;
-      s.symPattern = F_S;
-
-      s.frameType = NFC_FRAME_POLL;
-      s.frameRate = rt.symbolsPerSecond;
-      s.frameStart = s.symStart;
-      s.frameEnd = 0;
-
-      s.lockTech = NFC_TECH_F;
-      s.lockRate = (uint32_t)r;
+   if (nfcf_detect_rate<1>(c, s, mem, taps, now, minimumCorrelation))
       return true;
-   }
 
-   return false;
+   return nfcf_detect_rate<2>(c, s, mem, taps, now, minimumCorrelation);
 }
 
 /* Manchester data symbols, identical for both directions (NfcF.cpp:641-744 and 941-1042) */
 NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const uint32_t r = s.lockRate;
-   const NfcRate &rt = c.f[r];
-   NfcMod &m = s.modF[r];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
-   NfcCorr k = nfc_correlate_raw(mem, s, m, rt, c.corrOffset[2 + r], s.posF[r]);
+   const uint32_t lockPos = nfc_lock_pos(s);
+   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.lockBase, lockPos, true);
+   NfcCorr k = nfc_corr_apply(mem, m, tap, s.lockBase, lockPos);
    float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
 
    if (s.clock < m.winStart)
@@ -301,39 +322,35 @@ NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const N
 
 NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const uint32_t r = s.lockRate;
-   const NfcRate &rt = c.f[r];
-   NfcMod &m = s.modF[r];
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
    NfcTiming &t = s.tim[2];
 
    const uint32_t cur = s.clock - rt.delay;
+   const uint32_t base = s.lockBase;
+   const uint32_t pos = nfc_lock_pos(s);
+
+   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, base, pos, true);
+   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
 
    /* the box sum runs from the end of the poll frame, the ring only from one symbol before the guard */
-   m.acc += NFC_AT(mem.x, cur & NFC_HMASK);
-   m.acc -= NFC_AT(mem.x, (cur - rt.p2) & NFC_HMASK);
+   m.acc += tap.in;
+   m.acc -= tap.out;
 
    if (s.clock < (uint32_t)(t.guardEnd - rt.p1))
       return SYM_NONE;
 
-   const uint32_t base = c.corrOffset[2 + r];
-   const uint32_t pos = s.posF[r];
-   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
-   const uint32_t f3 = nfc_point(s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1);
-
    NFC_AT(mem.corr, base + pos) = m.acc;
 
-   float a = m.acc;
-   float b = NFC_AT(mem.corr, base + f2);
-   float d = NFC_AT(mem.corr, base + f3);
-   float s0 = a - b;
-   float s1 = b - d;
+   float s0 = m.acc - tap.c2;
+   float s1 = tap.c2 - tap.c3;
    float sd = nfc_abs(s0 - s1) / (float)rt.p2;
 
    if (s.clock < t.guardEnd)
       return SYM_NONE;
 
    if (s.clock == t.guardEnd)
-      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK) * 10.0f;
+      m.thr = guardDev * 10.0f;
 
    if (s.clock > t.waitingEnd)
       return SYM_TIMEOUT;
@@ -376,8 +393,7 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
 
          uint32_t total = s.bsBytes > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : s.bsBytes;
          const uint32_t start = s.frameStart, end = s.frameEnd, len = total - 2;
-         const uint32_t rate = c.f[s.lockRate].symbolsPerSecond;
-         const uint32_t lockedRate = s.lockRate;
+         const uint32_t rate = s.rt.symbolsPerSecond;
 
          nfcf_process(c, s, type, mem.bytes + 2, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_F, type, flags, phase, rate, start, end, mem.bytes + 2, len);
@@ -387,7 +403,7 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
             nfc_clear_assembly(s);
 
             if (s.lockTech == NFC_TECH_F)
-               nfc_poll_end_clear(mem, s.modF[lockedRate], c.corrOffset[2 + lockedRate], c.f[lockedRate].p1);
+               nfc_poll_end_clear(mem, s.lock, s.lockBase, s.rt.p1);
 
             return;
          }
@@ -407,7 +423,7 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
    }
 }
 
-NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
    if (s.frameType == NFC_FRAME_POLL)
    {

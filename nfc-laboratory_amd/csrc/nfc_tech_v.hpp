@@ -24,6 +24,7 @@ NFC_DEV void nfcv_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
    nfc_mod_clear(s.modV);
+   nfc_mod_clear(s.lock);
    nfc_zero_ring(mem.corr, c.corrOffset[5], c.v.p0);
 
    s.frameType = 0;
@@ -82,25 +83,31 @@ NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
    s.frameEnd = 0;
 }
 
-/* box sum over p2 of the raw signal delayed by two symbols; S0 compares it with half a symbol before */
-NFC_DEV float nfcv_pulse_correlation(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m)
+/* history reads of the pulse correlator: box sum over p2 of the raw signal delayed by two symbols; S0 compares
+ * it with half a symbol before */
+struct NfcTapsV
 {
-   const NfcRate &rt = c.v;
-   const uint32_t cur = s.clock - rt.delay;
+   NfcTap t;
+   float deep;
+};
 
-   m.acc += NFC_AT(mem.x, cur & NFC_HMASK);
-   m.acc -= NFC_AT(mem.x, (cur - rt.p2) & NFC_HMASK);
+NFC_DEV void nfcv_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsV &taps)
+{
+   taps.t = nfc_tap_raw(mem, s.clock, c.v, c.corrOffset[5], s.posV1, false);
+   taps.deep = NFC_AT(mem.depth, (s.clock - c.v.delay - c.v.p8) & NFC_HMASK);
+}
 
-   const uint32_t base = c.corrOffset[5];
-   const uint32_t pos = s.posV1;
-   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1);
+NFC_DEV float nfcv_pulse_apply(const NfcLaneMem &mem, NfcMod &m, const NfcTap &t, uint32_t base, uint32_t pos, const NfcRate &rt)
+{
+   m.acc += t.in;
+   m.acc -= t.out;
 
    NFC_AT(mem.corr, base + pos) = m.acc;
 
-   return (NFC_AT(mem.corr, base + f2) - m.acc) / (float)rt.p2;
+   return (t.c2 - m.acc) / (float)rt.p2;
 }
 
-NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsV &taps, const NfcNow &now)
 {
    if (s.clock < 1024u)
       return false;
@@ -112,9 +119,9 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    NfcMod &m = s.modV;
 
    const float minimumCorrelation = s.env * c.corrThreshold[3];
-   const float raw = NFC_AT(mem.x, (s.clock - rt.delay) & NFC_HMASK);
+   const float raw = taps.t.in;
 
-   float s0 = nfcv_pulse_correlation(c, s, mem, m);
+   float s0 = nfcv_pulse_apply(mem, m, taps.t, c.corrOffset[5], s.posV1, rt);
 
    if (m.peakTime && s.clock > m.peakTime + rt.p0)
    {
@@ -134,7 +141,7 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          m.winEnd = s.clock + rt.p4;
       }
 
-      float deep = NFC_AT(mem.depth, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+      float deep = taps.deep;
 
       if (deep > m.aux)
       {
@@ -195,18 +202,18 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    m.peak = 0;
    m.thr = minimumCorrelation;
 
-   s.lockTech = NFC_TECH_V;
-   s.lockRate = 0;
+   nfc_take_lock(s, m, rt, NFC_TECH_V, 0, c.corrOffset[5], s.posV1);
    return true;
 }
 
 /* one pulse-position symbol (2 or 8 bits), NfcV.cpp:672-795 */
 NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = c.v;
-   NfcMod &m = s.modV;
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
-   float s0 = nfcv_pulse_correlation(c, s, mem, m);
+   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.lockBase, s.posV1, false);
+   float s0 = nfcv_pulse_apply(mem, m, tap, s.lockBase, s.posV1, rt);
 
    if (s.clock < m.winStart)
       return SYM_NONE;
@@ -274,43 +281,45 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 }
 
 /* subcarrier power integrated over one symbol half (p1), ring of two symbols (p0) */
-NFC_DEV float nfcv_burst_correlation(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m)
+NFC_DEV float nfcv_burst_correlation(NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m)
 {
-   const NfcRate &rt = c.v;
+   const NfcRate &rt = s.rt;
    const uint32_t cur = s.clock - rt.delay;
+   const uint32_t base = s.lockBase;
+   const uint32_t pos = s.posV0;
 
-   float v = NFC_AT(mem.filt, cur & NFC_HMASK);
-   float sq = v * v * 10.0f;
+   const float v = NFC_AT(mem.filt, cur & NFC_HMASK);
+   const float old = NFC_AT(mem.prod, (cur - rt.p1) & NFC_PMASK);
+   const float c2 = NFC_AT(mem.corr, base + nfc_point(s.clock, rt.delay, pos, rt.p1, rt.p0));
+
+   const float sq = v * v * 10.0f;
 
    NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
 
    m.acc += sq;
-   m.acc -= NFC_AT(mem.prod, (cur - rt.p1) & NFC_PMASK);
-
-   const uint32_t base = c.corrOffset[5];
-   const uint32_t pos = s.posV0;
-   const uint32_t f2 = nfc_point(s.clock, rt.delay, pos, rt.p1, rt.p0);
+   m.acc -= old;
 
    NFC_AT(mem.corr, base + pos) = m.acc;
 
-   return NFC_AT(mem.corr, base + f2) - m.acc;
+   return c2 - m.acc;
 }
 
-NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const NfcRate &rt = c.v;
-   NfcMod &m = s.modV;
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
    NfcTiming &t = s.tim[3];
 
    const uint32_t cur = s.clock - rt.delay;
-   float deep = NFC_AT(mem.depth, s.clock & NFC_HMASK);
-   float s0 = nfcv_burst_correlation(c, s, mem, m);
+   const float deep = now.depth;
+   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   float s0 = nfcv_burst_correlation(s, mem, m);
 
    if (s.clock < t.guardEnd)
       return SYM_NONE;
 
    if (s.clock == t.guardEnd)
-      m.thr = NFC_AT(mem.mdev, cur & NFC_HMASK);
+      m.thr = guardDev;
 
    if (s.clock > t.waitingEnd)
       return SYM_TIMEOUT;
@@ -402,10 +411,10 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 
 NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = c.v;
-   NfcMod &m = s.modV;
+   const NfcRate &rt = s.rt;
+   NfcMod &m = s.lock;
 
-   float s0 = nfcv_burst_correlation(c, s, mem, m);
+   float s0 = nfcv_burst_correlation(s, mem, m);
    float sd = nfc_abs(s0);
 
    if (s.clock < m.winStart)
@@ -443,7 +452,7 @@ NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
    return s.symPattern;
 }
 
-NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
    NfcTiming &t = s.tim[3];
 
@@ -481,7 +490,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             nfc_clear_assembly(s);
 
             if (s.lockTech == NFC_TECH_V)
-               nfc_poll_end_clear(mem, s.modV, c.corrOffset[5], c.v.p0);
+               nfc_poll_end_clear(mem, s.lock, s.lockBase, s.rt.p0);
 
             return;
          }
@@ -507,7 +516,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (!s.frameStart)
    {
-      uint32_t pattern = nfcv_listen_start(c, s, mem);
+      uint32_t pattern = nfcv_listen_start(c, s, mem, now);
 
       if (pattern == V_S)
          s.frameStart = s.symStart;

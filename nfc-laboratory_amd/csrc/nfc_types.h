@@ -179,9 +179,16 @@ struct NfcStreamState
    NfcMod modF[3]; /* [0] unused */
    NfcMod modV;
 
+   /* working copies of the locked modulation: taken at lock time, dropped when the technology resets (which
+    * clears every modulation of that technology anyway); keeps the decode paths free of dynamic indexing */
+   NfcMod lock;
+   NfcRate rt;
+   uint32_t lockBase; /* correlation ring base of the locked modulation */
+   uint32_t lockPos;  /* ring position (idx % rt.p1) of the locked correlator, advanced every sample while locked */
+
    /* ---- bookkeeping ---- */
    uint32_t framesOut; /* frames emitted by this stream since it was opened */
-   uint32_t reserved[3];
+   uint32_t reserved[1];
 };
 
 /* header of one frame in the frame sink, followed by (length+3)/4 payload words */
