@@ -33,21 +33,28 @@
 /* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
 struct NfcLaneMem
 {
-   float *x;       /* samplingValue  [NFC_HIST][64] */
-   float *filt;    /* filteredValue  [NFC_HIST][64] */
-   float *mdev;    /* meanDeviation  [NFC_HIST][64] */
-   float *depth;   /* modulateDepth  [NFC_HIST][64] */
-   float *prod;    /* listen-mode product ring [NFC_PROD][64] */
-   float *corr;    /* correlation rings [corrTotal][64] */
+   float *ring;    /* stream-block ring storage (wave-uniform base), regions below, each [slots][64 lanes] */
+   uint32_t lane;  /* this stream's column */
+   bool exact;     /* take ring positions by exact modulo (stream start / 32-bit clock wrap) instead of incrementally */
    uint8_t *bytes; /* frame assembly buffer, NFC_STREAM_BYTES contiguous */
    uint32_t *sink;       /* frame sink shared by every stream of the launch (packed records) */
    uint32_t *sinkCursor; /* words used, advanced atomically */
    uint32_t *sinkDropped;
    uint32_t sinkWords;
    uint32_t streamId;
+   NfcStreamCold *cold;  /* protocol timing of this stream (HBM) */
 };
 
-#define NFC_AT(ptr, slot) ((ptr)[(uint32_t)(slot) * NFC_LANES])
+/* ring regions (in slots) inside a stream block */
+#define NFC_R_X 0u                         /* samplingValue  [NFC_HIST] */
+#define NFC_R_FILT (1u * NFC_HIST)         /* filteredValue  [NFC_HIST] */
+#define NFC_R_MDEV (2u * NFC_HIST)         /* meanDeviation  [NFC_HIST] */
+#define NFC_R_DEPTH (3u * NFC_HIST)        /* modulateDepth  [NFC_HIST] */
+#define NFC_R_PROD (4u * NFC_HIST)         /* listen-mode product ring [NFC_PROD] */
+#define NFC_R_CORR (4u * NFC_HIST + NFC_PROD) /* correlation rings [corrTotal] */
+
+/* 32-bit index from a wave-uniform base: the access becomes `global_load v, v_off, s[base]` */
+#define NFC_AT(m, region, slot) ((m).ring[((region) + (uint32_t)(slot)) * NFC_LANES + (m).lane])
 #define NFC_HMASK (NFC_HIST - 1u)
 #define NFC_PMASK (NFC_PROD - 1u)
 
@@ -81,6 +88,31 @@ NFC_DEV uint32_t nfc_tu(const NfcConfig &c, int units)
    return (uint32_t)(int)(c.stu * (double)units);
 }
 
+NFC_DEV void nfc_mod_clear(NfcDetA &m)
+{
+   m.winStart = 0; m.winEnd = 0; m.symStart = 0;
+   m.acc = 0; m.peak = 0; m.aux = 0; m.peakTime = 0;
+}
+
+NFC_DEV void nfc_mod_clear(NfcDetB &m)
+{
+   m.winStart = 0; m.winEnd = 0; m.thr = 0;
+   m.symStart = 0; m.symEnd = 0; m.aux = 0; m.auxTime = 0;
+}
+
+NFC_DEV void nfc_mod_clear(NfcDetF &m)
+{
+   m.winStart = 0; m.winEnd = 0; m.sync = 0; m.pulses = 0;
+   m.thr = 0; m.lastPhase = 0; m.lastValue = 0; m.syncValue = 0; m.c0 = 0;
+   m.symStart = 0; m.symEnd = 0; m.acc = 0; m.peak = 0; m.peakTime = 0;
+}
+
+NFC_DEV void nfc_mod_clear(NfcDetV &m)
+{
+   m.winStart = 0; m.winEnd = 0; m.symStart = 0;
+   m.acc = 0; m.peak = 0; m.aux = 0; m.peakTime = 0;
+}
+
 NFC_DEV void nfc_mod_clear(NfcMod &m)
 {
    m.stage = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0; m.pulses = 0;
@@ -91,10 +123,10 @@ NFC_DEV void nfc_mod_clear(NfcMod &m)
    m.peakTime = 0; m.auxTime = 0;
 }
 
-NFC_DEV void nfc_zero_ring(float *ring, uint32_t from, uint32_t count)
+NFC_DEV void nfc_zero_ring(const NfcLaneMem &mem, uint32_t from, uint32_t count)
 {
    for (uint32_t i = 0; i < count; i++)
-      NFC_AT(ring, from + i) = 0.0f;
+      NFC_AT(mem, 0u, from + i) = 0.0f;
 }
 
 /* what the reference does to the locked modulation at the end of every poll frame
@@ -104,19 +136,19 @@ NFC_DEV void nfc_poll_end_clear(const NfcLaneMem &mem, NfcMod &m, uint32_t corrF
    m.symStart = 0; m.symEnd = 0; m.acc = 0; m.phaseAcc = 0; m.stage = 0;
    m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
    m.lastValue = 0; m.lastPhase = 0; m.thr = 0; m.phaseThr = 0; m.peak = 0;
-   nfc_zero_ring(mem.prod, 0, NFC_PROD);
-   nfc_zero_ring(mem.corr, corrFrom, corrCount);
+   nfc_zero_ring(mem, NFC_R_PROD, NFC_PROD);
+   nfc_zero_ring(mem, NFC_R_CORR + corrFrom, corrCount);
 }
 
 NFC_DEV void nfc_clear_assembly(NfcStreamState &s)
 {
-   s.bsPrevious = 0; s.bsPattern = 0; s.bsBits = 0; s.bsSkip = 0;
+   s.bsPrevious = 0; s.bsBits = 0; s.bsSkip = 0;
    s.bsData = 0; s.bsFlags = 0; s.bsParity = 0; s.bsBytes = 0;
 }
 
 NFC_DEV void nfc_clear_symbol(NfcStreamState &s)
 {
-   s.symPattern = 0; s.symValue = 0; s.symStart = 0; s.symEnd = 0; s.symEdge = 0; s.symLength = 0;
+   s.symPattern = 0; s.symValue = 0; s.symStart = 0; s.symEnd = 0; s.symEdge = 0;
 }
 
 NFC_DEV void nfc_push_byte(const NfcLaneMem &mem, NfcStreamState &s, uint32_t value)
@@ -172,7 +204,7 @@ NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, u
    const uint32_t words = NFC_FRAME_HEADER_WORDS + ((len + 3u) >> 2);
    const uint32_t at = NFC_ATOMIC_ADD(mem.sinkCursor, words);
 
-   s.framesOut++;
+   mem.cold->framesOut++;
 
    /* a record is only written when a maximum-size record would still fit: everything that starts at or
     * below sinkWords - NFC_FRAME_MAX_WORDS is valid, everything above was dropped (no holes to guess) */
@@ -214,9 +246,20 @@ struct NfcNow
 NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
 {
    float env = s.env;
-   float diff = nfc_abs(value - env) / env;
 
-   if (diff < 0.05f || s.pulseFilter > (uint32_t)(c.etu * 10))
+   /* reference: |x - env| / env < 0.05f. Decided without the division unless the ratio is within 0.2 % of the
+    * limit (for env > 0: dev < 0.0499*env implies fl(dev/env) < 0.05f, dev > 0.0501*env implies the opposite) */
+   const float dev = nfc_abs(value - env);
+   bool tracking;
+
+   if (env > 0.0f && dev < 0.0499f * env)
+      tracking = true;
+   else if (env > 0.0f && dev > 0.0501f * env)
+      tracking = false;
+   else
+      tracking = (dev / env) < 0.05f;
+
+   if (tracking || s.pulseFilter > (uint32_t)(c.etu * 10))
    {
       s.pulseFilter = 0;
       env = env * c.envW0 + value * c.envW1;
@@ -245,10 +288,10 @@ NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLan
 
    const uint32_t slot = s.clock & NFC_HMASK;
 
-   NFC_AT(mem.x, slot) = now.x;
-   NFC_AT(mem.filt, slot) = now.filt;
-   NFC_AT(mem.mdev, slot) = now.mdev;
-   NFC_AT(mem.depth, slot) = now.depth;
+   NFC_AT(mem, NFC_R_X, slot) = now.x;
+   NFC_AT(mem, NFC_R_FILT, slot) = now.filt;
+   NFC_AT(mem, NFC_R_MDEV, slot) = now.mdev;
+   NFC_AT(mem, NFC_R_DEPTH, slot) = now.depth;
 
    float rectified = nfc_abs(filtered);
 
@@ -287,25 +330,25 @@ NFC_DEV uint32_t nfc_next_pos(uint32_t clock, bool exact, uint32_t pos, const Nf
    return exact ? (uint32_t)(1024u - rt.delay + clock) % period : nfc_bump(pos, period);
 }
 
-NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s)
+NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const bool exact = nfc_exact_zone(s.clock);
+   const bool exact = mem.exact;
 
    /* written out per correlator: every state field keeps a compile-time address, so the record stays in VGPRs */
    s.posA[0] = nfc_next_pos(s.clock, exact, s.posA[0], c.a[0], c.a[0].p1);
    s.posA[1] = nfc_next_pos(s.clock, exact, s.posA[1], c.a[1], c.a[1].p1);
    s.posA[2] = nfc_next_pos(s.clock, exact, s.posA[2], c.a[2], c.a[2].p1);
-   s.posF[1] = nfc_next_pos(s.clock, exact, s.posF[1], c.f[1], c.f[1].p1);
-   s.posF[2] = nfc_next_pos(s.clock, exact, s.posF[2], c.f[2], c.f[2].p1);
+   s.posF[0] = nfc_next_pos(s.clock, exact, s.posF[0], c.f[1], c.f[1].p1);
+   s.posF[1] = nfc_next_pos(s.clock, exact, s.posF[1], c.f[2], c.f[2].p1);
    s.posV1 = nfc_next_pos(s.clock, exact, s.posV1, c.v, c.v.p1);
    s.posV0 = nfc_next_pos(s.clock, exact, s.posV0, c.v, c.v.p0);
 }
 
 /* ring position of the locked correlator: a private copy taken at lock time and advanced alongside the others
  * (selecting among posA/posF by index would put the whole state record back into scratch memory) */
-NFC_DEV void nfc_advance_lock_pos(NfcStreamState &s)
+NFC_DEV void nfc_advance_lock_pos(NfcStreamState &s, const NfcLaneMem &mem)
 {
-   if (nfc_exact_zone(s.clock))
+   if (mem.exact)
       s.lockPos = (uint32_t)(1024u - s.rt.delay + s.clock) % s.rt.p1;
    else
       s.lockPos = nfc_bump(s.lockPos, s.rt.p1);
@@ -317,9 +360,9 @@ NFC_DEV uint32_t nfc_lock_pos(const NfcStreamState &s)
 }
 
 /* (idx + add) % period given pos = idx % period; exact modulo near the clock wrap */
-NFC_DEV uint32_t nfc_point(uint32_t clock, uint32_t delay, uint32_t pos, uint32_t add, uint32_t period)
+NFC_DEV uint32_t nfc_point(const NfcLaneMem &mem, uint32_t clock, uint32_t delay, uint32_t pos, uint32_t add, uint32_t period)
 {
-   if (nfc_exact_zone(clock))
+   if (mem.exact)
       return (uint32_t)(1024u - delay + clock + add) % period;
 
    uint32_t p = pos + add;
@@ -375,19 +418,20 @@ NFC_DEV NfcTap nfc_tap_raw(const NfcLaneMem &mem, uint32_t clock, const NfcRate 
 {
    NfcTap t;
    const uint32_t cur = clock - rt.delay;
-   t.in = NFC_AT(mem.x, cur & NFC_HMASK);
-   t.out = NFC_AT(mem.x, (cur - rt.p2) & NFC_HMASK);
-   t.c2 = NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p2, rt.p1));
-   t.c3 = needC3 ? NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p1 - 1u, rt.p1)) : 0.0f;
+   t.in = NFC_AT(mem, NFC_R_X, cur & NFC_HMASK);
+   t.out = NFC_AT(mem, NFC_R_X, (cur - rt.p2) & NFC_HMASK);
+   t.c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p2, rt.p1));
+   t.c3 = needC3 ? NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p1 - 1u, rt.p1)) : 0.0f;
    return t;
 }
 
-NFC_DEV NfcCorr nfc_corr_apply(const NfcLaneMem &mem, NfcMod &m, const NfcTap &t, uint32_t base, uint32_t pos)
+template <class M>
+NFC_DEV NfcCorr nfc_corr_apply(const NfcLaneMem &mem, M &m, const NfcTap &t, uint32_t base, uint32_t pos)
 {
    m.acc += t.in;
    m.acc -= t.out;
 
-   NFC_AT(mem.corr, base + pos) = m.acc;
+   NFC_AT(mem, NFC_R_CORR, base + pos) = m.acc;
 
    NfcCorr r;
    r.s0 = m.acc - t.c2;
@@ -400,19 +444,19 @@ NFC_DEV NfcCorr nfc_correlate_power(const NfcLaneMem &mem, uint32_t clock, NfcMo
 {
    const uint32_t cur = clock - rt.delay;
 
-   const float v = NFC_AT(mem.filt, cur & NFC_HMASK);
-   const float old = NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
-   const float c2 = NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p2, rt.p1));
-   const float c3 = NFC_AT(mem.corr, base + nfc_point(clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
+   const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
+   const float old = NFC_AT(mem, NFC_R_PROD, (cur - rt.p2) & NFC_PMASK);
+   const float c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p2, rt.p1));
+   const float c3 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
 
    const float sq = v * v * 10.0f;
 
-   NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
+   NFC_AT(mem, NFC_R_PROD, cur & NFC_PMASK) = sq;
 
    m.acc += sq;
    m.acc -= old;
 
-   NFC_AT(mem.corr, base + pos) = m.acc;
+   NFC_AT(mem, NFC_R_CORR, base + pos) = m.acc;
 
    NfcCorr r;
    r.s0 = m.acc - c2;
@@ -430,12 +474,12 @@ struct NfcPhase
 NFC_DEV NfcPhase nfc_phase_product(const NfcLaneMem &mem, uint32_t clock, const NfcRate &rt)
 {
    const uint32_t cur = clock - rt.delay;
-   const float a = NFC_AT(mem.filt, cur & NFC_HMASK);
-   const float b = NFC_AT(mem.filt, (cur - rt.p1) & NFC_HMASK);
+   const float a = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
+   const float b = NFC_AT(mem, NFC_R_FILT, (cur - rt.p1) & NFC_HMASK);
    NfcPhase p;
-   p.out = NFC_AT(mem.prod, (cur - rt.p4) & NFC_PMASK);
+   p.out = NFC_AT(mem, NFC_R_PROD, (cur - rt.p4) & NFC_PMASK);
    p.in = a * b * 10.0f;
-   NFC_AT(mem.prod, cur & NFC_PMASK) = p.in;
+   NFC_AT(mem, NFC_R_PROD, cur & NFC_PMASK) = p.in;
    return p;
 }
 
@@ -445,16 +489,24 @@ NFC_DEV void nfc_phase_integrate(NfcMod &m, const NfcPhase &p)
    m.phaseAcc -= p.out;
 }
 
-/* take the working copy of a modulation at lock time */
-NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcMod &m, const NfcRate &rt, uint32_t tech, uint32_t rate,
-                           uint32_t base, uint32_t pos)
+/* start the working copy of the locked modulation: everything zero, the caller fills in what the detector
+ * found (the reference's record at that point holds exactly those values, see nfc_types.h) */
+NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcRate &rt, uint32_t tech, uint32_t rate, uint32_t base, uint32_t pos)
 {
-   s.lock = m;
+   nfc_mod_clear(s.lock);
    s.rt = rt;
    s.lockBase = base;
    s.lockPos = pos;
    s.lockTech = tech;
    s.lockRate = rate;
+}
+
+/* a/w compared against +-limit: the IEEE division is only needed when |a| is within 0.1 % of w*limit or beyond
+ * it. If |a| <= 0.999*w*limit then |fl(a/w)| <= limit*0.999*(1+2^-23) < limit, so every `> limit` / `< -limit`
+ * test on the quotient is false and the quotient itself is never used; NaNs take the skip path on both sides. */
+NFC_DEV bool nfc_may_exceed(float a, float w, float limit)
+{
+   return nfc_abs(a) > w * limit * 0.999f;
 }
 
 #include "nfc_tech_a.hpp"
@@ -466,51 +518,57 @@ NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcMod &m, const NfcRate &rt
 /* one sample                                                                                 */
 /* ------------------------------------------------------------------------------------------ */
 
-NFC_DEV void nfc_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+/* One sample in search mode (no technology locked): NfcDecoder.cpp:394-418. EXACT selects how ring positions are
+ * obtained; the caller picks the exact variant for the rare tiles that touch the stream start or the 32-bit clock
+ * wrap, so the common variant carries no modulo code at all. All history reads of the eight detectors are issued
+ * before the front end stores this sample (none of them can alias the slot being written: their delays are > 0),
+ * so a step pays one memory latency. */
+template <bool EXACT>
+NFC_DEV void nfc_search_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
+{
+   NfcLaneMem mem = lane;
+   mem.exact = EXACT;
+
+   ++s.clock;
+   ++s.pulseFilter;
+
+   nfc_advance_positions(c, s, mem);
+
+   /* unconditional: the addresses are always inside the stream block, and a detector that is disabled or not
+    * yet armed (first 1024 samples) simply ignores what was read */
+   NfcTapsA ta;
+   NfcTapsB tb;
+   NfcTapsF tf;
+   NfcTapsV tv;
+
+   nfca_load_taps(c, s, mem, ta);
+   nfcb_load_taps(c, s, mem, tb);
+   nfcf_load_taps(c, s, mem, tf);
+   nfcv_load_taps(c, s, mem, tv);
+
+   const NfcNow now = nfc_front_end(c, s, mem, value);
+
+   nfc_detect_carrier(c, s, mem);
+
+   /* first detector that locks wins, later ones skip this sample */
+   if ((c.enabled & 1u) && nfca_detect(c, s, mem, ta, now))
+      return;
+   if ((c.enabled & 2u) && nfcb_detect(c, s, mem, tb, now))
+      return;
+   if ((c.enabled & 4u) && nfcf_detect(c, s, mem, tf, now))
+      return;
+   if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
+      return;
+}
+
+/* One sample with a technology locked (poll / listen frame decoding); `mem.exact` is a run-time flag here */
+NFC_DEV void nfc_decode_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
 {
    ++s.clock;
    ++s.pulseFilter;
 
-   nfc_advance_positions(c, s);
-
-   if (s.lockTech == 0)
-   {
-      /* search bank, NfcDecoder.cpp:394-418. All history reads of the eight detectors are issued before the
-       * front end stores this sample (none of them can alias the slot being written: their delays are > 0). */
-      NfcTapsA ta = {};
-      NfcTapsB tb = {};
-      NfcTapsF tf = {};
-      NfcTapsV tv = {};
-
-      const bool armed = s.clock >= 1024u;
-
-      if (armed && (c.enabled & 1u))
-         nfca_load_taps(c, s, mem, ta);
-      if (armed && (c.enabled & 2u))
-         nfcb_load_taps(c, s, mem, tb);
-      if (armed && (c.enabled & 4u))
-         nfcf_load_taps(c, s, mem, tf);
-      if (armed && (c.enabled & 8u))
-         nfcv_load_taps(c, s, mem, tv);
-
-      const NfcNow now = nfc_front_end(c, s, mem, value);
-
-      nfc_detect_carrier(c, s, mem);
-
-      /* first detector that locks wins, later ones skip this sample */
-      if ((c.enabled & 1u) && nfca_detect(c, s, mem, ta, now))
-         return;
-      if ((c.enabled & 2u) && nfcb_detect(c, s, mem, tb, now))
-         return;
-      if ((c.enabled & 4u) && nfcf_detect(c, s, mem, tf, now))
-         return;
-      if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
-         return;
-
-      return;
-   }
-
-   nfc_advance_lock_pos(s);
+   nfc_advance_positions(c, s, mem);
+   nfc_advance_lock_pos(s, mem);
 
    const NfcNow now = nfc_front_end(c, s, mem, value);
 
@@ -531,9 +589,28 @@ NFC_DEV void nfc_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &m
    }
 }
 
+/* One sample, whatever the mode. `exact` must be true whenever nfc_exact_zone(s.clock + 1) is (it may be true
+ * more often: the exact positions are always right, only slower to obtain). */
+NFC_DEV void nfc_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value, bool exact)
+{
+   if (s.lockTech == 0)
+   {
+      if (exact)
+         nfc_search_step<true>(c, s, lane, value);
+      else
+         nfc_search_step<false>(c, s, lane, value);
+   }
+   else
+   {
+      NfcLaneMem mem = lane;
+      mem.exact = exact;
+      nfc_decode_step(c, s, mem, value);
+   }
+}
+
 /* state of a freshly initialised decoder; `keep` carries over what the reference's initialize()
  * leaves untouched (envelope / IIR / EMA scalars, carrier bookkeeping): NfcDecoder.cpp:295-360 */
-NFC_DEV void nfc_state_init(const NfcConfig &c, NfcStreamState &s, bool keepFrontEnd)
+NFC_DEV void nfc_state_init(const NfcConfig &c, NfcStreamState &s, NfcStreamCold &cold, bool keepFrontEnd)
 {
    float env = s.env, n1 = s.n1, mdev = s.mdev, avg = s.avg, edgePeak = s.edgePeak;
    uint32_t pulse = s.pulseFilter, edgeTime = s.edgeTime, off = s.carrierOff, on = s.carrierOn;
@@ -541,6 +618,10 @@ NFC_DEV void nfc_state_init(const NfcConfig &c, NfcStreamState &s, bool keepFron
    uint32_t *w = (uint32_t *)&s;
    for (uint32_t i = 0; i < sizeof(NfcStreamState) / 4; i++)
       w[i] = 0;
+
+   uint32_t *k = (uint32_t *)&cold;
+   for (uint32_t i = 0; i < sizeof(NfcStreamCold) / 4; i++)
+      k[i] = 0;
 
    if (keepFrontEnd)
    {
@@ -550,15 +631,15 @@ NFC_DEV void nfc_state_init(const NfcConfig &c, NfcStreamState &s, bool keepFron
 
    s.clock = 0xFFFFFFFFu;
 
-   nfca_protocol_defaults(c, s);
-   nfcb_protocol_defaults(c, s);
-   nfcf_protocol_defaults(c, s);
-   nfcv_protocol_defaults(c, s);
+   nfca_protocol_defaults(c, cold.tim[0]);
+   nfcb_protocol_defaults(c, cold.tim[1]);
+   nfcf_protocol_defaults(c, cold.tim[2]);
+   nfcv_protocol_defaults(c, cold.tim[3]);
 
    for (int t = 0; t < 4; t++)
    {
-      s.tim[t].guardTime = s.tim[t].protoGuardTime;
-      s.tim[t].waitingTime = s.tim[t].protoWaitingTime;
+      cold.tim[t].guardTime = cold.tim[t].protoGuardTime;
+      cold.tim[t].waitingTime = cold.tim[t].protoWaitingTime;
    }
 }
 

@@ -22,12 +22,19 @@
 #include "nfc_core.hpp"
 #include "nfc_launch.h"
 
-#define TILE 64
-#define TILE_PITCH 65
+/* constant address space: uniform loads through it are always scalar (s_load), whatever else the kernel writes */
+typedef __attribute__((address_space(4))) NfcConfig NfcConfigConst;
 
-__global__ __launch_bounds__(64) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+#define TILE 32
+#define TILE_PITCH 33
+
+#ifndef NFC_MIN_WAVES
+#define NFC_MIN_WAVES 2
+#endif
+
+__global__ __launch_bounds__(64, NFC_MIN_WAVES) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
 {
-   __shared__ float tile[TILE * TILE_PITCH];
+   __shared__ float tile[NFC_LANES * TILE_PITCH];
    __shared__ NfcWork work[NFC_LANES];
 
    const uint32_t lane = threadIdx.x;
@@ -72,33 +79,30 @@ __global__ __launch_bounds__(64) void nfc_demod_kernel(const NfcConfig *__restri
 
    NfcStreamState s = L.states[slot];
 
-   float *ring = L.rings + (uint64_t)block * L.ringBlockFloats + lane;
-
    NfcLaneMem mem;
-   mem.x = ring;
-   mem.filt = ring + 1 * NFC_HIST * NFC_LANES;
-   mem.mdev = ring + 2 * NFC_HIST * NFC_LANES;
-   mem.depth = ring + 3 * NFC_HIST * NFC_LANES;
-   mem.prod = ring + 4 * NFC_HIST * NFC_LANES;
-   mem.corr = ring + (4 * NFC_HIST + NFC_PROD) * NFC_LANES;
+   mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats;
+   mem.lane = lane;
+   mem.exact = false;
    mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
    mem.sink = L.sink;
    mem.sinkCursor = L.sinkCtl;
    mem.sinkDropped = L.sinkCtl + 1;
    mem.sinkWords = L.sinkWords;
    mem.streamId = slot;
+   mem.cold = L.cold + slot;
 
    for (uint32_t base = 0; base < longest; base += TILE)
    {
-      /* stage: row r = stream r of the block, column = lane */
-      const uint32_t idx = base + lane;
+      /* stage: row r = stream r of the block; with TILE = 32 each instruction fetches two rows
+       * (lanes 0-31 row r, lanes 32-63 row r+1), 256 B of IQ per row */
+      const uint32_t col = lane % TILE;
+      const uint32_t sub = lane / TILE;
+      const uint32_t idx = base + col;
 
-      for (uint32_t r = 0; r < NFC_LANES; r++)
+      for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_LANES / TILE)
       {
+         const uint32_t r = r0 + sub;
          const NfcWork w = work[r];
-
-         if (base >= w.count)
-            continue;
 
          float v = 0.0f;
 
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(64) void nfc_demod_kernel(const NfcConfig *__restri
             }
          }
 
-         tile[r * TILE_PITCH + lane] = v;
+         tile[r * TILE_PITCH + col] = v;
       }
 
       __syncthreads();
@@ -125,8 +129,19 @@ __global__ __launch_bounds__(64) void nfc_demod_kernel(const NfcConfig *__restri
          const uint32_t left = mine.count - base;
          const uint32_t n = left < TILE ? left : TILE;
 
+         /* ring positions advance incrementally except in the few tiles that touch the stream start or the
+          * 32-bit clock wrap (s.clock + 1 .. s.clock + n), which take the exact-modulo variant */
+         const bool exact = nfc_exact_zone(s.clock + 1u) || nfc_exact_zone(s.clock + n);
+
          for (uint32_t k = 0; k < n; k++)
-            nfc_step(cfg, s, mem, tile[lane * TILE_PITCH + k]);
+         {
+            /* keep the ~100 configuration constants in the scalar cache instead of letting the compiler hoist
+             * them out of the sample loop into (spilled) registers */
+            const NfcConfigConst *cp = (const NfcConfigConst *)cfgPtr;
+            asm volatile("" : "+s"(cp));
+
+            nfc_step(*(const NfcConfig *)cp, s, mem, tile[lane * TILE_PITCH + k], exact);
+         }
       }
 
       __syncthreads();
@@ -150,8 +165,10 @@ __global__ __launch_bounds__(64) void nfc_init_kernel(const NfcConfig *__restric
    const NfcConfig &cfg = *cfgPtr;
 
    NfcStreamState s = L.states[slot];
-   nfc_state_init(cfg, s, keepFrontEnd != 0);
+   NfcStreamCold cold;
+   nfc_state_init(cfg, s, cold, keepFrontEnd != 0);
    L.states[slot] = s;
+   L.cold[slot] = cold;
 
    float *ring = L.rings + (uint64_t)block * L.ringBlockFloats + lane;
 

@@ -18,7 +18,8 @@ struct NfcWork
 
 struct NfcLaunch
 {
-   NfcStreamState *states; /* [maxStreams] */
+   NfcStreamState *states; /* [maxStreams] register-resident part */
+   NfcStreamCold *cold;    /* [maxStreams] protocol timing, touched at frame boundaries */
    float *rings;           /* [blocks][ringBlockFloats] */
    uint8_t *bytes;         /* [maxStreams][NFC_STREAM_BYTES] */
    uint32_t *sink;         /* packed frame records */

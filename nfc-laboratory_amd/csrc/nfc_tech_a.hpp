@@ -11,9 +11,8 @@
 #ifndef NFC_AMD_TECH_A_HPP
 #define NFC_AMD_TECH_A_HPP
 
-NFC_DEV void nfca_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+NFC_DEV void nfca_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 {
-   NfcTiming &t = s.tim[0];
    t.maxFrameSize = 256;
    t.protoGuardTime = nfc_tu(c, 1024);             /* NFCA_FGT_DEF */
    t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);  /* NFCA_FWT_DEF */
@@ -22,13 +21,13 @@ NFC_DEV void nfca_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
 /* resetModulation, NfcA.cpp:1451-1475 */
 NFC_DEV void nfca_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_mod_clear(s.modA[0]);
-   nfc_mod_clear(s.modA[1]);
-   nfc_mod_clear(s.modA[2]);
+   nfc_mod_clear(s.detA[0]);
+   nfc_mod_clear(s.detA[1]);
+   nfc_mod_clear(s.detA[2]);
    nfc_mod_clear(s.lock);
 
    /* the three rings are adjacent */
-   nfc_zero_ring(mem.corr, c.corrOffset[0], c.a[0].p1 + c.a[1].p1 + c.a[2].p1);
+   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[0], c.a[0].p1 + c.a[1].p1 + c.a[2].p1);
 
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
@@ -78,7 +77,7 @@ NFC_DEV void nfca_default_timing(const NfcConfig &c, NfcTiming &t)
 NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t type,
                           const uint8_t *data, uint32_t len, uint32_t &flags, uint32_t &phase)
 {
-   NfcTiming &t = s.tim[0];
+   NfcTiming &t = mem.cold->tim[0];
    const bool poll = (type == NFC_FRAME_POLL);
    const uint32_t b0 = nfc_byte(data, len, 0);
 
@@ -263,15 +262,15 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    {
       if (locked)
       {
-         t.guardEnd = s.frameEnd + t.guardTime + delay;
-         t.waitingEnd = s.frameEnd + t.waitingTime + delay;
+         s.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.waitingEnd = s.frameEnd + t.waitingTime + delay;
          s.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         t.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.guardEnd = s.frameEnd + t.guardTime + delay;
 
       s.frameType = 0;
       t.lastCommand = 0;
@@ -293,7 +292,7 @@ NFC_DEV void nfca_load_taps_rate(const NfcConfig &c, const NfcStreamState &s, co
 {
    const NfcRate &rt = c.a[R];
    taps.t[R] = nfc_tap_raw(mem, s.clock, rt, c.corrOffset[R], s.posA[R], true);
-   taps.deep[R] = NFC_AT(mem.depth, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+   taps.deep[R] = NFC_AT(mem, NFC_R_DEPTH, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
 }
 
 NFC_DEV void nfca_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsA &taps)
@@ -309,50 +308,52 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
                               float minimumCorrelation, float minimumDepth)
 {
    const NfcRate &rt = c.a[R];
-   NfcMod &m = s.modA[R];
+   NfcDetA &m = s.detA[R];
 
    NfcTap tap = taps.t[R];
    if (rt.delay == 0)
       tap.in = now.x; /* the newest sample is not in memory yet when the taps are read */
 
    NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[R], s.posA[R]);
-   float sd = (k.s0 - k.s1) / (float)rt.p2;
+   const float num = k.s0 - k.s1;
 
    if (m.peakTime && s.clock > m.peakTime + rt.p1)
    {
-      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
-      m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+      m.symStart = 0; m.winStart = 0; m.winEnd = 0;
+      m.aux = 0; m.peakTime = 0; m.peak = 0;
    }
 
    if (s.clock < m.winStart)
       return false;
 
-   if (!m.symStart)
+   if (nfc_may_exceed(num, (float)rt.p2, minimumCorrelation))
    {
-      if (sd < -minimumCorrelation)
-      {
-         float deep = taps.deep[R];
+      const float sd = num / (float)rt.p2;
 
-         if (sd < m.peak)
+      if (!m.symStart)
+      {
+         if (sd < -minimumCorrelation)
+         {
+            float deep = taps.deep[R];
+
+            if (sd < m.peak)
+            {
+               m.peak = sd;
+               m.peakTime = s.clock;
+               m.winEnd = s.clock + rt.p4;
+            }
+
+            if (deep > m.aux)
+               m.aux = deep;
+         }
+      }
+      else if (sd > minimumCorrelation)
+      {
+         if (sd > m.peak)
          {
             m.peak = sd;
             m.peakTime = s.clock;
-            m.winEnd = s.clock + rt.p4;
          }
-
-         if (deep > m.aux)
-         {
-            m.aux = deep;
-            m.auxTime = s.clock;
-         }
-      }
-   }
-   else if (sd > minimumCorrelation)
-   {
-      if (sd > m.peak)
-      {
-         m.peak = sd;
-         m.peakTime = s.clock;
       }
    }
 
@@ -363,41 +364,45 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    {
       if (m.aux < minimumDepth)
       {
-         m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
-         m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+         m.symStart = 0; m.winStart = 0; m.winEnd = 0;
+         m.peakTime = 0; m.peak = 0; m.aux = 0;
          return false;
       }
 
-      m.sync = m.peakTime + rt.p2;
-      m.winStart = m.sync - rt.p8;
-      m.winEnd = m.sync + rt.p8;
+      const uint32_t sync = m.peakTime + rt.p2;
+      m.winStart = sync - rt.p8;
+      m.winEnd = sync + rt.p8;
       m.symStart = m.peakTime - rt.p2;
       m.peakTime = 0;
       m.peak = 0;
       return false;
    }
 
-   m.symEnd = m.peakTime;
-   m.pulses = m.symEnd - m.symStart;
-
+   const uint32_t symEnd = m.peakTime;
+   const uint32_t width = symEnd - m.symStart;
    const uint32_t minimumWidth = rt.p1 - rt.p4;
    const uint32_t maximumWidth = rt.p1 + rt.p4;
 
-   if (m.peakTime == 0 || m.aux < minimumDepth || m.pulses < minimumWidth || m.pulses > maximumWidth)
+   if (m.peakTime == 0 || m.aux < minimumDepth || width < minimumWidth || width > maximumWidth)
    {
-      m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
-      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      m.symStart = 0; m.winStart = 0; m.winEnd = 0;
+      m.peakTime = 0; m.peak = 0; m.aux = 0;
       return false;
    }
 
-   m.sync = m.symEnd + rt.p1;
-   m.winStart = m.sync - rt.p8;
-   m.winEnd = m.sync + rt.p8;
-   m.thr = m.peak / 2;
-   m.c0 = 0;
-   m.c1 = 0;
-   m.peakTime = 0;
-   m.peak = 0;
+   /* SOF pause recognised: lock this bitrate */
+   nfc_take_lock(s, rt, NFC_TECH_A, (uint32_t)R, c.corrOffset[R], s.posA[R]);
+
+   NfcMod &d = s.lock;
+   d.symStart = m.symStart;
+   d.symEnd = symEnd;
+   d.pulses = width;
+   d.sync = symEnd + rt.p1;
+   d.winStart = d.sync - rt.p8;
+   d.winEnd = d.sync + rt.p8;
+   d.thr = m.peak / 2;
+   d.acc = m.acc;
+   d.aux = m.aux;
 
    s.frameType = NFC_FRAME_POLL;
    s.frameRate = rt.symbolsPerSecond;
@@ -406,11 +411,9 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
 
    s.symValue = 0;
    s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
+   s.symEnd = symEnd - rt.delay;
    s.symPattern = A_Z;
 
-   nfc_take_lock(s, m, rt, NFC_TECH_A, (uint32_t)R, c.corrOffset[R], s.posA[R]);
    return true;
 }
 
@@ -500,7 +503,6 @@ NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
    s.symEdge = m.symRise - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
 
    return s.symPattern;
 }
@@ -508,10 +510,8 @@ NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 /* ---- poll frame assembly, NfcA.cpp:432-563 ---- */
 NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t pattern)
 {
-   NfcTiming &t = s.tim[0];
+   NfcTiming &t = mem.cold->tim[0];
    bool frameEnd = false, truncated = false;
-
-   s.bsPattern = pattern;
 
    if (pattern == A_Y && (s.bsPrevious == A_Y || s.bsPrevious == A_Z))
       frameEnd = true;
@@ -577,7 +577,7 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
       }
    }
 
-   s.bsPrevious = s.bsPattern;
+   s.bsPrevious = pattern;
 }
 
 /* ---- listen SOF, 106k OOK subcarrier, NfcA.cpp:939-1090 ---- */
@@ -585,33 +585,33 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
 {
    const NfcRate &rt = s.rt;
    NfcMod &m = s.lock;
-   NfcTiming &t = s.tim[0];
+   NfcTiming &t = mem.cold->tim[0];
 
    /* this stage only forms S0 (NfcA.cpp:962-975): same ring, no S1 */
    const uint32_t cur = s.clock - rt.delay;
    const uint32_t pos = nfc_lock_pos(s);
 
-   const float v = NFC_AT(mem.filt, cur & NFC_HMASK);
-   const float old = NFC_AT(mem.prod, (cur - rt.p2) & NFC_PMASK);
-   const float c2 = NFC_AT(mem.corr, s.lockBase + nfc_point(s.clock, rt.delay, pos, rt.p2, rt.p1));
-   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
+   const float old = NFC_AT(mem, NFC_R_PROD, (cur - rt.p2) & NFC_PMASK);
+   const float c2 = NFC_AT(mem, NFC_R_CORR, s.lockBase + nfc_point(mem, s.clock, rt.delay, pos, rt.p2, rt.p1));
+   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    const float deep = now.depth;
    const float sq = v * v * 10.0f;
 
-   NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
+   NFC_AT(mem, NFC_R_PROD, cur & NFC_PMASK) = sq;
    m.acc += sq;
    m.acc -= old;
 
-   NFC_AT(mem.corr, s.lockBase + pos) = m.acc;
+   NFC_AT(mem, NFC_R_CORR, s.lockBase + pos) = m.acc;
    float s0 = m.acc - c2;
 
-   if (s.clock < t.guardEnd)
+   if (s.clock < s.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == t.guardEnd)
+   if (s.clock == s.guardEnd)
       m.thr = guardDev * (float)rt.p8;
 
-   if (s.clock > t.waitingEnd)
+   if (s.clock > s.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.minDepth[0])
@@ -670,7 +670,6 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
    s.symValue = 1;
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
    s.symPattern = A_D;
 
    return A_D;
@@ -740,7 +739,6 @@ NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, c
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
    s.symEdge = m.symRise - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
 
    return s.symPattern;
 }
@@ -750,20 +748,20 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
 {
    const NfcRate &rt = s.rt;
    NfcMod &m = s.lock;
-   NfcTiming &t = s.tim[0];
+   NfcTiming &t = mem.cold->tim[0];
 
    const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
-   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
 
-   if (s.clock < t.guardEnd)
+   if (s.clock < s.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == t.guardEnd)
+   if (s.clock == s.guardEnd)
       m.thr = guardDev;
 
-   if (s.clock > t.waitingEnd)
+   if (s.clock > s.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.minDepth[0])
@@ -805,7 +803,6 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
    s.symValue = 0;
    s.symStart = m.symStart - rt.p1 - rt.delay;
    s.symEnd = m.symEnd - rt.p1 - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
    s.symPattern = A_S;
 
    return A_S;
@@ -854,7 +851,6 @@ NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, 
 
    s.symStart = m.symStart - rt.p1 - rt.delay;
    s.symEnd = m.symEnd - rt.p1 - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
 
    return s.symPattern;
 }
@@ -874,7 +870,7 @@ NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const Nfc
 /* ---- one sample in locked NFC-A mode: decodeFrame, NfcA.cpp:416-803 ---- */
 NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   NfcTiming &t = s.tim[0];
+   NfcTiming &t = mem.cold->tim[0];
 
    if (s.frameType == NFC_FRAME_POLL)
    {

@@ -11,9 +11,8 @@
 #ifndef NFC_AMD_TECH_B_HPP
 #define NFC_AMD_TECH_B_HPP
 
-NFC_DEV void nfcb_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+NFC_DEV void nfcb_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 {
-   NfcTiming &t = s.tim[1];
    t.maxFrameSize = 256;
    t.protoGuardTime = nfc_tu(c, 1024);            /* NFCB_FGT_DEF = TR0min */
    t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16); /* NFCB_FWT_DEF */
@@ -21,9 +20,8 @@ NFC_DEV void nfcb_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
 
 NFC_DEV void nfcb_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_mod_clear(s.modB[0]);
-   nfc_mod_clear(s.modB[1]);
-   nfc_mod_clear(s.modB[2]);
+   nfc_mod_clear(s.detB[0]);
+   nfc_mod_clear(s.detB[1]);
    nfc_mod_clear(s.lock);
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
@@ -45,12 +43,12 @@ NFC_DEV bool nfcb_crc_ok(const uint8_t *data, uint32_t len)
    return res == crc;
 }
 
-NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, const uint8_t *data, uint32_t len,
+NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t type, const uint8_t *data, uint32_t len,
                           uint32_t &flags, uint32_t &phase)
 {
    static const uint16_t fsd[16] = {16, 24, 32, 40, 48, 64, 96, 128, 256, 512, 1024, 2048, 4096, 0, 0, 0};
 
-   NfcTiming &t = s.tim[1];
+   NfcTiming &t = mem.cold->tim[1];
    const bool poll = (type == NFC_FRAME_POLL);
    const uint32_t b0 = nfc_byte(data, len, 0);
 
@@ -128,15 +126,15 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
    {
       if (locked)
       {
-         t.guardEnd = s.frameEnd + t.guardTime + delay;
-         t.waitingEnd = s.frameEnd + t.waitingTime + delay;
+         s.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.waitingEnd = s.frameEnd + t.waitingTime + delay;
          s.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         t.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.guardEnd = s.frameEnd + t.guardTime + delay;
 
       s.frameType = 0;
       t.lastCommand = 0;
@@ -157,10 +155,10 @@ NFC_DEV void nfcb_load_taps(const NfcConfig &c, const NfcStreamState &s, const N
 {
    const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_HMASK;
    const uint32_t slot1 = (s.clock - c.b[1].delay) & NFC_HMASK;
-   taps.edge[0] = NFC_AT(mem.filt, slot0);
-   taps.deep[0] = NFC_AT(mem.depth, slot0);
-   taps.edge[1] = NFC_AT(mem.filt, slot1);
-   taps.deep[1] = NFC_AT(mem.depth, slot1);
+   taps.edge[0] = NFC_AT(mem, NFC_R_FILT, slot0);
+   taps.deep[0] = NFC_AT(mem, NFC_R_DEPTH, slot0);
+   taps.edge[1] = NFC_AT(mem, NFC_R_FILT, slot1);
+   taps.deep[1] = NFC_AT(mem, NFC_R_DEPTH, slot1);
 }
 
 /* ---- search: SOF = falling edge, 10-11 etu low, rising edge, 2-3 etu high, falling edge ----
@@ -169,7 +167,7 @@ template <int R>
 NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsB &taps, const NfcNow &now)
 {
    const NfcRate &rt = c.b[R];
-   NfcMod &m = s.modB[R];
+   NfcDetB &m = s.detB[R];
 
    /* with no delay the sample of interest is the one the front end has just produced */
    float edge = rt.delay ? taps.edge[R] : now.filt;
@@ -177,7 +175,7 @@ NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLan
 
    if (deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1))
    {
-      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
+      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
       m.auxTime = 0; m.aux = 0;
    }
 
@@ -268,20 +266,20 @@ NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLan
       return 2; /* the reference leaves the rate loop here (NfcB.cpp:396) */
    }
 
-   m.symEnd = m.auxTime;
-   m.sync = m.symEnd + rt.p2;
-   m.winStart = 0;
-   m.winEnd = 0;
-   m.thr = nfc_abs(m.aux * 0.5f);
-   m.auxTime = 0;
-   m.aux = 0;
+   /* SOF recognised: lock; the first bit is sampled half a symbol after the last edge, no search window yet */
+   nfc_take_lock(s, rt, NFC_TECH_B, (uint32_t)R, 0, 0);
+
+   NfcMod &d = s.lock;
+   d.symStart = m.symStart;
+   d.symEnd = m.auxTime;
+   d.sync = d.symEnd + rt.p2;
+   d.thr = nfc_abs(m.aux * 0.5f);
 
    s.frameType = NFC_FRAME_POLL;
    s.frameRate = rt.symbolsPerSecond;
    s.frameStart = m.symStart - rt.delay;
    s.frameEnd = 0;
 
-   nfc_take_lock(s, m, rt, NFC_TECH_B, (uint32_t)R, 0, 0);
    return 1;
 }
 
@@ -307,8 +305,8 @@ NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
    NfcMod &m = s.lock;
 
    const uint32_t slot = (s.clock - rt.delay) & NFC_HMASK;
-   float edge = NFC_AT(mem.filt, slot);
-   float deep = NFC_AT(mem.depth, slot);
+   float edge = NFC_AT(mem, NFC_R_FILT, slot);
+   float deep = NFC_AT(mem, NFC_R_DEPTH, slot);
 
    if (s.clock > m.winStart && s.clock < m.winEnd)
    {
@@ -344,7 +342,6 @@ NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
 
    return s.symPattern;
 }
@@ -354,22 +351,22 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 {
    const NfcRate &rt = s.rt;
    NfcMod &m = s.lock;
-   NfcTiming &t = s.tim[1];
+   NfcTiming &t = mem.cold->tim[1];
 
    const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
-   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
 
    nfc_phase_integrate(m, p);
 
-   if (s.clock < t.guardEnd)
+   if (s.clock < s.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == t.guardEnd)
+   if (s.clock == s.guardEnd)
       m.thr = guardDev;
 
-   if (s.clock > t.waitingEnd)
+   if (s.clock > s.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.maxDepth[1])
@@ -449,7 +446,6 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
       s.symValue = 1;
       s.symStart = m.symStart - rt.p1 - rt.delay;
       s.symEnd = m.symEnd - rt.p1 - rt.delay;
-      s.symLength = s.symEnd - s.symStart;
       s.symPattern = B_S;
 
       return B_S;
@@ -502,7 +498,6 @@ NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 
    s.symStart = m.symStart - rt.p1 - rt.delay;
    s.symEnd = m.symEnd - rt.p1 - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
 
    return s.symPattern;
 }
@@ -510,7 +505,7 @@ NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 /* ---- one sample in locked NFC-B mode ---- */
 NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   NfcTiming &t = s.tim[1];
+   NfcTiming &t = mem.cold->tim[1];
 
    if (s.frameType == NFC_FRAME_POLL)
    {
@@ -541,7 +536,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
             const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.rt.symbolsPerSecond;
 
-            nfcb_process(c, s, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
+            nfcb_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
             nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
 
             nfc_clear_assembly(s);
@@ -612,7 +607,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
          const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.rt.symbolsPerSecond;
 
-         nfcb_process(c, s, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
+         nfcb_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
       }
 

@@ -11,9 +11,8 @@
 #ifndef NFC_AMD_TECH_F_HPP
 #define NFC_AMD_TECH_F_HPP
 
-NFC_DEV void nfcf_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+NFC_DEV void nfcf_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 {
-   NfcTiming &t = s.tim[2];
    t.maxFrameSize = 256;
    t.protoGuardTime = nfc_tu(c, 1024);            /* NFCF_FGT_DEF */
    t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16); /* NFCF_FWT_DEF */
@@ -21,12 +20,12 @@ NFC_DEV void nfcf_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
 
 NFC_DEV void nfcf_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_mod_clear(s.modF[1]);
-   nfc_mod_clear(s.modF[2]);
+   nfc_mod_clear(s.detF[0]);
+   nfc_mod_clear(s.detF[1]);
    nfc_mod_clear(s.lock);
 
    /* the two rings are adjacent */
-   nfc_zero_ring(mem.corr, c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
+   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
 
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
@@ -48,10 +47,10 @@ NFC_DEV bool nfcf_crc_ok(const uint8_t *data, uint32_t len)
    return res == crc;
 }
 
-NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, const uint8_t *data, uint32_t len,
+NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t type, const uint8_t *data, uint32_t len,
                           uint32_t &flags, uint32_t &phase)
 {
-   NfcTiming &t = s.tim[2];
+   NfcTiming &t = mem.cold->tim[2];
    const bool poll = (type == NFC_FRAME_POLL);
 
    t.guardTime = t.protoGuardTime;
@@ -95,15 +94,15 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
    {
       if (locked)
       {
-         t.guardEnd = s.frameEnd + t.guardTime + delay;
-         t.waitingEnd = s.frameEnd + t.waitingTime + delay;
+         s.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.waitingEnd = s.frameEnd + t.waitingTime + delay;
          s.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         t.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.guardEnd = s.frameEnd + t.guardTime + delay;
 
       s.frameType = 0;
       t.lastCommand = 0;
@@ -115,7 +114,8 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
 
 /* the preamble tracker shared by search (NfcF.cpp:267-405) and listen-SOF (NfcF.cpp:815-933);
  * returns true when a complete, length-checked preamble has just ended */
-NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, NfcMod &m, const NfcRate &rt, float sd, float s0, bool above)
+template <class M>
+NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, float sd, float s0, bool above, uint32_t &polarity)
 {
    if (above)
    {
@@ -182,7 +182,7 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, NfcMod &m, const NfcRate &rt
       return false;
    }
 
-   m.stage = m.lastPhase > 0 ? 0u : 1u; /* observed / reversed polarity */
+   polarity = m.lastPhase > 0 ? 0u : 1u; /* observed / reversed polarity (the reference's searchModeState) */
    m.sync = m.sync + rt.p2;
    m.winStart = m.sync - rt.p4;
    m.winEnd = m.sync + rt.p4;
@@ -200,8 +200,8 @@ struct NfcTapsF
 
 NFC_DEV void nfcf_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsF &taps)
 {
-   taps.t[1] = nfc_tap_raw(mem, s.clock, c.f[1], c.corrOffset[3], s.posF[1], true);
-   taps.t[2] = nfc_tap_raw(mem, s.clock, c.f[2], c.corrOffset[4], s.posF[2], true);
+   taps.t[1] = nfc_tap_raw(mem, s.clock, c.f[1], c.corrOffset[3], s.posF[0], true);
+   taps.t[2] = nfc_tap_raw(mem, s.clock, c.f[2], c.corrOffset[4], s.posF[1], true);
 }
 
 template <int R>
@@ -209,31 +209,47 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
                               float minimumCorrelation)
 {
    const NfcRate &rt = c.f[R];
-   NfcMod &m = s.modF[R];
+   NfcDetF &m = s.detF[R - 1];
 
    /* NFC-F correlates the undelayed signal: the entering sample and its depth are the current ones */
    NfcTap tap = taps.t[R];
    tap.in = now.x;
    const float deep = now.depth;
 
-   NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[2 + R], s.posF[R]);
-   float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
+   NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[2 + R], s.posF[R - 1]);
+   const float num = k.s0 - k.s1;
 
    if (deep > c.maxDepth[2] || (m.peakTime && s.clock > m.peakTime + rt.p1))
    {
+      /* (detectorPeak* are never set by this detector: nothing to clear) */
       m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
-      m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+      m.peakTime = 0; m.peak = 0;
    }
 
    if (s.clock < m.winStart)
       return false;
 
-   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation))
+   /* the quotient is needed when it can exceed the threshold, and at the synchronisation sample (captured) */
+   float sd = 0.0f;
+   if (nfc_may_exceed(num, (float)rt.p2, minimumCorrelation) || s.clock == m.sync)
+      sd = nfc_abs(num) / (float)rt.p2;
+
+   uint32_t polarity = 0;
+
+   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity))
       return false;
+
+   /* preamble complete: lock this bitrate, the sync bytes follow */
+   nfc_take_lock(s, rt, NFC_TECH_F, (uint32_t)R, c.corrOffset[2 + R], s.posF[R - 1]);
+
+   NfcMod &d = s.lock;
+   d.stage = polarity;
+   d.winStart = m.winStart; d.winEnd = m.winEnd; d.sync = m.sync; d.pulses = m.pulses;
+   d.thr = m.thr; d.lastPhase = m.lastPhase; d.lastValue = m.lastValue; d.syncValue = m.syncValue; d.c0 = m.c0;
+   d.symStart = m.symStart; d.symEnd = m.symEnd; d.acc = m.acc; d.peak = m.peak; d.peakTime = m.peakTime;
 
    s.symStart = m.symStart;
    s.symEnd = m.symEnd;
-   s.symLength = s.symEnd - s.symStart;
    s.symPattern = F_S;
 
    s.frameType = NFC_FRAME_POLL;
@@ -241,7 +257,6 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    s.frameStart = s.symStart;
    s.frameEnd = 0;
 
-   nfc_take_lock(s, m, rt, NFC_TECH_F, (uint32_t)R, c.corrOffset[2 + R], s.posF[R]);
    return true;
 }
 
@@ -304,7 +319,6 @@ NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const N
 
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
 
    if ((m.stage == 0 && m.c0 > m.c1) || (m.stage == 1 && m.c0 < m.c1))
    {
@@ -324,46 +338,49 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 {
    const NfcRate &rt = s.rt;
    NfcMod &m = s.lock;
-   NfcTiming &t = s.tim[2];
+   NfcTiming &t = mem.cold->tim[2];
 
    const uint32_t cur = s.clock - rt.delay;
    const uint32_t base = s.lockBase;
    const uint32_t pos = nfc_lock_pos(s);
 
    const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, base, pos, true);
-   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
 
    /* the box sum runs from the end of the poll frame, the ring only from one symbol before the guard */
    m.acc += tap.in;
    m.acc -= tap.out;
 
-   if (s.clock < (uint32_t)(t.guardEnd - rt.p1))
+   if (s.clock < (uint32_t)(s.guardEnd - rt.p1))
       return SYM_NONE;
 
-   NFC_AT(mem.corr, base + pos) = m.acc;
+   NFC_AT(mem, NFC_R_CORR, base + pos) = m.acc;
 
    float s0 = m.acc - tap.c2;
    float s1 = tap.c2 - tap.c3;
    float sd = nfc_abs(s0 - s1) / (float)rt.p2;
 
-   if (s.clock < t.guardEnd)
+   if (s.clock < s.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == t.guardEnd)
+   if (s.clock == s.guardEnd)
       m.thr = guardDev * 10.0f;
 
-   if (s.clock > t.waitingEnd)
+   if (s.clock > s.waitingEnd)
       return SYM_TIMEOUT;
 
    if (s.clock < m.winStart)
       return SYM_NONE;
 
-   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd >= m.thr))
+   uint32_t polarity = 0;
+
+   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd >= m.thr, polarity))
       return SYM_NONE;
+
+   m.stage = polarity;
 
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
    s.symPattern = F_S;
 
    return F_S;
@@ -372,7 +389,7 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 /* bits are MSB first, no parity; frame = 2 sync bytes + payload */
 NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t pattern, uint32_t type)
 {
-   NfcTiming &t = s.tim[2];
+   NfcTiming &t = mem.cold->tim[2];
    bool frameEnd = false, truncated = false;
 
    if (pattern == F_E)
@@ -395,7 +412,7 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
          const uint32_t start = s.frameStart, end = s.frameEnd, len = total - 2;
          const uint32_t rate = s.rt.symbolsPerSecond;
 
-         nfcf_process(c, s, type, mem.bytes + 2, len, flags, phase);
+         nfcf_process(c, s, mem, type, mem.bytes + 2, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_F, type, flags, phase, rate, start, end, mem.bytes + 2, len);
 
          if (type == NFC_FRAME_POLL)

@@ -11,9 +11,8 @@
 #ifndef NFC_AMD_TECH_V_HPP
 #define NFC_AMD_TECH_V_HPP
 
-NFC_DEV void nfcv_protocol_defaults(const NfcConfig &c, NfcStreamState &s)
+NFC_DEV void nfcv_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 {
-   NfcTiming &t = s.tim[3];
    t.maxFrameSize = 256;
    t.protoGuardTime = nfc_tu(c, 1024);            /* NFCV_FGT_DEF */
    t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16); /* NFCV_FWT_DEF */
@@ -23,9 +22,9 @@ NFC_DEV void nfcv_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
 {
    nfc_clear_assembly(s);
    nfc_clear_symbol(s);
-   nfc_mod_clear(s.modV);
+   nfc_mod_clear(s.detV);
    nfc_mod_clear(s.lock);
-   nfc_zero_ring(mem.corr, c.corrOffset[5], c.v.p0);
+   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[5], c.v.p0);
 
    s.frameType = 0;
    s.frameStart = 0;
@@ -44,10 +43,10 @@ NFC_DEV bool nfcv_crc_ok(const uint8_t *data, uint32_t len)
    return res == crc;
 }
 
-NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, const uint8_t *data, uint32_t len,
+NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t type, const uint8_t *data, uint32_t len,
                           uint32_t &flags, uint32_t &phase)
 {
-   NfcTiming &t = s.tim[3];
+   NfcTiming &t = mem.cold->tim[3];
    const bool poll = (type == NFC_FRAME_POLL);
 
    t.guardTime = t.protoGuardTime;
@@ -65,15 +64,15 @@ NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, uint32_t type, 
       if (locked)
       {
          /* note the sign: the poll side runs on the delayed signal (NfcV.cpp:1145-1148) */
-         t.guardEnd = s.frameEnd + t.guardTime - c.v.delay;
-         t.waitingEnd = s.frameEnd + t.waitingTime - c.v.delay;
+         s.guardEnd = s.frameEnd + t.guardTime - c.v.delay;
+         s.waitingEnd = s.frameEnd + t.waitingTime - c.v.delay;
          s.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         t.guardEnd = s.frameEnd + t.guardTime + c.v.delay;
+         s.guardEnd = s.frameEnd + t.guardTime + c.v.delay;
 
       s.frameType = 0;
       t.lastCommand = 0;
@@ -94,15 +93,16 @@ struct NfcTapsV
 NFC_DEV void nfcv_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsV &taps)
 {
    taps.t = nfc_tap_raw(mem, s.clock, c.v, c.corrOffset[5], s.posV1, false);
-   taps.deep = NFC_AT(mem.depth, (s.clock - c.v.delay - c.v.p8) & NFC_HMASK);
+   taps.deep = NFC_AT(mem, NFC_R_DEPTH, (s.clock - c.v.delay - c.v.p8) & NFC_HMASK);
 }
 
-NFC_DEV float nfcv_pulse_apply(const NfcLaneMem &mem, NfcMod &m, const NfcTap &t, uint32_t base, uint32_t pos, const NfcRate &rt)
+template <class M>
+NFC_DEV float nfcv_pulse_apply(const NfcLaneMem &mem, M &m, const NfcTap &t, uint32_t base, uint32_t pos, const NfcRate &rt)
 {
    m.acc += t.in;
    m.acc -= t.out;
 
-   NFC_AT(mem.corr, base + pos) = m.acc;
+   NFC_AT(mem, NFC_R_CORR, base + pos) = m.acc;
 
    return (t.c2 - m.acc) / (float)rt.p2;
 }
@@ -116,37 +116,40 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return false;
 
    const NfcRate &rt = c.v;
-   NfcMod &m = s.modV;
+   NfcDetV &m = s.detV;
 
    const float minimumCorrelation = s.env * c.corrThreshold[3];
    const float raw = taps.t.in;
 
-   float s0 = nfcv_pulse_apply(mem, m, taps.t, c.corrOffset[5], s.posV1, rt);
+   m.acc += taps.t.in;
+   m.acc -= taps.t.out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[5] + s.posV1) = m.acc;
+   const float num = taps.t.c2 - m.acc;
 
    if (m.peakTime && s.clock > m.peakTime + rt.p0)
    {
-      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
-      m.auxTime = 0; m.aux = 0; m.peakTime = 0; m.peak = 0;
+      m.symStart = 0; m.winStart = 0; m.winEnd = 0;
+      m.aux = 0; m.peakTime = 0; m.peak = 0;
    }
 
    if (s.clock < m.winStart)
       return false;
 
-   if (s0 > minimumCorrelation)
+   if (nfc_may_exceed(num, (float)rt.p2, minimumCorrelation))
    {
-      if (s0 > m.peak)
-      {
-         m.peak = s0;
-         m.peakTime = s.clock;
-         m.winEnd = s.clock + rt.p4;
-      }
+      const float s0 = num / (float)rt.p2;
 
-      float deep = taps.deep;
-
-      if (deep > m.aux)
+      if (s0 > minimumCorrelation)
       {
-         m.aux = deep;
-         m.auxTime = s.clock;
+         if (s0 > m.peak)
+         {
+            m.peak = s0;
+            m.peakTime = s.clock;
+            m.winEnd = s.clock + rt.p4;
+         }
+
+         if (taps.deep > m.aux)
+            m.aux = taps.deep;
       }
    }
 
@@ -155,8 +158,8 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (raw < minimumCorrelation || m.peakTime == 0 || m.aux < c.minDepth[3])
    {
-      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
-      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      m.symStart = 0; m.winStart = 0; m.winEnd = 0;
+      m.peakTime = 0; m.peak = 0; m.aux = 0;
       return false;
    }
 
@@ -165,44 +168,52 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       m.symStart = m.peakTime - rt.p2;
       m.winStart = m.symStart + (2 * rt.p1);
       m.winEnd = m.symStart + (4 * rt.p1);
-      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      m.peakTime = 0; m.peak = 0; m.aux = 0;
       return false;
    }
+
+   uint32_t symEnd, length, rate, code;
 
    if (m.peakTime > (m.symStart + 3 * rt.p1 - rt.p8) && m.peakTime < (m.symStart + 3 * rt.p1 + rt.p8))
    {
-      m.symEnd = m.peakTime + rt.p1;
-      m.sync = m.symEnd;
-      m.winStart = m.sync;
-      m.winEnd = m.sync + (uint32_t)c.vLen2;
-      s.frameRate = rt.symbolsPerSecond / 2;
-      s.pulseCode = 0;
+      symEnd = m.peakTime + rt.p1;
+      length = (uint32_t)c.vLen2;
+      rate = rt.symbolsPerSecond / 2;
+      code = 0;
    }
    else if (m.peakTime > (m.symStart + 4 * rt.p1 - rt.p8) && m.peakTime < (m.symStart + 4 * rt.p1 + rt.p8))
    {
-      m.symEnd = m.peakTime;
-      m.sync = m.symEnd;
-      m.winStart = m.sync;
-      m.winEnd = m.sync + (uint32_t)c.vLen8;
-      s.frameRate = rt.symbolsPerSecond / 32;
-      s.pulseCode = 1;
+      symEnd = m.peakTime;
+      length = (uint32_t)c.vLen8;
+      rate = rt.symbolsPerSecond / 32;
+      code = 1;
    }
    else
    {
-      m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
-      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      m.symStart = 0; m.winStart = 0; m.winEnd = 0;
+      m.peakTime = 0; m.peak = 0; m.aux = 0;
       return false;
    }
 
+   /* SOF (two pulses) recognised: lock */
+   nfc_take_lock(s, rt, NFC_TECH_V, 0, c.corrOffset[5], s.posV1);
+
+   NfcMod &d = s.lock;
+   d.symStart = m.symStart;
+   d.symEnd = symEnd;
+   d.sync = symEnd;
+   d.winStart = symEnd;
+   d.winEnd = symEnd + length;
+   d.thr = minimumCorrelation;
+   d.acc = m.acc;
+   d.aux = m.aux;
+
+   s.frameRate = rate;
+   s.pulseCode = code;
    s.frameType = NFC_FRAME_POLL;
    s.frameStart = m.symStart - rt.delay;
    s.frameEnd = 0;
 
-   m.peakTime = 0;
-   m.peak = 0;
-   m.thr = minimumCorrelation;
-
-   nfc_take_lock(s, m, rt, NFC_TECH_V, 0, c.corrOffset[5], s.posV1);
    return true;
 }
 
@@ -239,7 +250,6 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
       s.symValue = 0;
       s.symStart = m.symStart - rt.delay;
       s.symEnd = m.symEnd - rt.delay;
-      s.symLength = s.symEnd - s.symStart;
       s.symPattern = V_S;
       return V_S;
    }
@@ -247,7 +257,6 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
    s.symValue = 0;
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
    s.symPattern = V_E;
 
    const int periods = s.pulseCode ? 256 : 4;
@@ -271,7 +280,6 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
          s.symValue = (uint32_t)i;
          s.symStart = m.symStart - rt.delay;
          s.symEnd = m.symEnd - rt.delay;
-         s.symLength = s.symEnd - s.symStart;
          s.symPattern = s.pulseCode ? V_8 : V_2;
          return s.symPattern;
       }
@@ -288,18 +296,18 @@ NFC_DEV float nfcv_burst_correlation(NfcStreamState &s, const NfcLaneMem &mem, N
    const uint32_t base = s.lockBase;
    const uint32_t pos = s.posV0;
 
-   const float v = NFC_AT(mem.filt, cur & NFC_HMASK);
-   const float old = NFC_AT(mem.prod, (cur - rt.p1) & NFC_PMASK);
-   const float c2 = NFC_AT(mem.corr, base + nfc_point(s.clock, rt.delay, pos, rt.p1, rt.p0));
+   const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
+   const float old = NFC_AT(mem, NFC_R_PROD, (cur - rt.p1) & NFC_PMASK);
+   const float c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, s.clock, rt.delay, pos, rt.p1, rt.p0));
 
    const float sq = v * v * 10.0f;
 
-   NFC_AT(mem.prod, cur & NFC_PMASK) = sq;
+   NFC_AT(mem, NFC_R_PROD, cur & NFC_PMASK) = sq;
 
    m.acc += sq;
    m.acc -= old;
 
-   NFC_AT(mem.corr, base + pos) = m.acc;
+   NFC_AT(mem, NFC_R_CORR, base + pos) = m.acc;
 
    return c2 - m.acc;
 }
@@ -308,20 +316,20 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 {
    const NfcRate &rt = s.rt;
    NfcMod &m = s.lock;
-   NfcTiming &t = s.tim[3];
+   NfcTiming &t = mem.cold->tim[3];
 
    const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
-   const float guardDev = NFC_AT(mem.mdev, cur & NFC_HMASK);
+   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    float s0 = nfcv_burst_correlation(s, mem, m);
 
-   if (s.clock < t.guardEnd)
+   if (s.clock < s.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == t.guardEnd)
+   if (s.clock == s.guardEnd)
       m.thr = guardDev;
 
-   if (s.clock > t.waitingEnd)
+   if (s.clock > s.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.maxDepth[3])
@@ -401,7 +409,6 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
       s.symValue = 0;
       s.symStart = m.symStart - rt.delay;
       s.symEnd = m.symEnd - rt.delay;
-      s.symLength = s.symEnd - s.symStart;
       s.symPattern = V_S;
       return V_S;
    }
@@ -446,7 +453,6 @@ NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
    s.symValue = m.c0 > m.c1 ? 0u : 1u;
    s.symStart = m.symStart - rt.delay;
    s.symEnd = m.symEnd - rt.delay;
-   s.symLength = s.symEnd - s.symStart;
    s.symPattern = s.symValue ? V_1 : V_0;
 
    return s.symPattern;
@@ -454,7 +460,7 @@ NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 
 NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   NfcTiming &t = s.tim[3];
+   NfcTiming &t = mem.cold->tim[3];
 
    if (s.frameType == NFC_FRAME_POLL)
    {
@@ -484,7 +490,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
             const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.frameRate;
 
-            nfcv_process(c, s, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
+            nfcv_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
             nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
 
             nfc_clear_assembly(s);
@@ -552,7 +558,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
          const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.frameRate;
 
-         nfcv_process(c, s, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
+         nfcv_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
       }
 

@@ -128,19 +128,56 @@ struct NfcMod
    uint32_t auxTime;   /* detectorPeakTime   */
 };
 
+/* per-technology protocol timing (frameStatus / protocolStatus of the reference); lives in HBM, touched only
+ * at frame boundaries */
 struct NfcTiming
 {
    uint32_t lastCommand;
    uint32_t guardTime;   /* frameStatus.frameGuardTime   */
    uint32_t waitingTime; /* frameStatus.frameWaitingTime */
-   uint32_t guardEnd;
-   uint32_t waitingEnd;
-   /* protocolStatus */
    uint32_t maxFrameSize;
    uint32_t protoGuardTime;
    uint32_t protoWaitingTime;
 };
 
+/* search-mode detector state, one record per (tech, bitrate): only the NfcMod fields a detector reads back
+ * between samples. Everything else of the reference's NfcModulationStatus is, while searching, either provably
+ * zero (only written in decode mode; the whole record is cleared when the technology resets) or write-only until
+ * the lock (searchSyncTime, symbolEndTime, searchPulseWidth ... are then set directly in the working copy).
+ * detectorPeakTime of NFC-A/V is never read before it is overwritten and is not tracked. */
+struct NfcDetA
+{
+   uint32_t winStart, winEnd, symStart;
+   float acc, peak, aux;
+   uint32_t peakTime;
+};
+
+struct NfcDetB
+{
+   uint32_t winStart, winEnd;
+   float thr;
+   uint32_t symStart, symEnd;
+   float aux;
+   uint32_t auxTime;
+};
+
+struct NfcDetF
+{
+   uint32_t winStart, winEnd, sync, pulses;
+   float thr, lastPhase, lastValue, syncValue, c0;
+   uint32_t symStart, symEnd;
+   float acc, peak;
+   uint32_t peakTime;
+};
+
+struct NfcDetV
+{
+   uint32_t winStart, winEnd, symStart;
+   float acc, peak, aux;
+   uint32_t peakTime;
+};
+
+/* the part of a stream's state that the kernel keeps in registers for the whole launch */
 struct NfcStreamState
 {
    /* ---- front end (NfcTech.h:317-393) ---- */
@@ -159,36 +196,40 @@ struct NfcStreamState
    uint32_t lockTech;  /* NFC_TECH_* or 0 */
    uint32_t lockRate;  /* rate type 0..2 */
    uint32_t pulseCode; /* NFC-V: 0 -> 1 of 4, 1 -> 1 of 256 */
+   uint32_t lockBase;  /* correlation ring base of the locked modulation */
+   uint32_t lockPos;   /* ring position (idx % rt.p1) of the locked correlator, advanced every sample while locked */
+   uint32_t guardEnd;  /* frameStatus.guardEnd / waitingEnd of the locked technology (always written by the poll */
+   uint32_t waitingEnd;/* frame's process() before a listen window reads them) */
 
    /* ---- shared symbol / bit stream / frame assembly ---- */
-   uint32_t symPattern, symValue, symStart, symEnd, symEdge, symLength;
-   uint32_t bsPrevious, bsPattern, bsBits, bsSkip, bsData, bsFlags, bsParity, bsBytes;
+   uint32_t symPattern, symValue, symStart, symEnd, symEdge;
+   uint32_t bsPrevious, bsBits, bsSkip, bsData, bsFlags, bsParity, bsBytes;
    uint32_t frameType, frameRate, frameStart, frameEnd;
    uint32_t chainedA;
 
-   /* ---- ring positions (idx % period), kept for every correlator ---- */
+   /* ---- ring positions (idx % period) of every correlator ---- */
    uint32_t posA[3];
-   uint32_t posF[3];
-   uint32_t posV1; /* mod p1 */
-   uint32_t posV0; /* mod p0 */
+   uint32_t posF[2]; /* 212k, 424k */
+   uint32_t posV1;   /* mod p1 */
+   uint32_t posV0;   /* mod p0 */
 
-   NfcTiming tim[4]; /* A B F V */
+   /* ---- search-mode detectors ---- */
+   NfcDetA detA[3];
+   NfcDetB detB[2];
+   NfcDetF detF[2]; /* 212k, 424k */
+   NfcDetV detV;
 
-   NfcMod modA[3];
-   NfcMod modB[3];
-   NfcMod modF[3]; /* [0] unused */
-   NfcMod modV;
-
-   /* working copies of the locked modulation: taken at lock time, dropped when the technology resets (which
-    * clears every modulation of that technology anyway); keeps the decode paths free of dynamic indexing */
+   /* ---- working copy of the locked modulation: taken at lock time, dropped when the technology resets ---- */
    NfcMod lock;
    NfcRate rt;
-   uint32_t lockBase; /* correlation ring base of the locked modulation */
-   uint32_t lockPos;  /* ring position (idx % rt.p1) of the locked correlator, advanced every sample while locked */
+};
 
-   /* ---- bookkeeping ---- */
-   uint32_t framesOut; /* frames emitted by this stream since it was opened */
-   uint32_t reserved[1];
+/* the part that stays in HBM and is only touched at frame boundaries */
+struct NfcStreamCold
+{
+   NfcTiming tim[4]; /* A B F V */
+   uint32_t framesOut;
+   uint32_t reserved[7];
 };
 
 /* header of one frame in the frame sink, followed by (length+3)/4 payload words */

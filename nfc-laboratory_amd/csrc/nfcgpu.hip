@@ -54,6 +54,7 @@ struct nfcgpu_ctx
    uint32_t blocks = 0;
 
    NfcStreamState *dStates = nullptr;
+   NfcStreamCold *dCold = nullptr;
    float *dRings = nullptr;
    uint8_t *dBytes = nullptr;
    uint32_t *dSink = nullptr;
@@ -110,6 +111,7 @@ NfcLaunch base_launch(nfcgpu_ctx *ctx)
    NfcLaunch L;
    std::memset(&L, 0, sizeof(L));
    L.states = ctx->dStates;
+   L.cold = ctx->dCold;
    L.rings = ctx->dRings;
    L.bytes = ctx->dBytes;
    L.sink = ctx->dSink;
@@ -400,6 +402,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
 
    ok = ok && hipMalloc((void **)&ctx->dStates, sizeof(NfcStreamState) * (size_t)maxStreams) == hipSuccess;
+   ok = ok && hipMalloc((void **)&ctx->dCold, sizeof(NfcStreamCold) * (size_t)maxStreams) == hipSuccess;
    ok = ok && hipMalloc((void **)&ctx->dRings, sizeof(float) * (size_t)kRingBlockFloats * ctx->blocks) == hipSuccess;
    ok = ok && hipMalloc((void **)&ctx->dBytes, (size_t)NFC_STREAM_BYTES * maxStreams) == hipSuccess;
    ok = ok && hipMalloc((void **)&ctx->dSink, ctx->sinkWords * 4) == hipSuccess;
@@ -410,6 +413,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    if (ok)
    {
       ok = ok && hipMemsetAsync(ctx->dStates, 0, sizeof(NfcStreamState) * (size_t)maxStreams, ctx->stream) == hipSuccess;
+      ok = ok && hipMemsetAsync(ctx->dCold, 0, sizeof(NfcStreamCold) * (size_t)maxStreams, ctx->stream) == hipSuccess;
       ok = ok && hipMemsetAsync(ctx->dRings, 0, sizeof(float) * (size_t)kRingBlockFloats * ctx->blocks, ctx->stream) == hipSuccess;
       ok = ok && hipMemsetAsync(ctx->dBytes, 0, (size_t)NFC_STREAM_BYTES * maxStreams, ctx->stream) == hipSuccess;
       ok = ok && hipMemsetAsync(ctx->dSinkCtl, 0, 16, ctx->stream) == hipSuccess;
@@ -458,6 +462,7 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
       (void)hipEventDestroy(e);
 
    (void)hipFree(ctx->dStates);
+   (void)hipFree(ctx->dCold);
    (void)hipFree(ctx->dRings);
    (void)hipFree(ctx->dBytes);
    (void)hipFree(ctx->ownSink ? ctx->ownSink : ctx->dSink);

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnfcgpu.so")
+LIB_PATH = os.environ.get("NFCGPU_LIB", os.path.join(HERE, "libnfcgpu.so"))
 
 TECH_A, TECH_B, TECH_F, TECH_V = 1, 2, 4, 8
 LOC_HOST, LOC_DEVICE = 0, 1

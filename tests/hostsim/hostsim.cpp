@@ -49,13 +49,9 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
    std::vector<uint32_t> arena(1u << 22, 0);
 
    NfcLaneMem mem;
-   float *base = rings.data() + lane;
-   mem.x = base;
-   mem.filt = base + 1 * NFC_HIST * NFC_LANES;
-   mem.mdev = base + 2 * NFC_HIST * NFC_LANES;
-   mem.depth = base + 3 * NFC_HIST * NFC_LANES;
-   mem.prod = base + 4 * NFC_HIST * NFC_LANES;
-   mem.corr = base + (4 * NFC_HIST + NFC_PROD) * NFC_LANES;
+   mem.ring = rings.data();
+   mem.lane = lane;
+   mem.exact = true;
    mem.bytes = bytes.data();
    uint32_t ctl[2] = {0, 0};
    mem.sink = arena.data();
@@ -65,8 +61,11 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
    mem.streamId = lane;
 
    NfcStreamState s;
+   NfcStreamCold cold;
    std::memset(&s, 0, sizeof(s));
-   nfc_state_init(cfg, s, false);
+   std::memset(&cold, 0, sizeof(cold));
+   mem.cold = &cold;
+   nfc_state_init(cfg, s, cold, false);
 
    for (uint64_t i = 0; i < count; i++)
    {
@@ -80,7 +79,8 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
       else
          v = samples[i];
 
-      nfc_step(cfg, s, mem, v);
+      /* same choice as the kernel: exact ring positions near the stream start / clock wrap, incremental otherwise */
+      nfc_step(cfg, s, mem, v, nfc_exact_zone(s.clock + 1u));
    }
 
    long n = 0;
