@@ -1,0 +1,249 @@
+/*
+ * Drop-in implementation of lab::NfcDecoder on top of libnfcgpu.so.
+ *
+ * Compiled against the reference's own public headers
+ *   src/nfc-lib/lib-lab/lab-radio/src/main/include/lab/nfc/NfcDecoder.h  (class declaration, unchanged)
+ *   src/nfc-lib/lib-hw/hw-dev/src/main/include/hw/SignalBuffer.h
+ *   src/nfc-lib/lib-lab/lab-data/src/main/include/lab/data/RawFrame.h
+ * it provides exactly the symbols that RadioDecoderTask.o, nfc-rx and test-sdr import from lab-radio
+ * (SURVEY.md 8(b)), so those link and run unchanged; the per-sample work happens in HIP kernels behind the
+ * C ABI of include/nfcgpu.h. One NfcDecoder instance == one nfcgpu stream; all instances of a process share
+ * one nfcgpu context (one GPU). There is no CPU decoding path: if the GPU runtime cannot be initialised the
+ * constructor throws.
+ *
+ * This file replaces src/nfc-lib/lib-lab/lab-radio/src/main/cpp/NfcDecoder.cpp (+ NfcTech.cpp, tech/*.cpp)
+ * in the reference's lab-radio library; see INTEGRATION.md.
+ */
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <hw/SignalType.h>
+#include <hw/SignalBuffer.h>
+
+#include <lab/data/RawFrame.h>
+#include <lab/nfc/NfcDecoder.h>
+
+#include <nfcgpu.h>
+
+namespace lab {
+
+namespace {
+
+struct SharedContext
+{
+   nfcgpu_ctx *ctx = nullptr;
+   std::mutex mutex;
+
+   nfcgpu_ctx *get()
+   {
+      std::lock_guard<std::mutex> lock(mutex);
+
+      if (!ctx)
+      {
+         nfcgpu_options options {};
+         const char *device = std::getenv("NFCGPU_DEVICE");
+         const char *streams = std::getenv("NFCGPU_MAX_STREAMS");
+         options.max_streams = streams ? (uint32_t)std::atoi(streams) : 64;
+
+         int rc = nfcgpu_init(device ? std::atoi(device) : 0, &options, &ctx);
+
+         if (rc != NFCGPU_OK)
+            throw std::runtime_error(std::string("nfcgpu_init failed: ") + nfcgpu_strerror(rc));
+      }
+
+      return ctx;
+   }
+};
+
+SharedContext shared;
+
+}
+
+struct NfcDecoder::Impl
+{
+   nfcgpu_ctx *ctx;
+   uint32_t stream = 0;
+   nfcgpu_params params {};
+   bool debugEnabled = false;
+   bool dirty = false; /* params changed since last push to the device side */
+
+   Impl() : ctx(shared.get())
+   {
+      nfcgpu_default_params(&params);
+
+      int rc = nfcgpu_stream_open(ctx, &params, &stream);
+
+      if (rc != NFCGPU_OK)
+         throw std::runtime_error(std::string("nfcgpu_stream_open failed: ") + nfcgpu_strerror(rc));
+   }
+
+   ~Impl()
+   {
+      nfcgpu_stream_close(ctx, stream);
+   }
+
+   void push()
+   {
+      if (dirty)
+      {
+         nfcgpu_stream_configure(ctx, stream, &params);
+         dirty = false;
+      }
+   }
+
+   void setTech(uint32_t bit, bool enabled)
+   {
+      params.tech_mask = enabled ? (params.tech_mask | bit) : (params.tech_mask & ~bit);
+      dirty = true;
+   }
+
+   void setDepth(int tech, float min, float max)
+   {
+      if (!std::isnan(min))
+         params.min_modulation_depth[tech] = min;
+      if (!std::isnan(max))
+         params.max_modulation_depth[tech] = max;
+      dirty = true;
+   }
+
+   void setCorrelation(int tech, float value)
+   {
+      if (!std::isnan(value))
+         params.corr_threshold[tech] = value;
+      dirty = true;
+   }
+
+   std::list<RawFrame> collect()
+   {
+      std::list<RawFrame> frames;
+      std::vector<nfcgpu_frame> chunk(64);
+      uint32_t count = 0;
+
+      do
+      {
+         if (nfcgpu_poll(ctx, stream, chunk.data(), (uint32_t)chunk.size(), &count) < 0 && count == 0)
+            break;
+
+         for (uint32_t i = 0; i < count; i++)
+         {
+            const nfcgpu_frame &f = chunk[i];
+
+            RawFrame frame(f.tech_type, f.frame_type);
+
+            frame.setFrameRate(f.frame_rate);
+            frame.setFramePhase(f.frame_phase);
+            frame.setFrameFlags(f.frame_flags);
+            frame.setSampleStart(f.sample_start);
+            frame.setSampleEnd(f.sample_end);
+            frame.setSampleRate(f.sample_rate);
+            frame.setTimeStart(static_cast<double>(f.sample_start) / static_cast<double>(f.sample_rate));
+            frame.setTimeEnd(static_cast<double>(f.sample_end) / static_cast<double>(f.sample_rate));
+            frame.setDateTime(params.stream_time + frame.timeStart());
+            frame.put(f.data, f.length).flip();
+
+            frames.push_back(frame);
+         }
+      }
+      while (count == chunk.size());
+
+      return frames;
+   }
+};
+
+NfcDecoder::NfcDecoder() : impl(std::make_shared<Impl>())
+{
+}
+
+void NfcDecoder::initialize()
+{
+   impl->push();
+   nfcgpu_stream_reset(impl->ctx, impl->stream);
+}
+
+void NfcDecoder::cleanup()
+{
+}
+
+std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
+{
+   impl->push();
+
+   if (samples.isValid())
+   {
+      /* like the reference, only magnitude buffers advance the decoder (NfcTech.cpp:30); interleaved IQ buffers
+       * are accepted as an extension and demodulated from IQ on the GPU */
+      const unsigned int type = samples.type();
+      const unsigned int stride = type == hw::SignalType::SIGNAL_TYPE_RADIO_IQ ? 2 : 1;
+
+      if (type == hw::SignalType::SIGNAL_TYPE_RADIO_SAMPLES || type == hw::SignalType::SIGNAL_TYPE_RADIO_IQ)
+      {
+         const unsigned int count = samples.remaining() / stride;
+
+         if (count)
+            nfcgpu_submit(impl->ctx, impl->stream, samples.ptr(), count, stride, samples.sampleRate());
+
+         impl->params.sample_rate = samples.sampleRate();
+      }
+   }
+   else
+   {
+      nfcgpu_flush(impl->ctx, impl->stream);
+   }
+
+   return impl->collect();
+}
+
+bool NfcDecoder::isDebugEnabled() const { return impl->debugEnabled; }
+void NfcDecoder::setEnableDebug(bool enabled) { impl->debugEnabled = enabled; /* signal debug taps are a CPU-oracle facility */ }
+
+bool NfcDecoder::isNfcAEnabled() const { return impl->params.tech_mask & NFCGPU_TECH_A; }
+void NfcDecoder::setEnableNfcA(bool enabled) { impl->setTech(NFCGPU_TECH_A, enabled); }
+bool NfcDecoder::isNfcBEnabled() const { return impl->params.tech_mask & NFCGPU_TECH_B; }
+void NfcDecoder::setEnableNfcB(bool enabled) { impl->setTech(NFCGPU_TECH_B, enabled); }
+bool NfcDecoder::isNfcFEnabled() const { return impl->params.tech_mask & NFCGPU_TECH_F; }
+void NfcDecoder::setEnableNfcF(bool enabled) { impl->setTech(NFCGPU_TECH_F, enabled); }
+bool NfcDecoder::isNfcVEnabled() const { return impl->params.tech_mask & NFCGPU_TECH_V; }
+void NfcDecoder::setEnableNfcV(bool enabled) { impl->setTech(NFCGPU_TECH_V, enabled); }
+
+long NfcDecoder::sampleRate() const { return impl->params.sample_rate; }
+
+void NfcDecoder::setSampleRate(long sampleRate)
+{
+   /* the reference only stores the value; the decoder re-initialises when a buffer with another rate arrives */
+   impl->params.sample_rate = (uint32_t)sampleRate;
+   impl->dirty = true;
+}
+
+long NfcDecoder::streamTime() const { return (long)impl->params.stream_time; }
+void NfcDecoder::setStreamTime(long referenceTime) { impl->params.stream_time = referenceTime; impl->dirty = true; }
+
+float NfcDecoder::powerLevelThreshold() const { return impl->params.power_level_threshold; }
+void NfcDecoder::setPowerLevelThreshold(float value) { impl->params.power_level_threshold = value; impl->dirty = true; }
+
+float NfcDecoder::modulationThresholdNfcAMin() const { return impl->params.min_modulation_depth[0]; }
+float NfcDecoder::modulationThresholdNfcAMax() const { return impl->params.max_modulation_depth[0]; }
+void NfcDecoder::setModulationThresholdNfcA(float min, float max) { impl->setDepth(0, min, max); }
+float NfcDecoder::modulationThresholdNfcBMin() const { return impl->params.min_modulation_depth[1]; }
+float NfcDecoder::modulationThresholdNfcBMax() const { return impl->params.max_modulation_depth[1]; }
+void NfcDecoder::setModulationThresholdNfcB(float min, float max) { impl->setDepth(1, min, max); }
+float NfcDecoder::modulationThresholdNfcFMin() const { return impl->params.min_modulation_depth[2]; }
+float NfcDecoder::modulationThresholdNfcFMax() const { return impl->params.max_modulation_depth[2]; }
+void NfcDecoder::setModulationThresholdNfcF(float min, float max) { impl->setDepth(2, min, max); }
+float NfcDecoder::modulationThresholdNfcVMin() const { return impl->params.min_modulation_depth[3]; }
+float NfcDecoder::modulationThresholdNfcVMax() const { return impl->params.max_modulation_depth[3]; }
+void NfcDecoder::setModulationThresholdNfcV(float min, float max) { impl->setDepth(3, min, max); }
+
+float NfcDecoder::correlationThresholdNfcA() const { return impl->params.corr_threshold[0]; }
+void NfcDecoder::setCorrelationThresholdNfcA(float value) { impl->setCorrelation(0, value); }
+float NfcDecoder::correlationThresholdNfcB() const { return impl->params.corr_threshold[1]; }
+void NfcDecoder::setCorrelationThresholdNfcB(float value) { impl->setCorrelation(1, value); }
+float NfcDecoder::correlationThresholdNfcF() const { return impl->params.corr_threshold[2]; }
+void NfcDecoder::setCorrelationThresholdNfcF(float value) { impl->setCorrelation(2, value); }
+float NfcDecoder::correlationThresholdNfcV() const { return impl->params.corr_threshold[3]; }
+void NfcDecoder::setCorrelationThresholdNfcV(float value) { impl->setCorrelation(3, value); }
+
+}

@@ -178,3 +178,26 @@ def test_frame_sink_overflow_is_reported_not_silent(built):
         with pytest.raises(nfclab_amd.NfcGpuError) as e:
             g.poll(sid)
         assert e.value.code == -6
+
+
+def test_reference_test_sdr_harness_runs_unchanged_on_the_gpu_decoder(built, tmp_path):
+    """Drop-in check: the reference's own test-sdr main.cpp, linked against our lab::NfcDecoder shim
+    (nfc-laboratory_amd/host/NfcDecoder.cpp -> C ABI -> HIP), must print PASS for its golden files."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+    exe = os.path.join(T.ROOT, "oracle", "_ref", "test-sdr-gpu")
+    if not os.path.exists(exe):
+        pytest.skip("test-sdr-gpu not built (needs the reference tree at build time)")
+    names = ["test_NFC-A_106kbps_001", "test_NFC-A_424kbps_001", "test_NFC-B_106kbps_001", "test_POLL_AB_001"]
+    for name in names:
+        raw = T.load_fixture_i16(name).tobytes()
+        with open(tmp_path / (name + ".wav"), "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE")
+            f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, FS, FS * 2, 2, 16))
+            f.write(b"data" + struct.pack("<I", len(raw)) + raw)
+        shutil.copyfile(os.path.join(T.GOLDEN, "wav", name + ".json"), tmp_path / (name + ".json"))
+    out = subprocess.run([exe, str(tmp_path) + "/"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900).stdout
+    for name in names:
+        assert "TEST FILE %s.wav: PASS" % name in out, out
