@@ -26,27 +26,14 @@ FS = 10000000
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def parse_sink(words, used):
-    """packed records -> {stream: [frame tuples]} (same tuple order as nfclab_amd.Frame.as_tuple)."""
-    frames = {}
-    pos = 0
-    while pos < used:
-        sid, tech, typ, flags, phase, rate, start, end, length = (int(v) & 0xFFFFFFFF for v in words[pos:pos + 9])
-        nwords = (length + 3) // 4
-        payload = words[pos + 9:pos + 9 + nwords].tobytes()[:length]
-        frames.setdefault(sid, []).append((tech, typ, flags, phase, rate, start, end, FS, payload))
-        pos += 9 + nwords
-    return frames
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("NFC_BENCH_STREAMS", "32768")), help="streams per GPU")
-    ap.add_argument("--samples", type=int, default=16384, help="samples per stream per step")
-    ap.add_argument("--cpu-streams", type=int, default=1024, help="streams of rank 0 replayed on the host CPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("NFC_BENCH_STREAMS", "131072")), help="streams per GPU")
+    ap.add_argument("--samples", type=int, default=8192, help="samples per stream per step")
+    ap.add_argument("--cpu-streams", type=int, default=8192, help="streams of rank 0 replayed on the host CPU")
     ap.add_argument("--check-streams", type=int, default=64, help="streams compared frame-by-frame with the reference")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -76,6 +63,7 @@ def main():
 
     import nfclab_amd
     import synth
+    import frames as framelib
 
     S, L, K, W = args.streams, args.samples, args.steps, args.warmup
     T = (K + W) * L
@@ -121,18 +109,14 @@ def main():
     gpu.sync()
 
     # frame gather: every rank's packed records to every rank (RCCL over xGMI), or to the host when N == 1
-    used = ctl[:1].clone()
+    host_used = int(ctl[0].item())
     if world > 1:
-        counts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(world)]
-        dist.all_gather(counts, used)
-        longest = int(max(int(c.item()) for c in counts))
-        gathered = torch.empty(world * max(longest, 1), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(gathered, sink[:max(longest, 1)].contiguous())
-        host_used = int(used.item())
-        host_words = sink[:host_used].cpu().numpy()
+        gathered, counts = framelib.gather_sinks(sink, host_used, world)
+        host_words = gathered[rank, :host_used].cpu().numpy()
+        total_words = sum(counts)
     else:
-        host_used = int(used.item())
         host_words = sink[:host_used].cpu().numpy()
+        total_words = host_used
 
     fence()
     t1 = time.perf_counter()
@@ -200,9 +184,10 @@ def main():
         "frames_dropped": dropped,
     }
 
-    frames = parse_sink(host_words, host_used) if rank == 0 else {}
+    frames = framelib.parse_sink(host_words, host_used, FS) if rank == 0 else {}
     if rank == 0:
         result["config"]["frames_decoded_rank0"] = sum(len(v) for v in frames.values())
+        result["config"]["frame_words_gathered"] = int(total_words)
 
     # ---- CPU baseline + parity check against the real reference (rank 0, N == 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -210,29 +195,32 @@ def main():
         import nfc_testlib as TL
         lib = TL.reference_lib()
         if lib is not None:
-            from concurrent.futures import ThreadPoolExecutor
             C = min(S, args.cpu_streams)
             mags = torch.sqrt(data[:C, :, 0] * data[:C, :, 0] + data[:C, :, 1] * data[:C, :, 1]).cpu().numpy()
+            mags = np.ascontiguousarray(mags, dtype=np.float32)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
-            def run(s):
-                fr, secs = TL.reference_decode(mags[s], sample_rate=FS, chunk=L, keep_carrier=True, cap=8192)
-                return s, fr, secs
+            lib.nfcref_decode_many.restype = ctypes.c_long
+            lib.nfcref_decode_many.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32,
+                                               ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
 
-            tc0 = time.perf_counter()
-            one = [run(s) for s in range(min(C, 32))]
-            single_seconds = time.perf_counter() - tc0
-            single = min(C, 32) * T / single_seconds / 1e6
+            def timed(streams, threads):
+                secs = ctypes.c_double(0)
+                lib.nfcref_decode_many(mags.ctypes.data, T, streams, T, FS, L, threads, ctypes.byref(secs))
+                return streams * T / secs.value / 1e6, secs.value
 
-            tc0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as pool:
-                outs = list(pool.map(run, range(C)))
-            multi_seconds = time.perf_counter() - tc0
-            multi = C * T / multi_seconds / 1e6
+            n_single = max(1, min(C, int(150e6 // T)))
+            single, single_seconds = timed(n_single, 1)
+            multi, multi_seconds = timed(C, cores)
+
+            checked = min(C, args.check_streams)
+            outs = []
+            for s in range(checked):
+                fr, _ = TL.reference_decode(mags[s], sample_rate=FS, chunk=L, keep_carrier=True, cap=8192)
+                outs.append((s, fr, 0.0))
 
             bad = 0
-            checked = min(C, args.check_streams)
-            for s, fr, _ in outs[:checked]:
+            for s, fr, _ in outs:
                 if frames.get(first + s, []) != fr:
                     bad += 1
 
@@ -242,8 +230,8 @@ def main():
                 "cores": cores,
                 "kind": "reference",
                 "sample": "reference lab::NfcDecoder (oracle/_ref, built from /root/reference) on the magnitudes of the first %d "
-                          "streams x %d samples, %d-sample buffers, one decoder per stream, %d threads; single thread: %.1f Msamples/s"
-                          % (C, T, L, cores, single),
+                          "streams x %d samples (%.1f s), %d-sample buffers, one decoder per stream, %d threads; single thread on %d "
+                          "streams: %.1f Msamples/s (%.1f s)" % (C, T, multi_seconds, L, cores, n_single, single, single_seconds),
                 "single_thread_value": round(single, 3),
             }
             result["parity"] = {"streams_checked": checked, "streams_mismatching": bad,

@@ -18,6 +18,9 @@
 #include <cstring>
 #include <chrono>
 #include <list>
+#include <thread>
+#include <vector>
+#include <atomic>
 
 #include <hw/SignalType.h>
 #include <hw/SignalBuffer.h>
@@ -154,6 +157,52 @@ void nfcref_magnitude(const float *iq, uint64_t count, float *out)
       volatile float qq = iq[2 * i + 1] * iq[2 * i + 1];
       out[i] = __builtin_sqrtf(ii + qq);
    }
+}
+
+/* CPU baseline: `streams` independent decoders (one lab::NfcDecoder each), statically partitioned over `threads`
+ * host threads; stream i reads `count` floats at base + i*pitch. Returns total frames; *seconds = wall time of the
+ * decode phase only (decoders constructed before the clock starts). */
+long nfcref_decode_many(const float *base, uint64_t pitch_floats, uint32_t streams, uint64_t count, uint32_t sample_rate,
+                        uint32_t chunk, uint32_t threads, double *seconds)
+{
+   if (!threads)
+      threads = 1;
+   if (!chunk)
+      chunk = 65536;
+
+   std::atomic<long> total {0};
+   std::vector<std::thread> pool;
+
+   auto t0 = std::chrono::steady_clock::now();
+
+   for (uint32_t t = 0; t < threads; t++)
+   {
+      pool.emplace_back([=, &total]() {
+         long frames = 0;
+         for (uint32_t s = t; s < streams; s += threads)
+         {
+            lab::NfcDecoder decoder;
+            const float *data = base + (uint64_t)s * pitch_floats;
+
+            for (uint64_t pos = 0; pos < count; pos += chunk)
+            {
+               uint32_t n = (count - pos) < chunk ? (uint32_t)(count - pos) : chunk;
+               hw::SignalBuffer buffer(n, 1, 1, sample_rate, 0, 0, hw::SignalType::SIGNAL_TYPE_RADIO_SAMPLES, 0);
+               buffer.put(data + pos, n).flip();
+               frames += (long)decoder.nextFrames(buffer).size();
+            }
+         }
+         total += frames;
+      });
+   }
+
+   for (auto &th: pool)
+      th.join();
+
+   if (seconds)
+      *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+   return total.load();
 }
 
 unsigned int nfcref_frame_size()
