@@ -173,10 +173,11 @@ def test_frame_sink_overflow_is_reported_not_silent(built):
     import nfclab_amd
     x = T.load_fixture("test_NFC-A_424kbps_002")
     with nfclab_amd.NfcGpu(device=0, max_streams=64, frame_sink_bytes=4096) as g:
-        sid = g.open()
-        g.submit(sid, x, FS)
+        first = g.open(count=8)
+        for i in range(8):  # ~600 frames in total: more than a 4 KiB sink can hold
+            g.submit(first + i, x, FS)
         with pytest.raises(nfclab_amd.NfcGpuError) as e:
-            g.poll(sid)
+            g.poll(first)
         assert e.value.code == -6
 
 
