@@ -425,6 +425,18 @@ NFC_DEV NfcTap nfc_tap_raw(const NfcLaneMem &mem, uint32_t clock, const NfcRate 
    return t;
 }
 
+/* ring[(idx - 1) % p1] for a search-mode correlator: when the detector bank stepped on the previous sample it is
+ * exactly the running sum before this sample's update (that is what was stored there one sample ago, and resets
+ * clear ring and sum together); only after a gap in the search does it have to be read back */
+template <class M>
+NFC_DEV float nfc_previous_sum(const NfcLaneMem &mem, const NfcStreamState &s, const M &m, const NfcRate &rt, uint32_t base, uint32_t pos)
+{
+   if (s.bankClock == s.clock - 1u)
+      return m.acc;
+
+   return NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
+}
+
 template <class M>
 NFC_DEV NfcCorr nfc_corr_apply(const NfcLaneMem &mem, M &m, const NfcTap &t, uint32_t base, uint32_t pos)
 {
@@ -559,6 +571,11 @@ NFC_DEV void nfc_search_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
       return;
    if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
       return;
+
+   /* every detector that is enabled stepped its correlator on this sample (or none did: the gates are common):
+    * on the next sample ring[(idx - 1) % p1] is known to equal the running sum and need not be read back */
+   if (s.clock >= 1024u && !(s.env < c.powerThreshold))
+      s.bankClock = s.clock;
 }
 
 /* One sample with a technology locked (poll / listen frame decoding); `mem.exact` is a run-time flag here */

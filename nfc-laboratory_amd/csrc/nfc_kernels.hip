@@ -32,7 +32,8 @@ typedef __attribute__((address_space(4))) NfcConfig NfcConfigConst;
 #define NFC_MIN_WAVES 2
 #endif
 
-__global__ __launch_bounds__(64, NFC_MIN_WAVES) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+/* exactly NFC_MIN_WAVES waves per SIMD: spilling state to scratch to reach a higher occupancy costs 5-10x */
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVES, NFC_MIN_WAVES))) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
    __shared__ NfcWork work[NFC_LANES];
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(64, NFC_MIN_WAVES) void nfc_demod_kernel(const NfcC
             /* keep the ~100 configuration constants in the scalar cache instead of letting the compiler hoist
              * them out of the sample loop into (spilled) registers */
             const NfcConfigConst *cp = (const NfcConfigConst *)cfgPtr;
+#ifdef NFC_RELOAD_CONFIG
             asm volatile("" : "+s"(cp));
+#endif
 
             nfc_step(*(const NfcConfig *)cp, s, mem, tile[lane * TILE_PITCH + k], exact);
          }

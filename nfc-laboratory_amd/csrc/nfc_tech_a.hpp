@@ -284,15 +284,13 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 struct NfcTapsA
 {
    NfcTap t[3];
-   float deep[3];
 };
 
 template <int R>
 NFC_DEV void nfca_load_taps_rate(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsA &taps)
 {
-   const NfcRate &rt = c.a[R];
-   taps.t[R] = nfc_tap_raw(mem, s.clock, rt, c.corrOffset[R], s.posA[R], true);
-   taps.deep[R] = NFC_AT(mem, NFC_R_DEPTH, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+   /* ring[(idx - 1) % p1] is read in nfca_detect_rate only after a gap in the search (see bankClock) */
+   taps.t[R] = nfc_tap_raw(mem, s.clock, c.a[R], c.corrOffset[R], s.posA[R], false);
 }
 
 NFC_DEV void nfca_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsA &taps)
@@ -314,6 +312,8 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    if (rt.delay == 0)
       tap.in = now.x; /* the newest sample is not in memory yet when the taps are read */
 
+   tap.c3 = nfc_previous_sum(mem, s, m, rt, c.corrOffset[R], s.posA[R]);
+
    NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[R], s.posA[R]);
    const float num = k.s0 - k.s1;
 
@@ -334,7 +334,8 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
       {
          if (sd < -minimumCorrelation)
          {
-            float deep = taps.deep[R];
+            /* modulation depth one eighth of a symbol back: only needed while a pause is being tracked */
+            float deep = NFC_AT(mem, NFC_R_DEPTH, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
 
             if (sd < m.peak)
             {

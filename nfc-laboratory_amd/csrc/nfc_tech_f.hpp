@@ -200,8 +200,8 @@ struct NfcTapsF
 
 NFC_DEV void nfcf_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsF &taps)
 {
-   taps.t[1] = nfc_tap_raw(mem, s.clock, c.f[1], c.corrOffset[3], s.posF[0], true);
-   taps.t[2] = nfc_tap_raw(mem, s.clock, c.f[2], c.corrOffset[4], s.posF[1], true);
+   taps.t[1] = nfc_tap_raw(mem, s.clock, c.f[1], c.corrOffset[3], s.posF[0], false);
+   taps.t[2] = nfc_tap_raw(mem, s.clock, c.f[2], c.corrOffset[4], s.posF[1], false);
 }
 
 template <int R>
@@ -214,6 +214,7 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    /* NFC-F correlates the undelayed signal: the entering sample and its depth are the current ones */
    NfcTap tap = taps.t[R];
    tap.in = now.x;
+   tap.c3 = nfc_previous_sum(mem, s, m, rt, c.corrOffset[2 + R], s.posF[R - 1]);
    const float deep = now.depth;
 
    NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[2 + R], s.posF[R - 1]);

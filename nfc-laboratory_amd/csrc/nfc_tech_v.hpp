@@ -87,13 +87,11 @@ NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 struct NfcTapsV
 {
    NfcTap t;
-   float deep;
 };
 
 NFC_DEV void nfcv_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsV &taps)
 {
    taps.t = nfc_tap_raw(mem, s.clock, c.v, c.corrOffset[5], s.posV1, false);
-   taps.deep = NFC_AT(mem, NFC_R_DEPTH, (s.clock - c.v.delay - c.v.p8) & NFC_HMASK);
 }
 
 template <class M>
@@ -148,8 +146,11 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             m.winEnd = s.clock + rt.p4;
          }
 
-         if (taps.deep > m.aux)
-            m.aux = taps.deep;
+         /* modulation depth one eighth of a symbol back: only needed while a pulse is being tracked */
+         const float deep = NFC_AT(mem, NFC_R_DEPTH, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+
+         if (deep > m.aux)
+            m.aux = deep;
       }
    }
 

@@ -198,6 +198,7 @@ struct NfcStreamState
    uint32_t pulseCode; /* NFC-V: 0 -> 1 of 4, 1 -> 1 of 256 */
    uint32_t lockBase;  /* correlation ring base of the locked modulation */
    uint32_t lockPos;   /* ring position (idx % rt.p1) of the locked correlator, advanced every sample while locked */
+   uint32_t bankClock; /* clock of the last sample at which the whole detector bank was stepped (search mode) */
    uint32_t guardEnd;  /* frameStatus.guardEnd / waitingEnd of the locked technology (always written by the poll */
    uint32_t waitingEnd;/* frame's process() before a listen window reads them) */
 
