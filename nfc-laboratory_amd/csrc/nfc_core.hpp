@@ -125,6 +125,7 @@ NFC_DEV void nfc_mod_clear(NfcMod &m)
 
 NFC_DEV void nfc_zero_ring(const NfcLaneMem &mem, uint32_t from, uint32_t count)
 {
+#pragma clang loop unroll(disable)
    for (uint32_t i = 0; i < count; i++)
       NFC_AT(mem, 0u, from + i) = 0.0f;
 }
@@ -142,21 +143,16 @@ NFC_DEV void nfc_poll_end_clear(const NfcLaneMem &mem, NfcMod &m, uint32_t corrF
 
 NFC_DEV void nfc_clear_assembly(NfcStreamState &s)
 {
-   s.bsPrevious = 0; s.bsBits = 0; s.bsSkip = 0;
-   s.bsData = 0; s.bsFlags = 0; s.bsParity = 0; s.bsBytes = 0;
-}
-
-NFC_DEV void nfc_clear_symbol(NfcStreamState &s)
-{
-   s.symPattern = 0; s.symValue = 0; s.symStart = 0; s.symEnd = 0; s.symEdge = 0;
+   s.u.decode.bsPrevious = 0; s.u.decode.bsBits = 0; s.u.decode.bsSkip = 0;
+   s.u.decode.bsData = 0; s.u.decode.bsFlags = 0; s.u.decode.bsParity = 0; s.u.decode.bsBytes = 0;
 }
 
 NFC_DEV void nfc_push_byte(const NfcLaneMem &mem, NfcStreamState &s, uint32_t value)
 {
    /* the reference's buffer is 512 bytes (NfcTech.h:288); beyond that it would overrun, we drop */
-   if (s.bsBytes < NFC_STREAM_BYTES)
-      mem.bytes[s.bsBytes] = (uint8_t)value;
-   s.bsBytes++;
+   if (s.u.decode.bsBytes < NFC_STREAM_BYTES)
+      mem.bytes[s.u.decode.bsBytes] = (uint8_t)value;
+   s.u.decode.bsBytes++;
 }
 
 NFC_DEV uint32_t nfc_byte(const uint8_t *data, uint32_t len, uint32_t i)
@@ -174,18 +170,22 @@ NFC_DEV uint32_t nfc_crc16(const uint8_t *data, uint32_t count, uint32_t init, b
 
    if (reflected)
    {
+#pragma clang loop unroll(disable)
       for (uint32_t i = 0; i < count; i++)
       {
          crc ^= data[i];
+#pragma clang loop unroll(disable)
          for (int k = 0; k < 8; k++)
             crc = (crc & 1u) ? (crc >> 1) ^ 0x8408u : (crc >> 1);
       }
    }
    else
    {
+#pragma clang loop unroll(disable)
       for (uint32_t i = 0; i < count; i++)
       {
          crc ^= ((uint32_t)data[i]) << 8;
+#pragma clang loop unroll(disable)
          for (int k = 0; k < 8; k++)
             crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x1021u) & 0xFFFFu : (crc << 1) & 0xFFFFu;
       }
@@ -220,9 +220,11 @@ NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, u
    w[1] = tech; w[2] = type; w[3] = flags; w[4] = phase;
    w[5] = rate; w[6] = start; w[7] = end; w[8] = len;
 
+#pragma clang loop unroll(disable)
    for (uint32_t i = 0; i < len; i += 4)
    {
       uint32_t v = 0;
+#pragma clang loop unroll(disable)
       for (uint32_t k = 0; k < 4 && i + k < len; k++)
          v |= ((uint32_t)data[i + k]) << (8 * k);
       w[NFC_FRAME_HEADER_WORDS + (i >> 2)] = v;
@@ -349,14 +351,14 @@ NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s, const 
 NFC_DEV void nfc_advance_lock_pos(NfcStreamState &s, const NfcLaneMem &mem)
 {
    if (mem.exact)
-      s.lockPos = (uint32_t)(1024u - s.rt.delay + s.clock) % s.rt.p1;
+      s.u.decode.lockPos = (uint32_t)(1024u - s.u.decode.rt.delay + s.clock) % s.u.decode.rt.p1;
    else
-      s.lockPos = nfc_bump(s.lockPos, s.rt.p1);
+      s.u.decode.lockPos = nfc_bump(s.u.decode.lockPos, s.u.decode.rt.p1);
 }
 
 NFC_DEV uint32_t nfc_lock_pos(const NfcStreamState &s)
 {
-   return s.lockPos;
+   return s.u.decode.lockPos;
 }
 
 /* (idx + add) % period given pos = idx % period; exact modulo near the clock wrap */
@@ -501,16 +503,37 @@ NFC_DEV void nfc_phase_integrate(NfcMod &m, const NfcPhase &p)
    m.phaseAcc -= p.out;
 }
 
-/* start the working copy of the locked modulation: everything zero, the caller fills in what the detector
- * found (the reference's record at that point holds exactly those values, see nfc_types.h) */
-NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcRate &rt, uint32_t tech, uint32_t rate, uint32_t base, uint32_t pos)
+/* Enter decode mode, in place: park the detector records (they stay frozen while locked), then start the decode
+ * register set from zero. The caller copies what it needs from its detector record into locals BEFORE this call
+ * (the two register sets share storage) and fills in what the detector found afterwards; the reference's record at
+ * that point holds exactly those values (see nfc_types.h). */
+NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcLaneMem &mem, const NfcRate &rt, uint32_t tech, uint32_t rate,
+                           uint32_t base, uint32_t pos)
 {
-   nfc_mod_clear(s.lock);
-   s.rt = rt;
-   s.lockBase = base;
-   s.lockPos = pos;
+   mem.cold->parked = s.u.search;
+
+   NfcDecodeRegs &d = s.u.decode;
+
+   nfc_mod_clear(d.lock);
+   d.rt = rt;
+   d.lockRate = rate;
+   d.pulseCode = 0;
+   d.lockBase = base;
+   d.lockPos = pos;
+   d.guardEnd = 0;
+   d.waitingEnd = 0;
+   d.symPattern = 0; d.symValue = 0; d.symStart = 0; d.symEnd = 0; d.symEdge = 0;
+   d.bsPrevious = 0; d.bsBits = 0; d.bsSkip = 0; d.bsData = 0; d.bsFlags = 0; d.bsParity = 0; d.bsBytes = 0;
+   d.frameType = 0; d.frameRate = 0; d.frameStart = 0; d.frameEnd = 0;
+
    s.lockTech = tech;
-   s.lockRate = rate;
+}
+
+/* leave decode mode (the technology resets): bring the detector records back */
+NFC_DEV void nfc_leave_lock(NfcStreamState &s, const NfcLaneMem &mem)
+{
+   s.u.search = mem.cold->parked;
+   s.lockTech = 0;
 }
 
 /* a/w compared against +-limit: the IEEE division is only needed when |a| is within 0.1 % of w*limit or beyond

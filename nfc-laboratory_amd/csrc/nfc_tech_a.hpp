@@ -21,21 +21,16 @@ NFC_DEV void nfca_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 /* resetModulation, NfcA.cpp:1451-1475 */
 NFC_DEV void nfca_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_mod_clear(s.detA[0]);
-   nfc_mod_clear(s.detA[1]);
-   nfc_mod_clear(s.detA[2]);
-   nfc_mod_clear(s.lock);
+   /* back to search mode: the decode register set (working copy, symbol, bit stream, frame) dies here, which is
+    * the reference zeroing it; the detector records return from their parking place */
+   nfc_leave_lock(s, mem);
+
+   nfc_mod_clear(s.u.search.detA[0]);
+   nfc_mod_clear(s.u.search.detA[1]);
+   nfc_mod_clear(s.u.search.detA[2]);
 
    /* the three rings are adjacent */
    nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[0], c.a[0].p1 + c.a[1].p1 + c.a[2].p1);
-
-   nfc_clear_assembly(s);
-   nfc_clear_symbol(s);
-
-   s.frameType = 0;
-   s.frameStart = 0;
-   s.frameEnd = 0;
-   s.lockTech = 0;
 }
 
 /* resetFrameSearch, NfcA.cpp:1426-1446 */
@@ -44,7 +39,7 @@ NFC_DEV void nfca_reset_search(NfcStreamState &s, NfcMod &m)
    m.symStart = 0; m.symEnd = 0; m.symRise = 0;
    m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
    m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
-   s.frameStart = 0;
+   s.u.decode.frameStart = 0;
 }
 
 NFC_DEV bool nfca_crc_ok(const uint8_t *data, uint32_t len)
@@ -60,10 +55,12 @@ NFC_DEV bool nfca_crc_ok(const uint8_t *data, uint32_t len)
 /* odd parity check as NfcA.cpp:1994-2005: returns the parity bit xor-ed with every set data bit */
 NFC_DEV uint32_t nfca_parity(uint32_t value, uint32_t parity)
 {
-   for (uint32_t i = 0; i < 8; i++)
-      if (value & (1u << i))
-         parity ^= 1u;
-   return parity;
+   /* parity of the low byte, folded: same result as flipping the bit once per set data bit */
+   uint32_t v = value & 0xFFu;
+   v ^= v >> 4;
+   v ^= v >> 2;
+   v ^= v >> 1;
+   return parity ^ (v & 1u);
 }
 
 NFC_DEV void nfca_default_timing(const NfcConfig &c, NfcTiming &t)
@@ -256,28 +253,31 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    flags |= s.chainedA;
 
    const bool locked = (s.lockTech == NFC_TECH_A);
-   const uint32_t delay = locked ? s.rt.delay : 0u;
+   const uint32_t delay = locked ? s.u.decode.rt.delay : 0u;
 
    if (poll)
    {
       if (locked)
       {
-         s.guardEnd = s.frameEnd + t.guardTime + delay;
-         s.waitingEnd = s.frameEnd + t.waitingTime + delay;
-         s.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
+         s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime + delay;
+         s.u.decode.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         s.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
 
-      s.frameType = 0;
+      s.u.decode.frameType = 0;
       t.lastCommand = 0;
    }
 
-   s.frameStart = 0;
-   s.frameEnd = 0;
+   if (locked)
+   {
+      s.u.decode.frameStart = 0;
+      s.u.decode.frameEnd = 0;
+   }
 }
 
 /* history reads of the three poll-SOF correlators, issued before the front end stores the new sample */
@@ -306,7 +306,7 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
                               float minimumCorrelation, float minimumDepth)
 {
    const NfcRate &rt = c.a[R];
-   NfcDetA &m = s.detA[R];
+   NfcDetA &m = s.u.search.detA[R];
 
    NfcTap tap = taps.t[R];
    if (rt.delay == 0)
@@ -391,29 +391,33 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
       return false;
    }
 
-   /* SOF pause recognised: lock this bitrate */
-   nfc_take_lock(s, rt, NFC_TECH_A, (uint32_t)R, c.corrOffset[R], s.posA[R]);
+   /* SOF pause recognised: lock this bitrate (the detector record is about to be parked: take what is needed) */
+   const uint32_t symStart = m.symStart, pos = s.posA[R];
+   const float peak = m.peak, acc = m.acc, aux = m.aux;
 
-   NfcMod &d = s.lock;
-   d.symStart = m.symStart;
+   nfc_take_lock(s, mem, rt, NFC_TECH_A, (uint32_t)R, c.corrOffset[R], pos);
+
+   NfcDecodeRegs &out = s.u.decode;
+   NfcMod &d = out.lock;
+   d.symStart = symStart;
    d.symEnd = symEnd;
    d.pulses = width;
    d.sync = symEnd + rt.p1;
    d.winStart = d.sync - rt.p8;
    d.winEnd = d.sync + rt.p8;
-   d.thr = m.peak / 2;
-   d.acc = m.acc;
-   d.aux = m.aux;
+   d.thr = peak / 2;
+   d.acc = acc;
+   d.aux = aux;
 
-   s.frameType = NFC_FRAME_POLL;
-   s.frameRate = rt.symbolsPerSecond;
-   s.frameStart = m.symStart - rt.delay;
-   s.frameEnd = 0;
+   out.frameType = NFC_FRAME_POLL;
+   out.frameRate = rt.symbolsPerSecond;
+   out.frameStart = symStart - rt.delay;
+   out.frameEnd = 0;
 
-   s.symValue = 0;
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = symEnd - rt.delay;
-   s.symPattern = A_Z;
+   out.symValue = 0;
+   out.symStart = symStart - rt.delay;
+   out.symEnd = symEnd - rt.delay;
+   out.symPattern = A_Z;
 
    return true;
 }
@@ -442,12 +446,12 @@ NFC_DEV bool nfca_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 /* ---- poll frame symbols (modified Miller), NfcA.cpp:812-934 ---- */
 NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
    const uint32_t pos = nfc_lock_pos(s);
-   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.lockBase, pos, true);
-   NfcCorr k = nfc_corr_apply(mem, m, tap, s.lockBase, pos);
+   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.u.decode.lockBase, pos, true);
+   NfcCorr k = nfc_corr_apply(mem, m, tap, s.u.decode.lockBase, pos);
    float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
 
    if (s.clock < m.winStart)
@@ -474,24 +478,24 @@ NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
       m.symStart = m.symEnd;
       m.symEnd = m.sync;
       m.symRise = m.symStart;
-      s.symValue = 1;
-      s.symPattern = A_Y;
+      s.u.decode.symValue = 1;
+      s.u.decode.symPattern = A_Y;
    }
    else if (m.c0 > m.c1)
    {
       m.symStart = m.symEnd;
       m.symEnd = m.peakTime;
       m.symRise = m.peakTime - rt.p2;
-      s.symValue = 0;
-      s.symPattern = A_Z;
+      s.u.decode.symValue = 0;
+      s.u.decode.symPattern = A_Z;
    }
    else
    {
       m.symStart = m.symEnd;
       m.symEnd = m.peakTime;
       m.symRise = m.peakTime;
-      s.symValue = 1;
-      s.symPattern = A_X;
+      s.u.decode.symValue = 1;
+      s.u.decode.symPattern = A_X;
    }
 
    m.sync = m.symEnd + rt.p1;
@@ -501,11 +505,11 @@ NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
    m.peakTime = 0;
    m.peak = 0;
 
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
-   s.symEdge = m.symRise - rt.delay;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symEdge = m.symRise - rt.delay;
 
-   return s.symPattern;
+   return s.u.decode.symPattern;
 }
 
 /* ---- poll frame assembly, NfcA.cpp:432-563 ---- */
@@ -514,36 +518,37 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
    NfcTiming &t = mem.cold->tim[0];
    bool frameEnd = false, truncated = false;
 
-   if (pattern == A_Y && (s.bsPrevious == A_Y || s.bsPrevious == A_Z))
+   if (pattern == A_Y && (s.u.decode.bsPrevious == A_Y || s.u.decode.bsPrevious == A_Z))
       frameEnd = true;
-   else if (s.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == t.maxFrameSize)
       truncated = true;
 
    if (frameEnd || truncated)
    {
-      if (s.bsBytes > 0 || s.bsBits == 7)
+      if (s.u.decode.bsBytes > 0 || s.u.decode.bsBits == 7)
       {
-         if (s.bsBits >= 7)
-            nfc_push_byte(mem, s, s.bsData);
+         if (s.u.decode.bsBits >= 7)
+            nfc_push_byte(mem, s, s.u.decode.bsData);
 
          uint32_t flags = 0, phase = 0;
 
-         if (s.bsFlags & NFC_FLAG_PARITY)
+         if (s.u.decode.bsFlags & NFC_FLAG_PARITY)
             flags |= NFC_FLAG_PARITY;
          if (truncated)
             flags |= NFC_FLAG_TRUNCATED;
-         if (s.bsBytes == 1 && s.bsBits == 7)
+         if (s.u.decode.bsBytes == 1 && s.u.decode.bsBits == 7)
             flags |= NFC_FLAG_SHORT;
 
-         const uint32_t start = s.frameStart, end = s.frameEnd, rate = s.frameRate, len = s.bsBytes;
+         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, rate = s.u.decode.frameRate, len = s.u.decode.bsBytes;
 
          nfca_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
 
-         nfc_clear_assembly(s);
-
-         if (s.lockTech == NFC_TECH_A)
-            nfc_poll_end_clear(mem, s.lock, s.lockBase, s.rt.p1);
+         if (s.lockTech == NFC_TECH_A) /* HLTA resets inside process() */
+         {
+            nfc_clear_assembly(s);
+            nfc_poll_end_clear(mem, s.u.decode.lock, s.u.decode.lockBase, s.u.decode.rt.p1);
+         }
 
          return;
       }
@@ -552,24 +557,24 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
       return;
    }
 
-   if (s.symEdge)
-      s.frameEnd = s.symEdge;
+   if (s.u.decode.symEdge)
+      s.u.decode.frameEnd = s.u.decode.symEdge;
 
-   if (s.bsPrevious)
+   if (s.u.decode.bsPrevious)
    {
-      uint32_t value = (s.bsPrevious == A_X) ? 1u : 0u;
+      uint32_t value = (s.u.decode.bsPrevious == A_X) ? 1u : 0u;
 
-      if (s.bsBits < 8)
+      if (s.u.decode.bsBits < 8)
       {
-         s.bsData |= value << s.bsBits++;
+         s.u.decode.bsData |= value << s.u.decode.bsBits++;
       }
-      else if (s.bsBytes < t.maxFrameSize)
+      else if (s.u.decode.bsBytes < t.maxFrameSize)
       {
-         nfc_push_byte(mem, s, s.bsData);
-         if (!nfca_parity(s.bsData, value))
-            s.bsFlags |= NFC_FLAG_PARITY;
-         s.bsData = 0;
-         s.bsBits = 0;
+         nfc_push_byte(mem, s, s.u.decode.bsData);
+         if (!nfca_parity(s.u.decode.bsData, value))
+            s.u.decode.bsFlags |= NFC_FLAG_PARITY;
+         s.u.decode.bsData = 0;
+         s.u.decode.bsBits = 0;
       }
       else
       {
@@ -578,14 +583,14 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
       }
    }
 
-   s.bsPrevious = pattern;
+   s.u.decode.bsPrevious = pattern;
 }
 
 /* ---- listen SOF, 106k OOK subcarrier, NfcA.cpp:939-1090 ---- */
 NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
    NfcTiming &t = mem.cold->tim[0];
 
    /* this stage only forms S0 (NfcA.cpp:962-975): same ring, no S1 */
@@ -594,7 +599,7 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
 
    const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
    const float old = NFC_AT(mem, NFC_R_PROD, (cur - rt.p2) & NFC_PMASK);
-   const float c2 = NFC_AT(mem, NFC_R_CORR, s.lockBase + nfc_point(mem, s.clock, rt.delay, pos, rt.p2, rt.p1));
+   const float c2 = NFC_AT(mem, NFC_R_CORR, s.u.decode.lockBase + nfc_point(mem, s.clock, rt.delay, pos, rt.p2, rt.p1));
    const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    const float deep = now.depth;
    const float sq = v * v * 10.0f;
@@ -603,16 +608,16 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
    m.acc += sq;
    m.acc -= old;
 
-   NFC_AT(mem, NFC_R_CORR, s.lockBase + pos) = m.acc;
+   NFC_AT(mem, NFC_R_CORR, s.u.decode.lockBase + pos) = m.acc;
    float s0 = m.acc - c2;
 
-   if (s.clock < s.guardEnd)
+   if (s.clock < s.u.decode.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == s.guardEnd)
+   if (s.clock == s.u.decode.guardEnd)
       m.thr = guardDev * (float)rt.p8;
 
-   if (s.clock > s.waitingEnd)
+   if (s.clock > s.u.decode.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.minDepth[0])
@@ -668,10 +673,10 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
    m.peakTime = 0;
    m.peak = 0;
 
-   s.symValue = 1;
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
-   s.symPattern = A_D;
+   s.u.decode.symValue = 1;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symPattern = A_D;
 
    return A_D;
 }
@@ -679,10 +684,10 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
 /* ---- listen symbols, 106k Manchester, NfcA.cpp:1095-1214 ---- */
 NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
-   NfcCorr k = nfc_correlate_power(mem, s.clock, m, rt, s.lockBase, nfc_lock_pos(s));
+   NfcCorr k = nfc_correlate_power(mem, s.clock, m, rt, s.u.decode.lockBase, nfc_lock_pos(s));
    float sd = nfc_abs(k.s0 - k.s1);
 
    if (s.clock < m.winStart)
@@ -713,14 +718,14 @@ NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, c
       if (m.c0 > m.c1)
       {
          m.symRise = m.sync;
-         s.symValue = 0;
-         s.symPattern = A_E;
+         s.u.decode.symValue = 0;
+         s.u.decode.symPattern = A_E;
       }
       else
       {
          m.symRise = m.sync - rt.p2;
-         s.symValue = 1;
-         s.symPattern = A_D;
+         s.u.decode.symValue = 1;
+         s.u.decode.symPattern = A_D;
       }
    }
    else
@@ -728,7 +733,7 @@ NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, c
       m.symStart = m.symEnd;
       m.symEnd = m.sync;
       m.symRise = 0;
-      s.symPattern = A_F;
+      s.u.decode.symPattern = A_F;
    }
 
    m.sync = m.symEnd + rt.p1;
@@ -737,18 +742,18 @@ NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, c
    m.peakTime = 0;
    m.peak = 0;
 
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
-   s.symEdge = m.symRise - rt.delay;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symEdge = m.symRise - rt.delay;
 
-   return s.symPattern;
+   return s.u.decode.symPattern;
 }
 
 /* ---- listen SOF, BPSK (212k/424k), NfcA.cpp:1220-1329 ---- */
 NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
    NfcTiming &t = mem.cold->tim[0];
 
    const uint32_t cur = s.clock - rt.delay;
@@ -756,13 +761,13 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
    const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
 
-   if (s.clock < s.guardEnd)
+   if (s.clock < s.u.decode.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == s.guardEnd)
+   if (s.clock == s.u.decode.guardEnd)
       m.thr = guardDev;
 
-   if (s.clock > s.waitingEnd)
+   if (s.clock > s.u.decode.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.minDepth[0])
@@ -801,10 +806,10 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
    m.phaseThr = nfc_abs(m.phaseAcc * 0.25f);
    m.auxTime = 0;
 
-   s.symValue = 0;
-   s.symStart = m.symStart - rt.p1 - rt.delay;
-   s.symEnd = m.symEnd - rt.p1 - rt.delay;
-   s.symPattern = A_S;
+   s.u.decode.symValue = 0;
+   s.u.decode.symStart = m.symStart - rt.p1 - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.p1 - rt.delay;
+   s.u.decode.symPattern = A_S;
 
    return A_S;
 }
@@ -812,8 +817,8 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
 /* ---- listen symbols, BPSK, NfcA.cpp:1334-1421 ---- */
 NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
    const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
    nfc_phase_integrate(m, p);
@@ -842,26 +847,26 @@ NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, 
 
    if (m.phaseAcc < -m.phaseThr)
    {
-      s.symValue = !s.symValue;
-      s.symPattern = (s.symPattern == A_M) ? A_N : A_M;
+      s.u.decode.symValue = !s.u.decode.symValue;
+      s.u.decode.symPattern = (s.u.decode.symPattern == A_M) ? A_N : A_M;
    }
    else
    {
       m.phaseThr = m.phaseAcc * 0.25f;
    }
 
-   s.symStart = m.symStart - rt.p1 - rt.delay;
-   s.symEnd = m.symEnd - rt.p1 - rt.delay;
+   s.u.decode.symStart = m.symStart - rt.p1 - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.p1 - rt.delay;
 
-   return s.symPattern;
+   return s.u.decode.symPattern;
 }
 
 /* emit a listen frame and fall back to search, shared by ASK and BPSK paths */
 NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t flags)
 {
    uint32_t phase = 0;
-   const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes;
-   const uint32_t rate = s.rt.symbolsPerSecond;
+   const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes;
+   const uint32_t rate = s.u.decode.rt.symbolsPerSecond;
 
    nfca_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
    nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
@@ -873,7 +878,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 {
    NfcTiming &t = mem.cold->tim[0];
 
-   if (s.frameType == NFC_FRAME_POLL)
+   if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
       uint32_t pattern = nfca_poll_symbol(c, s, mem);
 
@@ -883,17 +888,17 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   if (s.frameType != NFC_FRAME_LISTEN)
+   if (s.u.decode.frameType != NFC_FRAME_LISTEN)
       return;
 
-   if (s.lockRate == 0)
+   if (s.u.decode.lockRate == 0)
    {
-      if (!s.frameStart)
+      if (!s.u.decode.frameStart)
       {
          uint32_t pattern = nfca_listen_ask_start(c, s, mem, now);
 
          if (pattern == A_D)
-            s.frameStart = s.symStart;
+            s.u.decode.frameStart = s.u.decode.symStart;
          else if (pattern == SYM_TIMEOUT)
             nfca_reset(c, s, mem);
 
@@ -909,46 +914,46 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
       if (pattern == A_F)
          frameEnd = true;
-      else if (s.bsBytes == t.maxFrameSize)
+      else if (s.u.decode.bsBytes == t.maxFrameSize)
          truncated = true;
 
       if (frameEnd || truncated)
       {
-         if (s.bsBytes > 0 || s.bsBits == 4)
+         if (s.u.decode.bsBytes > 0 || s.u.decode.bsBits == 4)
          {
-            if (s.bsBits == 4)
-               nfc_push_byte(mem, s, s.bsData);
+            if (s.u.decode.bsBits == 4)
+               nfc_push_byte(mem, s, s.u.decode.bsData);
 
             uint32_t flags = 0;
-            if (s.bsFlags & NFC_FLAG_PARITY)
+            if (s.u.decode.bsFlags & NFC_FLAG_PARITY)
                flags |= NFC_FLAG_PARITY;
             if (truncated)
                flags |= NFC_FLAG_TRUNCATED;
-            if (s.bsBytes == 1 && s.bsBits == 4)
+            if (s.u.decode.bsBytes == 1 && s.u.decode.bsBits == 4)
                flags |= NFC_FLAG_SHORT;
 
             nfca_finish_listen(c, s, mem, flags);
             return;
          }
 
-         nfca_reset_search(s, s.lock);
+         nfca_reset_search(s, s.u.decode.lock);
          return;
       }
 
-      if (s.symEdge)
-         s.frameEnd = s.symEdge;
+      if (s.u.decode.symEdge)
+         s.u.decode.frameEnd = s.u.decode.symEdge;
 
-      if (s.bsBits < 8)
+      if (s.u.decode.bsBits < 8)
       {
-         s.bsData |= (s.symValue << s.bsBits++);
+         s.u.decode.bsData |= (s.u.decode.symValue << s.u.decode.bsBits++);
       }
-      else if (s.bsBytes < t.maxFrameSize)
+      else if (s.u.decode.bsBytes < t.maxFrameSize)
       {
-         nfc_push_byte(mem, s, s.bsData);
-         if (!nfca_parity(s.bsData, s.symValue))
-            s.bsFlags |= NFC_FLAG_PARITY;
-         s.bsData = 0;
-         s.bsBits = 0;
+         nfc_push_byte(mem, s, s.u.decode.bsData);
+         if (!nfca_parity(s.u.decode.bsData, s.u.decode.symValue))
+            s.u.decode.bsFlags |= NFC_FLAG_PARITY;
+         s.u.decode.bsData = 0;
+         s.u.decode.bsBits = 0;
       }
       else
       {
@@ -959,12 +964,12 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    }
 
    /* 212k / 424k: BPSK */
-   if (!s.frameStart)
+   if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfca_listen_bpsk_start(c, s, mem, now);
 
       if (pattern == A_S)
-         s.frameStart = s.symStart;
+         s.u.decode.frameStart = s.u.decode.symStart;
       else if (pattern == SYM_TIMEOUT)
          nfca_reset(c, s, mem);
 
@@ -980,25 +985,25 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (pattern == A_O)
       frameEnd = true;
-   else if (s.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == t.maxFrameSize)
       truncated = true;
 
    if (frameEnd || truncated)
    {
-      if (s.bsBits == 9)
+      if (s.u.decode.bsBits == 9)
       {
-         nfc_push_byte(mem, s, s.bsData);
+         nfc_push_byte(mem, s, s.u.decode.bsData);
 
-         if (nfca_parity(s.bsData, s.bsParity))
-            s.bsFlags |= NFC_FLAG_PARITY;
+         if (nfca_parity(s.u.decode.bsData, s.u.decode.bsParity))
+            s.u.decode.bsFlags |= NFC_FLAG_PARITY;
       }
 
-      if (s.bsBytes > 0)
+      if (s.u.decode.bsBytes > 0)
       {
-         s.frameEnd = s.symEnd;
+         s.u.decode.frameEnd = s.u.decode.symEnd;
 
          uint32_t flags = 0;
-         if (s.bsFlags & NFC_FLAG_PARITY)
+         if (s.u.decode.bsFlags & NFC_FLAG_PARITY)
             flags |= NFC_FLAG_PARITY;
          if (truncated)
             flags |= NFC_FLAG_TRUNCATED;
@@ -1011,24 +1016,24 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   if (s.bsBits < 8)
+   if (s.u.decode.bsBits < 8)
    {
-      s.bsData |= (s.symValue << s.bsBits);
+      s.u.decode.bsData |= (s.u.decode.symValue << s.u.decode.bsBits);
    }
-   else if (s.bsBits < 9)
+   else if (s.u.decode.bsBits < 9)
    {
-      s.bsParity = s.symValue;
+      s.u.decode.bsParity = s.u.decode.symValue;
    }
    else
    {
-      nfc_push_byte(mem, s, s.bsData);
-      if (!nfca_parity(s.bsData, s.bsParity))
-         s.bsFlags |= NFC_FLAG_PARITY;
-      s.bsData = s.symValue;
-      s.bsBits = 0;
+      nfc_push_byte(mem, s, s.u.decode.bsData);
+      if (!nfca_parity(s.u.decode.bsData, s.u.decode.bsParity))
+         s.u.decode.bsFlags |= NFC_FLAG_PARITY;
+      s.u.decode.bsData = s.u.decode.symValue;
+      s.u.decode.bsBits = 0;
    }
 
-   s.bsBits++;
+   s.u.decode.bsBits++;
 }
 
 #endif

@@ -20,16 +20,10 @@ NFC_DEV void nfcb_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 
 NFC_DEV void nfcb_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_mod_clear(s.detB[0]);
-   nfc_mod_clear(s.detB[1]);
-   nfc_mod_clear(s.lock);
-   nfc_clear_assembly(s);
-   nfc_clear_symbol(s);
+   nfc_leave_lock(s, mem);
 
-   s.frameType = 0;
-   s.frameStart = 0;
-   s.frameEnd = 0;
-   s.lockTech = 0;
+   nfc_mod_clear(s.u.search.detB[0]);
+   nfc_mod_clear(s.u.search.detB[1]);
 }
 
 /* ISO/IEC 13239 CRC_B */
@@ -120,28 +114,28 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    /* chained flags are always zero for NFC-B */
 
    const bool locked = (s.lockTech == NFC_TECH_B);
-   const uint32_t delay = locked ? s.rt.delay : 0u;
+   const uint32_t delay = locked ? s.u.decode.rt.delay : 0u;
 
    if (poll)
    {
       if (locked)
       {
-         s.guardEnd = s.frameEnd + t.guardTime + delay;
-         s.waitingEnd = s.frameEnd + t.waitingTime + delay;
-         s.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
+         s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime + delay;
+         s.u.decode.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         s.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
 
-      s.frameType = 0;
+      s.u.decode.frameType = 0;
       t.lastCommand = 0;
    }
 
-   s.frameStart = 0;
-   s.frameEnd = 0;
+   s.u.decode.frameStart = 0;
+   s.u.decode.frameEnd = 0;
 }
 
 /* history reads of the edge detectors (rate 0 looks at the current sample, rate 1 one 106k symbol back) */
@@ -167,7 +161,7 @@ template <int R>
 NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsB &taps, const NfcNow &now)
 {
    const NfcRate &rt = c.b[R];
-   NfcDetB &m = s.detB[R];
+   NfcDetB &m = s.u.search.detB[R];
 
    /* with no delay the sample of interest is the one the front end has just produced */
    float edge = rt.delay ? taps.edge[R] : now.filt;
@@ -267,18 +261,22 @@ NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLan
    }
 
    /* SOF recognised: lock; the first bit is sampled half a symbol after the last edge, no search window yet */
-   nfc_take_lock(s, rt, NFC_TECH_B, (uint32_t)R, 0, 0);
+   const uint32_t symStart = m.symStart, symEnd = m.auxTime;
+   const float aux = m.aux;
 
-   NfcMod &d = s.lock;
-   d.symStart = m.symStart;
-   d.symEnd = m.auxTime;
-   d.sync = d.symEnd + rt.p2;
-   d.thr = nfc_abs(m.aux * 0.5f);
+   nfc_take_lock(s, mem, rt, NFC_TECH_B, (uint32_t)R, 0, 0);
 
-   s.frameType = NFC_FRAME_POLL;
-   s.frameRate = rt.symbolsPerSecond;
-   s.frameStart = m.symStart - rt.delay;
-   s.frameEnd = 0;
+   NfcDecodeRegs &out = s.u.decode;
+   NfcMod &d = out.lock;
+   d.symStart = symStart;
+   d.symEnd = symEnd;
+   d.sync = symEnd + rt.p2;
+   d.thr = nfc_abs(aux * 0.5f);
+
+   out.frameType = NFC_FRAME_POLL;
+   out.frameRate = rt.symbolsPerSecond;
+   out.frameStart = symStart - rt.delay;
+   out.frameEnd = 0;
 
    return 1;
 }
@@ -301,8 +299,8 @@ NFC_DEV bool nfcb_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 /* ---- poll symbols: sample modulation depth at bit centres, resync on edges ---- */
 NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
    const uint32_t slot = (s.clock - rt.delay) & NFC_HMASK;
    float edge = NFC_AT(mem, NFC_R_FILT, slot);
@@ -331,26 +329,26 @@ NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 
    if (deep > c.minDepth[1])
    {
-      s.symValue = 0;
-      s.symPattern = B_L;
+      s.u.decode.symValue = 0;
+      s.u.decode.symPattern = B_L;
    }
    else
    {
-      s.symValue = 1;
-      s.symPattern = B_H;
+      s.u.decode.symValue = 1;
+      s.u.decode.symPattern = B_H;
    }
 
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
 
-   return s.symPattern;
+   return s.u.decode.symPattern;
 }
 
 /* ---- listen SOF: TR1 subcarrier, then two phase changes (S1, S2) ---- */
 NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
    NfcTiming &t = mem.cold->tim[1];
 
    const uint32_t cur = s.clock - rt.delay;
@@ -360,13 +358,13 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 
    nfc_phase_integrate(m, p);
 
-   if (s.clock < s.guardEnd)
+   if (s.clock < s.u.decode.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == s.guardEnd)
+   if (s.clock == s.u.decode.guardEnd)
       m.thr = guardDev;
 
-   if (s.clock > s.waitingEnd)
+   if (s.clock > s.u.decode.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.maxDepth[1])
@@ -443,10 +441,10 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
       m.winEnd = 0;
       m.aux = 0;
 
-      s.symValue = 1;
-      s.symStart = m.symStart - rt.p1 - rt.delay;
-      s.symEnd = m.symEnd - rt.p1 - rt.delay;
-      s.symPattern = B_S;
+      s.u.decode.symValue = 1;
+      s.u.decode.symStart = m.symStart - rt.p1 - rt.delay;
+      s.u.decode.symEnd = m.symEnd - rt.p1 - rt.delay;
+      s.u.decode.symPattern = B_S;
 
       return B_S;
    }
@@ -458,8 +456,8 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 /* ---- listen symbols: BPSK phase at bit centres ---- */
 NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
    const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
    nfc_phase_integrate(m, p);
@@ -488,18 +486,18 @@ NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 
    if (m.phaseAcc < -m.phaseThr)
    {
-      s.symValue = !s.symValue;
-      s.symPattern = (s.symPattern == B_M) ? B_N : B_M;
+      s.u.decode.symValue = !s.u.decode.symValue;
+      s.u.decode.symPattern = (s.u.decode.symPattern == B_M) ? B_N : B_M;
    }
    else
    {
       m.phaseThr = m.phaseAcc * 0.25f;
    }
 
-   s.symStart = m.symStart - rt.p1 - rt.delay;
-   s.symEnd = m.symEnd - rt.p1 - rt.delay;
+   s.u.decode.symStart = m.symStart - rt.p1 - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.p1 - rt.delay;
 
-   return s.symPattern;
+   return s.u.decode.symPattern;
 }
 
 /* ---- one sample in locked NFC-B mode ---- */
@@ -507,7 +505,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 {
    NfcTiming &t = mem.cold->tim[1];
 
-   if (s.frameType == NFC_FRAME_POLL)
+   if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
       uint32_t pattern = nfcb_poll_symbol(c, s, mem);
 
@@ -516,25 +514,25 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
       bool frameEnd = false, truncated = false, streamError = false;
 
-      if (s.bsBits == 9 && !s.bsData && pattern == B_L)
+      if (s.u.decode.bsBits == 9 && !s.u.decode.bsData && pattern == B_L)
          frameEnd = true;
-      else if (s.bsBits == 9 && pattern == B_L)
+      else if (s.u.decode.bsBits == 9 && pattern == B_L)
          streamError = true;
-      else if (s.bsBits == 0 && pattern == B_H && s.bsSkip == 6)
+      else if (s.u.decode.bsBits == 0 && pattern == B_H && s.u.decode.bsSkip == 6)
          streamError = true;
-      else if (s.bsBytes == t.maxFrameSize)
+      else if (s.u.decode.bsBytes == t.maxFrameSize)
          truncated = true;
-      else if ((s.bsBits == 0 && pattern == B_H) && ++s.bsSkip)
+      else if ((s.u.decode.bsBits == 0 && pattern == B_H) && ++s.u.decode.bsSkip)
          return; /* extra guard time between characters */
 
       if (frameEnd || streamError || truncated)
       {
-         if (s.bsBytes > 2)
+         if (s.u.decode.bsBytes > 2)
          {
-            s.frameEnd = s.symEnd;
+            s.u.decode.frameEnd = s.u.decode.symEnd;
 
             uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-            const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.rt.symbolsPerSecond;
+            const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.rt.symbolsPerSecond;
 
             nfcb_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
             nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
@@ -542,7 +540,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             nfc_clear_assembly(s);
 
             if (s.lockTech == NFC_TECH_B)
-               nfc_poll_end_clear(mem, s.lock, 0, 0);
+               nfc_poll_end_clear(mem, s.u.decode.lock, 0, 0);
 
             return;
          }
@@ -551,33 +549,33 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          return;
       }
 
-      if (s.bsBits < 9)
+      if (s.u.decode.bsBits < 9)
       {
-         if (s.bsBits > 0)
-            s.bsData |= (s.symValue << (s.bsBits - 1));
+         if (s.u.decode.bsBits > 0)
+            s.u.decode.bsData |= (s.u.decode.symValue << (s.u.decode.bsBits - 1));
 
-         s.bsBits++;
+         s.u.decode.bsBits++;
       }
       else
       {
-         nfc_push_byte(mem, s, s.bsData);
-         s.bsData = 0;
-         s.bsBits = 0;
-         s.bsSkip = 0;
+         nfc_push_byte(mem, s, s.u.decode.bsData);
+         s.u.decode.bsData = 0;
+         s.u.decode.bsBits = 0;
+         s.u.decode.bsSkip = 0;
       }
 
       return;
    }
 
-   if (s.frameType != NFC_FRAME_LISTEN)
+   if (s.u.decode.frameType != NFC_FRAME_LISTEN)
       return;
 
-   if (!s.frameStart)
+   if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfcb_listen_start(c, s, mem, now);
 
       if (pattern == B_S)
-         s.frameStart = s.symStart;
+         s.u.decode.frameStart = s.u.decode.symStart;
       else if (pattern == SYM_TIMEOUT)
          nfcb_reset(c, s, mem);
 
@@ -591,21 +589,21 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    bool frameEnd = false, truncated = false, streamError = false;
 
-   if (s.bsBits == 9 && !s.bsData && pattern == B_M)
+   if (s.u.decode.bsBits == 9 && !s.u.decode.bsData && pattern == B_M)
       frameEnd = true;
-   else if ((s.bsBits == 0 && pattern == B_N) || (s.bsBits == 9 && pattern == B_M))
+   else if ((s.u.decode.bsBits == 0 && pattern == B_N) || (s.u.decode.bsBits == 9 && pattern == B_M))
       streamError = true;
-   else if (s.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == t.maxFrameSize)
       truncated = true;
 
    if (frameEnd || streamError || truncated)
    {
-      if (s.bsBytes > 0)
+      if (s.u.decode.bsBytes > 0)
       {
-         s.frameEnd = s.symEnd + nfc_tu(c, 352); /* EOS is not tracked to its end */
+         s.u.decode.frameEnd = s.u.decode.symEnd + nfc_tu(c, 352); /* EOS is not tracked to its end */
 
          uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-         const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.rt.symbolsPerSecond;
+         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.rt.symbolsPerSecond;
 
          nfcb_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
@@ -615,18 +613,18 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   if (s.bsBits < 9)
+   if (s.u.decode.bsBits < 9)
    {
-      if (s.bsBits > 0)
-         s.bsData |= (s.symValue << (s.bsBits - 1));
+      if (s.u.decode.bsBits > 0)
+         s.u.decode.bsData |= (s.u.decode.symValue << (s.u.decode.bsBits - 1));
 
-      s.bsBits++;
+      s.u.decode.bsBits++;
    }
    else
    {
-      nfc_push_byte(mem, s, s.bsData);
-      s.bsData = 0;
-      s.bsBits = 0;
+      nfc_push_byte(mem, s, s.u.decode.bsData);
+      s.u.decode.bsData = 0;
+      s.u.decode.bsBits = 0;
    }
 }
 

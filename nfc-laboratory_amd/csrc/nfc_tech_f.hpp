@@ -20,20 +20,13 @@ NFC_DEV void nfcf_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 
 NFC_DEV void nfcf_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_mod_clear(s.detF[0]);
-   nfc_mod_clear(s.detF[1]);
-   nfc_mod_clear(s.lock);
+   nfc_leave_lock(s, mem);
+
+   nfc_mod_clear(s.u.search.detF[0]);
+   nfc_mod_clear(s.u.search.detF[1]);
 
    /* the two rings are adjacent */
    nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
-
-   nfc_clear_assembly(s);
-   nfc_clear_symbol(s);
-
-   s.frameType = 0;
-   s.frameStart = 0;
-   s.frameEnd = 0;
-   s.lockTech = 0;
 }
 
 /* CRC-16/XMODEM, big-endian on the wire */
@@ -88,28 +81,28 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    }
 
    const bool locked = (s.lockTech == NFC_TECH_F);
-   const uint32_t delay = locked ? s.rt.delay : 0u;
+   const uint32_t delay = locked ? s.u.decode.rt.delay : 0u;
 
    if (poll)
    {
       if (locked)
       {
-         s.guardEnd = s.frameEnd + t.guardTime + delay;
-         s.waitingEnd = s.frameEnd + t.waitingTime + delay;
-         s.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
+         s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime + delay;
+         s.u.decode.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         s.guardEnd = s.frameEnd + t.guardTime + delay;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
 
-      s.frameType = 0;
+      s.u.decode.frameType = 0;
       t.lastCommand = 0;
    }
 
-   s.frameStart = 0;
-   s.frameEnd = 0;
+   s.u.decode.frameStart = 0;
+   s.u.decode.frameEnd = 0;
 }
 
 /* the preamble tracker shared by search (NfcF.cpp:267-405) and listen-SOF (NfcF.cpp:815-933);
@@ -209,7 +202,7 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
                               float minimumCorrelation)
 {
    const NfcRate &rt = c.f[R];
-   NfcDetF &m = s.detF[R - 1];
+   NfcDetF &m = s.u.search.detF[R - 1];
 
    /* NFC-F correlates the undelayed signal: the entering sample and its depth are the current ones */
    NfcTap tap = taps.t[R];
@@ -240,23 +233,27 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity))
       return false;
 
-   /* preamble complete: lock this bitrate, the sync bytes follow */
-   nfc_take_lock(s, rt, NFC_TECH_F, (uint32_t)R, c.corrOffset[2 + R], s.posF[R - 1]);
+   /* preamble complete: lock this bitrate, the sync bytes follow (copy the detector record before it is parked) */
+   const NfcDetF k0 = m;
+   const uint32_t pos = s.posF[R - 1];
 
-   NfcMod &d = s.lock;
+   nfc_take_lock(s, mem, rt, NFC_TECH_F, (uint32_t)R, c.corrOffset[2 + R], pos);
+
+   NfcDecodeRegs &out = s.u.decode;
+   NfcMod &d = out.lock;
    d.stage = polarity;
-   d.winStart = m.winStart; d.winEnd = m.winEnd; d.sync = m.sync; d.pulses = m.pulses;
-   d.thr = m.thr; d.lastPhase = m.lastPhase; d.lastValue = m.lastValue; d.syncValue = m.syncValue; d.c0 = m.c0;
-   d.symStart = m.symStart; d.symEnd = m.symEnd; d.acc = m.acc; d.peak = m.peak; d.peakTime = m.peakTime;
+   d.winStart = k0.winStart; d.winEnd = k0.winEnd; d.sync = k0.sync; d.pulses = k0.pulses;
+   d.thr = k0.thr; d.lastPhase = k0.lastPhase; d.lastValue = k0.lastValue; d.syncValue = k0.syncValue; d.c0 = k0.c0;
+   d.symStart = k0.symStart; d.symEnd = k0.symEnd; d.acc = k0.acc; d.peak = k0.peak; d.peakTime = k0.peakTime;
 
-   s.symStart = m.symStart;
-   s.symEnd = m.symEnd;
-   s.symPattern = F_S;
+   out.symStart = k0.symStart;
+   out.symEnd = k0.symEnd;
+   out.symPattern = F_S;
 
-   s.frameType = NFC_FRAME_POLL;
-   s.frameRate = rt.symbolsPerSecond;
-   s.frameStart = s.symStart;
-   s.frameEnd = 0;
+   out.frameType = NFC_FRAME_POLL;
+   out.frameRate = rt.symbolsPerSecond;
+   out.frameStart = k0.symStart;
+   out.frameEnd = 0;
 
    return true;
 }
@@ -280,12 +277,12 @@ NFC_DEV bool nfcf_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 /* Manchester data symbols, identical for both directions (NfcF.cpp:641-744 and 941-1042) */
 NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
    const uint32_t lockPos = nfc_lock_pos(s);
-   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.lockBase, lockPos, true);
-   NfcCorr k = nfc_corr_apply(mem, m, tap, s.lockBase, lockPos);
+   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.u.decode.lockBase, lockPos, true);
+   NfcCorr k = nfc_corr_apply(mem, m, tap, s.u.decode.lockBase, lockPos);
    float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
 
    if (s.clock < m.winStart)
@@ -318,31 +315,31 @@ NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const N
    m.peakTime = 0;
    m.peak = 0;
 
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
 
    if ((m.stage == 0 && m.c0 > m.c1) || (m.stage == 1 && m.c0 < m.c1))
    {
-      s.symValue = 0;
-      s.symPattern = F_L;
+      s.u.decode.symValue = 0;
+      s.u.decode.symPattern = F_L;
    }
    else
    {
-      s.symValue = 1;
-      s.symPattern = F_H;
+      s.u.decode.symValue = 1;
+      s.u.decode.symPattern = F_H;
    }
 
-   return s.symPattern;
+   return s.u.decode.symPattern;
 }
 
 NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
    NfcTiming &t = mem.cold->tim[2];
 
    const uint32_t cur = s.clock - rt.delay;
-   const uint32_t base = s.lockBase;
+   const uint32_t base = s.u.decode.lockBase;
    const uint32_t pos = nfc_lock_pos(s);
 
    const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, base, pos, true);
@@ -352,7 +349,7 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
    m.acc += tap.in;
    m.acc -= tap.out;
 
-   if (s.clock < (uint32_t)(s.guardEnd - rt.p1))
+   if (s.clock < (uint32_t)(s.u.decode.guardEnd - rt.p1))
       return SYM_NONE;
 
    NFC_AT(mem, NFC_R_CORR, base + pos) = m.acc;
@@ -361,13 +358,13 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
    float s1 = tap.c2 - tap.c3;
    float sd = nfc_abs(s0 - s1) / (float)rt.p2;
 
-   if (s.clock < s.guardEnd)
+   if (s.clock < s.u.decode.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == s.guardEnd)
+   if (s.clock == s.u.decode.guardEnd)
       m.thr = guardDev * 10.0f;
 
-   if (s.clock > s.waitingEnd)
+   if (s.clock > s.u.decode.waitingEnd)
       return SYM_TIMEOUT;
 
    if (s.clock < m.winStart)
@@ -380,9 +377,9 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 
    m.stage = polarity;
 
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
-   s.symPattern = F_S;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symPattern = F_S;
 
    return F_S;
 }
@@ -395,23 +392,23 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
 
    if (pattern == F_E)
       frameEnd = true;
-   else if (s.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == t.maxFrameSize)
       truncated = true;
 
    if (frameEnd || truncated)
    {
-      if (s.bsBytes > 2)
+      if (s.u.decode.bsBytes > 2)
       {
-         s.frameEnd = s.symEnd;
+         s.u.decode.frameEnd = s.u.decode.symEnd;
 
          uint32_t flags = truncated ? NFC_FLAG_TRUNCATED : 0, phase = 0;
 
          if (mem.bytes[0] != 0xB2 || mem.bytes[1] != 0x4D)
             flags |= NFC_FLAG_SYNC;
 
-         uint32_t total = s.bsBytes > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : s.bsBytes;
-         const uint32_t start = s.frameStart, end = s.frameEnd, len = total - 2;
-         const uint32_t rate = s.rt.symbolsPerSecond;
+         uint32_t total = s.u.decode.bsBytes > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : s.u.decode.bsBytes;
+         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = total - 2;
+         const uint32_t rate = s.u.decode.rt.symbolsPerSecond;
 
          nfcf_process(c, s, mem, type, mem.bytes + 2, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_F, type, flags, phase, rate, start, end, mem.bytes + 2, len);
@@ -421,7 +418,7 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
             nfc_clear_assembly(s);
 
             if (s.lockTech == NFC_TECH_F)
-               nfc_poll_end_clear(mem, s.lock, s.lockBase, s.rt.p1);
+               nfc_poll_end_clear(mem, s.u.decode.lock, s.u.decode.lockBase, s.u.decode.rt.p1);
 
             return;
          }
@@ -431,19 +428,19 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
       return;
    }
 
-   s.bsData = (s.bsData << 1) | s.symValue;
+   s.u.decode.bsData = (s.u.decode.bsData << 1) | s.u.decode.symValue;
 
-   if (++s.bsBits == 8)
+   if (++s.u.decode.bsBits == 8)
    {
-      nfc_push_byte(mem, s, s.bsData);
-      s.bsData = 0;
-      s.bsBits = 0;
+      nfc_push_byte(mem, s, s.u.decode.bsData);
+      s.u.decode.bsData = 0;
+      s.u.decode.bsBits = 0;
    }
 }
 
 NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   if (s.frameType == NFC_FRAME_POLL)
+   if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
       uint32_t pattern = nfcf_data_symbol(c, s, mem);
 
@@ -453,15 +450,15 @@ NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   if (s.frameType != NFC_FRAME_LISTEN)
+   if (s.u.decode.frameType != NFC_FRAME_LISTEN)
       return;
 
-   if (!s.frameStart)
+   if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfcf_listen_start(c, s, mem);
 
       if (pattern == F_S)
-         s.frameStart = s.symStart;
+         s.u.decode.frameStart = s.u.decode.symStart;
       else if (pattern == SYM_TIMEOUT)
          nfcf_reset(c, s, mem);
 

@@ -20,17 +20,10 @@ NFC_DEV void nfcv_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 
 NFC_DEV void nfcv_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_clear_assembly(s);
-   nfc_clear_symbol(s);
-   nfc_mod_clear(s.detV);
-   nfc_mod_clear(s.lock);
-   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[5], c.v.p0);
+   nfc_leave_lock(s, mem);
 
-   s.frameType = 0;
-   s.frameStart = 0;
-   s.frameEnd = 0;
-   s.pulseCode = 0;
-   s.lockTech = 0;
+   nfc_mod_clear(s.u.search.detV);
+   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[5], c.v.p0);
 }
 
 NFC_DEV bool nfcv_crc_ok(const uint8_t *data, uint32_t len)
@@ -64,22 +57,22 @@ NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       if (locked)
       {
          /* note the sign: the poll side runs on the delayed signal (NfcV.cpp:1145-1148) */
-         s.guardEnd = s.frameEnd + t.guardTime - c.v.delay;
-         s.waitingEnd = s.frameEnd + t.waitingTime - c.v.delay;
-         s.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime - c.v.delay;
+         s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime - c.v.delay;
+         s.u.decode.frameType = NFC_FRAME_LISTEN;
       }
    }
    else
    {
       if (locked)
-         s.guardEnd = s.frameEnd + t.guardTime + c.v.delay;
+         s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + c.v.delay;
 
-      s.frameType = 0;
+      s.u.decode.frameType = 0;
       t.lastCommand = 0;
    }
 
-   s.frameStart = 0;
-   s.frameEnd = 0;
+   s.u.decode.frameStart = 0;
+   s.u.decode.frameEnd = 0;
 }
 
 /* history reads of the pulse correlator: box sum over p2 of the raw signal delayed by two symbols; S0 compares
@@ -114,7 +107,7 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return false;
 
    const NfcRate &rt = c.v;
-   NfcDetV &m = s.detV;
+   NfcDetV &m = s.u.search.detV;
 
    const float minimumCorrelation = s.env * c.corrThreshold[3];
    const float raw = taps.t.in;
@@ -196,24 +189,28 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return false;
    }
 
-   /* SOF (two pulses) recognised: lock */
-   nfc_take_lock(s, rt, NFC_TECH_V, 0, c.corrOffset[5], s.posV1);
+   /* SOF (two pulses) recognised: lock (the detector record is about to be parked: take what is needed) */
+   const uint32_t symStart = m.symStart, pos = s.posV1;
+   const float acc = m.acc, aux = m.aux;
 
-   NfcMod &d = s.lock;
-   d.symStart = m.symStart;
+   nfc_take_lock(s, mem, rt, NFC_TECH_V, 0, c.corrOffset[5], pos);
+
+   NfcDecodeRegs &out = s.u.decode;
+   NfcMod &d = out.lock;
+   d.symStart = symStart;
    d.symEnd = symEnd;
    d.sync = symEnd;
    d.winStart = symEnd;
    d.winEnd = symEnd + length;
    d.thr = minimumCorrelation;
-   d.acc = m.acc;
-   d.aux = m.aux;
+   d.acc = acc;
+   d.aux = aux;
 
-   s.frameRate = rate;
-   s.pulseCode = code;
-   s.frameType = NFC_FRAME_POLL;
-   s.frameStart = m.symStart - rt.delay;
-   s.frameEnd = 0;
+   out.frameRate = rate;
+   out.pulseCode = code;
+   out.frameType = NFC_FRAME_POLL;
+   out.frameStart = symStart - rt.delay;
+   out.frameEnd = 0;
 
    return true;
 }
@@ -221,11 +218,11 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 /* one pulse-position symbol (2 or 8 bits), NfcV.cpp:672-795 */
 NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
-   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.lockBase, s.posV1, false);
-   float s0 = nfcv_pulse_apply(mem, m, tap, s.lockBase, s.posV1, rt);
+   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.u.decode.lockBase, s.posV1, false);
+   float s0 = nfcv_pulse_apply(mem, m, tap, s.u.decode.lockBase, s.posV1, rt);
 
    if (s.clock < m.winStart)
       return SYM_NONE;
@@ -248,22 +245,23 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
    {
       m.symEnd = m.peakTime + rt.p2;
 
-      s.symValue = 0;
-      s.symStart = m.symStart - rt.delay;
-      s.symEnd = m.symEnd - rt.delay;
-      s.symPattern = V_S;
+      s.u.decode.symValue = 0;
+      s.u.decode.symStart = m.symStart - rt.delay;
+      s.u.decode.symEnd = m.symEnd - rt.delay;
+      s.u.decode.symPattern = V_S;
       return V_S;
    }
 
-   s.symValue = 0;
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
-   s.symPattern = V_E;
+   s.u.decode.symValue = 0;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symPattern = V_E;
 
-   const int periods = s.pulseCode ? 256 : 4;
-   const int length = s.pulseCode ? c.vLen8 : c.vLen2;
-   const int32_t *ends = s.pulseCode ? c.vSlotEnd8 : c.vSlotEnd2;
+   const int periods = s.u.decode.pulseCode ? 256 : 4;
+   const int length = s.u.decode.pulseCode ? c.vLen8 : c.vLen2;
+   const int32_t *ends = s.u.decode.pulseCode ? c.vSlotEnd8 : c.vSlotEnd2;
 
+#pragma clang loop unroll(disable)
    for (int i = 0; i < periods; i++)
    {
       const uint32_t slotEnd = (uint32_t)ends[i];
@@ -278,11 +276,11 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
          m.peakTime = 0;
          m.peak = 0;
 
-         s.symValue = (uint32_t)i;
-         s.symStart = m.symStart - rt.delay;
-         s.symEnd = m.symEnd - rt.delay;
-         s.symPattern = s.pulseCode ? V_8 : V_2;
-         return s.symPattern;
+         s.u.decode.symValue = (uint32_t)i;
+         s.u.decode.symStart = m.symStart - rt.delay;
+         s.u.decode.symEnd = m.symEnd - rt.delay;
+         s.u.decode.symPattern = s.u.decode.pulseCode ? V_8 : V_2;
+         return s.u.decode.symPattern;
       }
    }
 
@@ -292,9 +290,9 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 /* subcarrier power integrated over one symbol half (p1), ring of two symbols (p0) */
 NFC_DEV float nfcv_burst_correlation(NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m)
 {
-   const NfcRate &rt = s.rt;
+   const NfcRate &rt = s.u.decode.rt;
    const uint32_t cur = s.clock - rt.delay;
-   const uint32_t base = s.lockBase;
+   const uint32_t base = s.u.decode.lockBase;
    const uint32_t pos = s.posV0;
 
    const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
@@ -315,8 +313,8 @@ NFC_DEV float nfcv_burst_correlation(NfcStreamState &s, const NfcLaneMem &mem, N
 
 NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
    NfcTiming &t = mem.cold->tim[3];
 
    const uint32_t cur = s.clock - rt.delay;
@@ -324,13 +322,13 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
    const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    float s0 = nfcv_burst_correlation(s, mem, m);
 
-   if (s.clock < s.guardEnd)
+   if (s.clock < s.u.decode.guardEnd)
       return SYM_NONE;
 
-   if (s.clock == s.guardEnd)
+   if (s.clock == s.u.decode.guardEnd)
       m.thr = guardDev;
 
-   if (s.clock > s.waitingEnd)
+   if (s.clock > s.u.decode.waitingEnd)
       return SYM_TIMEOUT;
 
    if (deep > c.maxDepth[3])
@@ -407,10 +405,10 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
       m.peakTime = 0;
       m.peak = 0;
 
-      s.symValue = 0;
-      s.symStart = m.symStart - rt.delay;
-      s.symEnd = m.symEnd - rt.delay;
-      s.symPattern = V_S;
+      s.u.decode.symValue = 0;
+      s.u.decode.symStart = m.symStart - rt.delay;
+      s.u.decode.symEnd = m.symEnd - rt.delay;
+      s.u.decode.symPattern = V_S;
       return V_S;
    }
 
@@ -419,8 +417,8 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 
 NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   const NfcRate &rt = s.rt;
-   NfcMod &m = s.lock;
+   const NfcRate &rt = s.u.decode.rt;
+   NfcMod &m = s.u.decode.lock;
 
    float s0 = nfcv_burst_correlation(s, mem, m);
    float sd = nfc_abs(s0);
@@ -451,19 +449,19 @@ NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
    m.peakTime = 0;
    m.peak = 0;
 
-   s.symValue = m.c0 > m.c1 ? 0u : 1u;
-   s.symStart = m.symStart - rt.delay;
-   s.symEnd = m.symEnd - rt.delay;
-   s.symPattern = s.symValue ? V_1 : V_0;
+   s.u.decode.symValue = m.c0 > m.c1 ? 0u : 1u;
+   s.u.decode.symStart = m.symStart - rt.delay;
+   s.u.decode.symEnd = m.symEnd - rt.delay;
+   s.u.decode.symPattern = s.u.decode.symValue ? V_1 : V_0;
 
-   return s.symPattern;
+   return s.u.decode.symPattern;
 }
 
 NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
 {
    NfcTiming &t = mem.cold->tim[3];
 
-   if (s.frameType == NFC_FRAME_POLL)
+   if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
       uint32_t pattern = nfcv_poll_symbol(c, s, mem);
 
@@ -476,20 +474,20 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          frameEnd = true;
       else if (pattern == V_E)
          streamError = true;
-      else if (s.bsBytes == t.maxFrameSize)
+      else if (s.u.decode.bsBytes == t.maxFrameSize)
          truncated = true;
 
       if (frameEnd || streamError || truncated)
       {
-         if (s.bsBytes > 0)
+         if (s.u.decode.bsBytes > 0)
          {
-            if (s.bsBits == 8)
-               nfc_push_byte(mem, s, s.bsData);
+            if (s.u.decode.bsBits == 8)
+               nfc_push_byte(mem, s, s.u.decode.bsData);
 
-            s.frameEnd = s.symEnd;
+            s.u.decode.frameEnd = s.u.decode.symEnd;
 
             uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-            const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.frameRate;
+            const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.frameRate;
 
             nfcv_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
             nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
@@ -497,7 +495,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
             nfc_clear_assembly(s);
 
             if (s.lockTech == NFC_TECH_V)
-               nfc_poll_end_clear(mem, s.lock, s.lockBase, s.rt.p0);
+               nfc_poll_end_clear(mem, s.u.decode.lock, s.u.decode.lockBase, s.u.decode.rt.p0);
 
             return;
          }
@@ -506,27 +504,27 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          return;
       }
 
-      if (s.bsBits == 8)
+      if (s.u.decode.bsBits == 8)
       {
-         nfc_push_byte(mem, s, s.bsData);
-         s.bsData = 0;
-         s.bsBits = 0;
+         nfc_push_byte(mem, s, s.u.decode.bsData);
+         s.u.decode.bsData = 0;
+         s.u.decode.bsBits = 0;
       }
 
-      s.bsData |= (s.symValue << s.bsBits);
-      s.bsBits += s.pulseCode ? 8u : 2u;
+      s.u.decode.bsData |= (s.u.decode.symValue << s.u.decode.bsBits);
+      s.u.decode.bsBits += s.u.decode.pulseCode ? 8u : 2u;
       return;
    }
 
-   if (s.frameType != NFC_FRAME_LISTEN)
+   if (s.u.decode.frameType != NFC_FRAME_LISTEN)
       return;
 
-   if (!s.frameStart)
+   if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfcv_listen_start(c, s, mem, now);
 
       if (pattern == V_S)
-         s.frameStart = s.symStart;
+         s.u.decode.frameStart = s.u.decode.symStart;
       else if (pattern == SYM_TIMEOUT)
          nfcv_reset(c, s, mem);
 
@@ -544,20 +542,20 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       frameEnd = true;
    else if (pattern == V_E)
       streamError = true;
-   else if (s.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == t.maxFrameSize)
       truncated = true;
 
    if (frameEnd || streamError || truncated)
    {
-      if (s.bsBytes > 0)
+      if (s.u.decode.bsBytes > 0)
       {
-         if (s.bsBits == 8)
-            nfc_push_byte(mem, s, s.bsData);
+         if (s.u.decode.bsBits == 8)
+            nfc_push_byte(mem, s, s.u.decode.bsData);
 
-         s.frameEnd = s.symEnd;
+         s.u.decode.frameEnd = s.u.decode.symEnd;
 
          uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-         const uint32_t start = s.frameStart, end = s.frameEnd, len = s.bsBytes, rate = s.frameRate;
+         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.frameRate;
 
          nfcv_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
          nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
@@ -567,15 +565,15 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   if (s.bsBits == 8)
+   if (s.u.decode.bsBits == 8)
    {
-      nfc_push_byte(mem, s, s.bsData);
-      s.bsData = 0;
-      s.bsBits = 0;
+      nfc_push_byte(mem, s, s.u.decode.bsData);
+      s.u.decode.bsData = 0;
+      s.u.decode.bsBits = 0;
    }
 
-   s.bsData |= (s.symValue << s.bsBits);
-   s.bsBits++;
+   s.u.decode.bsData |= (s.u.decode.symValue << s.u.decode.bsBits);
+   s.u.decode.bsBits++;
 }
 
 #endif

@@ -177,7 +177,37 @@ struct NfcDetV
    uint32_t peakTime;
 };
 
-/* the part of a stream's state that the kernel keeps in registers for the whole launch */
+/* search-mode registers: the eight detector records */
+struct NfcSearchRegs
+{
+   NfcDetA detA[3];
+   NfcDetB detB[2];
+   NfcDetF detF[2]; /* 212k, 424k */
+   NfcDetV detV;
+};
+
+/* decode-mode registers: working copy of the locked modulation + symbol / bit stream / frame assembly */
+struct NfcDecodeRegs
+{
+   NfcMod lock;
+   NfcRate rt;
+   uint32_t lockRate;  /* rate type 0..2 */
+   uint32_t pulseCode; /* NFC-V: 0 -> 1 of 4, 1 -> 1 of 256 */
+   uint32_t lockBase;  /* correlation ring base of the locked modulation */
+   uint32_t lockPos;   /* ring position (idx % rt.p1) of the locked correlator, advanced every sample while locked */
+   uint32_t guardEnd;  /* frameStatus.guardEnd / waitingEnd of the locked technology (always written by the poll */
+   uint32_t waitingEnd;/* frame's process() before a listen window reads them) */
+   uint32_t symPattern, symValue, symStart, symEnd, symEdge;
+   uint32_t bsPrevious, bsBits, bsSkip, bsData, bsFlags, bsParity, bsBytes;
+   uint32_t frameType, frameRate, frameStart, frameEnd;
+};
+
+/* The part of a stream's state that the kernel keeps in registers for the whole launch. A lane is either searching
+ * or decoding, never both, so the two register sets share storage: at lock time the (frozen) detector records are
+ * parked in NfcStreamCold::parked and the decode set is initialised in their place; when the technology resets
+ * (the only way out of a lock) the detector records are brought back and those of the technology that was locked
+ * are cleared, exactly what the reference's resetModulation() does. Decode-set fields have no meaning while
+ * searching (the reference zeroes them at reset and rewrites them at the next lock). */
 struct NfcStreamState
 {
    /* ---- front end (NfcTech.h:317-393) ---- */
@@ -192,21 +222,9 @@ struct NfcStreamState
    uint32_t carrierOff;
    uint32_t carrierOn;
 
-   /* ---- lock ---- */
    uint32_t lockTech;  /* NFC_TECH_* or 0 */
-   uint32_t lockRate;  /* rate type 0..2 */
-   uint32_t pulseCode; /* NFC-V: 0 -> 1 of 4, 1 -> 1 of 256 */
-   uint32_t lockBase;  /* correlation ring base of the locked modulation */
-   uint32_t lockPos;   /* ring position (idx % rt.p1) of the locked correlator, advanced every sample while locked */
    uint32_t bankClock; /* clock of the last sample at which the whole detector bank was stepped (search mode) */
-   uint32_t guardEnd;  /* frameStatus.guardEnd / waitingEnd of the locked technology (always written by the poll */
-   uint32_t waitingEnd;/* frame's process() before a listen window reads them) */
-
-   /* ---- shared symbol / bit stream / frame assembly ---- */
-   uint32_t symPattern, symValue, symStart, symEnd, symEdge;
-   uint32_t bsPrevious, bsBits, bsSkip, bsData, bsFlags, bsParity, bsBytes;
-   uint32_t frameType, frameRate, frameStart, frameEnd;
-   uint32_t chainedA;
+   uint32_t chainedA;  /* NFC-A chained frame flags (Encrypted after AUTH) */
 
    /* ---- ring positions (idx % period) of every correlator ---- */
    uint32_t posA[3];
@@ -214,23 +232,20 @@ struct NfcStreamState
    uint32_t posV1;   /* mod p1 */
    uint32_t posV0;   /* mod p0 */
 
-   /* ---- search-mode detectors ---- */
-   NfcDetA detA[3];
-   NfcDetB detB[2];
-   NfcDetF detF[2]; /* 212k, 424k */
-   NfcDetV detV;
-
-   /* ---- working copy of the locked modulation: taken at lock time, dropped when the technology resets ---- */
-   NfcMod lock;
-   NfcRate rt;
+   union
+   {
+      NfcSearchRegs search;
+      NfcDecodeRegs decode;
+   } u;
 };
 
 /* the part that stays in HBM and is only touched at frame boundaries */
 struct NfcStreamCold
 {
-   NfcTiming tim[4]; /* A B F V */
+   NfcTiming tim[4];     /* A B F V */
+   NfcSearchRegs parked; /* detector records while a technology is locked */
    uint32_t framesOut;
-   uint32_t reserved[7];
+   uint32_t reserved[5];
 };
 
 /* header of one frame in the frame sink, followed by (length+3)/4 payload words */

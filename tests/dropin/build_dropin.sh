@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the drop-in demonstration: the reference's OWN golden-vector harness
+# TEST INFRASTRUCTURE. Builds the drop-in demonstration: the reference's OWN golden-vector harness
 # (src/nfc-test/test-sdr/src/main/cpp/main.cpp, unmodified, compiled where it lies) linked against
 #   - nfc-laboratory_amd/host/NfcDecoder.cpp  (lab::NfcDecoder implemented on the nfcgpu C ABI)
 #   - libnfcgpu.so                            (HIP kernels)
@@ -9,6 +9,7 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
+HOST="$ROOT/nfc-laboratory_amd/host"
 REF="${NFC_REFERENCE_ROOT:-/root/reference}"
 R="$REF/src/nfc-lib"
 OUT="$ROOT/oracle/_ref"
@@ -19,7 +20,7 @@ OUT="$ROOT/oracle/_ref"
 INC="-I$R/lib-rt/rt-lang/src/main/include -I$R/lib-hw/hw-dev/src/main/include -I$R/lib-lab/lab-data/src/main/include \
  -I$R/lib-lab/lab-radio/src/main/include -I$R/lib-ext/nlohmann/src/main/cpp -I$ROOT/include"
 
-g++ -std=c++17 -O2 -pthread -w $INC -c "$HERE/NfcDecoder.cpp" -o "$OUT/obj/NfcDecoder_gpu.o"
+g++ -std=c++17 -O2 -pthread -w $INC -c "$HOST/NfcDecoder.cpp" -o "$OUT/obj/NfcDecoder_gpu.o"
 g++ -std=c++17 -O2 -pthread -w $INC "$REF/src/nfc-test/test-sdr/src/main/cpp/main.cpp" "$OUT/obj/NfcDecoder_gpu.o" \
     "$OUT/libnfcref_support.a" -L"$ROOT/nfc-laboratory_amd" -lnfcgpu -Wl,-rpath,'$ORIGIN/../../nfc-laboratory_amd' \
     -o "$OUT/test-sdr-gpu"
