@@ -454,15 +454,10 @@ NFC_DEV NfcCorr nfc_corr_apply(const NfcLaneMem &mem, M &m, const NfcTap &t, uin
 }
 
 /* same correlator over 10*filtered^2 (listen ASK, NfcA.cpp:1115-1131); window w = p2 (NFC-A) */
-NFC_DEV NfcCorr nfc_correlate_power(const NfcLaneMem &mem, uint32_t clock, NfcMod &m, const NfcRate &rt, uint32_t base, uint32_t pos)
+NFC_DEV NfcCorr nfc_correlate_power(const NfcLaneMem &mem, uint32_t clock, NfcMod &m, const NfcRate &rt, uint32_t base, uint32_t pos,
+                                    float v, float old, float c2, float c3)
 {
    const uint32_t cur = clock - rt.delay;
-
-   const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
-   const float old = NFC_AT(mem, NFC_R_PROD, (cur - rt.p2) & NFC_PMASK);
-   const float c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p2, rt.p1));
-   const float c3 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
-
    const float sq = v * v * 10.0f;
 
    NFC_AT(mem, NFC_R_PROD, cur & NFC_PMASK) = sq;
@@ -485,13 +480,11 @@ struct NfcPhase
    float in, out;
 };
 
-NFC_DEV NfcPhase nfc_phase_product(const NfcLaneMem &mem, uint32_t clock, const NfcRate &rt)
+NFC_DEV NfcPhase nfc_phase_product(const NfcLaneMem &mem, uint32_t clock, const NfcRate &rt, float a, float b, float leaving)
 {
    const uint32_t cur = clock - rt.delay;
-   const float a = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
-   const float b = NFC_AT(mem, NFC_R_FILT, (cur - rt.p1) & NFC_HMASK);
    NfcPhase p;
-   p.out = NFC_AT(mem, NFC_R_PROD, (cur - rt.p4) & NFC_PMASK);
+   p.out = leaving;
    p.in = a * b * 10.0f;
    NFC_AT(mem, NFC_R_PROD, cur & NFC_PMASK) = p.in;
    return p;
@@ -542,6 +535,48 @@ NFC_DEV void nfc_leave_lock(NfcStreamState &s, const NfcLaneMem &mem)
 NFC_DEV bool nfc_may_exceed(float a, float w, float limit)
 {
    return nfc_abs(a) > w * limit * 0.999f;
+}
+
+/* History reads of one decode-mode step, whatever the locked technology and frame stage: issued together before
+ * the front end stores the new sample so that the step pays one memory latency instead of one per (divergent)
+ * decode path. Which of them a path uses depends on its stage; unused ones are harmless (addresses always valid). */
+struct NfcDecTaps
+{
+   float x0, x2; /* raw signal at the (delayed) decode point and half a symbol before        */
+   float f0, f1; /* DC-removed signal at the decode point and one symbol before               */
+   float m0, d0; /* mean deviation / modulation depth at the decode point                     */
+   float pp;     /* product ring entry leaving the listen-mode integration window             */
+   float c2, c3; /* correlation ring entries half a symbol (V listen: one symbol) / one sample back */
+};
+
+NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamState &s)
+{
+   const NfcDecodeRegs &d = s.u.decode;
+   const NfcRate &rt = d.rt;
+   const uint32_t cur = s.clock - rt.delay;
+   const bool vListen = (s.lockTech == NFC_TECH_V) && (d.frameType == NFC_FRAME_LISTEN);
+
+   /* integration window of the listen-mode product ring: p2 for NFC-A 106k (ASK), p1 for NFC-V, p4 for BPSK */
+   const uint32_t window = (s.lockTech == NFC_TECH_A && d.lockRate == 0) ? rt.p2 : ((s.lockTech == NFC_TECH_V) ? rt.p1 : rt.p4);
+
+   NfcDecTaps t;
+
+   t.x0 = NFC_AT(mem, NFC_R_X, cur & NFC_HMASK);
+   t.x2 = NFC_AT(mem, NFC_R_X, (cur - rt.p2) & NFC_HMASK);
+   t.f0 = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
+   t.f1 = NFC_AT(mem, NFC_R_FILT, (cur - rt.p1) & NFC_HMASK);
+   t.m0 = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
+   t.d0 = NFC_AT(mem, NFC_R_DEPTH, cur & NFC_HMASK);
+   t.pp = NFC_AT(mem, NFC_R_PROD, (cur - window) & NFC_PMASK);
+
+   const uint32_t p2 = vListen ? nfc_point(mem, s.clock, rt.delay, s.posV0, rt.p1, rt.p0)
+                               : nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p2, rt.p1);
+   const uint32_t p3 = nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p1 - 1u, rt.p1);
+
+   t.c2 = NFC_AT(mem, NFC_R_CORR, d.lockBase + p2);
+   t.c3 = NFC_AT(mem, NFC_R_CORR, d.lockBase + p3);
+
+   return t;
 }
 
 #include "nfc_tech_a.hpp"
@@ -610,21 +645,33 @@ NFC_DEV void nfc_decode_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
    nfc_advance_positions(c, s, mem);
    nfc_advance_lock_pos(s, mem);
 
+   NfcDecTaps taps = nfc_load_decode_taps(mem, s);
+
    const NfcNow now = nfc_front_end(c, s, mem, value);
+
+   /* without delay the decode point is the sample the front end has just produced (not in memory when the taps
+    * were read) */
+   if (s.u.decode.rt.delay == 0)
+   {
+      taps.x0 = now.x;
+      taps.f0 = now.filt;
+      taps.m0 = now.mdev;
+      taps.d0 = now.depth;
+   }
 
    switch (s.lockTech)
    {
       case NFC_TECH_A:
-         nfca_decode(c, s, mem, now);
+         nfca_decode(c, s, mem, now, taps);
          break;
       case NFC_TECH_B:
-         nfcb_decode(c, s, mem, now);
+         nfcb_decode(c, s, mem, now, taps);
          break;
       case NFC_TECH_F:
-         nfcf_decode(c, s, mem, now);
+         nfcf_decode(c, s, mem, now, taps);
          break;
       default:
-         nfcv_decode(c, s, mem, now);
+         nfcv_decode(c, s, mem, now, taps);
          break;
    }
 }

@@ -444,13 +444,14 @@ NFC_DEV bool nfca_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 }
 
 /* ---- poll frame symbols (modified Miller), NfcA.cpp:812-934 ---- */
-NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
    const uint32_t pos = nfc_lock_pos(s);
-   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.u.decode.lockBase, pos, true);
+   NfcTap tap;
+   tap.in = taps.x0; tap.out = taps.x2; tap.c2 = taps.c2; tap.c3 = taps.c3;
    NfcCorr k = nfc_corr_apply(mem, m, tap, s.u.decode.lockBase, pos);
    float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
 
@@ -587,7 +588,7 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
 }
 
 /* ---- listen SOF, 106k OOK subcarrier, NfcA.cpp:939-1090 ---- */
-NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
@@ -597,10 +598,10 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
    const uint32_t cur = s.clock - rt.delay;
    const uint32_t pos = nfc_lock_pos(s);
 
-   const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
-   const float old = NFC_AT(mem, NFC_R_PROD, (cur - rt.p2) & NFC_PMASK);
-   const float c2 = NFC_AT(mem, NFC_R_CORR, s.u.decode.lockBase + nfc_point(mem, s.clock, rt.delay, pos, rt.p2, rt.p1));
-   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
+   const float v = taps.f0;
+   const float old = taps.pp;
+   const float c2 = taps.c2;
+   const float guardDev = taps.m0;
    const float deep = now.depth;
    const float sq = v * v * 10.0f;
 
@@ -682,12 +683,12 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
 }
 
 /* ---- listen symbols, 106k Manchester, NfcA.cpp:1095-1214 ---- */
-NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
-   NfcCorr k = nfc_correlate_power(mem, s.clock, m, rt, s.u.decode.lockBase, nfc_lock_pos(s));
+   NfcCorr k = nfc_correlate_power(mem, s.clock, m, rt, s.u.decode.lockBase, nfc_lock_pos(s), taps.f0, taps.pp, taps.c2, taps.c3);
    float sd = nfc_abs(k.s0 - k.s1);
 
    if (s.clock < m.winStart)
@@ -750,7 +751,7 @@ NFC_DEV uint32_t nfca_listen_ask_symbol(const NfcConfig &c, NfcStreamState &s, c
 }
 
 /* ---- listen SOF, BPSK (212k/424k), NfcA.cpp:1220-1329 ---- */
-NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
@@ -758,8 +759,8 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
 
    const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
-   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
-   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
+   const float guardDev = taps.m0;
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt, taps.f0, taps.f1, taps.pp);
 
    if (s.clock < s.u.decode.guardEnd)
       return SYM_NONE;
@@ -815,12 +816,12 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
 }
 
 /* ---- listen symbols, BPSK, NfcA.cpp:1334-1421 ---- */
-NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
-   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt, taps.f0, taps.f1, taps.pp);
    nfc_phase_integrate(m, p);
 
    if (!m.auxTime)
@@ -874,13 +875,13 @@ NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const Nfc
 }
 
 /* ---- one sample in locked NFC-A mode: decodeFrame, NfcA.cpp:416-803 ---- */
-NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    NfcTiming &t = mem.cold->tim[0];
 
    if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
-      uint32_t pattern = nfca_poll_symbol(c, s, mem);
+      uint32_t pattern = nfca_poll_symbol(c, s, mem, taps);
 
       if (pattern > SYM_TIMEOUT)
          nfca_poll_frame(c, s, mem, pattern);
@@ -895,7 +896,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    {
       if (!s.u.decode.frameStart)
       {
-         uint32_t pattern = nfca_listen_ask_start(c, s, mem, now);
+         uint32_t pattern = nfca_listen_ask_start(c, s, mem, now, taps);
 
          if (pattern == A_D)
             s.u.decode.frameStart = s.u.decode.symStart;
@@ -905,7 +906,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          return;
       }
 
-      uint32_t pattern = nfca_listen_ask_symbol(c, s, mem);
+      uint32_t pattern = nfca_listen_ask_symbol(c, s, mem, taps);
 
       if (pattern <= SYM_TIMEOUT)
          return;
@@ -966,7 +967,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    /* 212k / 424k: BPSK */
    if (!s.u.decode.frameStart)
    {
-      uint32_t pattern = nfca_listen_bpsk_start(c, s, mem, now);
+      uint32_t pattern = nfca_listen_bpsk_start(c, s, mem, now, taps);
 
       if (pattern == A_S)
          s.u.decode.frameStart = s.u.decode.symStart;
@@ -976,7 +977,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   uint32_t pattern = nfca_listen_bpsk_symbol(c, s, mem);
+   uint32_t pattern = nfca_listen_bpsk_symbol(c, s, mem, taps);
 
    if (pattern <= SYM_TIMEOUT)
       return;

@@ -297,14 +297,13 @@ NFC_DEV bool nfcb_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 }
 
 /* ---- poll symbols: sample modulation depth at bit centres, resync on edges ---- */
-NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
-   const uint32_t slot = (s.clock - rt.delay) & NFC_HMASK;
-   float edge = NFC_AT(mem, NFC_R_FILT, slot);
-   float deep = NFC_AT(mem, NFC_R_DEPTH, slot);
+   float edge = taps.f0;
+   float deep = taps.d0;
 
    if (s.clock > m.winStart && s.clock < m.winEnd)
    {
@@ -345,7 +344,7 @@ NFC_DEV uint32_t nfcb_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 }
 
 /* ---- listen SOF: TR1 subcarrier, then two phase changes (S1, S2) ---- */
-NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
@@ -353,8 +352,8 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 
    const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
-   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
-   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
+   const float guardDev = taps.m0;
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt, taps.f0, taps.f1, taps.pp);
 
    nfc_phase_integrate(m, p);
 
@@ -454,12 +453,12 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 }
 
 /* ---- listen symbols: BPSK phase at bit centres ---- */
-NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
-   const NfcPhase p = nfc_phase_product(mem, s.clock, rt);
+   const NfcPhase p = nfc_phase_product(mem, s.clock, rt, taps.f0, taps.f1, taps.pp);
    nfc_phase_integrate(m, p);
 
    if (!m.auxTime)
@@ -501,13 +500,13 @@ NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 }
 
 /* ---- one sample in locked NFC-B mode ---- */
-NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    NfcTiming &t = mem.cold->tim[1];
 
    if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
-      uint32_t pattern = nfcb_poll_symbol(c, s, mem);
+      uint32_t pattern = nfcb_poll_symbol(c, s, mem, taps);
 
       if (pattern <= SYM_TIMEOUT)
          return;
@@ -572,7 +571,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (!s.u.decode.frameStart)
    {
-      uint32_t pattern = nfcb_listen_start(c, s, mem, now);
+      uint32_t pattern = nfcb_listen_start(c, s, mem, now, taps);
 
       if (pattern == B_S)
          s.u.decode.frameStart = s.u.decode.symStart;
@@ -582,7 +581,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   uint32_t pattern = nfcb_listen_symbol(c, s, mem);
+   uint32_t pattern = nfcb_listen_symbol(c, s, mem, taps);
 
    if (pattern <= SYM_TIMEOUT)
       return;

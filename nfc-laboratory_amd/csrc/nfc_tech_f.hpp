@@ -275,13 +275,14 @@ NFC_DEV bool nfcf_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 }
 
 /* Manchester data symbols, identical for both directions (NfcF.cpp:641-744 and 941-1042) */
-NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
    const uint32_t lockPos = nfc_lock_pos(s);
-   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.u.decode.lockBase, lockPos, true);
+   NfcTap tap;
+   tap.in = taps.x0; tap.out = taps.x2; tap.c2 = taps.c2; tap.c3 = taps.c3;
    NfcCorr k = nfc_corr_apply(mem, m, tap, s.u.decode.lockBase, lockPos);
    float sd = nfc_abs(k.s0 - k.s1) / (float)rt.p2;
 
@@ -332,7 +333,7 @@ NFC_DEV uint32_t nfcf_data_symbol(const NfcConfig &c, NfcStreamState &s, const N
    return s.u.decode.symPattern;
 }
 
-NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
@@ -342,8 +343,9 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
    const uint32_t base = s.u.decode.lockBase;
    const uint32_t pos = nfc_lock_pos(s);
 
-   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, base, pos, true);
-   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
+   NfcTap tap;
+   tap.in = taps.x0; tap.out = taps.x2; tap.c2 = taps.c2; tap.c3 = taps.c3;
+   const float guardDev = taps.m0;
 
    /* the box sum runs from the end of the poll frame, the ring only from one symbol before the guard */
    m.acc += tap.in;
@@ -438,11 +440,11 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
    }
 }
 
-NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
-      uint32_t pattern = nfcf_data_symbol(c, s, mem);
+      uint32_t pattern = nfcf_data_symbol(c, s, mem, taps);
 
       if (pattern > SYM_TIMEOUT)
          nfcf_frame(c, s, mem, pattern, NFC_FRAME_POLL);
@@ -455,7 +457,7 @@ NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (!s.u.decode.frameStart)
    {
-      uint32_t pattern = nfcf_listen_start(c, s, mem);
+      uint32_t pattern = nfcf_listen_start(c, s, mem, taps);
 
       if (pattern == F_S)
          s.u.decode.frameStart = s.u.decode.symStart;
@@ -465,7 +467,7 @@ NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   uint32_t pattern = nfcf_data_symbol(c, s, mem);
+   uint32_t pattern = nfcf_data_symbol(c, s, mem, taps);
 
    if (pattern > SYM_TIMEOUT)
       nfcf_frame(c, s, mem, pattern, NFC_FRAME_LISTEN);

@@ -216,12 +216,13 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 }
 
 /* one pulse-position symbol (2 or 8 bits), NfcV.cpp:672-795 */
-NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
-   const NfcTap tap = nfc_tap_raw(mem, s.clock, rt, s.u.decode.lockBase, s.posV1, false);
+   NfcTap tap;
+   tap.in = taps.x0; tap.out = taps.x2; tap.c2 = taps.c2; tap.c3 = 0.0f;
    float s0 = nfcv_pulse_apply(mem, m, tap, s.u.decode.lockBase, s.posV1, rt);
 
    if (s.clock < m.winStart)
@@ -288,16 +289,16 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 }
 
 /* subcarrier power integrated over one symbol half (p1), ring of two symbols (p0) */
-NFC_DEV float nfcv_burst_correlation(NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m)
+NFC_DEV float nfcv_burst_correlation(NfcStreamState &s, const NfcLaneMem &mem, NfcMod &m, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    const uint32_t cur = s.clock - rt.delay;
    const uint32_t base = s.u.decode.lockBase;
    const uint32_t pos = s.posV0;
 
-   const float v = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
-   const float old = NFC_AT(mem, NFC_R_PROD, (cur - rt.p1) & NFC_PMASK);
-   const float c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, s.clock, rt.delay, pos, rt.p1, rt.p0));
+   const float v = taps.f0;
+   const float old = taps.pp;
+   const float c2 = taps.c2;
 
    const float sq = v * v * 10.0f;
 
@@ -311,7 +312,7 @@ NFC_DEV float nfcv_burst_correlation(NfcStreamState &s, const NfcLaneMem &mem, N
    return c2 - m.acc;
 }
 
-NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
@@ -319,8 +320,8 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 
    const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
-   const float guardDev = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
-   float s0 = nfcv_burst_correlation(s, mem, m);
+   const float guardDev = taps.m0;
+   float s0 = nfcv_burst_correlation(s, mem, m, taps);
 
    if (s.clock < s.u.decode.guardEnd)
       return SYM_NONE;
@@ -415,12 +416,12 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
    return SYM_NONE;
 }
 
-NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
 
-   float s0 = nfcv_burst_correlation(s, mem, m);
+   float s0 = nfcv_burst_correlation(s, mem, m, taps);
    float sd = nfc_abs(s0);
 
    if (s.clock < m.winStart)
@@ -457,13 +458,13 @@ NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
    return s.u.decode.symPattern;
 }
 
-NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now)
+NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    NfcTiming &t = mem.cold->tim[3];
 
    if (s.u.decode.frameType == NFC_FRAME_POLL)
    {
-      uint32_t pattern = nfcv_poll_symbol(c, s, mem);
+      uint32_t pattern = nfcv_poll_symbol(c, s, mem, taps);
 
       if (pattern <= SYM_TIMEOUT)
          return;
@@ -521,7 +522,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (!s.u.decode.frameStart)
    {
-      uint32_t pattern = nfcv_listen_start(c, s, mem, now);
+      uint32_t pattern = nfcv_listen_start(c, s, mem, now, taps);
 
       if (pattern == V_S)
          s.u.decode.frameStart = s.u.decode.symStart;
@@ -531,7 +532,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       return;
    }
 
-   uint32_t pattern = nfcv_listen_symbol(c, s, mem);
+   uint32_t pattern = nfcv_listen_symbol(c, s, mem, taps);
 
    if (pattern <= SYM_TIMEOUT)
       return;
