@@ -518,6 +518,7 @@ NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcLaneMem &mem, const NfcRa
    d.symPattern = 0; d.symValue = 0; d.symStart = 0; d.symEnd = 0; d.symEdge = 0;
    d.bsPrevious = 0; d.bsBits = 0; d.bsSkip = 0; d.bsData = 0; d.bsFlags = 0; d.bsParity = 0; d.bsBytes = 0;
    d.frameType = 0; d.frameRate = 0; d.frameStart = 0; d.frameEnd = 0;
+   d.maxFrame = mem.cold->tim[tech - NFC_TECH_A].maxFrameSize;
 
    s.lockTech = tech;
 }

@@ -262,6 +262,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
          s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime + delay;
          s.u.decode.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.maxFrame = t.maxFrameSize;
       }
    }
    else
@@ -521,7 +522,7 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
 
    if (pattern == A_Y && (s.u.decode.bsPrevious == A_Y || s.u.decode.bsPrevious == A_Z))
       frameEnd = true;
-   else if (s.u.decode.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
       truncated = true;
 
    if (frameEnd || truncated)
@@ -569,7 +570,7 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
       {
          s.u.decode.bsData |= value << s.u.decode.bsBits++;
       }
-      else if (s.u.decode.bsBytes < t.maxFrameSize)
+      else if (s.u.decode.bsBytes < s.u.decode.maxFrame)
       {
          nfc_push_byte(mem, s, s.u.decode.bsData);
          if (!nfca_parity(s.u.decode.bsData, value))
@@ -915,7 +916,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
       if (pattern == A_F)
          frameEnd = true;
-      else if (s.u.decode.bsBytes == t.maxFrameSize)
+      else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
          truncated = true;
 
       if (frameEnd || truncated)
@@ -948,7 +949,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       {
          s.u.decode.bsData |= (s.u.decode.symValue << s.u.decode.bsBits++);
       }
-      else if (s.u.decode.bsBytes < t.maxFrameSize)
+      else if (s.u.decode.bsBytes < s.u.decode.maxFrame)
       {
          nfc_push_byte(mem, s, s.u.decode.bsData);
          if (!nfca_parity(s.u.decode.bsData, s.u.decode.symValue))
@@ -986,7 +987,7 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (pattern == A_O)
       frameEnd = true;
-   else if (s.u.decode.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
       truncated = true;
 
    if (frameEnd || truncated)

@@ -123,6 +123,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
          s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime + delay;
          s.u.decode.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.maxFrame = t.maxFrameSize;
       }
    }
    else
@@ -519,7 +520,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          streamError = true;
       else if (s.u.decode.bsBits == 0 && pattern == B_H && s.u.decode.bsSkip == 6)
          streamError = true;
-      else if (s.u.decode.bsBytes == t.maxFrameSize)
+      else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
          truncated = true;
       else if ((s.u.decode.bsBits == 0 && pattern == B_H) && ++s.u.decode.bsSkip)
          return; /* extra guard time between characters */
@@ -592,7 +593,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       frameEnd = true;
    else if ((s.u.decode.bsBits == 0 && pattern == B_N) || (s.u.decode.bsBits == 9 && pattern == B_M))
       streamError = true;
-   else if (s.u.decode.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
       truncated = true;
 
    if (frameEnd || streamError || truncated)

@@ -90,6 +90,7 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
          s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime + delay;
          s.u.decode.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.maxFrame = t.maxFrameSize;
       }
    }
    else
@@ -394,7 +395,7 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
 
    if (pattern == F_E)
       frameEnd = true;
-   else if (s.u.decode.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
       truncated = true;
 
    if (frameEnd || truncated)

@@ -60,6 +60,7 @@ NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime - c.v.delay;
          s.u.decode.waitingEnd = s.u.decode.frameEnd + t.waitingTime - c.v.delay;
          s.u.decode.frameType = NFC_FRAME_LISTEN;
+         s.u.decode.maxFrame = t.maxFrameSize;
       }
    }
    else
@@ -475,7 +476,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          frameEnd = true;
       else if (pattern == V_E)
          streamError = true;
-      else if (s.u.decode.bsBytes == t.maxFrameSize)
+      else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
          truncated = true;
 
       if (frameEnd || streamError || truncated)
@@ -543,7 +544,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       frameEnd = true;
    else if (pattern == V_E)
       streamError = true;
-   else if (s.u.decode.bsBytes == t.maxFrameSize)
+   else if (s.u.decode.bsBytes == s.u.decode.maxFrame)
       truncated = true;
 
    if (frameEnd || streamError || truncated)

@@ -200,6 +200,7 @@ struct NfcDecodeRegs
    uint32_t symPattern, symValue, symStart, symEnd, symEdge;
    uint32_t bsPrevious, bsBits, bsSkip, bsData, bsFlags, bsParity, bsBytes;
    uint32_t frameType, frameRate, frameStart, frameEnd;
+   uint32_t maxFrame;  /* protocolStatus.maxFrameSize of the locked technology (register copy of NfcTiming) */
 };
 
 /* The part of a stream's state that the kernel keeps in registers for the whole launch. A lane is either searching
