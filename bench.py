@@ -73,6 +73,11 @@ def main():
 
     data = torch.empty((S, T, 2), dtype=torch.float32, device=dev)
     synth.fill_iq_torch(data, template_dev, first_stream=rank * S)
+    if os.environ.get("NFC_BENCH_IDLE") == "1":
+        # diagnostic only (not a benchmark configuration): unmodulated carrier with 2-LSB noise, every lane stays in search mode
+        noise = (torch.arange(T, device=dev) * 2654435761 % 5).to(torch.float32) / 32768.0
+        data[:, :, 0] = 0.25 + noise[None, :]
+        data[:, :, 1] = 0.0
 
     sink_words = 64 << 20
     sink = torch.zeros(sink_words, dtype=torch.int32, device=dev)
