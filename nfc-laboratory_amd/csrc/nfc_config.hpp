@@ -117,9 +117,10 @@ static inline bool nfc_build_config(const NfcHostParams &p, NfcConfig &c)
    const uint32_t deepest = c.v.delay + c.v.p2 + 1;
    const uint32_t deepestProd = c.v.p1 + 1;
    bool ok = deepest < NFC_HIST && deepestProd < NFC_PROD && (c.a[2].delay + c.a[2].p1 + 1) < NFC_HIST;
+   /* ring moduli must be usable: p2 + 1 < p1 keeps the three ring points of a correlator distinct */
    for (int r = 0; r < 3; r++)
-      ok = ok && c.a[r].p8 > 0 && c.a[r].p2 < c.a[r].p1 && c.f[r].p2 < c.f[r].p1;
-   ok = ok && c.v.p2 < c.v.p1 && c.v.p1 < c.v.p0 && c.etu > 0;
+      ok = ok && c.a[r].p8 > 0 && c.a[r].p2 >= 2 && c.a[r].p2 + 1 < c.a[r].p1 && c.f[r].p2 + 1 < c.f[r].p1;
+   ok = ok && c.v.p2 + 1 < c.v.p1 && c.v.p1 < c.v.p0 && c.etu > 0;
 
    return ok;
 }
