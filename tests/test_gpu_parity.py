@@ -202,3 +202,42 @@ def test_reference_test_sdr_harness_runs_unchanged_on_the_gpu_decoder(built, tmp
     out = subprocess.run([exe, str(tmp_path) + "/"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900).stdout
     for name in names:
         assert "TEST FILE %s.wav: PASS" % name in out, out
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzzed_streams_match_reference(gpu, seed):
+    """Random cut-and-paste of captures with arbitrary gains, offsets and noise (general fp32, not on the int16 grid)."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    from test_oracle_goldens import _fuzz_stream
+    streams = [_fuzz_stream(seed * 100 + i, 200000) for i in range(12)]
+    first = gpu.open(count=len(streams))
+    for pos in range(0, 200000, 50000):
+        parts = [np.ascontiguousarray(x[pos:pos + 50000]) for x in streams]
+        gpu.submit_batch([first + i for i in range(len(parts))], [p.ctypes.data for p in parts], [p.size for p in parts], FS)
+    for i, x in enumerate(streams):
+        ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384)
+        assert gpu.poll(first + i, capacity=16384) == ref, "stream %d" % i
+        gpu.close_stream(first + i)
+
+
+@pytest.mark.parametrize("rate,step", [(5000000, 2), (2500000, 4)])
+def test_other_sample_rates_match_reference(gpu, rate, step):
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    for name in ["test_NFC-A_106kbps_001", "test_NFC-B_106kbps_001", "test_NFC-F_212kbps_002", "test_NFC-V_26kbps_002"]:
+        x = np.ascontiguousarray(T.load_fixture(name)[::step])
+        ref, _ = T.reference_decode(x, sample_rate=rate, keep_carrier=True)
+        sid = gpu.open()
+        gpu.submit(sid, x, rate)
+        assert gpu.poll(sid) == ref, name
+        gpu.close_stream(sid)
+
+
+def test_unsupported_sample_rate_is_rejected_loudly(gpu):
+    import nfclab_amd
+    sid = gpu.open()
+    with pytest.raises(nfclab_amd.NfcGpuError) as e:
+        gpu.submit(sid, np.zeros(100, np.float32), 20000000)  # look-back would exceed the 512-deep history rings
+    assert e.value.code == -5
+    gpu.close_stream(sid)
