@@ -88,7 +88,8 @@ def main():
     gpu.sink_attach(sink.data_ptr(), sink_words, ctl.data_ptr())
     gpu.sink_hold(True)
     gpu.profile(True)
-    first = gpu.open(count=S)
+    params = nfclab_amd.default_params(tech_mask=int(os.environ.get("NFC_BENCH_TECH_MASK", "15")))  # diagnostic switch, default all four
+    first = gpu.open(params, count=S)
 
     pitch = T * 8
 
