@@ -523,11 +523,13 @@ NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcLaneMem &mem, const NfcRa
    s.lockTech = tech;
 }
 
-/* leave decode mode (the technology resets): bring the detector records back */
-NFC_DEV void nfc_leave_lock(NfcStreamState &s, const NfcLaneMem &mem)
+/* leave decode mode (the technology resets). The decode register set dies here; bringing the detector records
+ * back, clearing those of the technology that was locked and zeroing its rings (the reference's resetModulation)
+ * happens once, at the end of the decode step (nfc_finish_unlock), not at each of the many reset sites */
+NFC_DEV void nfc_leave_lock(NfcStreamState &s, uint32_t tech)
 {
-   s.u.search = mem.cold->parked;
    s.lockTech = 0;
+   s.unlock = tech;
 }
 
 /* a/w compared against +-limit: the IEEE division is only needed when |a| is within 0.1 % of w*limit or beyond
@@ -637,6 +639,40 @@ NFC_DEV void nfc_search_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
       s.bankClock = s.clock;
 }
 
+NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   const uint32_t tech = s.unlock;
+
+   s.unlock = 0;
+   s.u.search = mem.cold->parked;
+
+   if (tech == NFC_TECH_A)
+   {
+      nfc_mod_clear(s.u.search.detA[0]);
+      nfc_mod_clear(s.u.search.detA[1]);
+      nfc_mod_clear(s.u.search.detA[2]);
+      /* the three rings are adjacent */
+      nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[0], c.a[0].p1 + c.a[1].p1 + c.a[2].p1);
+   }
+   else if (tech == NFC_TECH_B)
+   {
+      nfc_mod_clear(s.u.search.detB[0]);
+      nfc_mod_clear(s.u.search.detB[1]);
+   }
+   else if (tech == NFC_TECH_F)
+   {
+      nfc_mod_clear(s.u.search.detF[0]);
+      nfc_mod_clear(s.u.search.detF[1]);
+      /* the two rings are adjacent */
+      nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
+   }
+   else
+   {
+      nfc_mod_clear(s.u.search.detV);
+      nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[5], c.v.p0);
+   }
+}
+
 /* One sample with a technology locked (poll / listen frame decoding); `mem.exact` is a run-time flag here */
 NFC_DEV void nfc_decode_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
 {
@@ -675,6 +711,9 @@ NFC_DEV void nfc_decode_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
          nfcv_decode(c, s, mem, now, taps);
          break;
    }
+
+   if (s.unlock)
+      nfc_finish_unlock(c, s, mem);
 }
 
 /* One sample, whatever the mode. `exact` must be true whenever nfc_exact_zone(s.clock + 1) is (it may be true

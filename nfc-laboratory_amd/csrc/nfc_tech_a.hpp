@@ -21,16 +21,7 @@ NFC_DEV void nfca_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 /* resetModulation, NfcA.cpp:1451-1475 */
 NFC_DEV void nfca_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   /* back to search mode: the decode register set (working copy, symbol, bit stream, frame) dies here, which is
-    * the reference zeroing it; the detector records return from their parking place */
-   nfc_leave_lock(s, mem);
-
-   nfc_mod_clear(s.u.search.detA[0]);
-   nfc_mod_clear(s.u.search.detA[1]);
-   nfc_mod_clear(s.u.search.detA[2]);
-
-   /* the three rings are adjacent */
-   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[0], c.a[0].p1 + c.a[1].p1 + c.a[2].p1);
+   nfc_leave_lock(s, NFC_TECH_A);
 }
 
 /* resetFrameSearch, NfcA.cpp:1426-1446 */

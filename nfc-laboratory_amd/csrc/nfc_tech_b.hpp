@@ -20,10 +20,7 @@ NFC_DEV void nfcb_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 
 NFC_DEV void nfcb_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_leave_lock(s, mem);
-
-   nfc_mod_clear(s.u.search.detB[0]);
-   nfc_mod_clear(s.u.search.detB[1]);
+   nfc_leave_lock(s, NFC_TECH_B);
 }
 
 /* ISO/IEC 13239 CRC_B */

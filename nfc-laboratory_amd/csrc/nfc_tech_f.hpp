@@ -20,13 +20,7 @@ NFC_DEV void nfcf_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 
 NFC_DEV void nfcf_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_leave_lock(s, mem);
-
-   nfc_mod_clear(s.u.search.detF[0]);
-   nfc_mod_clear(s.u.search.detF[1]);
-
-   /* the two rings are adjacent */
-   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
+   nfc_leave_lock(s, NFC_TECH_F);
 }
 
 /* CRC-16/XMODEM, big-endian on the wire */

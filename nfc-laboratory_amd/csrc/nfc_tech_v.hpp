@@ -20,10 +20,7 @@ NFC_DEV void nfcv_protocol_defaults(const NfcConfig &c, NfcTiming &t)
 
 NFC_DEV void nfcv_reset(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
 {
-   nfc_leave_lock(s, mem);
-
-   nfc_mod_clear(s.u.search.detV);
-   nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[5], c.v.p0);
+   nfc_leave_lock(s, NFC_TECH_V);
 }
 
 NFC_DEV bool nfcv_crc_ok(const uint8_t *data, uint32_t len)

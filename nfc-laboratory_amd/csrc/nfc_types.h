@@ -224,6 +224,7 @@ struct NfcStreamState
    uint32_t carrierOn;
 
    uint32_t lockTech;  /* NFC_TECH_* or 0 */
+   uint32_t unlock;    /* technology that reset during this decode step (its unparking is done once, at the end of the step) */
    uint32_t bankClock; /* clock of the last sample at which the whole detector bank was stepped (search mode) */
    uint32_t chainedA;  /* NFC-A chained frame flags (Encrypted after AUTH) */
 
