@@ -496,16 +496,13 @@ NFC_DEV void nfc_phase_integrate(NfcMod &m, const NfcPhase &p)
    m.phaseAcc -= p.out;
 }
 
-/* Enter decode mode, in place: park the detector records (they stay frozen while locked), then start the decode
- * register set from zero. The caller copies what it needs from its detector record into locals BEFORE this call
- * (the two register sets share storage) and fills in what the detector found afterwards; the reference's record at
- * that point holds exactly those values (see nfc_types.h). */
-NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcLaneMem &mem, const NfcRate &rt, uint32_t tech, uint32_t rate,
-                           uint32_t base, uint32_t pos)
+/* A detector that recognises its start-of-frame prepares the decode register set in HBM (NfcStreamCold::init):
+ * everything zero, then what the detector found (the reference's record at that point holds exactly those values,
+ * see nfc_types.h). Installing it happens once per search step, in nfc_enter_lock: eight inlined copies of a
+ * 120-register state swap would otherwise surround the hot path with register shuffling. */
+NFC_DEV NfcDecodeRegs &nfc_take_lock(const NfcLaneMem &mem, const NfcRate &rt, uint32_t rate, uint32_t base, uint32_t pos)
 {
-   mem.cold->parked = s.u.search;
-
-   NfcDecodeRegs &d = s.u.decode;
+   NfcDecodeRegs &d = mem.cold->init;
 
    nfc_mod_clear(d.lock);
    d.rt = rt;
@@ -518,8 +515,17 @@ NFC_DEV void nfc_take_lock(NfcStreamState &s, const NfcLaneMem &mem, const NfcRa
    d.symPattern = 0; d.symValue = 0; d.symStart = 0; d.symEnd = 0; d.symEdge = 0;
    d.bsPrevious = 0; d.bsBits = 0; d.bsSkip = 0; d.bsData = 0; d.bsFlags = 0; d.bsParity = 0; d.bsBytes = 0;
    d.frameType = 0; d.frameRate = 0; d.frameStart = 0; d.frameEnd = 0;
-   d.maxFrame = mem.cold->tim[tech - NFC_TECH_A].maxFrameSize;
+   d.maxFrame = 0;
 
+   return d;
+}
+
+/* enter decode mode: park the detector records (they stay frozen while locked) and install the prepared decode set */
+NFC_DEV void nfc_enter_lock(NfcStreamState &s, const NfcLaneMem &mem, uint32_t tech)
+{
+   mem.cold->parked = s.u.search;
+   s.u.decode = mem.cold->init;
+   s.u.decode.maxFrame = mem.cold->tim[tech - NFC_TECH_A].maxFrameSize;
    s.lockTech = tech;
 }
 
@@ -624,14 +630,22 @@ NFC_DEV void nfc_search_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
    nfc_detect_carrier(c, s, mem);
 
    /* first detector that locks wins, later ones skip this sample */
+   uint32_t locked = 0;
+
    if ((c.enabled & 1u) && nfca_detect(c, s, mem, ta, now))
+      locked = NFC_TECH_A;
+   else if ((c.enabled & 2u) && nfcb_detect(c, s, mem, tb, now))
+      locked = NFC_TECH_B;
+   else if ((c.enabled & 4u) && nfcf_detect(c, s, mem, tf, now))
+      locked = NFC_TECH_F;
+   else if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
+      locked = NFC_TECH_V;
+
+   if (locked)
+   {
+      nfc_enter_lock(s, mem, locked);
       return;
-   if ((c.enabled & 2u) && nfcb_detect(c, s, mem, tb, now))
-      return;
-   if ((c.enabled & 4u) && nfcf_detect(c, s, mem, tf, now))
-      return;
-   if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
-      return;
+   }
 
    /* every detector that is enabled stepped its correlator on this sample (or none did: the gates are common):
     * on the next sample ring[(idx - 1) % p1] is known to equal the running sum and need not be read back */

@@ -387,9 +387,7 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    const uint32_t symStart = m.symStart, pos = s.posA[R];
    const float peak = m.peak, acc = m.acc, aux = m.aux;
 
-   nfc_take_lock(s, mem, rt, NFC_TECH_A, (uint32_t)R, c.corrOffset[R], pos);
-
-   NfcDecodeRegs &out = s.u.decode;
+   NfcDecodeRegs &out = nfc_take_lock(mem, rt, (uint32_t)R, c.corrOffset[R], pos);
    NfcMod &d = out.lock;
    d.symStart = symStart;
    d.symEnd = symEnd;

@@ -262,9 +262,7 @@ NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLan
    const uint32_t symStart = m.symStart, symEnd = m.auxTime;
    const float aux = m.aux;
 
-   nfc_take_lock(s, mem, rt, NFC_TECH_B, (uint32_t)R, 0, 0);
-
-   NfcDecodeRegs &out = s.u.decode;
+   NfcDecodeRegs &out = nfc_take_lock(mem, rt, (uint32_t)R, 0, 0);
    NfcMod &d = out.lock;
    d.symStart = symStart;
    d.symEnd = symEnd;

@@ -232,9 +232,7 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    const NfcDetF k0 = m;
    const uint32_t pos = s.posF[R - 1];
 
-   nfc_take_lock(s, mem, rt, NFC_TECH_F, (uint32_t)R, c.corrOffset[2 + R], pos);
-
-   NfcDecodeRegs &out = s.u.decode;
+   NfcDecodeRegs &out = nfc_take_lock(mem, rt, (uint32_t)R, c.corrOffset[2 + R], pos);
    NfcMod &d = out.lock;
    d.stage = polarity;
    d.winStart = k0.winStart; d.winEnd = k0.winEnd; d.sync = k0.sync; d.pulses = k0.pulses;

@@ -191,9 +191,7 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    const uint32_t symStart = m.symStart, pos = s.posV1;
    const float acc = m.acc, aux = m.aux;
 
-   nfc_take_lock(s, mem, rt, NFC_TECH_V, 0, c.corrOffset[5], pos);
-
-   NfcDecodeRegs &out = s.u.decode;
+   NfcDecodeRegs &out = nfc_take_lock(mem, rt, 0, c.corrOffset[5], pos);
    NfcMod &d = out.lock;
    d.symStart = symStart;
    d.symEnd = symEnd;

@@ -246,8 +246,9 @@ struct NfcStreamCold
 {
    NfcTiming tim[4];     /* A B F V */
    NfcSearchRegs parked; /* detector records while a technology is locked */
+   NfcDecodeRegs init;   /* decode register set prepared by the detector that locked, installed by nfc_enter_lock */
    uint32_t framesOut;
-   uint32_t reserved[5];
+   uint32_t reserved[4];
 };
 
 /* header of one frame in the frame sink, followed by (length+3)/4 payload words */
