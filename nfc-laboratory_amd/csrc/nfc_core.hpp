@@ -516,6 +516,8 @@ NFC_DEV NfcDecodeRegs &nfc_take_lock(const NfcLaneMem &mem, const NfcRate &rt, u
    d.bsPrevious = 0; d.bsBits = 0; d.bsSkip = 0; d.bsData = 0; d.bsFlags = 0; d.bsParity = 0; d.bsBytes = 0;
    d.frameType = 0; d.frameRate = 0; d.frameStart = 0; d.frameEnd = 0;
    d.maxFrame = 0;
+   d.pendType = 0;
+   d.pendFlags = 0;
 
    return d;
 }
@@ -588,6 +590,14 @@ NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamSt
    return t;
 }
 
+/* a frame has been assembled on this sample: remember it; classification (process*), emission and the mode change
+ * that follows are done in one place per decode step */
+NFC_DEV void nfc_pend_frame(NfcStreamState &s, uint32_t type, uint32_t flags)
+{
+   s.u.decode.pendType = type;
+   s.u.decode.pendFlags = flags;
+}
+
 #include "nfc_tech_a.hpp"
 #include "nfc_tech_b.hpp"
 #include "nfc_tech_f.hpp"
@@ -651,6 +661,65 @@ NFC_DEV void nfc_search_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
     * on the next sample ring[(idx - 1) % p1] is known to equal the running sum and need not be read back */
    if (s.clock >= 1024u && !(s.env < c.powerThreshold))
       s.bankClock = s.clock;
+}
+
+/* the tail of the reference's decodePollFrame / decodeListenFrame for all four technologies: build the frame, run the
+ * protocol processing (which feeds the timing back), emit it, then either prepare the listen window (poll frames:
+ * "clear modulation status for receiving card response") or fall back to search (listen frames: resetModulation) */
+NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
+{
+   NfcDecodeRegs &d = s.u.decode;
+
+   const uint32_t tech = s.lockTech;
+   const uint32_t type = d.pendType;
+   uint32_t flags = d.pendFlags;
+   uint32_t phase = 0;
+
+   d.pendType = 0;
+   d.pendFlags = 0;
+
+   const uint8_t *data = mem.bytes;
+   uint32_t len = d.bsBytes > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : d.bsBytes;
+
+   if (tech == NFC_TECH_F)
+   {
+      /* the two synchronisation bytes are checked and stripped (NfcF.cpp:467-472) */
+      if (mem.bytes[0] != 0xB2 || mem.bytes[1] != 0x4D)
+         flags |= NFC_FLAG_SYNC;
+
+      data += 2;
+      len -= 2;
+   }
+
+   const uint32_t start = d.frameStart, end = d.frameEnd, rate = d.frameRate;
+
+   /* ring of the locked correlator, for the poll-end clearing */
+   const uint32_t ringBase = d.lockBase;
+   const uint32_t ringSlots = tech == NFC_TECH_B ? 0u : (tech == NFC_TECH_V ? d.rt.p0 : d.rt.p1);
+
+   if (tech == NFC_TECH_A)
+      nfca_process(c, s, mem, type, data, len, flags, phase);
+   else if (tech == NFC_TECH_B)
+      nfcb_process(c, s, mem, type, data, len, flags, phase);
+   else if (tech == NFC_TECH_F)
+      nfcf_process(c, s, mem, type, data, len, flags, phase);
+   else
+      nfcv_process(c, s, mem, type, data, len, flags, phase);
+
+   nfc_emit(mem, s, tech, type, flags, phase, rate, start, end, data, len);
+
+   if (type == NFC_FRAME_POLL)
+   {
+      if (s.lockTech == tech) /* NFC-A HLTA resets inside process() */
+      {
+         nfc_clear_assembly(s);
+         nfc_poll_end_clear(mem, d.lock, ringBase, ringSlots);
+      }
+   }
+   else
+   {
+      nfc_leave_lock(s, tech);
+   }
 }
 
 NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
@@ -725,6 +794,9 @@ NFC_DEV void nfc_decode_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
          nfcv_decode(c, s, mem, now, taps);
          break;
    }
+
+   if (s.lockTech && s.u.decode.pendType)
+      nfc_finish_frame(c, s, mem);
 
    if (s.unlock)
       nfc_finish_unlock(c, s, mem);

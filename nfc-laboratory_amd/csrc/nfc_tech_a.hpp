@@ -68,6 +68,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    NfcTiming &t = mem.cold->tim[0];
    const bool poll = (type == NFC_FRAME_POLL);
    const uint32_t b0 = nfc_byte(data, len, 0);
+   const bool crcOk = nfca_crc_ok(data, len); /* one CRC pass per frame, used by whichever classification applies */
 
    if (poll)
    {
@@ -105,7 +106,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    if (!done && poll && b0 == 0x50 && len == 4 && !(flags & NFC_FLAG_CRC))
    {
       phase = NFC_PHASE_SELECTION;
-      if (!nfca_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
       t.lastCommand = b0;
       nfca_default_timing(c, t);
@@ -172,7 +173,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             }
 
             phase = NFC_PHASE_SELECTION;
-            if (!nfca_crc_ok(data, len))
+            if (!crcOk)
                flags |= NFC_FLAG_CRC;
          }
          /* PPS */
@@ -181,7 +182,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             if (poll)
                t.lastCommand = b0 & 0xF0;
             phase = NFC_PHASE_SELECTION;
-            if (!nfca_crc_ok(data, len))
+            if (!crcOk)
                flags |= NFC_FLAG_CRC;
          }
          /* Mifare AUTH */
@@ -191,7 +192,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             if (poll)
             {
                t.lastCommand = b0;
-               if (!nfca_crc_ok(data, len))
+               if (!crcOk)
                   flags |= NFC_FLAG_CRC;
             }
             else
@@ -205,7 +206,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             if (poll)
                t.lastCommand = b0 & 0xE2;
             phase = NFC_PHASE_APPLICATION;
-            if (!nfca_crc_ok(data, len))
+            if (!crcOk)
                flags |= NFC_FLAG_CRC;
          }
          /* R-Block */
@@ -214,7 +215,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             if (poll)
                t.lastCommand = b0 & 0xE6;
             phase = NFC_PHASE_APPLICATION;
-            if (!nfca_crc_ok(data, len))
+            if (!crcOk)
                flags |= NFC_FLAG_CRC;
          }
          /* S-Block */
@@ -223,13 +224,13 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             if (poll)
                t.lastCommand = b0 & 0xC7;
             phase = NFC_PHASE_APPLICATION;
-            if (!nfca_crc_ok(data, len))
+            if (!crcOk)
                flags |= NFC_FLAG_CRC;
          }
          else
          {
             phase = NFC_PHASE_APPLICATION;
-            if (!nfca_crc_ok(data, len))
+            if (!crcOk)
                flags |= NFC_FLAG_CRC;
          }
       }
@@ -521,7 +522,7 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
          if (s.u.decode.bsBits >= 7)
             nfc_push_byte(mem, s, s.u.decode.bsData);
 
-         uint32_t flags = 0, phase = 0;
+         uint32_t flags = 0;
 
          if (s.u.decode.bsFlags & NFC_FLAG_PARITY)
             flags |= NFC_FLAG_PARITY;
@@ -530,17 +531,7 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
          if (s.u.decode.bsBytes == 1 && s.u.decode.bsBits == 7)
             flags |= NFC_FLAG_SHORT;
 
-         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, rate = s.u.decode.frameRate, len = s.u.decode.bsBytes;
-
-         nfca_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
-         nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
-
-         if (s.lockTech == NFC_TECH_A) /* HLTA resets inside process() */
-         {
-            nfc_clear_assembly(s);
-            nfc_poll_end_clear(mem, s.u.decode.lock, s.u.decode.lockBase, s.u.decode.rt.p1);
-         }
-
+         nfc_pend_frame(s, NFC_FRAME_POLL, flags);
          return;
       }
 
@@ -852,16 +843,11 @@ NFC_DEV uint32_t nfca_listen_bpsk_symbol(const NfcConfig &c, NfcStreamState &s, 
    return s.u.decode.symPattern;
 }
 
-/* emit a listen frame and fall back to search, shared by ASK and BPSK paths */
+/* a listen frame is complete: it is classified, emitted and followed by the fall back to search at the end of
+ * the decode step (nfc_finish_frame) */
 NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t flags)
 {
-   uint32_t phase = 0;
-   const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes;
-   const uint32_t rate = s.u.decode.rt.symbolsPerSecond;
-
-   nfca_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
-   nfc_emit(mem, s, NFC_TECH_A, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
-   nfca_reset(c, s, mem);
+   nfc_pend_frame(s, NFC_FRAME_LISTEN, flags);
 }
 
 /* ---- one sample in locked NFC-A mode: decodeFrame, NfcA.cpp:416-803 ---- */

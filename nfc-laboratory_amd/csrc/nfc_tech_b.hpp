@@ -42,6 +42,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    NfcTiming &t = mem.cold->tim[1];
    const bool poll = (type == NFC_FRAME_POLL);
    const uint32_t b0 = nfc_byte(data, len, 0);
+   const bool crcOk = nfcb_crc_ok(data, len);
 
    t.guardTime = t.protoGuardTime;
    if (poll)
@@ -57,7 +58,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       t.guardTime = nfc_tu(c, 1024);   /* NFCB_TR0_MIN  */
       t.waitingTime = nfc_tu(c, 7680); /* NFCB_FWT_ATQB */
       phase = NFC_PHASE_SELECTION;
-      if (!nfcb_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
    }
    else if (!poll && t.lastCommand == 0x05)
@@ -69,7 +70,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       t.protoWaitingTime = nfc_tu(c, 4096 << fwi);
 
       phase = NFC_PHASE_SELECTION;
-      if (!nfcb_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
    }
    /* ATTRIB */
@@ -94,7 +95,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       t.waitingTime = nfc_tu(c, 71680); /* NFC_FWT_ACTIVATION */
 
       phase = NFC_PHASE_SELECTION;
-      if (!nfcb_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
    }
    else if (!poll && t.lastCommand == 0x1d)
@@ -104,7 +105,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    else
    {
       phase = NFC_PHASE_APPLICATION;
-      if (!nfcb_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
    }
 
@@ -526,17 +527,7 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
          {
             s.u.decode.frameEnd = s.u.decode.symEnd;
 
-            uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-            const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.rt.symbolsPerSecond;
-
-            nfcb_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
-            nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
-
-            nfc_clear_assembly(s);
-
-            if (s.lockTech == NFC_TECH_B)
-               nfc_poll_end_clear(mem, s.u.decode.lock, 0, 0);
-
+            nfc_pend_frame(s, NFC_FRAME_POLL, (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0);
             return;
          }
 
@@ -597,11 +588,8 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       {
          s.u.decode.frameEnd = s.u.decode.symEnd + nfc_tu(c, 352); /* EOS is not tracked to its end */
 
-         uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.rt.symbolsPerSecond;
-
-         nfcb_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
-         nfc_emit(mem, s, NFC_TECH_B, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
+         nfc_pend_frame(s, NFC_FRAME_LISTEN, (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0);
+         return;
       }
 
       nfcb_reset(c, s, mem);

@@ -39,6 +39,7 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 {
    NfcTiming &t = mem.cold->tim[2];
    const bool poll = (type == NFC_FRAME_POLL);
+   const bool crcOk = nfcf_crc_ok(data, len);
 
    t.guardTime = t.protoGuardTime;
    if (poll)
@@ -58,19 +59,19 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       t.waitingTime = (uint32_t)(c.stu * (double)(512 * 64 + (tsn + 1) * 256 * 64)); /* FDT_ATQC + slots */
 
       phase = NFC_PHASE_SELECTION;
-      if (!nfcf_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
    }
    else if (!poll && t.lastCommand == 0x00)
    {
       phase = NFC_PHASE_SELECTION;
-      if (!nfcf_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
    }
    else
    {
       phase = NFC_PHASE_APPLICATION;
-      if (!nfcf_crc_ok(data, len))
+      if (!crcOk)
          flags |= NFC_FLAG_CRC;
    }
 
@@ -396,27 +397,8 @@ NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem 
       {
          s.u.decode.frameEnd = s.u.decode.symEnd;
 
-         uint32_t flags = truncated ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-
-         if (mem.bytes[0] != 0xB2 || mem.bytes[1] != 0x4D)
-            flags |= NFC_FLAG_SYNC;
-
-         uint32_t total = s.u.decode.bsBytes > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : s.u.decode.bsBytes;
-         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = total - 2;
-         const uint32_t rate = s.u.decode.rt.symbolsPerSecond;
-
-         nfcf_process(c, s, mem, type, mem.bytes + 2, len, flags, phase);
-         nfc_emit(mem, s, NFC_TECH_F, type, flags, phase, rate, start, end, mem.bytes + 2, len);
-
-         if (type == NFC_FRAME_POLL)
-         {
-            nfc_clear_assembly(s);
-
-            if (s.lockTech == NFC_TECH_F)
-               nfc_poll_end_clear(mem, s.u.decode.lock, s.u.decode.lockBase, s.u.decode.rt.p1);
-
-            return;
-         }
+         nfc_pend_frame(s, type, truncated ? NFC_FLAG_TRUNCATED : 0);
+         return;
       }
 
       nfcf_reset(c, s, mem);

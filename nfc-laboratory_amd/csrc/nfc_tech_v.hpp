@@ -483,17 +483,7 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
             s.u.decode.frameEnd = s.u.decode.symEnd;
 
-            uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-            const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.frameRate;
-
-            nfcv_process(c, s, mem, NFC_FRAME_POLL, mem.bytes, len, flags, phase);
-            nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_POLL, flags, phase, rate, start, end, mem.bytes, len);
-
-            nfc_clear_assembly(s);
-
-            if (s.lockTech == NFC_TECH_V)
-               nfc_poll_end_clear(mem, s.u.decode.lock, s.u.decode.lockBase, s.u.decode.rt.p0);
-
+            nfc_pend_frame(s, NFC_FRAME_POLL, (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0);
             return;
          }
 
@@ -551,11 +541,8 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
          s.u.decode.frameEnd = s.u.decode.symEnd;
 
-         uint32_t flags = (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0, phase = 0;
-         const uint32_t start = s.u.decode.frameStart, end = s.u.decode.frameEnd, len = s.u.decode.bsBytes, rate = s.u.decode.frameRate;
-
-         nfcv_process(c, s, mem, NFC_FRAME_LISTEN, mem.bytes, len, flags, phase);
-         nfc_emit(mem, s, NFC_TECH_V, NFC_FRAME_LISTEN, flags, phase, rate, start, end, mem.bytes, len);
+         nfc_pend_frame(s, NFC_FRAME_LISTEN, (truncated || streamError) ? NFC_FLAG_TRUNCATED : 0);
+         return;
       }
 
       nfcv_reset(c, s, mem);

@@ -201,6 +201,8 @@ struct NfcDecodeRegs
    uint32_t bsPrevious, bsBits, bsSkip, bsData, bsFlags, bsParity, bsBytes;
    uint32_t frameType, frameRate, frameStart, frameEnd;
    uint32_t maxFrame;  /* protocolStatus.maxFrameSize of the locked technology (register copy of NfcTiming) */
+   uint32_t pendType;  /* a frame completed on this sample: NFC_FRAME_POLL / NFC_FRAME_LISTEN, classified and emitted */
+   uint32_t pendFlags; /* once, at the end of the decode step (nfc_finish_frame) */
 };
 
 /* The part of a stream's state that the kernel keeps in registers for the whole launch. A lane is either searching
