@@ -30,6 +30,17 @@
 #error "define NFC_ATOMIC_ADD(ptr, value) (returns the old value) before including nfc_core.hpp"
 #endif
 
+/* Divergent control flow is written as a sequence of independent `if` regions, never as if / else-if chains over
+ * regions that update the stream state: the AMDGPU back end linearises `if (a) X else Y` into X then Y, the values
+ * X produced and the originals Y still reads are live together, and every state register one arm leaves untouched
+ * is copied (v_mov) on the other, at every nesting level. Mutually exclusive predicates are taken from a snapshot
+ * and passed through NFC_OPAQUE so that the optimiser cannot fold the sequence back into a chain. */
+#ifdef __HIP_DEVICE_COMPILE__
+#define NFC_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define NFC_OPAQUE(x) asm volatile("" : "+r"(x))
+#endif
+
 /* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
 struct NfcLaneMem
 {
@@ -607,39 +618,13 @@ NFC_DEV void nfc_pend_frame(NfcStreamState &s, uint32_t type, uint32_t flags)
 /* one sample                                                                                 */
 /* ------------------------------------------------------------------------------------------ */
 
-/* One sample in search mode (no technology locked): NfcDecoder.cpp:394-418. EXACT selects how ring positions are
- * obtained; the caller picks the exact variant for the rare tiles that touch the stream start or the 32-bit clock
- * wrap, so the common variant carries no modulo code at all. All history reads of the eight detectors are issued
- * before the front end stores this sample (none of them can alias the slot being written: their delays are > 0),
- * so a step pays one memory latency. */
-template <bool EXACT>
-NFC_DEV void nfc_search_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
+/* Search mode (no technology locked), NfcDecoder.cpp:394-418: the detector bank on the sample the front end has just
+ * produced; the first detector that recognises its start of frame wins, later ones skip this sample. */
+NFC_DEV void nfc_search_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now,
+                               const NfcTapsA &ta, const NfcTapsB &tb, const NfcTapsF &tf, const NfcTapsV &tv)
 {
-   NfcLaneMem mem = lane;
-   mem.exact = EXACT;
-
-   ++s.clock;
-   ++s.pulseFilter;
-
-   nfc_advance_positions(c, s, mem);
-
-   /* unconditional: the addresses are always inside the stream block, and a detector that is disabled or not
-    * yet armed (first 1024 samples) simply ignores what was read */
-   NfcTapsA ta;
-   NfcTapsB tb;
-   NfcTapsF tf;
-   NfcTapsV tv;
-
-   nfca_load_taps(c, s, mem, ta);
-   nfcb_load_taps(c, s, mem, tb);
-   nfcf_load_taps(c, s, mem, tf);
-   nfcv_load_taps(c, s, mem, tv);
-
-   const NfcNow now = nfc_front_end(c, s, mem, value);
-
    nfc_detect_carrier(c, s, mem);
 
-   /* first detector that locks wins, later ones skip this sample */
    uint32_t locked = 0;
 
    if ((c.enabled & 1u) && nfca_detect(c, s, mem, ta, now))
@@ -651,16 +636,13 @@ NFC_DEV void nfc_search_step(const NfcConfig &c, NfcStreamState &s, const NfcLan
    else if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
       locked = NFC_TECH_V;
 
-   if (locked)
-   {
-      nfc_enter_lock(s, mem, locked);
-      return;
-   }
-
    /* every detector that is enabled stepped its correlator on this sample (or none did: the gates are common):
     * on the next sample ring[(idx - 1) % p1] is known to equal the running sum and need not be read back */
-   if (s.clock >= 1024u && !(s.env < c.powerThreshold))
+   if (!locked && s.clock >= 1024u && !(s.env < c.powerThreshold))
       s.bankClock = s.clock;
+
+   if (locked)
+      nfc_enter_lock(s, mem, locked);
 }
 
 /* the tail of the reference's decodePollFrame / decodeListenFrame for all four technologies: build the frame, run the
@@ -697,29 +679,35 @@ NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLa
    const uint32_t ringBase = d.lockBase;
    const uint32_t ringSlots = tech == NFC_TECH_B ? 0u : (tech == NFC_TECH_V ? d.rt.p0 : d.rt.p1);
 
-   if (tech == NFC_TECH_A)
+   uint32_t isA = tech, isB = tech, isF = tech, isV = tech;
+   NFC_OPAQUE(isA);
+   NFC_OPAQUE(isB);
+   NFC_OPAQUE(isF);
+   NFC_OPAQUE(isV);
+
+   if (isA == NFC_TECH_A)
       nfca_process(c, s, mem, type, data, len, flags, phase);
-   else if (tech == NFC_TECH_B)
+   if (isB == NFC_TECH_B)
       nfcb_process(c, s, mem, type, data, len, flags, phase);
-   else if (tech == NFC_TECH_F)
+   if (isF == NFC_TECH_F)
       nfcf_process(c, s, mem, type, data, len, flags, phase);
-   else
+   if (isV == NFC_TECH_V)
       nfcv_process(c, s, mem, type, data, len, flags, phase);
 
    nfc_emit(mem, s, tech, type, flags, phase, rate, start, end, data, len);
 
-   if (type == NFC_FRAME_POLL)
+   /* NFC-A HLTA resets inside process() */
+   const bool listenNext = type == NFC_FRAME_POLL && s.lockTech == tech;
+   const bool searchNext = type != NFC_FRAME_POLL;
+
+   if (listenNext)
    {
-      if (s.lockTech == tech) /* NFC-A HLTA resets inside process() */
-      {
-         nfc_clear_assembly(s);
-         nfc_poll_end_clear(mem, d.lock, ringBase, ringSlots);
-      }
+      nfc_clear_assembly(s);
+      nfc_poll_end_clear(mem, d.lock, ringBase, ringSlots);
    }
-   else
-   {
+
+   if (searchNext)
       nfc_leave_lock(s, tech);
-   }
 }
 
 NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
@@ -729,7 +717,13 @@ NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcL
    s.unlock = 0;
    s.u.search = mem.cold->parked;
 
-   if (tech == NFC_TECH_A)
+   uint32_t isA = tech, isB = tech, isF = tech, isV = tech;
+   NFC_OPAQUE(isA);
+   NFC_OPAQUE(isB);
+   NFC_OPAQUE(isF);
+   NFC_OPAQUE(isV);
+
+   if (isA == NFC_TECH_A)
    {
       nfc_mod_clear(s.u.search.detA[0]);
       nfc_mod_clear(s.u.search.detA[1]);
@@ -737,88 +731,129 @@ NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcL
       /* the three rings are adjacent */
       nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[0], c.a[0].p1 + c.a[1].p1 + c.a[2].p1);
    }
-   else if (tech == NFC_TECH_B)
+
+   if (isB == NFC_TECH_B)
    {
       nfc_mod_clear(s.u.search.detB[0]);
       nfc_mod_clear(s.u.search.detB[1]);
    }
-   else if (tech == NFC_TECH_F)
+
+   if (isF == NFC_TECH_F)
    {
       nfc_mod_clear(s.u.search.detF[0]);
       nfc_mod_clear(s.u.search.detF[1]);
       /* the two rings are adjacent */
       nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
    }
-   else
+
+   if (isV == NFC_TECH_V)
    {
       nfc_mod_clear(s.u.search.detV);
       nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[5], c.v.p0);
    }
 }
 
-/* One sample with a technology locked (poll / listen frame decoding); `mem.exact` is a run-time flag here */
-NFC_DEV void nfc_decode_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+/* One sample. The mode the sample is handled in is the one the stream is in when the sample arrives (a detector
+ * that locks, or a frame end that unlocks, takes effect with the next sample, as in the reference where the locked
+ * decoder is entered / left after the sample that decided it). `exact` is wave-uniform and must be true whenever
+ * nfc_exact_zone(s.clock + 1) is for any lane (it may be true more often: the exact ring positions are always
+ * right, only slower to obtain).
+ *
+ * All history reads of the step (the eight detectors' in search mode, the locked correlator's in decode mode) are
+ * issued before the front end stores this sample: none of them can alias the slot being written (their delays are
+ * > 0, or the value is patched in below), so a step pays one memory latency. */
+template <bool EXACT>
+NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
 {
+   NfcLaneMem mem = lane;
+   mem.exact = EXACT;
+
    ++s.clock;
    ++s.pulseFilter;
 
    nfc_advance_positions(c, s, mem);
-   nfc_advance_lock_pos(s, mem);
 
-   NfcDecTaps taps = nfc_load_decode_taps(mem, s);
+   const uint32_t mode = s.lockTech;
 
-   const NfcNow now = nfc_front_end(c, s, mem, value);
+   uint32_t inSearch = mode, inDecode = mode;
+   NFC_OPAQUE(inSearch);
+   NFC_OPAQUE(inDecode);
 
-   /* without delay the decode point is the sample the front end has just produced (not in memory when the taps
-    * were read) */
-   if (s.u.decode.rt.delay == 0)
+   /* each mode is a self-contained region (reads, front end, its machines): the front end is cheap enough to appear
+    * twice, and values that cross a region boundary would have to be waited for at the boundary */
+   if (inSearch == 0)
    {
-      taps.x0 = now.x;
-      taps.f0 = now.filt;
-      taps.m0 = now.mdev;
-      taps.d0 = now.depth;
+      /* unconditional within search mode: the addresses are always inside the stream block, and a detector that
+       * is disabled or not yet armed (first 1024 samples) simply ignores what was read */
+      NfcTapsA ta;
+      NfcTapsB tb;
+      NfcTapsF tf;
+      NfcTapsV tv;
+
+      nfca_load_taps(c, s, mem, ta);
+      nfcb_load_taps(c, s, mem, tb);
+      nfcf_load_taps(c, s, mem, tf);
+      nfcv_load_taps(c, s, mem, tv);
+
+      const NfcNow now = nfc_front_end(c, s, mem, value);
+
+      nfc_search_detect(c, s, mem, now, ta, tb, tf, tv);
    }
 
-   switch (s.lockTech)
+   if (inDecode != 0)
    {
-      case NFC_TECH_A:
+      nfc_advance_lock_pos(s, mem);
+
+      NfcDecTaps taps = nfc_load_decode_taps(mem, s);
+
+      const NfcNow now = nfc_front_end(c, s, mem, value);
+
+      /* without delay the decode point is the sample the front end has just produced (not in memory when the taps
+       * were read) */
+      if (s.u.decode.rt.delay == 0)
+      {
+         taps.x0 = now.x;
+         taps.f0 = now.filt;
+         taps.m0 = now.mdev;
+         taps.d0 = now.depth;
+      }
+
+      uint32_t isA = mode, isB = mode, isF = mode, isV = mode;
+      NFC_OPAQUE(isA);
+      NFC_OPAQUE(isB);
+      NFC_OPAQUE(isF);
+      NFC_OPAQUE(isV);
+
+      if (isA == NFC_TECH_A)
          nfca_decode(c, s, mem, now, taps);
-         break;
-      case NFC_TECH_B:
+
+      if (isB == NFC_TECH_B)
          nfcb_decode(c, s, mem, now, taps);
-         break;
-      case NFC_TECH_F:
+
+      if (isF == NFC_TECH_F)
          nfcf_decode(c, s, mem, now, taps);
-         break;
-      default:
+
+      if (isV == NFC_TECH_V)
          nfcv_decode(c, s, mem, now, taps);
-         break;
    }
 
-   if (s.lockTech && s.u.decode.pendType)
+   uint32_t pending = mode ? s.u.decode.pendType : 0u;
+   NFC_OPAQUE(pending);
+
+   if (pending)
       nfc_finish_frame(c, s, mem);
 
    if (s.unlock)
       nfc_finish_unlock(c, s, mem);
 }
 
-/* One sample, whatever the mode. `exact` must be true whenever nfc_exact_zone(s.clock + 1) is (it may be true
- * more often: the exact positions are always right, only slower to obtain). */
+/* run-time selection of the variant (CPU test build of this text; the kernels instantiate one variant each) */
 NFC_DEV void nfc_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value, bool exact)
 {
-   if (s.lockTech == 0)
-   {
-      if (exact)
-         nfc_search_step<true>(c, s, lane, value);
-      else
-         nfc_search_step<false>(c, s, lane, value);
-   }
+   if (exact)
+      nfc_step_as<true>(c, s, lane, value);
    else
-   {
-      NfcLaneMem mem = lane;
-      mem.exact = exact;
-      nfc_decode_step(c, s, mem, value);
-   }
+      nfc_step_as<false>(c, s, lane, value);
 }
 
 /* state of a freshly initialised decoder; `keep` carries over what the reference's initialize()

@@ -32,11 +32,22 @@ typedef __attribute__((address_space(4))) NfcConfig NfcConfigConst;
 #define NFC_MIN_WAVES 2
 #endif
 
-/* exactly NFC_MIN_WAVES waves per SIMD: spilling state to scratch to reach a higher occupancy costs 5-10x */
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVES, NFC_MIN_WAVES))) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+/* Ring positions advance incrementally (add, compare) in the common kernel. While a stream is within 1024 samples
+ * of its start or of the 32-bit wrap of its sample clock (once per 7 minutes at 10 MS/s) the positions are taken by
+ * exact modulo instead, as the reference computes them: that variant is a kernel of its own, so that the common one
+ * carries neither the modulo code nor branches between its history reads. Both kernels see the same launch; a
+ * stream block is handled by exactly one of them, decided from the device state (the host only skips the launch of
+ * the exact kernel when no stream of the launch can be near either point). */
+__device__ __forceinline__ bool nfc_exact_span(uint32_t clock, uint32_t count)
 {
-   __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ NfcWork work[NFC_LANES];
+   const uint32_t start = clock + 1u + 1024u; /* first sample clock of the launch, zone = [0, 2048) after the shift */
+   const uint32_t untilWrap = 0u - start;
+   return count != 0 && (start < 2048u || untilWrap < count);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, float *tile, NfcWork *work)
+{
 
    const uint32_t lane = threadIdx.x;
    const uint32_t block = L.firstBlock + blockIdx.x;
@@ -76,9 +87,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVE
    if (longest == 0)
       return;
 
-   const NfcConfig &cfg = *cfgPtr;
-
    NfcStreamState s = L.states[slot];
+
+   if ((__any(nfc_exact_span(s.clock, mine.count)) != 0) != EXACT)
+      return;
 
    NfcLaneMem mem;
    mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats;
@@ -130,20 +142,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVE
          const uint32_t left = mine.count - base;
          const uint32_t n = left < TILE ? left : TILE;
 
-         /* ring positions advance incrementally except in the few tiles that touch the stream start or the
-          * 32-bit clock wrap (s.clock + 1 .. s.clock + n), which take the exact-modulo variant */
-         const bool exact = nfc_exact_zone(s.clock + 1u) || nfc_exact_zone(s.clock + n);
+         /* keep the ~100 configuration constants in the scalar cache instead of letting the compiler hoist
+          * them out of the sample loop into (spilled) registers */
+         const NfcConfigConst *cp = (const NfcConfigConst *)cfgPtr;
 
          for (uint32_t k = 0; k < n; k++)
          {
-            /* keep the ~100 configuration constants in the scalar cache instead of letting the compiler hoist
-             * them out of the sample loop into (spilled) registers */
-            const NfcConfigConst *cp = (const NfcConfigConst *)cfgPtr;
 #ifdef NFC_RELOAD_CONFIG
             asm volatile("" : "+s"(cp));
 #endif
-
-            nfc_step(*(const NfcConfig *)cp, s, mem, tile[lane * TILE_PITCH + k], exact);
+            nfc_step_as<EXACT>(*(const NfcConfig *)cp, s, mem, tile[lane * TILE_PITCH + k]);
          }
       }
 
@@ -152,6 +160,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVE
 
    if (mine.count)
       L.states[slot] = s;
+}
+
+/* exactly NFC_MIN_WAVES waves per SIMD: spilling state to scratch to reach a higher occupancy costs 5-10x */
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVES, NFC_MIN_WAVES))) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+{
+   __shared__ float tile[NFC_LANES * TILE_PITCH];
+   __shared__ NfcWork work[NFC_LANES];
+
+   nfc_demod_body<false>(cfgPtr, L, tile, work);
+}
+
+/* stream start / clock wrap variant (rare, not tuned: whatever occupancy the register allocator ends up with) */
+__global__ __launch_bounds__(64) void nfc_demod_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+{
+   __shared__ float tile[NFC_LANES * TILE_PITCH];
+   __shared__ NfcWork work[NFC_LANES];
+
+   nfc_demod_body<true>(cfgPtr, L, tile, work);
 }
 
 __global__ __launch_bounds__(64) void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd)

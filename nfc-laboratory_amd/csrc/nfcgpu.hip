@@ -20,6 +20,7 @@
 #include "nfc_launch.h"
 
 __global__ void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_demod_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd);
 
 namespace {
@@ -35,8 +36,19 @@ struct StreamInfo
    nfcgpu_params params {};
    float powerAtInit = 0.01f; /* carrier thresholds are derived when the decoder (re)initialises */
    uint32_t config = 0;
+   uint32_t clock = 0xFFFFFFFFu; /* mirror of the device sample clock (NfcStreamState::clock) */
    std::deque<nfcgpu_frame> queue;
 };
+
+/* advance the clock mirror by one submission; true when the stream is, during it, within 1024 samples of its start
+ * or of the 32-bit clock wrap (same test as nfc_exact_span in nfc_kernels.hip, which decides per stream block) */
+bool advance_clock(StreamInfo &si, uint32_t count)
+{
+   const uint32_t start = si.clock + 1u + 1024u;
+   const uint32_t untilWrap = 0u - start;
+   si.clock += count;
+   return count != 0 && (start < 2048u || untilWrap < count);
+}
 
 struct ProfiledLaunch
 {
@@ -224,6 +236,7 @@ int initialize_pending(nfcgpu_ctx *ctx, uint32_t first, uint32_t count)
       {
          ctx->streams[k].needInit = false;
          ctx->streams[k].initialized = true;
+         ctx->streams[k].clock = 0xFFFFFFFFu;
       }
 
       i = j;
@@ -245,7 +258,7 @@ hipEvent_t take_event(nfcgpu_ctx *ctx)
    return e;
 }
 
-int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t samples)
+int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t samples, bool exactPossible)
 {
    const uint32_t firstBlock = L.firstSlot / NFC_LANES;
    const uint32_t lastBlock = (L.firstSlot + L.slotCount - 1) / NFC_LANES;
@@ -264,6 +277,14 @@ int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t sample
    hipLaunchKernelGGL(nfc_demod_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0, ctx->stream,
                       ctx->dConfigs + config, L);
    HIP_TRY(ctx, hipGetLastError());
+
+   /* stream blocks near their start / the clock wrap skip the kernel above and are handled by this one */
+   if (exactPossible)
+   {
+      hipLaunchKernelGGL(nfc_demod_exact_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0, ctx->stream,
+                         ctx->dConfigs + config, L);
+      HIP_TRY(ctx, hipGetLastError());
+   }
 
    if (ctx->profile)
    {
@@ -693,6 +714,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
    {
       uint32_t first = 0xFFFFFFFFu, last = 0;
       uint64_t groupSamples = 0;
+      bool exactPossible = false;
 
       for (uint32_t i = 0; i < b->n_streams; i++)
       {
@@ -702,6 +724,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
          first = id < first ? id : first;
          last = id > last ? id : last;
          groupSamples += b->n_samples[i];
+         exactPossible = advance_clock(ctx->streams[id], b->n_samples[i]) || exactPossible;
       }
 
       /* slots of other configurations inside [first,last] must stay idle in this launch */
@@ -730,7 +753,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       L.firstSlot = first;
       L.slotCount = last - first + 1;
 
-      rc = launch_demod(ctx, c, L, groupSamples);
+      rc = launch_demod(ctx, c, L, groupSamples, exactPossible);
       if (rc)
       {
          clearWorks();
@@ -830,7 +853,11 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       L.firstSlot = i;
       L.slotCount = j - i;
 
-      rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i));
+      bool exactPossible = false;
+      for (uint32_t k = i; k < j; k++)
+         exactPossible = advance_clock(ctx->streams[k], n) || exactPossible;
+
+      rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i), exactPossible);
       if (rc)
          return rc;
 
