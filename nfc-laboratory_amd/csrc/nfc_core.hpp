@@ -54,6 +54,7 @@ struct NfcLaneMem
    uint32_t sinkWords;
    uint32_t streamId;
    NfcStreamCold *cold;  /* protocol timing of this stream (HBM) */
+   const NfcConfig *tables; /* configuration in memory, for its dynamically indexed tables (NFC-V pulse slots) */
 };
 
 /* ring regions (in slots) inside a stream block */

@@ -22,6 +22,10 @@
 #include "nfc_core.hpp"
 #include "nfc_launch.h"
 
+/* sample-rate-derived constants of the most common configuration as literals (generated at build time) */
+#define NFC_FIXED_FN __device__ __forceinline__
+#include "nfc_config_fixed.inc"
+
 /* constant address space: uniform loads through it are always scalar (s_load), whatever else the kernel writes */
 typedef __attribute__((address_space(4))) NfcConfig NfcConfigConst;
 
@@ -45,7 +49,7 @@ __device__ __forceinline__ bool nfc_exact_span(uint32_t clock, uint32_t count)
    return count != 0 && (start < 2048u || untilWrap < count);
 }
 
-template <bool EXACT>
+template <bool EXACT, bool FIXED>
 __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, float *tile, NfcWork *work)
 {
 
@@ -103,6 +107,7 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
    mem.sinkWords = L.sinkWords;
    mem.streamId = slot;
    mem.cold = L.cold + slot;
+   mem.tables = cfgPtr;
 
    for (uint32_t base = 0; base < longest; base += TILE)
    {
@@ -146,12 +151,39 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
           * them out of the sample loop into (spilled) registers */
          const NfcConfigConst *cp = (const NfcConfigConst *)cfgPtr;
 
-         for (uint32_t k = 0; k < n; k++)
+         if (FIXED)
          {
+            /* periods, delays, ring offsets and filter weights are literals; thresholds and the enable mask are
+             * the run-time part */
+            NfcConfig cc;
+            nfc_fixed_config(cc);
+            cc.enabled = cp->enabled;
+            cc.powerThreshold = cp->powerThreshold;
+            cc.lowThreshold = cp->lowThreshold;
+            cc.highThreshold = cp->highThreshold;
+            for (int t = 0; t < 4; t++)
+            {
+               cc.corrThreshold[t] = cp->corrThreshold[t];
+               cc.minDepth[t] = cp->minDepth[t];
+               cc.maxDepth[t] = cp->maxDepth[t];
+            }
+
+            for (uint32_t k = 0; k < n; k++)
+            {
+               /* address arithmetic on literals would otherwise be hoisted out of the loop, one register per tap */
+               asm volatile("" : "+v"(mem.lane));
+               nfc_step_as<EXACT>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+            }
+         }
+         else
+         {
+            for (uint32_t k = 0; k < n; k++)
+            {
 #ifdef NFC_RELOAD_CONFIG
-            asm volatile("" : "+s"(cp));
+               asm volatile("" : "+s"(cp));
 #endif
-            nfc_step_as<EXACT>(*(const NfcConfig *)cp, s, mem, tile[lane * TILE_PITCH + k]);
+               nfc_step_as<EXACT>(*(const NfcConfig *)cp, s, mem, tile[lane * TILE_PITCH + k]);
+            }
          }
       }
 
@@ -162,23 +194,24 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
       L.states[slot] = s;
 }
 
+#define NFC_DEMOD_KERNEL(name, exact, fixed, attrs)                                                        \
+   __global__ __launch_bounds__(64) attrs void name(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) \
+   {                                                                                                   \
+      __shared__ float tile[NFC_LANES * TILE_PITCH];                                                   \
+      __shared__ NfcWork work[NFC_LANES];                                                              \
+      nfc_demod_body<exact, fixed>(cfgPtr, L, tile, work);                                             \
+   }
+
 /* exactly NFC_MIN_WAVES waves per SIMD: spilling state to scratch to reach a higher occupancy costs 5-10x */
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVES, NFC_MIN_WAVES))) void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
-{
-   __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ NfcWork work[NFC_LANES];
+#define NFC_PINNED __attribute__((amdgpu_waves_per_eu(NFC_MIN_WAVES, NFC_MIN_WAVES)))
 
-   nfc_demod_body<false>(cfgPtr, L, tile, work);
-}
-
-/* stream start / clock wrap variant (rare, not tuned: whatever occupancy the register allocator ends up with) */
-__global__ __launch_bounds__(64) void nfc_demod_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
-{
-   __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ NfcWork work[NFC_LANES];
-
-   nfc_demod_body<true>(cfgPtr, L, tile, work);
-}
+/* any decodable sample rate */
+NFC_DEMOD_KERNEL(nfc_demod_kernel, false, false, NFC_PINNED)
+/* NFC_FIXED_SAMPLE_RATE with constants as literals */
+NFC_DEMOD_KERNEL(nfc_demod_fixed_kernel, false, true, NFC_PINNED)
+/* stream start / clock wrap variants (rare, not tuned: whatever occupancy the register allocator ends up with) */
+NFC_DEMOD_KERNEL(nfc_demod_exact_kernel, true, false, )
+NFC_DEMOD_KERNEL(nfc_demod_fixed_exact_kernel, true, true, )
 
 __global__ __launch_bounds__(64) void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd)
 {

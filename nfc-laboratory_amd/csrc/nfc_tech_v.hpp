@@ -256,7 +256,8 @@ NFC_DEV uint32_t nfcv_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 
    const int periods = s.u.decode.pulseCode ? 256 : 4;
    const int length = s.u.decode.pulseCode ? c.vLen8 : c.vLen2;
-   const int32_t *ends = s.u.decode.pulseCode ? c.vSlotEnd8 : c.vSlotEnd2;
+   /* the slot tables are read from the configuration in memory (dynamic index), never from a register copy */
+   const int32_t *ends = s.u.decode.pulseCode ? mem.tables->vSlotEnd8 : mem.tables->vSlotEnd2;
 
 #pragma clang loop unroll(disable)
    for (int i = 0; i < periods; i++)

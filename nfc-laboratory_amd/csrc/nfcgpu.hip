@@ -21,6 +21,12 @@
 
 __global__ void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_demod_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_demod_fixed_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_demod_fixed_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+
+/* the table the specialised kernels were compiled with (generated at build time, see gen_fixed_config.cpp) */
+#define NFC_FIXED_FN static inline
+#include "nfc_config_fixed.inc"
 __global__ void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd);
 
 namespace {
@@ -77,6 +83,7 @@ struct nfcgpu_ctx
    uint64_t ownSinkWords = 0;
    NfcWork *dWorks = nullptr;
    NfcConfig *dConfigs = nullptr;
+   bool genericOnly = false; /* NFCGPU_GENERIC_KERNELS=1: never use the sample-rate-specialised kernels (testing) */
    uint8_t *dStage = nullptr;
    size_t stageBytes = 0;
 
@@ -131,6 +138,18 @@ NfcLaunch base_launch(nfcgpu_ctx *ctx)
    L.sinkWords = (uint32_t)ctx->sinkWords;
    L.ringBlockFloats = kRingBlockFloats;
    return L;
+}
+
+/* true when every sample-rate-derived constant of `cfg` equals the table compiled into the specialised kernels
+ * (thresholds and the enable mask are run-time values there as well) */
+bool matches_fixed_table(const NfcConfig &cfg)
+{
+   if (cfg.sampleRate != NFC_FIXED_SAMPLE_RATE)
+      return false;
+
+   NfcConfig probe = cfg;
+   nfc_fixed_config(probe);
+   return std::memcmp(&probe, &cfg, sizeof(cfg)) == 0;
 }
 
 /* find or create the device-side NfcConfig for a stream's parameters */
@@ -274,15 +293,17 @@ int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t sample
       HIP_TRY(ctx, hipEventRecord(pl.start, ctx->stream));
    }
 
-   hipLaunchKernelGGL(nfc_demod_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0, ctx->stream,
-                      ctx->dConfigs + config, L);
+   const bool fixed = !ctx->genericOnly && matches_fixed_table(ctx->configs[config]);
+
+   hipLaunchKernelGGL(fixed ? nfc_demod_fixed_kernel : nfc_demod_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0,
+                      ctx->stream, ctx->dConfigs + config, L);
    HIP_TRY(ctx, hipGetLastError());
 
    /* stream blocks near their start / the clock wrap skip the kernel above and are handled by this one */
    if (exactPossible)
    {
-      hipLaunchKernelGGL(nfc_demod_exact_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0, ctx->stream,
-                         ctx->dConfigs + config, L);
+      hipLaunchKernelGGL(fixed ? nfc_demod_fixed_exact_kernel : nfc_demod_exact_kernel, dim3(lastBlock - firstBlock + 1),
+                         dim3(NFC_LANES), 0, ctx->stream, ctx->dConfigs + config, L);
       HIP_TRY(ctx, hipGetLastError());
    }
 
@@ -405,6 +426,9 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
       return NFCGPU_ENOMEM;
 
    ctx->device = device;
+
+   const char *generic = std::getenv("NFCGPU_GENERIC_KERNELS");
+   ctx->genericOnly = generic && generic[0] == '1';
 
    uint32_t maxStreams = options && options->max_streams ? options->max_streams : 1024;
    uint64_t sinkBytes = options && options->frame_sink_bytes ? options->frame_sink_bytes : (64ull << 20);

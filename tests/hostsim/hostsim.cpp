@@ -65,6 +65,7 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
    std::memset(&s, 0, sizeof(s));
    std::memset(&cold, 0, sizeof(cold));
    mem.cold = &cold;
+   mem.tables = &cfg;
    nfc_state_init(cfg, s, cold, false);
 
    for (uint64_t i = 0; i < count; i++)
