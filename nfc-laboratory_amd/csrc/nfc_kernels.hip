@@ -29,8 +29,8 @@
 /* constant address space: uniform loads through it are always scalar (s_load), whatever else the kernel writes */
 typedef __attribute__((address_space(4))) NfcConfig NfcConfigConst;
 
-#define TILE 32
-#define TILE_PITCH 33
+#define TILE 64
+#define TILE_PITCH 65
 
 #ifndef NFC_MIN_WAVES
 #define NFC_MIN_WAVES 2
@@ -49,51 +49,127 @@ __device__ __forceinline__ bool nfc_exact_span(uint32_t clock, uint32_t count)
    return count != 0 && (start < 2048u || untilWrap < count);
 }
 
-template <bool EXACT, bool FIXED>
-__device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, float *tile, NfcWork *work)
+/* magnitude of one IQ sample, the reference's scalar formula (RadioDeviceTask.cpp:626-642): products and sum rounded
+ * separately (no contraction), correctly rounded square root */
+__device__ __forceinline__ float nfc_iq_magnitude(float i, float q)
 {
+   return __builtin_sqrtf(__fadd_rn(__fmul_rn(i, i), __fmul_rn(q, q)));
+}
 
-   const uint32_t lane = threadIdx.x;
-   const uint32_t block = L.firstBlock + blockIdx.x;
-   const uint32_t slot = block * NFC_LANES + lane;
+/* input row of one stream slot for this launch; every field is wave-uniform (the slot is) */
+struct NfcRow
+{
+   const uint8_t *data;
+   uint32_t count;
+};
 
-   NfcWork mine;
-   mine.data = nullptr;
-   mine.count = 0;
-   mine.stride = 1;
+typedef __attribute__((address_space(4))) const NfcWork NfcWorkConst;
+
+__device__ __forceinline__ NfcRow nfc_row(const NfcLaunch &L, uint32_t slot)
+{
+   NfcRow row;
+   row.data = nullptr;
+   row.count = 0;
 
    if (slot >= L.firstSlot && slot < L.firstSlot + L.slotCount)
    {
       if (L.works)
       {
-         mine = L.works[slot];
+         /* constant address space: a uniform read through it is a scalar load */
+         NfcWorkConst *w = (NfcWorkConst *)L.works + slot;
+         row.data = w->data;
+         row.count = w->count;
       }
       else
       {
-         mine.data = L.uniformBase + (uint64_t)(slot - L.firstSlot) * L.uniformPitch;
-         mine.count = L.uniformCount;
-         mine.stride = L.uniformStride;
+         row.data = L.uniformBase + (uint64_t)(slot - L.firstSlot) * L.uniformPitch;
+         row.count = L.uniformCount;
       }
    }
 
-   work[lane] = mine;
+   return row;
+}
+
+/* Stage samples [base, base + TILE) of the 64 streams of a block into LDS as magnitudes, transposed: row r of the
+ * tile is stream r, and one wave-wide load fetches 64 consecutive samples of one stream (512 B of IQ, 256 B of
+ * magnitude). Rows are fetched NFC_STAGE_ROWS at a time, all loads of a batch in flight together; samples past the
+ * end of a row read as zero (their lanes never consume them). S = floats per sample (2 IQ, 1 magnitude). */
+#define NFC_STAGE_ROWS 16
+
+template <uint32_t S>
+__device__ __forceinline__ void nfc_stage_tile(const NfcLaunch &L, uint32_t block, uint32_t base, uint32_t lane, float *tile)
+{
+   const uint32_t idx = base + lane;
+
+#pragma clang loop unroll(disable)
+   for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_STAGE_ROWS)
+   {
+      float re[NFC_STAGE_ROWS], im[NFC_STAGE_ROWS];
+      uint32_t count[NFC_STAGE_ROWS];
+
+#pragma unroll
+      for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
+      {
+         const NfcRow row = nfc_row(L, block * NFC_LANES + r0 + j);
+
+         /* an empty row reads (and discards) from the ring storage, which is always there */
+         const float *p = row.count ? (const float *)row.data : (const float *)L.rings;
+         const uint32_t last = row.count ? row.count - 1u : 0u;
+         const uint32_t at = idx < last ? idx : last;
+
+         count[j] = row.count;
+
+         if (S == 2)
+         {
+            const float2 iq = reinterpret_cast<const float2 *>(p)[at];
+            re[j] = iq.x;
+            im[j] = iq.y;
+         }
+         else
+         {
+            re[j] = p[at];
+            im[j] = 0.0f;
+         }
+      }
+
+#pragma unroll
+      for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
+      {
+         const float v = S == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
+         tile[(r0 + j) * TILE_PITCH + lane] = idx < count[j] ? v : 0.0f;
+      }
+   }
+}
+
+template <bool EXACT, bool FIXED>
+__device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, float *tile)
+{
+   const uint32_t lane = threadIdx.x;
+   const uint32_t block = L.firstBlock + blockIdx.x;
+   const uint32_t slot = block * NFC_LANES + lane;
+
+   /* this lane's own row (per lane: the rows of a block may differ in length) */
+   uint32_t mineCount = 0;
+
+   if (slot >= L.firstSlot && slot < L.firstSlot + L.slotCount)
+      mineCount = L.works ? L.works[slot].count : L.uniformCount;
 
    /* longest row of the block (wave-wide max) */
-   uint32_t longest = mine.count;
+   uint32_t longest = mineCount;
    for (int off = 32; off > 0; off >>= 1)
    {
       uint32_t other = __shfl_xor(longest, off, 64);
       longest = other > longest ? other : longest;
    }
 
-   __syncthreads();
+   longest = __builtin_amdgcn_readfirstlane(longest);
 
    if (longest == 0)
       return;
 
    NfcStreamState s = L.states[slot];
 
-   if ((__any(nfc_exact_span(s.clock, mine.count)) != 0) != EXACT)
+   if ((__any(nfc_exact_span(s.clock, mineCount)) != 0) != EXACT)
       return;
 
    NfcLaneMem mem;
@@ -111,40 +187,16 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
 
    for (uint32_t base = 0; base < longest; base += TILE)
    {
-      /* stage: row r = stream r of the block; with TILE = 32 each instruction fetches two rows
-       * (lanes 0-31 row r, lanes 32-63 row r+1), 256 B of IQ per row */
-      const uint32_t col = lane % TILE;
-      const uint32_t sub = lane / TILE;
-      const uint32_t idx = base + col;
-
-      for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_LANES / TILE)
-      {
-         const uint32_t r = r0 + sub;
-         const NfcWork w = work[r];
-
-         float v = 0.0f;
-
-         if (idx < w.count)
-         {
-            if (w.stride == 2)
-            {
-               const float2 iq = reinterpret_cast<const float2 *>(w.data)[idx];
-               v = __fsqrt_rn(__fadd_rn(__fmul_rn(iq.x, iq.x), __fmul_rn(iq.y, iq.y)));
-            }
-            else
-            {
-               v = reinterpret_cast<const float *>(w.data)[idx];
-            }
-         }
-
-         tile[r * TILE_PITCH + col] = v;
-      }
+      if (L.uniformStride == 2)
+         nfc_stage_tile<2>(L, block, base, lane, tile);
+      else
+         nfc_stage_tile<1>(L, block, base, lane, tile);
 
       __syncthreads();
 
-      if (base < mine.count)
+      if (base < mineCount)
       {
-         const uint32_t left = mine.count - base;
+         const uint32_t left = mineCount - base;
          const uint32_t n = left < TILE ? left : TILE;
 
          /* keep the ~100 configuration constants in the scalar cache instead of letting the compiler hoist
@@ -169,11 +221,7 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
             }
 
             for (uint32_t k = 0; k < n; k++)
-            {
-               /* address arithmetic on literals would otherwise be hoisted out of the loop, one register per tap */
-               asm volatile("" : "+v"(mem.lane));
                nfc_step_as<EXACT>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-            }
          }
          else
          {
@@ -190,7 +238,7 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
       __syncthreads();
    }
 
-   if (mine.count)
+   if (mineCount)
       L.states[slot] = s;
 }
 
@@ -198,8 +246,7 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
    __global__ __launch_bounds__(64) attrs void name(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) \
    {                                                                                                   \
       __shared__ float tile[NFC_LANES * TILE_PITCH];                                                   \
-      __shared__ NfcWork work[NFC_LANES];                                                              \
-      nfc_demod_body<exact, fixed>(cfgPtr, L, tile, work);                                             \
+      nfc_demod_body<exact, fixed>(cfgPtr, L, tile);                                                   \
    }
 
 /* exactly NFC_MIN_WAVES waves per SIMD: spilling state to scratch to reach a higher occupancy costs 5-10x */

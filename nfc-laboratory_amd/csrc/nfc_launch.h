@@ -13,7 +13,7 @@ struct NfcWork
 {
    const uint8_t *data; /* device pointer: count*stride floats */
    uint32_t count;      /* samples */
-   uint32_t stride;     /* 1 magnitude, 2 interleaved IQ */
+   uint32_t stride;     /* 1 magnitude, 2 interleaved IQ (host bookkeeping; a launch has one format, NfcLaunch::uniformStride) */
 };
 
 struct NfcLaunch
@@ -28,7 +28,7 @@ struct NfcLaunch
    const uint8_t *uniformBase;
    uint64_t uniformPitch;
    uint32_t uniformCount;
-   uint32_t uniformStride;
+   uint32_t uniformStride; /* floats per sample of every row of the launch (both layouts): 1 magnitude, 2 IQ */
    uint32_t sinkWords;
    uint32_t firstBlock;
    uint32_t firstSlot;

@@ -774,6 +774,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
 
       NfcLaunch L = base_launch(ctx);
       L.works = ctx->dWorks;
+      L.uniformStride = b->stride; /* one sample format per batch */
       L.firstSlot = first;
       L.slotCount = last - first + 1;
 
