@@ -134,6 +134,14 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *batch);
 int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first_stream_id, uint32_t count, const void *base, uint64_t pitch_bytes,
                           uint32_t n_samples, uint32_t stride, uint32_t location, uint32_t sample_rate);
 
+/* Magnitude of interleaved float IQ, out[i] = sqrtf(I*I + Q*Q) with the reference's roundings (products and sum
+ * rounded separately, correctly rounded root): the conversion RadioDeviceTask applies before publishing a
+ * SIGNAL_TYPE_RADIO_SAMPLES buffer (RadioDeviceTask.cpp:547-656, scalar form 626-642). The decoder entry points do
+ * this on the fly for stride-2 input; this call exposes the same device function for hosts that also want the
+ * magnitudes (storage, display) and for bit-exact testing. `location` applies to both pointers; the call returns
+ * when `out` is complete. */
+int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n_samples, float *out, uint32_t location);
+
 int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t stream_id);
 int nfcgpu_sync(nfcgpu_ctx *ctx);
 int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t stream_id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count);

@@ -260,6 +260,18 @@ NFC_DEMOD_KERNEL(nfc_demod_fixed_kernel, false, true, NFC_PINNED)
 NFC_DEMOD_KERNEL(nfc_demod_exact_kernel, true, false, )
 NFC_DEMOD_KERNEL(nfc_demod_fixed_exact_kernel, true, true, )
 
+/* out[i] = |iq[i]|, the formula the demodulation kernels apply while staging */
+__global__ __launch_bounds__(256) void nfc_magnitude_kernel(const float2 *__restrict__ iq, float *__restrict__ out, uint64_t n)
+{
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+
+   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+   {
+      const float2 v = iq[i];
+      out[i] = nfc_iq_magnitude(v.x, v.y);
+   }
+}
+
 __global__ __launch_bounds__(64) void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd)
 {
    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;

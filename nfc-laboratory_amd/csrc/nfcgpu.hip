@@ -21,6 +21,7 @@
 
 __global__ void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_demod_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_magnitude_kernel(const float2 *__restrict__ iq, float *__restrict__ out, uint64_t n);
 __global__ void nfc_demod_fixed_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_demod_fixed_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 
@@ -814,6 +815,46 @@ int nfcgpu_submit(nfcgpu_ctx *ctx, uint32_t id, const float *data, uint32_t n, u
    b.data = &ptr;
    b.n_samples = &n;
    return nfcgpu_submit_batch(ctx, &b);
+}
+
+int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n, float *out, uint32_t location)
+{
+   if (!ctx || !iq || !out || (location != NFCGPU_LOC_HOST && location != NFCGPU_LOC_DEVICE))
+      return NFCGPU_EINVAL;
+   if (n == 0)
+      return NFCGPU_OK;
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+   const float2 *src = (const float2 *)iq;
+   float *dst = out;
+
+   if (location == NFCGPU_LOC_HOST)
+   {
+      /* staging area: IQ first, magnitudes behind it */
+      const size_t inBytes = (size_t)n * 8, outBytes = (size_t)n * 4;
+      int rc = ensure_stage(ctx, inBytes + outBytes);
+      if (rc)
+         return rc;
+
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->dStage, iq, inBytes, hipMemcpyHostToDevice, ctx->stream));
+      src = (const float2 *)ctx->dStage;
+      dst = (float *)(ctx->dStage + inBytes);
+   }
+
+   const uint32_t threads = 256;
+   const uint64_t wanted = (n + threads - 1) / threads;
+   const uint32_t grid = (uint32_t)(wanted < 16384 ? wanted : 16384);
+
+   hipLaunchKernelGGL(nfc_magnitude_kernel, dim3(grid), dim3(threads), 0, ctx->stream, src, dst, n);
+   HIP_TRY(ctx, hipGetLastError());
+
+   if (location == NFCGPU_LOC_HOST)
+      HIP_TRY(ctx, hipMemcpyAsync(out, dst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   return NFCGPU_OK;
 }
 
 int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const void *base, uint64_t pitch, uint32_t n,

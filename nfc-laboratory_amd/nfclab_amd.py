@@ -7,6 +7,8 @@ library or a GPU is missing, NfcGpu() raises.
 import ctypes
 import os
 
+import numpy as np
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFCGPU_LIB", os.path.join(HERE, "libnfcgpu.so"))
 
@@ -115,6 +117,7 @@ def load_library(path=LIB_PATH):
     lib.nfcgpu_submit.argtypes = [vp, u32, vp, u32, u32, u32]
     lib.nfcgpu_submit_batch.argtypes = [vp, P(Batch)]
     lib.nfcgpu_submit_uniform.argtypes = [vp, u32, u32, vp, u64, u32, u32, u32, u32]
+    lib.nfcgpu_magnitude.argtypes = [vp, vp, u64, vp, u32]
     lib.nfcgpu_flush.argtypes = [vp, u32]
     lib.nfcgpu_sync.argtypes = [vp]
     lib.nfcgpu_poll.argtypes = [vp, u32, P(Frame), u32, P(u32)]
@@ -206,6 +209,15 @@ class NfcGpu:
     def submit_uniform(self, first, count, base_ptr, pitch_bytes, n_samples, sample_rate, stride=1, location=LOC_DEVICE):
         self._check(self.lib.nfcgpu_submit_uniform(self.ctx, first, count, base_ptr, pitch_bytes, n_samples, stride,
                                                    location, sample_rate))
+
+    def magnitude(self, iq):
+        """|IQ| of an interleaved float32 numpy array (host memory), computed on the device with the reference's
+        roundings."""
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        n = iq.size // 2
+        out = np.empty(n, dtype=np.float32)
+        self._check(self.lib.nfcgpu_magnitude(self.ctx, iq.ctypes.data, n, out.ctypes.data, LOC_HOST))
+        return out
 
     def flush(self, stream):
         self._check(self.lib.nfcgpu_flush(self.ctx, stream))

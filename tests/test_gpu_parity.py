@@ -1,6 +1,8 @@
 """GPU parity tests: every call goes through the C ABI of libnfcgpu.so (HIP kernels on the MI355X) and is
 compared bit-for-bit with the oracle: the reference's golden vectors (tests/golden) and the reference decoder
 itself (oracle/_ref/libnfcref.so, built from /root/reference and shipped with the snapshot)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -102,6 +104,42 @@ def test_iq_entry_matches_magnitude_entry(gpu):
     T.reference_lib().nfcref_magnitude(iq.ctypes.data, m.size, mag.ctypes.data)
     ref, _ = T.reference_decode(mag, keep_carrier=True)
     assert decode_chunked(gpu, iq, 65536, stride=2) == ref
+
+
+def test_iq_magnitude_is_bit_exact(gpu):
+    """nfcgpu_magnitude (the device function the decoder applies to stride-2 input) against the reference's
+    conversion (RadioDeviceTask.cpp:626-642 through oracle/_ref) on values spanning the float range: normal,
+    tiny (denormal squares), large, signed zeros, exact squares."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    expo = rng.integers(-70, 60, n).astype(np.float32)
+    iq = (rng.standard_normal(2 * n).astype(np.float32) * np.exp2(np.repeat(expo, 2)).astype(np.float32)).astype(np.float32)
+    iq[:8] = [0.0, 0.0, -0.0, 0.0, 3.0, 4.0, 1e-30, 1e-30]
+    iq[8:16] = [1.0, 0.0, 0.0, -1.0, 0.5, 0.5, 1e19, 1e19]
+    want = np.empty(n, np.float32)
+    T.reference_lib().nfcref_magnitude(iq.ctypes.data, n, want.ctypes.data)
+    got = gpu.magnitude(iq)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_generic_kernels_at_the_specialised_rate(gpu):
+    """10 MS/s normally runs the kernels with the derived constants compiled in; the generic kernels (any sample
+    rate) must give the same frames at that rate. A second context with NFCGPU_GENERIC_KERNELS=1 decodes a fixture."""
+    import nfclab_amd
+    name = "test_POLL_ABF_001"
+    os.environ["NFCGPU_GENERIC_KERNELS"] = "1"
+    try:
+        with nfclab_amd.NfcGpu(device=0, max_streams=64) as generic:
+            first = generic.open(count=1)
+            x = T.load_fixture(name)
+            for pos in range(0, x.size, 50000):
+                generic.submit(first, np.ascontiguousarray(x[pos:pos + 50000]), FS)
+            got = data_frames(generic.poll(first))
+    finally:
+        del os.environ["NFCGPU_GENERIC_KERNELS"]
+    assert got == T.load_golden(name)
 
 
 def test_uniform_device_batch_synthetic_streams(gpu):
