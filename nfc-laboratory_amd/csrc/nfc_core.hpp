@@ -780,8 +780,21 @@ NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    NFC_OPAQUE(inSearch);
    NFC_OPAQUE(inDecode);
 
-   /* each mode is a self-contained region (reads, front end, its machines): the front end is cheap enough to appear
-    * twice, and values that cross a region boundary would have to be waited for at the boundary */
+   uint32_t readDecode = mode;
+   NFC_OPAQUE(readDecode);
+
+   /* a block with streams in both modes runs both regions below: the decode-mode reads are issued before the search
+    * region so that its wait covers them too (one memory latency per step instead of two) */
+   NfcDecTaps taps;
+
+   if (readDecode != 0)
+   {
+      nfc_advance_lock_pos(s, mem);
+      taps = nfc_load_decode_taps(mem, s);
+   }
+
+   /* each mode is a self-contained region (front end, its machines): the front end is cheap enough to appear
+    * twice, and values produced in one region and consumed after it would have to be waited for at its end */
    if (inSearch == 0)
    {
       /* unconditional within search mode: the addresses are always inside the stream block, and a detector that
@@ -803,10 +816,6 @@ NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (inDecode != 0)
    {
-      nfc_advance_lock_pos(s, mem);
-
-      NfcDecTaps taps = nfc_load_decode_taps(mem, s);
-
       const NfcNow now = nfc_front_end(c, s, mem, value);
 
       /* without delay the decode point is the sample the front end has just produced (not in memory when the taps
