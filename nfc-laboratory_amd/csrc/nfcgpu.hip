@@ -86,6 +86,8 @@ struct nfcgpu_ctx
    NfcConfig *dConfigs = nullptr;
    bool genericOnly = false; /* NFCGPU_GENERIC_KERNELS=1: never use the sample-rate-specialised kernels (testing) */
    uint8_t *dStage = nullptr;
+   uint8_t *hStage = nullptr; /* pinned mirror of dStage: caller memory is copied here by the CPU and never handed to the
+                                 GPU runtime (no page locking of memory whose lifetime belongs to the caller) */
    size_t stageBytes = 0;
 
    std::vector<NfcConfig> configs;
@@ -331,13 +333,22 @@ int ensure_stage(nfcgpu_ctx *ctx, size_t bytes)
 
    if (ctx->dStage)
       (void)hipFree(ctx->dStage);
+   if (ctx->hStage)
+      (void)hipHostFree(ctx->hStage);
 
    ctx->dStage = nullptr;
+   ctx->hStage = nullptr;
    ctx->stageBytes = 0;
 
    size_t want = bytes + bytes / 2;
    if (hipMalloc((void **)&ctx->dStage, want) != hipSuccess)
       return fail(ctx, NFCGPU_ENOMEM, "staging buffer allocation failed");
+   if (hipHostMalloc((void **)&ctx->hStage, want, hipHostMallocDefault) != hipSuccess)
+   {
+      (void)hipFree(ctx->dStage);
+      ctx->dStage = nullptr;
+      return fail(ctx, NFCGPU_ENOMEM, "pinned staging buffer allocation failed");
+   }
 
    ctx->stageBytes = want;
    return NFCGPU_OK;
@@ -516,6 +527,8 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    (void)hipFree(ctx->dWorks);
    (void)hipFree(ctx->dConfigs);
    (void)hipFree(ctx->dStage);
+   if (ctx->hStage)
+      (void)hipHostFree(ctx->hStage);
 
    if (ctx->stream)
       (void)hipStreamDestroy(ctx->stream);
@@ -703,21 +716,25 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
 
       if (b->location == NFCGPU_LOC_HOST)
       {
+         /* every submission ends with a stream synchronisation, so the pinned buffer is free here */
          w.data = ctx->dStage + stageAt;
          if (bytes)
-         {
-            hipError_t err = hipMemcpyAsync(ctx->dStage + stageAt, b->data[i], bytes, hipMemcpyHostToDevice, ctx->stream);
-            if (err != hipSuccess)
-            {
-               clearWorks();
-               return fail(ctx, NFCGPU_EHIP, "hipMemcpyAsync(H2D samples)", err);
-            }
-         }
+            std::memcpy(ctx->hStage + stageAt, b->data[i], bytes);
          stageAt += (bytes + 255) & ~(size_t)255;
       }
       else
       {
          w.data = (const uint8_t *)b->data[i];
+      }
+   }
+
+   if (stageAt)
+   {
+      hipError_t err = hipMemcpyAsync(ctx->dStage, ctx->hStage, stageAt, hipMemcpyHostToDevice, ctx->stream);
+      if (err != hipSuccess)
+      {
+         clearWorks();
+         return fail(ctx, NFCGPU_EHIP, "hipMemcpyAsync(H2D samples)", err);
       }
    }
 
@@ -787,7 +804,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       }
    }
 
-   /* pageable H2D copies above are complete on return (HIP stages them), but `table` is not: wait */
+   /* the staging copy and the work table must have been consumed before either is reused: wait */
    if (cfgs.size() == 1)
    {
       hipError_t err = hipStreamSynchronize(ctx->stream);
@@ -837,7 +854,9 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n, float *out, u
       if (rc)
          return rc;
 
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->dStage, iq, inBytes, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* staging buffers idle */
+      std::memcpy(ctx->hStage, iq, inBytes);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->dStage, ctx->hStage, inBytes, hipMemcpyHostToDevice, ctx->stream));
       src = (const float2 *)ctx->dStage;
       dst = (float *)(ctx->dStage + inBytes);
    }
@@ -850,9 +869,12 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n, float *out, u
    HIP_TRY(ctx, hipGetLastError());
 
    if (location == NFCGPU_LOC_HOST)
-      HIP_TRY(ctx, hipMemcpyAsync(out, dst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->hStage + (size_t)n * 8, dst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
 
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   if (location == NFCGPU_LOC_HOST)
+      std::memcpy(out, ctx->hStage + (size_t)n * 8, (size_t)n * 4);
 
    return NFCGPU_OK;
 }
@@ -891,7 +913,11 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       if (rc)
          return rc;
 
-      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->dStage, devPitch, base, pitch, row, count, hipMemcpyHostToDevice, ctx->stream));
+      /* the previous host submission ended with a stream synchronisation: the pinned buffer is free */
+      for (uint32_t r = 0; r < count; r++)
+         std::memcpy(ctx->hStage + (size_t)r * devPitch, (const uint8_t *)base + (size_t)r * pitch, row);
+
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->dStage, ctx->hStage, devPitch * count, hipMemcpyHostToDevice, ctx->stream));
       devBase = ctx->dStage;
    }
 

@@ -36,11 +36,26 @@ namespace {
 struct SharedContext
 {
    nfcgpu_ctx *ctx = nullptr;
+   bool closed = false;
    std::mutex mutex;
+
+   /* Decoders owned by long-lived objects (the RadioDecoderTask worker, static subjects) may be destroyed while the
+    * process is exiting, after the GPU runtime has begun to unload. The context is therefore released by an atexit
+    * hook registered after the runtime's own (it runs before it); decoders destroyed later find it closed. */
+   static void atExit();
+
+   bool alive()
+   {
+      std::lock_guard<std::mutex> lock(mutex);
+      return ctx != nullptr && !closed;
+   }
 
    nfcgpu_ctx *get()
    {
       std::lock_guard<std::mutex> lock(mutex);
+
+      if (closed)
+         throw std::runtime_error("nfcgpu context already shut down");
 
       if (!ctx)
       {
@@ -53,6 +68,8 @@ struct SharedContext
 
          if (rc != NFCGPU_OK)
             throw std::runtime_error(std::string("nfcgpu_init failed: ") + nfcgpu_strerror(rc));
+
+         std::atexit(&SharedContext::atExit);
       }
 
       return ctx;
@@ -60,6 +77,17 @@ struct SharedContext
 };
 
 SharedContext shared;
+
+void SharedContext::atExit()
+{
+   std::lock_guard<std::mutex> lock(shared.mutex);
+
+   if (shared.ctx)
+      nfcgpu_shutdown(shared.ctx);
+
+   shared.ctx = nullptr;
+   shared.closed = true;
+}
 
 }
 
@@ -83,7 +111,8 @@ struct NfcDecoder::Impl
 
    ~Impl()
    {
-      nfcgpu_stream_close(ctx, stream);
+      if (shared.alive())
+         nfcgpu_stream_close(ctx, stream);
    }
 
    void push()
@@ -160,6 +189,9 @@ NfcDecoder::NfcDecoder() : impl(std::make_shared<Impl>())
 
 void NfcDecoder::initialize()
 {
+   if (!shared.alive())
+      return;
+
    impl->push();
    nfcgpu_stream_reset(impl->ctx, impl->stream);
 }
@@ -170,6 +202,9 @@ void NfcDecoder::cleanup()
 
 std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
 {
+   if (!shared.alive())
+      return {};
+
    impl->push();
 
    if (samples.isValid())

@@ -61,4 +61,19 @@ g++ $CXXFLAGS $INC -c "$HERE/ref_capi.cpp" -o "$OUT/obj/ref_capi.o"
 g++ -shared -o "$OUT/libnfcref.so" "$OUT/obj/ref_capi.o" $OBJS -pthread
 
 g++ $CXXFLAGS $INC "$REF/src/nfc-test/test-sdr/src/main/cpp/main.cpp" $OBJS -o "$OUT/test-sdr-ref" -pthread
-echo "built $OUT/libnfcref.so $OUT/test-sdr-ref"
+
+# task level (BASELINE configs[0], SURVEY 8(b) outer contract): the reference's RadioDecoderTask + executor, compiled in
+# place, driven by tests/dropin/task_harness.cpp the way the Qt app / nfc-rx drive it; here with the reference decoder
+TINC="$INC -I$R/lib-lab/lab-tasks/src/main/include -I$R/lib-lab/lab-tasks/src/main/cpp/tasks"
+TOBJS=""
+for s in "$R/lib-rt/rt-lang/src/main/cpp/Worker.cpp" "$R/lib-rt/rt-lang/src/main/cpp/Executor.cpp" \
+         "$R/lib-lab/lab-tasks/src/main/cpp/tasks/RadioDecoderTask.cpp"; do
+  o="$OUT/obj/$(basename "${s%.cpp}").o"
+  TOBJS="$TOBJS $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ]; then
+    g++ $CXXFLAGS $TINC -c "$s" -o "$o"
+  fi
+done
+ar rcs "$OUT/libnfcref_task.a" $TOBJS
+g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/task_harness.cpp" "$OUT/libnfcref_task.a" $OBJS -o "$OUT/task-ref" -pthread
+echo "built $OUT/libnfcref.so $OUT/test-sdr-ref $OUT/task-ref"

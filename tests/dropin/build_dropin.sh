@@ -15,7 +15,7 @@ R="$REF/src/nfc-lib"
 OUT="$ROOT/oracle/_ref"
 
 [ -d "$R" ] || { echo "reference tree not present; keeping prebuilt test-sdr-gpu" >&2; exit 0; }
-[ -f "$OUT/libnfcref_support.a" ] || bash "$ROOT/oracle/build_ref.sh"
+[ -f "$OUT/libnfcref_support.a" ] && [ -f "$OUT/libnfcref_task.a" ] || bash "$ROOT/oracle/build_ref.sh"
 
 INC="-I$R/lib-rt/rt-lang/src/main/include -I$R/lib-hw/hw-dev/src/main/include -I$R/lib-lab/lab-data/src/main/include \
  -I$R/lib-lab/lab-radio/src/main/include -I$R/lib-ext/nlohmann/src/main/cpp -I$ROOT/include"
@@ -24,4 +24,10 @@ g++ -std=c++17 -O2 -pthread -w $INC -c "$HOST/NfcDecoder.cpp" -o "$OUT/obj/NfcDe
 g++ -std=c++17 -O2 -pthread -w $INC "$REF/src/nfc-test/test-sdr/src/main/cpp/main.cpp" "$OUT/obj/NfcDecoder_gpu.o" \
     "$OUT/libnfcref_support.a" -L"$ROOT/nfc-laboratory_amd" -lnfcgpu -Wl,-rpath,'$ORIGIN/../../nfc-laboratory_amd' \
     -o "$OUT/test-sdr-gpu"
-echo "built $OUT/test-sdr-gpu"
+
+# the same at task level: the reference's RadioDecoderTask (unmodified) on top of the GPU decoder
+TINC="$INC -I$R/lib-lab/lab-tasks/src/main/include -I$R/lib-lab/lab-tasks/src/main/cpp/tasks"
+g++ -std=c++17 -O2 -pthread -w $TINC "$HERE/task_harness.cpp" "$OUT/libnfcref_task.a" "$OUT/obj/NfcDecoder_gpu.o" \
+    "$OUT/libnfcref_support.a" -L"$ROOT/nfc-laboratory_amd" -lnfcgpu -Wl,-rpath,'$ORIGIN/../../nfc-laboratory_amd' \
+    -o "$OUT/task-gpu"
+echo "built $OUT/test-sdr-gpu $OUT/task-gpu"

@@ -147,6 +147,41 @@ def hostsim_decode(samples, sample_rate=10000000, lane=0, tech_mask=0xF, stride=
     return frames_to_tuples(out, n, keep_carrier=keep_carrier)
 
 
+def write_wav(path, samples_i16, sample_rate=10000000):
+    """Mono 16-bit PCM WAV as the reference's hw::RecordDevice reads it."""
+    import struct
+    raw = np.ascontiguousarray(samples_i16, dtype=np.int16).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sample_rate, sample_rate * 2, 2, 16))
+        f.write(b"data" + struct.pack("<I", len(raw)) + raw)
+
+
+def run_task_harness(exe, names, tmp_path, timeout=900):
+    """Run tests/dropin/task_harness.cpp (reference RadioDecoderTask driven through its subjects) on fixtures;
+    returns {name: [frame tuples in load_golden() order]}."""
+    import subprocess
+    paths = []
+    for name in names:
+        wav = os.path.join(str(tmp_path), name + ".wav")
+        write_wav(wav, load_fixture_i16(name))
+        paths.append(wav)
+    proc = subprocess.run([exe] + paths, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out = {name: [] for name in names}
+    done = set()
+    for line in proc.stdout.splitlines():
+        w = line.split()
+        if w and w[0] == "FRAME":
+            name = os.path.basename(w[1])[:-4]
+            payload = bytes.fromhex(w[10]) if w[10] != "-" else b""
+            out[name].append((int(w[2]), int(w[3]), int(w[4]), int(w[5]), int(w[6]), int(w[7]), int(w[8]), int(w[9]), payload))
+        elif w and w[0] == "DONE":
+            done.add(os.path.basename(w[1])[:-4])
+    assert done == set(names), proc.stdout[-2000:] + proc.stderr[-2000:]
+    return out
+
+
 def describe(t):
     return "tech=%x type=%x flags=%x phase=%x rate=%d start=%d end=%d data=%s" % (
         t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[8].hex(":"))

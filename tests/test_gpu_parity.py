@@ -242,6 +242,19 @@ def test_reference_test_sdr_harness_runs_unchanged_on_the_gpu_decoder(built, tmp
         assert "TEST FILE %s.wav: PASS" % name in out, out
 
 
+def test_reference_radio_decoder_task_runs_unchanged_on_the_gpu_decoder(built, tmp_path):
+    """Task-level drop-in (SURVEY 8(b) outer contract): the reference's RadioDecoderTask, compiled unmodified,
+    submitted to rt::Executor, configured / started over radio.decoder.command and fed SignalBuffers over
+    radio.signal.raw; its frames on radio.decoder.frame must equal the goldens with the GPU decoder underneath."""
+    exe = os.path.join(T.ROOT, "oracle", "_ref", "task-gpu")
+    if not os.path.exists(exe):
+        pytest.skip("task-gpu not built (needs the reference tree at build time)")
+    names = ["test_NFC-A_106kbps_001", "test_NFC-F_212kbps_001", "test_NFC-V_26kbps_001", "test_POLL_ABF_001"]
+    got = T.run_task_harness(exe, names, tmp_path)
+    for name in names:
+        assert got[name] == T.load_golden(name), name
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_fuzzed_streams_match_reference(gpu, seed):
     """Random cut-and-paste of captures with arbitrary gains, offsets and noise (general fp32, not on the int16 grid)."""

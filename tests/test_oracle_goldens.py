@@ -1,6 +1,7 @@
 """CPU tests: the oracle (the real reference, oracle/_ref) is pinned against the reference's golden
 vectors, and the CPU build of the device state machine (tests/hostsim) is checked against both."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -113,3 +114,16 @@ def test_step_machine_matches_reference_at_other_sample_rates(built, name, rate,
     got = T.hostsim_decode(x, sample_rate=rate, keep_carrier=True, lane=9)
     assert got == ref
     assert any(f[1] in (0x102, 0x103) for f in ref)
+
+
+def test_reference_radio_decoder_task_plumbing(tmp_path):
+    """BASELINE configs[0]: a fixture through the reference's own RadioDecoderTask (subjects + executor, reference CPU
+    decoder underneath, oracle/_ref/task-ref) yields the golden frames; the GPU twin of this test is in
+    test_gpu_parity.py with the same harness linked against libnfcgpu.so."""
+    exe = os.path.join(T.ROOT, "oracle", "_ref", "task-ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/task-ref not built")
+    names = ["test_NFC-A_106kbps_001", "test_POLL_ABF_001"]
+    got = T.run_task_harness(exe, names, tmp_path)
+    for name in names:
+        assert got[name] == T.load_golden(name), name
