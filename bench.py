@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("NFC_BENCH_STREAMS", "131072")), help="streams per GPU")
     ap.add_argument("--samples", type=int, default=8192, help="samples per stream per step")
-    ap.add_argument("--cpu-streams", type=int, default=8192, help="streams of rank 0 replayed on the host CPU")
+    ap.add_argument("--cpu-streams", type=int, default=24576, help="streams of rank 0 replayed on the host CPU")
     ap.add_argument("--check-streams", type=int, default=64, help="streams compared frame-by-frame with the reference")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
