@@ -183,9 +183,10 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic,
-            "kernel": "nfc_demod_kernel",
+            "kernel": "nfc_demod_fixed_kernel" if FS == 10000000 else "nfc_demod_kernel",
             "kernel_ms_avg": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": bytes_per_launch,
+            "traffic_frac_of_peak": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kernel_ms > 0 else None,
         },
         "frames_dropped": dropped,
     }

@@ -169,7 +169,7 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
 
    NfcStreamState s = L.states[slot];
 
-   if ((__any(nfc_exact_span(s.clock, mineCount)) != 0) != EXACT)
+   if ((L.forceExact != 0 || __any(nfc_exact_span(s.clock, mineCount)) != 0) != EXACT)
       return;
 
    NfcLaneMem mem;

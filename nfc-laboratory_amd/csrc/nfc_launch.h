@@ -34,7 +34,7 @@ struct NfcLaunch
    uint32_t firstSlot;
    uint32_t slotCount;
    uint32_t ringBlockFloats;
-   uint32_t reserved;
+   uint32_t forceExact; /* the host launches only the exact-modulo kernel: it takes every block, whatever the clocks say */
 };
 
 #endif

@@ -280,7 +280,7 @@ hipEvent_t take_event(nfcgpu_ctx *ctx)
    return e;
 }
 
-int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t samples, bool exactPossible)
+int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t samples, bool exactPossible, bool exactOnly)
 {
    const uint32_t firstBlock = L.firstSlot / NFC_LANES;
    const uint32_t lastBlock = (L.firstSlot + L.slotCount - 1) / NFC_LANES;
@@ -298,9 +298,16 @@ int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t sample
 
    const bool fixed = !ctx->genericOnly && matches_fixed_table(ctx->configs[config]);
 
-   hipLaunchKernelGGL(fixed ? nfc_demod_fixed_kernel : nfc_demod_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0,
-                      ctx->stream, ctx->dConfigs + config, L);
-   HIP_TRY(ctx, hipGetLastError());
+   /* every stream block picks its kernel from the device state; a launch in which every stream needs the exact
+    * variant (the first buffer of freshly opened streams) does not need the common kernel at all */
+   L.forceExact = exactOnly ? 1u : 0u;
+
+   if (!exactOnly)
+   {
+      hipLaunchKernelGGL(fixed ? nfc_demod_fixed_kernel : nfc_demod_kernel, dim3(lastBlock - firstBlock + 1), dim3(NFC_LANES), 0,
+                         ctx->stream, ctx->dConfigs + config, L);
+      HIP_TRY(ctx, hipGetLastError());
+   }
 
    /* stream blocks near their start / the clock wrap skip the kernel above and are handled by this one */
    if (exactPossible)
@@ -756,7 +763,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
    {
       uint32_t first = 0xFFFFFFFFu, last = 0;
       uint64_t groupSamples = 0;
-      bool exactPossible = false;
+      bool exactPossible = false, exactOnly = true;
 
       for (uint32_t i = 0; i < b->n_streams; i++)
       {
@@ -766,7 +773,9 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
          first = id < first ? id : first;
          last = id > last ? id : last;
          groupSamples += b->n_samples[i];
-         exactPossible = advance_clock(ctx->streams[id], b->n_samples[i]) || exactPossible;
+         const bool exact = advance_clock(ctx->streams[id], b->n_samples[i]);
+         exactPossible = exactPossible || exact;
+         exactOnly = exactOnly && (exact || b->n_samples[i] == 0);
       }
 
       /* slots of other configurations inside [first,last] must stay idle in this launch */
@@ -796,7 +805,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       L.firstSlot = first;
       L.slotCount = last - first + 1;
 
-      rc = launch_demod(ctx, c, L, groupSamples, exactPossible);
+      rc = launch_demod(ctx, c, L, groupSamples, exactPossible, exactOnly);
       if (rc)
       {
          clearWorks();
@@ -945,11 +954,15 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       L.firstSlot = i;
       L.slotCount = j - i;
 
-      bool exactPossible = false;
+      bool exactPossible = false, exactOnly = true;
       for (uint32_t k = i; k < j; k++)
-         exactPossible = advance_clock(ctx->streams[k], n) || exactPossible;
+      {
+         const bool exact = advance_clock(ctx->streams[k], n);
+         exactPossible = exactPossible || exact;
+         exactOnly = exactOnly && exact;
+      }
 
-      rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i), exactPossible);
+      rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i), exactPossible, exactOnly);
       if (rc)
          return rc;
 
