@@ -29,8 +29,12 @@
 /* constant address space: uniform loads through it are always scalar (s_load), whatever else the kernel writes */
 typedef __attribute__((address_space(4))) NfcConfig NfcConfigConst;
 
-#define TILE 64
-#define TILE_PITCH 65
+/* samples per input tile (<= 64: one row of the tile is fetched by one wave-wide load) */
+#ifndef NFC_TILE
+#define NFC_TILE 64
+#endif
+#define TILE NFC_TILE
+#define TILE_PITCH (NFC_TILE + 1)
 
 #ifndef NFC_MIN_WAVES
 #define NFC_MIN_WAVES 2
@@ -136,7 +140,8 @@ __device__ __forceinline__ void nfc_stage_tile(const NfcLaunch &L, uint32_t bloc
       for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
       {
          const float v = S == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
-         tile[(r0 + j) * TILE_PITCH + lane] = idx < count[j] ? v : 0.0f;
+         if (TILE == NFC_LANES || lane < TILE)
+            tile[(r0 + j) * TILE_PITCH + lane] = idx < count[j] ? v : 0.0f;
       }
    }
 }

@@ -7,7 +7,10 @@
  * "radio.decoder.frame". Linked once against the reference decoder (oracle/_ref/task-ref, the CPU plumbing run of
  * BASELINE configs[0]) and once against the GPU shim + libnfcgpu.so (oracle/_ref/task-gpu): same binary otherwise.
  *
- * usage: task-harness file.wav [file.wav ...]
+ * usage: task-harness [--iq] file.wav [file.wav ...]
+ *    --iq   publish SIGNAL_TYPE_RADIO_IQ buffers (interleaved I/Q, |IQ| equal to the capture's magnitude) instead of
+ *           magnitude buffers: what a receiver task would hand over if it skipped its host-side magnitude pass
+ *           (SURVEY 8(f) rank 2). The GPU decoder demodulates them from IQ; the reference decoder ignores them.
  * prints one line per NFC poll/listen frame:
  *    FRAME <file> tech type flags phase rate sampleStart sampleEnd sampleRate hexdata
  * and "DONE <file> <frames> <seconds>" per file.
@@ -56,7 +59,7 @@ bool command(rt::Subject<rt::Event> *subject, int code, const json &data)
    return outcome == 1;
 }
 
-int decodeFile(const std::string &path, rt::Subject<rt::Event> *commands, rt::Subject<hw::SignalBuffer> *signal)
+int decodeFile(const std::string &path, rt::Subject<rt::Event> *commands, rt::Subject<hw::SignalBuffer> *signal, bool iq)
 {
    hw::RecordDevice source(path);
 
@@ -88,13 +91,36 @@ int decodeFile(const std::string &path, rt::Subject<rt::Event> *commands, rt::Su
       return -3;
 
    const auto begin = std::chrono::steady_clock::now();
+   unsigned long published = 0;
 
    while (!source.isEof())
    {
       hw::SignalBuffer samples(65536 * channels, channels, 1, sampleRate, 0, 0, hw::SignalType::SIGNAL_TYPE_RADIO_SAMPLES, 0);
 
       if (source.read(samples) > 0)
-         signal->next(samples);
+      {
+         if (iq && channels == 1)
+         {
+            /* the sample goes on +I, +Q, -I, -Q in turn (axis changes every 4096 samples): sqrtf(m*m + 0) == |m| */
+            const unsigned int count = samples.remaining();
+            hw::SignalBuffer complex(count * 2, 2, 1, sampleRate, 0, 0, hw::SignalType::SIGNAL_TYPE_RADIO_IQ, 0);
+
+            for (unsigned int i = 0; i < count; i++)
+            {
+               const float m = samples[i];
+               const unsigned int axis = ((published + i) >> 12) & 3;
+               complex.put(axis == 0 ? m : (axis == 2 ? -m : 0.0f)).put(axis == 1 ? m : (axis == 3 ? -m : 0.0f));
+            }
+
+            complex.flip();
+            published += count;
+            signal->next(complex);
+         }
+         else
+         {
+            signal->next(samples);
+         }
+      }
 
       /* optional pacing (milliseconds per buffer), e.g. 6.5 = the real-time rate of a 10 MS/s receiver */
       if (const char *pace = std::getenv("TASK_HARNESS_PACE_MS"))
@@ -171,10 +197,17 @@ int main(int argc, char *argv[])
    std::this_thread::sleep_for(std::chrono::milliseconds(100));
 
    int status = 0;
+   bool iq = false;
 
    for (int i = 1; i < argc; i++)
    {
-      if (decodeFile(argv[i], commands, signal) < 0)
+      if (std::string(argv[i]) == "--iq")
+      {
+         iq = true;
+         continue;
+      }
+
+      if (decodeFile(argv[i], commands, signal, iq) < 0)
       {
          std::fprintf(stderr, "FAILED %s\n", argv[i]);
          status = 1;

@@ -157,7 +157,7 @@ def write_wav(path, samples_i16, sample_rate=10000000):
         f.write(b"data" + struct.pack("<I", len(raw)) + raw)
 
 
-def run_task_harness(exe, names, tmp_path, timeout=900):
+def run_task_harness(exe, names, tmp_path, timeout=900, iq=False):
     """Run tests/dropin/task_harness.cpp (reference RadioDecoderTask driven through its subjects) on fixtures;
     returns {name: [frame tuples in load_golden() order]}."""
     import subprocess
@@ -166,7 +166,8 @@ def run_task_harness(exe, names, tmp_path, timeout=900):
         wav = os.path.join(str(tmp_path), name + ".wav")
         write_wav(wav, load_fixture_i16(name))
         paths.append(wav)
-    proc = subprocess.run([exe] + paths, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    proc = subprocess.run([exe] + (["--iq"] if iq else []) + paths, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=timeout)
     assert proc.returncode == 0, proc.stderr[-2000:]
     out = {name: [] for name in names}
     done = set()

@@ -255,6 +255,18 @@ def test_reference_radio_decoder_task_runs_unchanged_on_the_gpu_decoder(built, t
         assert got[name] == T.load_golden(name), name
 
 
+def test_radio_decoder_task_fed_with_iq_buffers(built, tmp_path):
+    """the task publishes interleaved IQ (SIGNAL_TYPE_RADIO_IQ) instead of host-computed
+    magnitudes; the GPU decoder behind the unchanged RadioDecoderTask demodulates from IQ and yields the goldens."""
+    exe = os.path.join(T.ROOT, "oracle", "_ref", "task-gpu")
+    if not os.path.exists(exe):
+        pytest.skip("task-gpu not built (needs the reference tree at build time)")
+    names = ["test_NFC-B_106kbps_001", "test_NFC-A_424kbps_001"]
+    got = T.run_task_harness(exe, names, tmp_path, iq=True)
+    for name in names:
+        assert got[name] == T.load_golden(name), name
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_fuzzed_streams_match_reference(gpu, seed):
     """Random cut-and-paste of captures with arbitrary gains, offsets and noise (general fp32, not on the int16 grid)."""
