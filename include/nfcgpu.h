@@ -142,6 +142,18 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first_stream_id, uint32_t co
  * when `out` is complete. */
 int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n_samples, float *out, uint32_t location);
 
+/* Adaptive resampling of magnitude buffers for display, the radio branch of the reference's SignalResamplingTask
+ * (SignalResamplingTask.cpp:168-226: `processRadioSignal`, the other per-sample consumer of "radio.signal.raw"): every
+ * buffer of n_samples floats is reduced to (value, sample offset) control points wherever the sample departs from its
+ * 51-sample centred mean by more than 0.005, or every 255 samples; each buffer is independent (the running mean
+ * restarts with it), the output of buffer b is written as float pairs at out + b * out_pitch_bytes and its pair count
+ * to counts[b] — the contents of the SIGNAL_TYPE_RADIO_SIGNAL buffer the reference publishes on "adaptive.signal".
+ * capacity_pairs bounds what is written per buffer (the worst case is n_samples + n_samples / 255 + 2 pairs); a buffer
+ * that needs more keeps counting and the call returns NFCGPU_EOVERFLOW. n_samples >= 25. `location` applies to `in`,
+ * `out` and `counts` alike. */
+int nfcgpu_resample_radio(nfcgpu_ctx *ctx, const float *in, uint64_t in_pitch_bytes, uint32_t n_buffers, uint32_t n_samples,
+                          float *out, uint64_t out_pitch_bytes, uint32_t capacity_pairs, uint32_t *counts, uint32_t location);
+
 int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t stream_id);
 int nfcgpu_sync(nfcgpu_ctx *ctx);
 int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t stream_id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count);

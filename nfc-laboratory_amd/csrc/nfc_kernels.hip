@@ -277,6 +277,133 @@ __global__ __launch_bounds__(256) void nfc_magnitude_kernel(const float2 *__rest
    }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* adaptive resampler (SignalResamplingTask.cpp:168-226), one lane per buffer                   */
+/* ------------------------------------------------------------------------------------------ */
+
+#define NFC_RS_WINDOW 51      /* WINDOW */
+#define NFC_RS_INTERVAL 255   /* RADIO_INTERVAL */
+#define NFC_RS_TILE 32        /* samples staged per pass */
+#define NFC_RS_RING 96        /* per-lane sample window in LDS: >= WINDOW + TILE, multiple of TILE */
+#define NFC_RS_PITCH 97
+
+/* The running mean is a sequential fp32 sum per buffer (add the sample entering the centred window, subtract the one
+ * leaving it, in that order), so a buffer is one lane's work; 64 buffers share a wave. Input rows are staged 32
+ * samples at a time (two rows per load, 128 B each) into a per-lane ring in LDS that always holds the 51-sample
+ * window of the sample being decided; a sample is decided once the 25 samples after it are there. */
+__global__ __launch_bounds__(64) void nfc_resample_radio_kernel(const float *__restrict__ in, uint64_t pitchFloats, uint32_t nBuffers, uint32_t n,
+                                                               float *__restrict__ out, uint64_t outPitchFloats, uint32_t capacityPairs,
+                                                               uint32_t *__restrict__ counts)
+{
+   __shared__ float ring[NFC_LANES * NFC_RS_PITCH];
+
+   const uint32_t lane = threadIdx.x;
+   const uint32_t buffer = blockIdx.x * NFC_LANES + lane;
+   const bool mine = buffer < nBuffers;
+
+   float *dst = out + (uint64_t)buffer * outPitchFloats;
+   uint32_t count = 0;
+
+   auto put = [&](float value, float offset) {
+      if (mine && count < capacityPairs)
+      {
+         dst[2 * count] = value;
+         dst[2 * count + 1] = offset;
+      }
+      count++;
+   };
+
+   const float *window = ring + lane * NFC_RS_PITCH;
+
+   float avrg = 0.0f, last = 0.0f;
+   const float filter = 0.005f; /* THRESHOLD */
+
+   int32_t i = 0, c = 0, p = -1;
+   uint32_t posI = 0, posA = NFC_RS_WINDOW / 2, posR = NFC_RS_RING - (NFC_RS_WINDOW / 2) - 1; /* ring columns of i, a, r */
+
+   const uint32_t col = lane % NFC_RS_TILE;
+   const uint32_t half = lane / NFC_RS_TILE;
+
+   for (uint32_t base = 0; base < n; base += NFC_RS_TILE)
+   {
+      const uint32_t idx = base + col;
+      const uint32_t at = (base % NFC_RS_RING) + col;
+
+#pragma clang loop unroll(disable)
+      for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += 32)
+      {
+         float v[16];
+
+#pragma unroll
+         for (uint32_t j = 0; j < 16; j++)
+         {
+            const uint32_t row = r0 + 2 * j + half;
+            const uint32_t rb = blockIdx.x * NFC_LANES + row;
+            const bool ok = rb < nBuffers && idx < n;
+            v[j] = ok ? in[(uint64_t)rb * pitchFloats + idx] : 0.0f;
+         }
+
+#pragma unroll
+         for (uint32_t j = 0; j < 16; j++)
+            ring[(r0 + 2 * j + half) * NFC_RS_PITCH + at] = v[j];
+      }
+
+      __syncthreads();
+
+      const uint32_t filled = base + NFC_RS_TILE < n ? base + NFC_RS_TILE : n;
+
+      if (base == 0)
+      {
+         /* "initialize average" and "always store first sample" */
+         for (uint32_t k = 0; k < NFC_RS_WINDOW / 2; k++)
+            avrg += window[k];
+
+         last = window[0];
+         put(window[0], 0.0f);
+      }
+
+      /* decide every sample whose window is complete (all of them once the buffer has been read to its end) */
+      const int32_t stop = filled == n ? (int32_t)n : (int32_t)filled - NFC_RS_WINDOW / 2;
+
+      for (; i < stop; ++i, ++p)
+      {
+         const float value = window[posI];
+
+         if ((uint32_t)(i + NFC_RS_WINDOW / 2) < n)
+            avrg += window[posA];
+
+         if (i - NFC_RS_WINDOW / 2 - 1 >= 0)
+            avrg -= window[posR];
+
+         const float stdev = fabsf(value - (avrg / (float)NFC_RS_WINDOW));
+
+         if (stdev > filter || (i - c) >= NFC_RS_INTERVAL)
+         {
+            if (stdev > filter && c < p)
+               put(last, (float)p);
+
+            put(value, (float)i);
+
+            c = i;
+         }
+
+         last = value;
+
+         posI = posI + 1 == NFC_RS_RING ? 0 : posI + 1;
+         posA = posA + 1 == NFC_RS_RING ? 0 : posA + 1;
+         posR = posR + 1 == NFC_RS_RING ? 0 : posR + 1;
+      }
+
+      __syncthreads();
+   }
+
+   if (c < p)
+      put(last, (float)p);
+
+   if (mine)
+      counts[buffer] = count;
+}
+
 __global__ __launch_bounds__(64) void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd)
 {
    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;

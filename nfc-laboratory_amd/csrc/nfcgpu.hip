@@ -22,6 +22,9 @@
 __global__ void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_demod_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_magnitude_kernel(const float2 *__restrict__ iq, float *__restrict__ out, uint64_t n);
+__global__ void nfc_resample_radio_kernel(const float *__restrict__ in, uint64_t pitchFloats, uint32_t nBuffers, uint32_t n,
+                                          float *__restrict__ out, uint64_t outPitchFloats, uint32_t capacityPairs,
+                                          uint32_t *__restrict__ counts);
 __global__ void nfc_demod_fixed_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_demod_fixed_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 
@@ -884,6 +887,76 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n, float *out, u
 
    if (location == NFCGPU_LOC_HOST)
       std::memcpy(out, ctx->hStage + (size_t)n * 8, (size_t)n * 4);
+
+   return NFCGPU_OK;
+}
+
+int nfcgpu_resample_radio(nfcgpu_ctx *ctx, const float *in, uint64_t inPitch, uint32_t nBuffers, uint32_t n, float *out, uint64_t outPitch,
+                          uint32_t capacityPairs, uint32_t *counts, uint32_t location)
+{
+   if (!ctx || !in || !out || !counts || n < 25 || (inPitch & 3) || (outPitch & 3) || inPitch < (uint64_t)n * 4 ||
+       outPitch < (uint64_t)capacityPairs * 8 || (location != NFCGPU_LOC_HOST && location != NFCGPU_LOC_DEVICE))
+      return NFCGPU_EINVAL;
+   if (nBuffers == 0)
+      return NFCGPU_OK;
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+   const float *dIn = in;
+   float *dOut = out;
+   uint32_t *dCounts = counts;
+   uint8_t *scratch = nullptr;
+   std::vector<uint32_t> hostCounts;
+
+   const size_t inBytes = (size_t)inPitch * nBuffers, outBytes = (size_t)outPitch * nBuffers, cntBytes = (size_t)nBuffers * 4;
+
+   if (location == NFCGPU_LOC_HOST)
+   {
+      /* one temporary device block: input, output, counts (this entry point is not on the streaming path) */
+      if (hipMalloc((void **)&scratch, inBytes + outBytes + cntBytes) != hipSuccess)
+         return fail(ctx, NFCGPU_ENOMEM, "resampler scratch allocation failed");
+
+      hipError_t err = hipMemcpy(scratch, in, inBytes, hipMemcpyHostToDevice);
+      if (err != hipSuccess)
+      {
+         (void)hipFree(scratch);
+         return fail(ctx, NFCGPU_EHIP, "hipMemcpy(H2D resampler input)", err);
+      }
+
+      dIn = (const float *)scratch;
+      dOut = (float *)(scratch + inBytes);
+      dCounts = (uint32_t *)(scratch + inBytes + outBytes);
+   }
+
+   hipLaunchKernelGGL(nfc_resample_radio_kernel, dim3((nBuffers + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dIn,
+                      inPitch / 4, nBuffers, n, dOut, outPitch / 4, capacityPairs, dCounts);
+
+   hipError_t err = hipGetLastError();
+   if (err == hipSuccess)
+      err = hipStreamSynchronize(ctx->stream);
+
+   hostCounts.resize(nBuffers);
+
+   if (err == hipSuccess)
+      err = hipMemcpy(hostCounts.data(), dCounts, cntBytes, hipMemcpyDeviceToHost);
+
+   if (err == hipSuccess && location == NFCGPU_LOC_HOST)
+   {
+      err = hipMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost);
+      std::memcpy(counts, hostCounts.data(), cntBytes);
+   }
+
+   if (scratch)
+      (void)hipFree(scratch);
+
+   if (err != hipSuccess)
+      return fail(ctx, NFCGPU_EHIP, "adaptive resampler", err);
+
+   for (uint32_t b = 0; b < nBuffers; b++)
+   {
+      if (hostCounts[b] > capacityPairs)
+         return fail(ctx, NFCGPU_EOVERFLOW, "resampler output capacity exceeded: raise capacity_pairs");
+   }
 
    return NFCGPU_OK;
 }

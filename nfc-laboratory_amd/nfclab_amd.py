@@ -118,6 +118,7 @@ def load_library(path=LIB_PATH):
     lib.nfcgpu_submit_batch.argtypes = [vp, P(Batch)]
     lib.nfcgpu_submit_uniform.argtypes = [vp, u32, u32, vp, u64, u32, u32, u32, u32]
     lib.nfcgpu_magnitude.argtypes = [vp, vp, u64, vp, u32]
+    lib.nfcgpu_resample_radio.argtypes = [vp, vp, u64, u32, u32, vp, u64, u32, vp, u32]
     lib.nfcgpu_flush.argtypes = [vp, u32]
     lib.nfcgpu_sync.argtypes = [vp]
     lib.nfcgpu_poll.argtypes = [vp, u32, P(Frame), u32, P(u32)]
@@ -218,6 +219,23 @@ class NfcGpu:
         out = np.empty(n, dtype=np.float32)
         self._check(self.lib.nfcgpu_magnitude(self.ctx, iq.ctypes.data, n, out.ctypes.data, LOC_HOST))
         return out
+
+    def resample_radio(self, buffers, capacity_pairs=None):
+        """Adaptive (value, offset) control points of each row of a 2-D float32 array of magnitude buffers (host memory);
+        returns a list of (pairs, 2) arrays."""
+        buffers = np.ascontiguousarray(buffers, dtype=np.float32)
+        nb, n = buffers.shape
+        cap = capacity_pairs or (n + n // 255 + 2)
+        out = np.zeros((nb, 2 * cap), dtype=np.float32)
+        counts = np.zeros(nb, dtype=np.uint32)
+        self._check(self.lib.nfcgpu_resample_radio(self.ctx, buffers.ctypes.data, n * 4, nb, n, out.ctypes.data, 2 * cap * 4, cap,
+                                                   counts.ctypes.data, LOC_HOST))
+        return [out[b, :2 * counts[b]].reshape(-1, 2) for b in range(nb)]
+
+    def resample_radio_device(self, in_ptr, in_pitch_bytes, n_buffers, n_samples, out_ptr, out_pitch_bytes, capacity_pairs, counts_ptr):
+        """Same with device pointers (input, output and counts resident in HBM)."""
+        self._check(self.lib.nfcgpu_resample_radio(self.ctx, in_ptr, in_pitch_bytes, n_buffers, n_samples, out_ptr, out_pitch_bytes,
+                                                   capacity_pairs, counts_ptr, LOC_DEVICE))
 
     def flush(self, stream):
         self._check(self.lib.nfcgpu_flush(self.ctx, stream))

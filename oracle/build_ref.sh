@@ -75,5 +75,14 @@ for s in "$R/lib-rt/rt-lang/src/main/cpp/Worker.cpp" "$R/lib-rt/rt-lang/src/main
   fi
 done
 ar rcs "$OUT/libnfcref_task.a" $TOBJS
+
+# adaptive resampler oracle: the reference's SignalResamplingTask behind its subjects
+RS="$R/lib-lab/lab-tasks/src/main/cpp/tasks/SignalResamplingTask.cpp"
+RO="$OUT/obj/SignalResamplingTask.o"
+if [ ! -f "$RO" ] || [ "$RS" -nt "$RO" ]; then
+  g++ $CXXFLAGS $TINC -c "$RS" -o "$RO"
+fi
+g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/resample_harness.cpp" "$RO" "$OUT/obj/Worker.o" "$OUT/obj/Executor.o" \
+    "$OUT/libnfcref_support.a" -o "$OUT/resample-ref" -pthread
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/task_harness.cpp" "$OUT/libnfcref_task.a" $OBJS -o "$OUT/task-ref" -pthread
-echo "built $OUT/libnfcref.so $OUT/test-sdr-ref $OUT/task-ref"
+echo "built $OUT/libnfcref.so $OUT/test-sdr-ref $OUT/task-ref $OUT/resample-ref"

@@ -183,6 +183,29 @@ def run_task_harness(exe, names, tmp_path, timeout=900, iq=False):
     return out
 
 
+def reference_resample(name, tmp_path, per_buffer=65536):
+    """Control points published by the reference's SignalResamplingTask for a fixture (oracle/_ref/resample-ref: the
+    real task behind its subjects); returns None when the oracle binary is absent, else a list of float32 arrays."""
+    import struct
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "resample-ref")
+    if not os.path.exists(exe):
+        return None
+    wav = os.path.join(str(tmp_path), name + ".wav")
+    dst = os.path.join(str(tmp_path), name + ".adaptive.bin")
+    write_wav(wav, load_fixture_i16(name))
+    proc = subprocess.run([exe, wav, dst, str(per_buffer)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    raw = open(dst, "rb").read()
+    out, pos = [], 0
+    while pos < len(raw):
+        count = struct.unpack_from("<I", raw, pos)[0]
+        pos += 4
+        out.append(np.frombuffer(raw, dtype=np.float32, count=count, offset=pos).copy())
+        pos += 4 * count
+    return out
+
+
 def describe(t):
     return "tech=%x type=%x flags=%x phase=%x rate=%d start=%d end=%d data=%s" % (
         t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[8].hex(":"))

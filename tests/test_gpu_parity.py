@@ -124,6 +124,25 @@ def test_iq_magnitude_is_bit_exact(gpu):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("name,per_buffer", [("test_NFC-A_106kbps_001", 65536), ("test_POLL_ABF_001", 65536), ("test_NFC-V_26kbps_001", 10007)])
+def test_adaptive_resampler_matches_reference_task(gpu, tmp_path, name, per_buffer):
+    """nfcgpu_resample_radio against the reference's SignalResamplingTask: the (value, offset)
+    control points of every buffer must be bit-identical, including the shorter last buffer."""
+    want = T.reference_resample(name, tmp_path, per_buffer)
+    if want is None:
+        pytest.skip("oracle/_ref/resample-ref not available")
+    x = T.load_fixture(name)
+    full = x.size // per_buffer
+    got = []
+    if full:
+        got += gpu.resample_radio(x[:full * per_buffer].reshape(full, per_buffer))
+    if x.size % per_buffer:
+        got += gpu.resample_radio(x[full * per_buffer:].reshape(1, -1))
+    assert len(got) == len(want)
+    for b, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g.reshape(-1).view(np.uint32), w.view(np.uint32)), "buffer %d: %d vs %d floats" % (b, g.size, w.size)
+
+
 def test_generic_kernels_at_the_specialised_rate(gpu):
     """10 MS/s normally runs the kernels with the derived constants compiled in; the generic kernels (any sample
     rate) must give the same frames at that rate. A second context with NFCGPU_GENERIC_KERNELS=1 decodes a fixture."""

@@ -127,3 +127,24 @@ def test_reference_radio_decoder_task_plumbing(tmp_path):
     got = T.run_task_harness(exe, names, tmp_path)
     for name in names:
         assert got[name] == T.load_golden(name), name
+
+
+def test_reference_resampler_oracle_runs(tmp_path):
+    """The adaptive-resampler oracle (reference SignalResamplingTask behind its subjects) runs here and obeys the
+    invariants of SignalResamplingTask.cpp:168-226: first pair = (first sample, 0), offsets non-decreasing, gaps of at
+    most 255 samples, last offset = last sample of the buffer."""
+    out = T.reference_resample("test_NFC-A_106kbps_001", tmp_path)
+    if out is None:
+        pytest.skip("oracle/_ref/resample-ref not built")
+    x = T.load_fixture("test_NFC-A_106kbps_001")
+    assert len(out) == (x.size + 65535) // 65536
+    pos = 0
+    for buf in out:
+        pairs = buf.reshape(-1, 2)
+        n = min(65536, x.size - pos)
+        assert pairs[0, 0] == x[pos] and pairs[0, 1] == 0.0
+        offsets = pairs[:, 1]
+        assert np.all(np.diff(offsets) >= 0) and np.max(np.diff(offsets)) <= 255
+        assert offsets[-1] == n - 1
+        assert np.array_equal(pairs[:, 0], x[pos + offsets.astype(np.int64)])
+        pos += n
