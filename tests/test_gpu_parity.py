@@ -323,3 +323,29 @@ def test_unsupported_sample_rate_is_rejected_loudly(gpu):
         gpu.submit(sid, np.zeros(100, np.float32), 20000000)  # look-back would exceed the 512-deep history rings
     assert e.value.code == -5
     gpu.close_stream(sid)
+
+
+def test_frame_gather_over_rccl_single_rank(gpu):
+    """The frame gather of bench.py on the GPU backend (torch.distributed "nccl" = RCCL) with a one-rank group: the
+    collectives run on device tensors and return this rank's records unchanged. (world_size 2 is covered on CPU with
+    gloo in test_distributed_gather.py; a one-GPU box cannot host two RCCL ranks.)"""
+    import torch
+    import torch.distributed as dist
+    import frames as framelib
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this interpreter")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        want = {3: [(0x0101, 0x0102, 0, 0x0102, 105938, 1000, 1940, FS, bytes([0x26]))],
+                9: [(0x0102, 0x0103, 2, 0x0103, 105938, 5000, 9000, FS, bytes(range(37)))]}
+        words = framelib.pack_frames(want)
+        sink = torch.zeros(4096, dtype=torch.int32, device="cuda:0")
+        sink[:words.size] = torch.from_numpy(words).to("cuda:0")
+        gathered, counts = framelib.gather_sinks(sink, int(words.size), 1)
+        torch.cuda.synchronize()
+        assert counts == [int(words.size)]
+        assert framelib.parse_sink(gathered[0, :counts[0]].cpu().numpy(), counts[0], FS) == want
+    finally:
+        dist.destroy_process_group()
