@@ -507,7 +507,6 @@ NFC_DEV uint32_t nfca_poll_symbol(const NfcConfig &c, NfcStreamState &s, const N
 /* ---- poll frame assembly, NfcA.cpp:432-563 ---- */
 NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t pattern)
 {
-   NfcTiming &t = mem.cold->tim[0];
    bool frameEnd = false, truncated = false;
 
    if (pattern == A_Y && (s.u.decode.bsPrevious == A_Y || s.u.decode.bsPrevious == A_Z))
@@ -573,7 +572,6 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
-   NfcTiming &t = mem.cold->tim[0];
 
    /* this stage only forms S0 (NfcA.cpp:962-975): same ring, no S1 */
    const uint32_t cur = s.clock - rt.delay;
@@ -736,9 +734,7 @@ NFC_DEV uint32_t nfca_listen_bpsk_start(const NfcConfig &c, NfcStreamState &s, c
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
-   NfcTiming &t = mem.cold->tim[0];
 
-   const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
    const float guardDev = taps.m0;
    const NfcPhase p = nfc_phase_product(mem, s.clock, rt, taps.f0, taps.f1, taps.pp);
@@ -853,7 +849,6 @@ NFC_DEV void nfca_finish_listen(const NfcConfig &c, NfcStreamState &s, const Nfc
 /* ---- one sample in locked NFC-A mode: decodeFrame, NfcA.cpp:416-803 ---- */
 NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
-   NfcTiming &t = mem.cold->tim[0];
 
    if (s.u.decode.frameType == NFC_FRAME_POLL)
    {

@@ -345,9 +345,7 @@ NFC_DEV uint32_t nfcb_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
-   NfcTiming &t = mem.cold->tim[1];
 
-   const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
    const float guardDev = taps.m0;
    const NfcPhase p = nfc_phase_product(mem, s.clock, rt, taps.f0, taps.f1, taps.pp);
@@ -499,7 +497,6 @@ NFC_DEV uint32_t nfcb_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 /* ---- one sample in locked NFC-B mode ---- */
 NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
-   NfcTiming &t = mem.cold->tim[1];
 
    if (s.u.decode.frameType == NFC_FRAME_POLL)
    {

@@ -331,9 +331,7 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
-   NfcTiming &t = mem.cold->tim[2];
 
-   const uint32_t cur = s.clock - rt.delay;
    const uint32_t base = s.u.decode.lockBase;
    const uint32_t pos = nfc_lock_pos(s);
 
@@ -383,7 +381,6 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 /* bits are MSB first, no parity; frame = 2 sync bytes + payload */
 NFC_DEV void nfcf_frame(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, uint32_t pattern, uint32_t type)
 {
-   NfcTiming &t = mem.cold->tim[2];
    bool frameEnd = false, truncated = false;
 
    if (pattern == F_E)

@@ -313,9 +313,7 @@ NFC_DEV uint32_t nfcv_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 {
    const NfcRate &rt = s.u.decode.rt;
    NfcMod &m = s.u.decode.lock;
-   NfcTiming &t = mem.cold->tim[3];
 
-   const uint32_t cur = s.clock - rt.delay;
    const float deep = now.depth;
    const float guardDev = taps.m0;
    float s0 = nfcv_burst_correlation(s, mem, m, taps);
@@ -457,7 +455,6 @@ NFC_DEV uint32_t nfcv_listen_symbol(const NfcConfig &c, NfcStreamState &s, const
 
 NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
-   NfcTiming &t = mem.cold->tim[3];
 
    if (s.u.decode.frameType == NFC_FRAME_POLL)
    {

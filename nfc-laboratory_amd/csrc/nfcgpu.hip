@@ -713,7 +713,6 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
    }
 
    size_t stageAt = 0;
-   uint64_t samples = 0;
 
    for (uint32_t i = 0; i < b->n_streams; i++)
    {
@@ -722,7 +721,6 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       const size_t bytes = (size_t)b->n_samples[i] * b->stride * 4;
 
       w.stride = b->stride;
-      samples += b->n_samples[i];
 
       if (b->location == NFCGPU_LOC_HOST)
       {
