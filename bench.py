@@ -241,6 +241,27 @@ def main():
                           "streams: %.1f Msamples/s (%.1f s)" % (C, T, multi_seconds, L, cores, n_single, single, single_seconds),
                 "single_thread_value": round(single, 3),
             }
+            # BASELINE configs[0]: the reference's RadioDecoderTask itself (subjects + executor + reference decoder, one stream)
+            task = os.path.join(ROOT, "oracle", "_ref", "task-ref")
+            if os.path.exists(task):
+                import subprocess
+                import tempfile
+                try:
+                    with tempfile.TemporaryDirectory() as tmp:
+                        wav = os.path.join(tmp, "plumbing.wav")
+                        one = np.clip(np.rint(mags[0] * 32768.0), -32768, 32767).astype(np.int16)
+                        TL.write_wav(wav, np.tile(one, max(1, int(40e6 // one.size))))
+                        out = subprocess.run([task, wav], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300).stdout
+                        done = [l.split() for l in out.splitlines() if l.startswith("DONE")]
+                        if done:
+                            n_task = one.size * max(1, int(40e6 // one.size))
+                            result["cpu_baseline"]["radio_decoder_task_value"] = round(n_task / float(done[0][3]) / 1e6, 3)
+                            result["cpu_baseline"]["sample"] += "; reference RadioDecoderTask (WAV -> radio.signal.raw -> task -> radio.decoder.frame," \
+                                                               " one stream, %d samples): %.1f Msamples/s" % (n_task, n_task / float(done[0][3]) / 1e6)
+                except Exception as exc:  # the plumbing figure is informative only
+                    result["cpu_baseline"]["radio_decoder_task_value"] = None
+                    result["cpu_baseline"]["sample"] += "; RadioDecoderTask run failed: %r" % (exc,)
+
             result["parity"] = {"streams_checked": checked, "streams_mismatching": bad,
                                 "reference_frames": sum(len(o[1]) for o in outs[:checked])}
         else:
