@@ -1,0 +1,56 @@
+"""Trace writer: what nfclab_amd/trz.py writes must be readable by the reference's own
+tools/py_nfclab reader (when the reference tree is present) and carry exactly the fields the reference's
+TraceStorageTask::readFrameEntry requires."""
+import json
+import os
+import sys
+import tarfile
+
+import pytest
+
+import nfc_testlib as T
+
+sys.path.insert(0, os.path.join(T.ROOT, "nfc-laboratory_amd"))
+import trz  # noqa: E402
+
+REQUIRED = ("techType", "frameType", "framePhase", "frameFlags", "frameRate", "sampleStart", "sampleEnd", "sampleRate",
+            "timeStart", "timeEnd", "dateTime")
+
+
+def test_trace_has_the_fields_the_reference_reader_requires(tmp_path):
+    frames = T.load_golden("test_POLL_ABF_001")
+    path = str(tmp_path / "poll.trz")
+    trz.write_trz(path, frames, stream_time=1700000000)
+    with tarfile.open(path, "r:gz") as tar:
+        data = json.load(tar.extractfile(tar.getmember("frame.json")))
+    assert len(data["frames"]) == len(frames)
+    golden = json.load(open(os.path.join(T.GOLDEN, "wav", "test_POLL_ABF_001.json")))["frames"]
+    for entry, frame, ref in zip(data["frames"], frames, golden):
+        for key in REQUIRED:
+            assert key in entry
+        # same values as the reference wrote into its own golden JSON for these frames
+        for key in ("techType", "frameType", "framePhase", "frameFlags", "frameRate", "sampleStart", "sampleEnd", "sampleRate"):
+            assert entry[key] == ref[key]
+        assert entry.get("frameData", "") == ref["frameData"]
+        assert entry["timeStart"] == ref["timeStart"] and entry["timeEnd"] == ref["timeEnd"]
+        assert entry["dateTime"] == 1700000000 + ref["timeStart"]
+
+
+def test_trace_opens_with_the_reference_python_reader(tmp_path):
+    tools = os.path.join(os.environ.get("NFC_REFERENCE_ROOT", "/root/reference"), "tools")
+    if not os.path.isdir(os.path.join(tools, "py_nfclab")):
+        pytest.skip("reference tree not present")
+    sys.path.insert(0, tools)
+    try:
+        from py_nfclab.readers import read_trz
+    except Exception as exc:  # the reference package may need modules this image lacks
+        pytest.skip("py_nfclab not importable here: %r" % (exc,))
+    frames = T.load_golden("test_NFC-A_106kbps_001") + T.load_golden("test_NFC-V_26kbps_001")
+    path = str(tmp_path / "mixed.trz")
+    trz.write_trz(path, frames)
+    got = read_trz(path)
+    assert len(got) == len(frames)
+    for g, f in zip(got, frames):
+        assert (int(g.tech_type), int(g.frame_type), g.sample_start, g.sample_end, g.sample_rate, g.frame_rate) == \
+               (f[0], f[1], f[5], f[6], f[7], f[4])
+        assert bytes(g.data) == f[8]
