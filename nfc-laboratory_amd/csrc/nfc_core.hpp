@@ -41,6 +41,11 @@
 #define NFC_OPAQUE(x) asm volatile("" : "+r"(x))
 #endif
 
+/* true when the predicate holds for any stream of the block (wave-uniform on the device) */
+#ifndef NFC_ANY
+#error "define NFC_ANY(predicate) before including nfc_core.hpp"
+#endif
+
 /* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
 struct NfcLaneMem
 {
@@ -572,7 +577,9 @@ struct NfcDecTaps
    float c2, c3; /* correlation ring entries half a symbol (V listen: one symbol) / one sample back */
 };
 
-NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamState &s)
+/* `valid` is false for lanes that are not in decode mode when the reads are issued for the whole block: their decode
+ * registers hold detector records, so their ring indices are forced in range (the values are never used) */
+NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamState &s, bool valid)
 {
    const NfcDecodeRegs &d = s.u.decode;
    const NfcRate &rt = d.rt;
@@ -596,8 +603,8 @@ NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamSt
                                : nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p2, rt.p1);
    const uint32_t p3 = nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p1 - 1u, rt.p1);
 
-   t.c2 = NFC_AT(mem, NFC_R_CORR, d.lockBase + p2);
-   t.c3 = NFC_AT(mem, NFC_R_CORR, d.lockBase + p3);
+   t.c2 = NFC_AT(mem, NFC_R_CORR, valid ? d.lockBase + p2 : 0u);
+   t.c3 = NFC_AT(mem, NFC_R_CORR, valid ? d.lockBase + p3 : 0u);
 
    return t;
 }
@@ -780,44 +787,42 @@ NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    NFC_OPAQUE(inSearch);
    NFC_OPAQUE(inDecode);
 
-   uint32_t readDecode = mode;
-   NFC_OPAQUE(readDecode);
-
-   /* a block with streams in both modes runs both regions below: the decode-mode reads are issued before the search
-    * region so that its wait covers them too (one memory latency per step instead of two) */
+   /* History reads of the step, issued for the whole block under wave-uniform conditions (values produced inside a
+    * divergent region and consumed in a later one would be waited for at the end of the first), all before the front
+    * end stores the sample: one memory latency per step whatever mix of modes the block is in. */
    NfcDecTaps taps;
+   NfcTapsA ta;
+   NfcTapsB tb;
+   NfcTapsF tf;
+   NfcTapsV tv;
 
-   if (readDecode != 0)
-   {
+   uint32_t locked = mode;
+   NFC_OPAQUE(locked);
+
+   if (locked != 0)
       nfc_advance_lock_pos(s, mem);
-      taps = nfc_load_decode_taps(mem, s);
-   }
 
-   /* each mode is a self-contained region (front end, its machines): the front end is cheap enough to appear
-    * twice, and values produced in one region and consumed after it would have to be waited for at its end */
-   if (inSearch == 0)
+   if (NFC_ANY(mode != 0))
+      taps = nfc_load_decode_taps(mem, s, mode != 0);
+
+   if (NFC_ANY(mode == 0))
    {
-      /* unconditional within search mode: the addresses are always inside the stream block, and a detector that
-       * is disabled or not yet armed (first 1024 samples) simply ignores what was read */
-      NfcTapsA ta;
-      NfcTapsB tb;
-      NfcTapsF tf;
-      NfcTapsV tv;
-
+      /* the addresses are always inside the stream block, and a detector that is disabled or not yet armed (first
+       * 1024 samples) simply ignores what was read */
       nfca_load_taps(c, s, mem, ta);
       nfcb_load_taps(c, s, mem, tb);
       nfcf_load_taps(c, s, mem, tf);
       nfcv_load_taps(c, s, mem, tv);
-
-      const NfcNow now = nfc_front_end(c, s, mem, value);
-
-      nfc_search_detect(c, s, mem, now, ta, tb, tf, tv);
    }
+
+   /* the front end is the same in both modes */
+   const NfcNow now = nfc_front_end(c, s, mem, value);
+
+   if (inSearch == 0)
+      nfc_search_detect(c, s, mem, now, ta, tb, tf, tv);
 
    if (inDecode != 0)
    {
-      const NfcNow now = nfc_front_end(c, s, mem, value);
-
       /* without delay the decode point is the sample the front end has just produced (not in memory when the taps
        * were read) */
       if (s.u.decode.rt.delay == 0)

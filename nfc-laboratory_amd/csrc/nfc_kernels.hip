@@ -18,6 +18,7 @@
 
 #define NFC_DEV __device__ __forceinline__
 #define NFC_ATOMIC_ADD(ptr, value) atomicAdd((ptr), (value))
+#define NFC_ANY(predicate) (__any(predicate) != 0)
 
 #include "nfc_core.hpp"
 #include "nfc_launch.h"
