@@ -583,21 +583,25 @@ NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamSt
 {
    const NfcDecodeRegs &d = s.u.decode;
    const NfcRate &rt = d.rt;
-   const uint32_t cur = s.clock - rt.delay;
    const bool vListen = (s.lockTech == NFC_TECH_V) && (d.frameType == NFC_FRAME_LISTEN);
 
    /* integration window of the listen-mode product ring: p2 for NFC-A 106k (ASK), p1 for NFC-V, p4 for BPSK */
    const uint32_t window = (s.lockTech == NFC_TECH_A && d.lockRate == 0) ? rt.p2 : ((s.lockTech == NFC_TECH_V) ? rt.p1 : rt.p4);
 
+   /* lanes without a lock read the current slot of each ring (rows the locked lanes of the block mostly read too)
+    * instead of wherever their detector records, taken for a bitrate, would point */
+   const uint32_t cur = s.clock - (valid ? rt.delay : 0u);
+   const uint32_t back1 = valid ? rt.p1 : 0u, back2 = valid ? rt.p2 : 0u, backW = valid ? window : 0u;
+
    NfcDecTaps t;
 
    t.x0 = NFC_AT(mem, NFC_R_X, cur & NFC_HMASK);
-   t.x2 = NFC_AT(mem, NFC_R_X, (cur - rt.p2) & NFC_HMASK);
+   t.x2 = NFC_AT(mem, NFC_R_X, (cur - back2) & NFC_HMASK);
    t.f0 = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
-   t.f1 = NFC_AT(mem, NFC_R_FILT, (cur - rt.p1) & NFC_HMASK);
+   t.f1 = NFC_AT(mem, NFC_R_FILT, (cur - back1) & NFC_HMASK);
    t.m0 = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
    t.d0 = NFC_AT(mem, NFC_R_DEPTH, cur & NFC_HMASK);
-   t.pp = NFC_AT(mem, NFC_R_PROD, (cur - window) & NFC_PMASK);
+   t.pp = NFC_AT(mem, NFC_R_PROD, (cur - backW) & NFC_PMASK);
 
    const uint32_t p2 = vListen ? nfc_point(mem, s.clock, rt.delay, s.posV0, rt.p1, rt.p0)
                                : nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p2, rt.p1);
