@@ -577,38 +577,56 @@ struct NfcDecTaps
    float c2, c3; /* correlation ring entries half a symbol (V listen: one symbol) / one sample back */
 };
 
-/* `valid` is false for lanes that are not in decode mode when the reads are issued for the whole block: their decode
- * registers hold detector records, so their ring indices are forced in range (the values are never used) */
+/* The decode-mode reads are issued for the whole block (nfc_step_as). What a lane really needs depends on its frame
+ * stage: the raw-signal correlators (poll frames of NFC-A/F/V, all of NFC-F) read x0 x2 c2 c3, the power / phase
+ * correlators (listen frames of NFC-A/B/V) f0 f1 pp c2 c3, NFC-B poll frames f0 d0; with no detection delay the four
+ * values at the decode point come from the front end, not from memory. A read a lane does not need (and every read
+ * of a lane that is not locked: `valid` false, its decode registers hold detector records) is pointed at the lane's
+ * correlation-ring entry, a row the block fetches anyway, and a read no lane of the block needs is not issued. */
 NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamState &s, bool valid)
 {
    const NfcDecodeRegs &d = s.u.decode;
    const NfcRate &rt = d.rt;
+   const uint32_t cur = s.clock - rt.delay;
    const bool vListen = (s.lockTech == NFC_TECH_V) && (d.frameType == NFC_FRAME_LISTEN);
 
    /* integration window of the listen-mode product ring: p2 for NFC-A 106k (ASK), p1 for NFC-V, p4 for BPSK */
    const uint32_t window = (s.lockTech == NFC_TECH_A && d.lockRate == 0) ? rt.p2 : ((s.lockTech == NFC_TECH_V) ? rt.p1 : rt.p4);
 
-   /* lanes without a lock read the current slot of each ring (rows the locked lanes of the block mostly read too)
-    * instead of wherever their detector records, taken for a bitrate, would point */
-   const uint32_t cur = s.clock - (valid ? rt.delay : 0u);
-   const uint32_t back1 = valid ? rt.p1 : 0u, back2 = valid ? rt.p2 : 0u, backW = valid ? window : 0u;
-
-   NfcDecTaps t;
-
-   t.x0 = NFC_AT(mem, NFC_R_X, cur & NFC_HMASK);
-   t.x2 = NFC_AT(mem, NFC_R_X, (cur - back2) & NFC_HMASK);
-   t.f0 = NFC_AT(mem, NFC_R_FILT, cur & NFC_HMASK);
-   t.f1 = NFC_AT(mem, NFC_R_FILT, (cur - back1) & NFC_HMASK);
-   t.m0 = NFC_AT(mem, NFC_R_MDEV, cur & NFC_HMASK);
-   t.d0 = NFC_AT(mem, NFC_R_DEPTH, cur & NFC_HMASK);
-   t.pp = NFC_AT(mem, NFC_R_PROD, (cur - backW) & NFC_PMASK);
+   const bool poll = d.frameType == NFC_FRAME_POLL;
+   const bool raw = valid && (s.lockTech == NFC_TECH_F || (poll && s.lockTech != NFC_TECH_B));
+   const bool filt = valid && !raw;
+   const bool stored = valid && rt.delay != 0; /* the decode point lies in the past: its values are in the rings */
 
    const uint32_t p2 = vListen ? nfc_point(mem, s.clock, rt.delay, s.posV0, rt.p1, rt.p0)
                                : nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p2, rt.p1);
    const uint32_t p3 = nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p1 - 1u, rt.p1);
 
-   t.c2 = NFC_AT(mem, NFC_R_CORR, valid ? d.lockBase + p2 : 0u);
-   t.c3 = NFC_AT(mem, NFC_R_CORR, valid ? d.lockBase + p3 : 0u);
+   /* slot index (within the stream block) of the row every lane reads anyway */
+   const uint32_t common = NFC_R_CORR + (valid ? d.lockBase + p2 : 0u);
+
+   NfcDecTaps t;
+
+   t.c2 = NFC_AT(mem, 0u, common);
+   t.c3 = NFC_AT(mem, 0u, valid ? NFC_R_CORR + d.lockBase + p3 : common);
+
+   t.x0 = t.x2 = t.f0 = t.f1 = t.m0 = t.d0 = t.pp = 0.0f;
+
+   if (NFC_ANY(raw && stored))
+      t.x0 = NFC_AT(mem, 0u, raw && stored ? NFC_R_X + (cur & NFC_HMASK) : common);
+   if (NFC_ANY(raw))
+      t.x2 = NFC_AT(mem, 0u, raw ? NFC_R_X + ((cur - rt.p2) & NFC_HMASK) : common);
+   if (NFC_ANY(filt && stored))
+      t.f0 = NFC_AT(mem, 0u, filt && stored ? NFC_R_FILT + (cur & NFC_HMASK) : common);
+   if (NFC_ANY(filt))
+   {
+      t.f1 = NFC_AT(mem, 0u, filt ? NFC_R_FILT + ((cur - rt.p1) & NFC_HMASK) : common);
+      t.pp = NFC_AT(mem, 0u, filt ? NFC_R_PROD + ((cur - window) & NFC_PMASK) : common);
+   }
+   if (NFC_ANY(stored))
+      t.m0 = NFC_AT(mem, 0u, stored ? NFC_R_MDEV + (cur & NFC_HMASK) : common);
+   if (NFC_ANY(filt && stored && poll))
+      t.d0 = NFC_AT(mem, 0u, filt && stored && poll ? NFC_R_DEPTH + (cur & NFC_HMASK) : common);
 
    return t;
 }
