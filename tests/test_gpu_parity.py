@@ -349,3 +349,41 @@ def test_frame_gather_over_rccl_single_rank(gpu):
         assert framelib.parse_sink(gathered[0, :counts[0]].cpu().numpy(), counts[0], FS) == want
     finally:
         dist.destroy_process_group()
+
+
+def test_streams_joining_a_block_at_different_times(gpu):
+    """Streams of one block opened at different moments and fed ragged buffer lengths: blocks then hold streams that
+    need the exact-modulo kernel (first 1024 samples) next to streams that do not, launches mix both kernels, and the
+    host-side clock mirrors must keep agreeing with the device. Every stream is compared with the reference."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    rng = np.random.default_rng(77)
+    from test_oracle_goldens import _fuzz_stream
+    total = 120000
+    n = 24
+    data = [_fuzz_stream(7000 + i, total) for i in range(n)]
+    start_step = [0 if i < 6 else int(rng.integers(1, 12)) for i in range(n)]
+    fed = [0] * n
+    ids = [None] * n
+    step = 0
+    while any(f < total for f in fed):
+        sel, ptrs, cnts, keep = [], [], [], []
+        for i in range(n):
+            if step < start_step[i] or fed[i] >= total:
+                continue
+            if ids[i] is None:
+                ids[i] = gpu.open()
+            if rng.random() < 0.2:
+                continue  # this stream skips the step
+            c = int(min(total - fed[i], rng.integers(1, 9000)))
+            part = np.ascontiguousarray(data[i][fed[i]:fed[i] + c])
+            keep.append(part)
+            sel.append(ids[i]); ptrs.append(part.ctypes.data); cnts.append(c)
+            fed[i] += c
+        if sel:
+            gpu.submit_batch(sel, ptrs, cnts, FS)
+        step += 1
+    for i in range(n):
+        ref, _ = T.reference_decode(data[i], keep_carrier=True, cap=16384)
+        assert gpu.poll(ids[i], capacity=16384) == ref, "stream %d" % i
+        gpu.close_stream(ids[i])
