@@ -655,21 +655,29 @@ NFC_DEV void nfc_search_detect(const NfcConfig &c, NfcStreamState &s, const NfcL
 {
    nfc_detect_carrier(c, s, mem);
 
+   /* the detectors run once the decoder has seen 1024 samples and while there is a carrier (the gates at the top of
+    * each detectModulation: NfcA.cpp:220-225, NfcB.cpp:241-246, NfcF.cpp:209-214, NfcV.cpp:239-244) */
+   const bool armed = s.clock >= 1024u && !(s.env < c.powerThreshold);
+
    uint32_t locked = 0;
 
-   if ((c.enabled & 1u) && nfca_detect(c, s, mem, ta, now))
-      locked = NFC_TECH_A;
-   else if ((c.enabled & 2u) && nfcb_detect(c, s, mem, tb, now))
-      locked = NFC_TECH_B;
-   else if ((c.enabled & 4u) && nfcf_detect(c, s, mem, tf, now))
-      locked = NFC_TECH_F;
-   else if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
-      locked = NFC_TECH_V;
+   if (armed)
+   {
+      /* first detector that recognises its start of frame wins, later ones skip this sample */
+      if ((c.enabled & 1u) && nfca_detect(c, s, mem, ta, now))
+         locked = NFC_TECH_A;
+      else if ((c.enabled & 2u) && nfcb_detect(c, s, mem, tb, now))
+         locked = NFC_TECH_B;
+      else if ((c.enabled & 4u) && nfcf_detect(c, s, mem, tf, now))
+         locked = NFC_TECH_F;
+      else if ((c.enabled & 8u) && nfcv_detect(c, s, mem, tv, now))
+         locked = NFC_TECH_V;
 
-   /* every detector that is enabled stepped its correlator on this sample (or none did: the gates are common):
-    * on the next sample ring[(idx - 1) % p1] is known to equal the running sum and need not be read back */
-   if (!locked && s.clock >= 1024u && !(s.env < c.powerThreshold))
-      s.bankClock = s.clock;
+      /* every detector that is enabled stepped its correlator on this sample: on the next sample
+       * ring[(idx - 1) % p1] is known to equal the running sum and need not be read back */
+      if (!locked)
+         s.bankClock = s.clock;
+   }
 
    if (locked)
       nfc_enter_lock(s, mem, locked);

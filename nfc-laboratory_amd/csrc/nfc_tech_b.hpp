@@ -278,14 +278,9 @@ NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLan
    return 1;
 }
 
+/* the caller has checked that the search bank is armed (nfc_search_detect) */
 NFC_DEV bool nfcb_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsB &taps, const NfcNow &now)
 {
-   if (s.clock < 1024u)
-      return false;
-
-   if (s.env < c.powerThreshold)
-      return false;
-
    int r0 = nfcb_detect_rate<0>(c, s, mem, taps, now);
    if (r0)
       return r0 == 1;

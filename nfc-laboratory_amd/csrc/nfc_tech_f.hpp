@@ -252,14 +252,9 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    return true;
 }
 
+/* the caller has checked that the search bank is armed (nfc_search_detect) */
 NFC_DEV bool nfcf_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsF &taps, const NfcNow &now)
 {
-   if (s.clock < 1024u)
-      return false;
-
-   if (s.env < c.powerThreshold)
-      return false;
-
    const float minimumCorrelation = s.env * c.corrThreshold[2];
 
    if (nfcf_detect_rate<1>(c, s, mem, taps, now, minimumCorrelation))

@@ -96,14 +96,9 @@ NFC_DEV float nfcv_pulse_apply(const NfcLaneMem &mem, M &m, const NfcTap &t, uin
    return (t.c2 - m.acc) / (float)rt.p2;
 }
 
+/* the caller has checked that the search bank is armed (nfc_search_detect) */
 NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsV &taps, const NfcNow &now)
 {
-   if (s.clock < 1024u)
-      return false;
-
-   if (s.env < c.powerThreshold)
-      return false;
-
    const NfcRate &rt = c.v;
    NfcDetV &m = s.u.search.detV;
 
