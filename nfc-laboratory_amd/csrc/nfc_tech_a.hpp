@@ -310,7 +310,16 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[R], s.posA[R]);
    const float num = k.s0 - k.s1;
 
-   if (m.peakTime && s.clock > m.peakTime + rt.p1)
+   /* nothing below changes the record or returns true unless the tracked pause timed out, or the search window is
+    * open and either the correlation can exceed the threshold or the window ends now: one branch for the common
+    * case instead of one per condition */
+   const bool timeout = m.peakTime && s.clock > m.peakTime + rt.p1;
+   const bool eventful = s.clock >= m.winStart && (nfc_may_exceed(num, (float)rt.p2, minimumCorrelation) || s.clock == m.winEnd);
+
+   if (!timeout && !eventful)
+      return false;
+
+   if (timeout)
    {
       m.symStart = 0; m.winStart = 0; m.winEnd = 0;
       m.aux = 0; m.peakTime = 0; m.peak = 0;

@@ -166,7 +166,15 @@ NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLan
    float edge = rt.delay ? taps.edge[R] : now.filt;
    float deep = rt.delay ? taps.deep[R] : now.depth;
 
-   if (deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1))
+   /* one branch for the common case: no start of frame is being tracked, no reset, no falling edge beyond the threshold
+    * and the (closed) window does not end now. The threshold of that state is recomputed on every sample before it is
+    * used, so not storing it on the early exit changes nothing. */
+   const bool reset = deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1);
+
+   if (!reset && !m.symStart && !(edge < -(s.env * c.minDepth[1])) && s.clock != m.winEnd)
+      return 0;
+
+   if (reset)
    {
       m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
       m.auxTime = 0; m.aux = 0;

@@ -209,7 +209,16 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[2 + R], s.posF[R - 1]);
    const float num = k.s0 - k.s1;
 
-   if (deep > c.maxDepth[2] || (m.peakTime && s.clock > m.peakTime + rt.p1))
+   /* one branch for the common case: without a reset, with the window closed or with a correlation that cannot exceed
+    * the threshold away from the synchronisation point and the window end, nothing below changes the record */
+   const bool reset = deep > c.maxDepth[2] || (m.peakTime && s.clock > m.peakTime + rt.p1);
+   const bool eventful = s.clock >= m.winStart &&
+                         (nfc_may_exceed(num, (float)rt.p2, minimumCorrelation) || s.clock == m.sync || s.clock == m.winEnd);
+
+   if (!reset && !eventful)
+      return false;
+
+   if (reset)
    {
       /* (detectorPeak* are never set by this detector: nothing to clear) */
       m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;

@@ -110,7 +110,14 @@ NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    NFC_AT(mem, NFC_R_CORR, c.corrOffset[5] + s.posV1) = m.acc;
    const float num = taps.t.c2 - m.acc;
 
-   if (m.peakTime && s.clock > m.peakTime + rt.p0)
+   /* one branch for the common case (see nfca_detect_rate) */
+   const bool timeout = m.peakTime && s.clock > m.peakTime + rt.p0;
+   const bool eventful = s.clock >= m.winStart && (nfc_may_exceed(num, (float)rt.p2, minimumCorrelation) || s.clock == m.winEnd);
+
+   if (!timeout && !eventful)
+      return false;
+
+   if (timeout)
    {
       m.symStart = 0; m.winStart = 0; m.winEnd = 0;
       m.aux = 0; m.peakTime = 0; m.peak = 0;
