@@ -46,6 +46,14 @@
 #error "define NFC_ANY(predicate) before including nfc_core.hpp"
 #endif
 
+/* Marks a freshly loaded value as used at this point, so that the wait for the load is placed here (inside the rare
+ * branch that issued it) and not where the branch rejoins the common path. */
+#ifdef __HIP_DEVICE_COMPILE__
+#define NFC_ARRIVED(x) asm volatile("" : "+v"(x))
+#else
+#define NFC_ARRIVED(x) ((void)(x))
+#endif
+
 /* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
 struct NfcLaneMem
 {
@@ -453,7 +461,13 @@ NFC_DEV float nfc_previous_sum(const NfcLaneMem &mem, const NfcStreamState &s, c
    if (s.bankClock == s.clock - 1u)
       return m.acc;
 
-   return NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
+   /* rare (first search sample after a gap). The value is marked as used here so that the wait for this load sits in
+    * this branch: otherwise the compiler waits where the two paths meet, on every sample, and with an in-order memory
+    * counter that wait also covers the ring store of the detector before this one (a full store round trip per
+    * correlator per sample: it was 40 % of the idle step) */
+   float previous = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
+   NFC_ARRIVED(previous);
+   return previous;
 }
 
 template <class M>
