@@ -277,6 +277,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 struct NfcTapsA
 {
    NfcTap t[3];
+   float deep[3]; /* modulation depth one eighth of a symbol before the (delayed) sample: used while a pause is tracked */
 };
 
 template <int R>
@@ -284,6 +285,11 @@ NFC_DEV void nfca_load_taps_rate(const NfcConfig &c, const NfcStreamState &s, co
 {
    /* ring[(idx - 1) % p1] is read in nfca_detect_rate only after a gap in the search (see bankClock) */
    taps.t[R] = nfc_tap_raw(mem, s.clock, c.a[R], c.corrOffset[R], s.posA[R], false);
+
+   /* read with the others although only needed during a pause: a load inside the detector is waited for with
+    * everything else outstanding, the ring stores of the detectors before it included (p8 >= 1: never the slot being
+    * written) */
+   taps.deep[R] = NFC_AT(mem, NFC_R_DEPTH, (s.clock - c.a[R].delay - c.a[R].p8) & NFC_HMASK);
 }
 
 NFC_DEV void nfca_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsA &taps)
@@ -336,8 +342,7 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
       {
          if (sd < -minimumCorrelation)
          {
-            /* modulation depth one eighth of a symbol back: only needed while a pause is being tracked */
-            float deep = NFC_AT(mem, NFC_R_DEPTH, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+            const float deep = taps.deep[R];
 
             if (sd < m.peak)
             {
