@@ -149,7 +149,7 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n_samples, float
  * restarts with it), the output of buffer b is written as float pairs at out + b * out_pitch_bytes and its pair count
  * to counts[b] — the contents of the SIGNAL_TYPE_RADIO_SIGNAL buffer the reference publishes on "adaptive.signal".
  * capacity_pairs bounds what is written per buffer (the worst case is n_samples + n_samples / 255 + 2 pairs); a buffer
- * that needs more keeps counting and the call returns NFCGPU_EOVERFLOW. n_samples >= 25. `location` applies to `in`,
+ * that needs more keeps counting and the call returns NFCGPU_EOVERFLOW. n_samples >= 25. `out` and out_pitch_bytes are 8-byte aligned. `location` applies to `in`,
  * `out` and `counts` alike. */
 int nfcgpu_resample_radio(nfcgpu_ctx *ctx, const float *in, uint64_t in_pitch_bytes, uint32_t n_buffers, uint32_t n_samples,
                           float *out, uint64_t out_pitch_bytes, uint32_t capacity_pairs, uint32_t *counts, uint32_t location);

@@ -307,10 +307,7 @@ __global__ __launch_bounds__(64) void nfc_resample_radio_kernel(const float *__r
 
    auto put = [&](float value, float offset) {
       if (mine && count < capacityPairs)
-      {
-         dst[2 * count] = value;
-         dst[2 * count + 1] = offset;
-      }
+         reinterpret_cast<float2 *>(dst)[count] = make_float2(value, offset); /* rows are 8-byte aligned (pitch % 8 == 0) */
       count++;
    };
 

@@ -892,7 +892,7 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n, float *out, u
 int nfcgpu_resample_radio(nfcgpu_ctx *ctx, const float *in, uint64_t inPitch, uint32_t nBuffers, uint32_t n, float *out, uint64_t outPitch,
                           uint32_t capacityPairs, uint32_t *counts, uint32_t location)
 {
-   if (!ctx || !in || !out || !counts || n < 25 || (inPitch & 3) || (outPitch & 3) || inPitch < (uint64_t)n * 4 ||
+   if (!ctx || !in || !out || !counts || n < 25 || (inPitch & 3) || (outPitch & 7) || ((uintptr_t)out & 7) || inPitch < (uint64_t)n * 4 ||
        outPitch < (uint64_t)capacityPairs * 8 || (location != NFCGPU_LOC_HOST && location != NFCGPU_LOC_DEVICE))
       return NFCGPU_EINVAL;
    if (nBuffers == 0)
