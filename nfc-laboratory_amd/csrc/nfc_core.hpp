@@ -54,6 +54,16 @@
 #define NFC_ARRIVED(x) ((void)(x))
 #endif
 
+/* Wait for every outstanding memory operation. Used after the bulk state reloads of the rare lock / unlock events and
+ * after the state record is read at kernel start: left outstanding into the sample loop, each of those ~100 registers
+ * would carry a conservative wait (covering stores as well, see NFC_ARRIVED) to wherever it is first touched in the
+ * next step - on the common path. */
+#ifdef __HIP_DEVICE_COMPILE__
+#define NFC_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0) */
+#else
+#define NFC_DRAIN() ((void)0)
+#endif
+
 /* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
 struct NfcLaneMem
 {
@@ -560,6 +570,7 @@ NFC_DEV void nfc_enter_lock(NfcStreamState &s, const NfcLaneMem &mem, uint32_t t
    s.u.decode = mem.cold->init;
    s.u.decode.maxFrame = mem.cold->tim[tech - NFC_TECH_A].maxFrameSize;
    s.lockTech = tech;
+   NFC_DRAIN();
 }
 
 /* leave decode mode (the technology resets). The decode register set dies here; bringing the detector records
@@ -803,6 +814,8 @@ NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcL
       nfc_mod_clear(s.u.search.detV);
       nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[5], c.v.p0);
    }
+
+   NFC_DRAIN();
 }
 
 /* One sample. The mode the sample is handled in is the one the stream is in when the sample arrives (a detector

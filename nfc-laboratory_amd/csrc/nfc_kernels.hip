@@ -191,6 +191,9 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
    mem.cold = L.cold + slot;
    mem.tables = cfgPtr;
 
+   /* receive the state record here, once (see NFC_DRAIN) */
+   NFC_DRAIN();
+
    for (uint32_t base = 0; base < longest; base += TILE)
    {
       if (L.uniformStride == 2)
