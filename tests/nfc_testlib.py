@@ -120,6 +120,28 @@ def reference_decode(samples, sample_rate=10000000, chunk=65536, tech_mask=0xF, 
     return frames_to_tuples(out, n, keep_carrier=True), secs.value
 
 
+def reference_decode_fresh(samples, **kw):
+    """reference_decode in a child process of its own. The reference classifies some truncated frames from bytes beyond
+    the frame length (ATS without its TB byte, NfcA.cpp:1736-1769; one-byte NFC-F polls, NfcF.cpp:1151-1160), i.e. from
+    whatever its recycled RawFrame storage (rt::Heap, Alloc.h:41-56) held before, so within one process its answer can
+    depend on the captures decoded earlier. A fresh process is its deterministic form: new storage reads as zero."""
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "x.npy"), np.ascontiguousarray(samples, dtype=np.float32))
+        with open(os.path.join(tmp, "kw.pkl"), "wb") as f:
+            pickle.dump(kw, f)
+        code = ("import sys, pickle, numpy as np; sys.path.insert(0, %r); import nfc_testlib as T; "
+                "kw = pickle.load(open(%r, 'rb')); out, _ = T.reference_decode(np.load(%r), **kw); "
+                "pickle.dump(out, open(%r, 'wb'))") % (os.path.join(ROOT, "tests"), os.path.join(tmp, "kw.pkl"),
+                                                       os.path.join(tmp, "x.npy"), os.path.join(tmp, "out.pkl"))
+        subprocess.run([sys.executable, "-c", code], check=True, timeout=600)
+        with open(os.path.join(tmp, "out.pkl"), "rb") as f:
+            return pickle.load(f)
+
+
 _sim = None
 
 

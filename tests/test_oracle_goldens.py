@@ -103,6 +103,20 @@ def test_step_machine_matches_reference_on_fuzzed_streams(built, seed):
     assert len(ref) > 0
 
 
+def test_truncated_ats_is_classified_as_in_fresh_reference_storage(built):
+    """Found by profiles/tools/long_fuzz.py (seed 31337, capture 292): an ATS cut to `05 78 33` announces TA and TB but
+    ends before TB, and the reference takes FWI from frame[3] beyond the frame (NfcA.cpp:1736-1769), so the waiting time
+    of every later poll frame depends on what its recycled frame storage held. Bytes beyond a frame read as zero here,
+    which is the reference's own answer in a fresh process."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    x = _fuzz_stream(31337 + 13 * 292, 250000)
+    ref = T.reference_decode_fresh(x, keep_carrier=True, cap=16384)
+    got = T.hostsim_decode(x, keep_carrier=True, cap=16384, lane=3)
+    assert got == ref
+    assert any(f[1] == 0x103 and f[-1] == bytes([0x05, 0x78, 0x33]) for f in ref)
+
+
 @pytest.mark.parametrize("rate,step", [(5000000, 2), (2500000, 4)])
 @pytest.mark.parametrize("name", ["test_NFC-A_106kbps_001", "test_NFC-B_106kbps_001", "test_NFC-F_212kbps_002", "test_NFC-V_26kbps_002"])
 def test_step_machine_matches_reference_at_other_sample_rates(built, name, rate, step):
