@@ -223,7 +223,7 @@ def main():
             checked = min(C, args.check_streams)
             outs = []
             for s in range(checked):
-                fr, _ = TL.reference_decode(mags[s], sample_rate=FS, chunk=L, keep_carrier=True, cap=8192)
+                fr, _ = TL.reference_decode(mags[s], sample_rate=FS, chunk=L, keep_carrier=True, cap=8192, defined_storage=True)
                 outs.append((s, fr, 0.0))
 
             bad = 0

@@ -58,7 +58,8 @@ for p in $pids; do wait $p; done
 ar rcs "$OUT/libnfcref_support.a" $(echo $OBJS | tr ' ' '\n' | grep -v -e NfcDecoder.o -e NfcTech.o -e NfcA.o -e NfcB.o -e NfcF.o -e NfcV.o)
 
 g++ $CXXFLAGS $INC -c "$HERE/ref_capi.cpp" -o "$OUT/obj/ref_capi.o"
-g++ -shared -o "$OUT/libnfcref.so" "$OUT/obj/ref_capi.o" $OBJS -pthread
+# posix_memalign is wrapped so that nfcref_decode_defined() can hand the reference cleared frame storage (ref_capi.cpp)
+g++ -shared -o "$OUT/libnfcref.so" "$OUT/obj/ref_capi.o" $OBJS -pthread -Wl,--wrap=posix_memalign
 
 g++ $CXXFLAGS $INC "$REF/src/nfc-test/test-sdr/src/main/cpp/main.cpp" $OBJS -o "$OUT/test-sdr-ref" -pthread
 

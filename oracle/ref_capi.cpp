@@ -27,6 +27,32 @@
 #include <lab/data/RawFrame.h>
 #include <lab/nfc/NfcDecoder.h>
 
+/*
+ * Defined frame storage. The reference classifies some truncated frames from bytes beyond the frame length (ATS without
+ * its TB byte, NfcA.cpp:1736-1769; an ATQB shorter than 12 bytes, NfcB.cpp:1186-1187; NFC-F polls shorter than 6 bytes,
+ * NfcF.cpp:1151-1160). RawFrame storage comes from posix_memalign without clearing (rt/Alloc.h:41-56) and is recycled
+ * first-fit through a process-wide pool (rt/Heap.h:41-56), so those bytes are whatever an earlier frame, an earlier
+ * capture or malloc left there: the same capture can decode differently depending on what the process did before and on
+ * how long the caller keeps its frames. nfcref_decode_defined() runs the same unmodified decoder with that storage
+ * defined: every frame of the capture is kept until the capture ends (as the consumers of the real application do), the
+ * pool is emptied before and after, and new blocks are cleared (the link wraps posix_memalign, oracle/build_ref.sh), so a
+ * byte beyond a frame reads as zero. That is the deterministic form of the reference the decoder under test is compared
+ * with on randomized captures.
+ */
+static std::atomic<int> clearNewStorage {0};
+
+extern "C" int __real_posix_memalign(void **ptr, size_t alignment, size_t size);
+
+extern "C" int __wrap_posix_memalign(void **ptr, size_t alignment, size_t size)
+{
+   int res = __real_posix_memalign(ptr, alignment, size);
+
+   if (res == 0 && clearNewStorage.load(std::memory_order_relaxed))
+      std::memset(*ptr, 0, size);
+
+   return res;
+}
+
 extern "C" {
 
 struct nfcref_frame
@@ -54,10 +80,9 @@ struct nfcref_params
    float max_depth[4];          // NaN => keep default
 };
 
-/* returns number of frames produced (may exceed cap; only cap are stored), <0 on error */
-long nfcref_decode(const float *samples, uint64_t count, uint32_t sample_rate, uint32_t chunk,
-                   const nfcref_params *params, int keep_carrier, int send_eof,
-                   nfcref_frame *out, uint32_t cap, double *seconds)
+static long decode_capture(const float *samples, uint64_t count, uint32_t sample_rate, uint32_t chunk,
+                           const nfcref_params *params, int keep_carrier, int send_eof,
+                           nfcref_frame *out, uint32_t cap, double *seconds, std::list<std::list<lab::RawFrame>> *kept)
 {
    if (!chunk)
       chunk = 65536;
@@ -134,16 +159,52 @@ long nfcref_decode(const float *samples, uint64_t count, uint32_t sample_rate, u
       elapsed += std::chrono::duration<double>(t1 - t0).count();
 
       emit(frames);
+
+      if (kept)
+         kept->push_back(std::move(frames));
    }
 
    if (send_eof)
    {
       hw::SignalBuffer invalid;
-      emit(decoder.nextFrames(invalid));
+      std::list<lab::RawFrame> frames = decoder.nextFrames(invalid);
+      emit(frames);
+
+      if (kept)
+         kept->push_back(std::move(frames));
    }
 
    if (seconds)
       *seconds = elapsed;
+
+   return total;
+}
+
+/* returns number of frames produced (may exceed cap; only cap are stored), <0 on error */
+long nfcref_decode(const float *samples, uint64_t count, uint32_t sample_rate, uint32_t chunk,
+                   const nfcref_params *params, int keep_carrier, int send_eof,
+                   nfcref_frame *out, uint32_t cap, double *seconds)
+{
+   return decode_capture(samples, count, sample_rate, chunk, params, keep_carrier, send_eof, out, cap, seconds, nullptr);
+}
+
+/* same, with defined frame storage (see the top of this file); not for timing, single caller at a time */
+long nfcref_decode_defined(const float *samples, uint64_t count, uint32_t sample_rate, uint32_t chunk,
+                           const nfcref_params *params, int keep_carrier, int send_eof,
+                           nfcref_frame *out, uint32_t cap, double *seconds)
+{
+   long total;
+
+   rt::Buffer<unsigned char>::heap.cleanup();
+   clearNewStorage = 1;
+
+   {
+      std::list<std::list<lab::RawFrame>> kept;
+      total = decode_capture(samples, count, sample_rate, chunk, params, keep_carrier, send_eof, out, cap, seconds, &kept);
+   }
+
+   clearNewStorage = 0;
+   rt::Buffer<unsigned char>::heap.cleanup();
 
    return total;
 }

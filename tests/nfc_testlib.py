@@ -100,13 +100,18 @@ def reference_lib():
         lib.nfcref_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
+        lib.nfcref_decode_defined.restype = ctypes.c_long
+        lib.nfcref_decode_defined.argtypes = lib.nfcref_decode.argtypes
         lib.nfcref_magnitude.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         _ref = lib
     return _ref
 
 
 def reference_decode(samples, sample_rate=10000000, chunk=65536, tech_mask=0xF, keep_carrier=False, send_eof=False,
-                     cap=4096, params=None):
+                     cap=4096, params=None, defined_storage=False):
+    """The reference decoder on one capture. defined_storage: run it with cleared, unrecycled frame storage
+    (oracle/ref_capi.cpp, nfcref_decode_defined): the reference classifies some truncated frames from bytes beyond the
+    frame length, which otherwise are leftovers of earlier frames, earlier captures or malloc."""
     lib = reference_lib()
     samples = np.ascontiguousarray(samples, dtype=np.float32)
     out = (Frame * cap)()
@@ -114,32 +119,11 @@ def reference_decode(samples, sample_rate=10000000, chunk=65536, tech_mask=0xF, 
     nan = float("nan")
     p = params or RefParams(tech_mask, nan, (ctypes.c_float * 4)(nan, nan, nan, nan),
                             (ctypes.c_float * 4)(nan, nan, nan, nan), (ctypes.c_float * 4)(nan, nan, nan, nan))
-    n = lib.nfcref_decode(samples.ctypes.data, len(samples), sample_rate, chunk, ctypes.byref(p),
-                          int(keep_carrier), int(send_eof), ctypes.byref(out), cap, ctypes.byref(secs))
+    decode = lib.nfcref_decode_defined if defined_storage else lib.nfcref_decode
+    n = decode(samples.ctypes.data, len(samples), sample_rate, chunk, ctypes.byref(p),
+               int(keep_carrier), int(send_eof), ctypes.byref(out), cap, ctypes.byref(secs))
     assert 0 <= n <= cap, n
     return frames_to_tuples(out, n, keep_carrier=True), secs.value
-
-
-def reference_decode_fresh(samples, **kw):
-    """reference_decode in a child process of its own. The reference classifies some truncated frames from bytes beyond
-    the frame length (ATS without its TB byte, NfcA.cpp:1736-1769; one-byte NFC-F polls, NfcF.cpp:1151-1160), i.e. from
-    whatever its recycled RawFrame storage (rt::Heap, Alloc.h:41-56) held before, so within one process its answer can
-    depend on the captures decoded earlier. A fresh process is its deterministic form: new storage reads as zero."""
-    import pickle
-    import subprocess
-    import sys
-    import tempfile
-    with tempfile.TemporaryDirectory() as tmp:
-        np.save(os.path.join(tmp, "x.npy"), np.ascontiguousarray(samples, dtype=np.float32))
-        with open(os.path.join(tmp, "kw.pkl"), "wb") as f:
-            pickle.dump(kw, f)
-        code = ("import sys, pickle, numpy as np; sys.path.insert(0, %r); import nfc_testlib as T; "
-                "kw = pickle.load(open(%r, 'rb')); out, _ = T.reference_decode(np.load(%r), **kw); "
-                "pickle.dump(out, open(%r, 'wb'))") % (os.path.join(ROOT, "tests"), os.path.join(tmp, "kw.pkl"),
-                                                       os.path.join(tmp, "x.npy"), os.path.join(tmp, "out.pkl"))
-        subprocess.run([sys.executable, "-c", code], check=True, timeout=600)
-        with open(os.path.join(tmp, "out.pkl"), "rb") as f:
-            return pickle.load(f)
 
 
 _sim = None

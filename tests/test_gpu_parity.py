@@ -178,7 +178,7 @@ def test_uniform_device_batch_synthetic_streams(gpu):
     gpu.sync()
     total = 0
     for s in range(streams):
-        ref, _ = T.reference_decode(np.abs(mags[s]), keep_carrier=True)
+        ref, _ = T.reference_decode(np.abs(mags[s]), keep_carrier=True, defined_storage=True)
         got = gpu.poll(first + s)
         assert got == ref, "stream %d" % s
         total += len(got)
@@ -298,7 +298,7 @@ def test_fuzzed_streams_match_reference(gpu, seed):
         parts = [np.ascontiguousarray(x[pos:pos + 50000]) for x in streams]
         gpu.submit_batch([first + i for i in range(len(parts))], [p.ctypes.data for p in parts], [p.size for p in parts], FS)
     for i, x in enumerate(streams):
-        ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384)
+        ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384, defined_storage=True)
         assert gpu.poll(first + i, capacity=16384) == ref, "stream %d" % i
         gpu.close_stream(first + i)
 
@@ -384,6 +384,6 @@ def test_streams_joining_a_block_at_different_times(gpu):
             gpu.submit_batch(sel, ptrs, cnts, FS)
         step += 1
     for i in range(n):
-        ref, _ = T.reference_decode(data[i], keep_carrier=True, cap=16384)
+        ref, _ = T.reference_decode(data[i], keep_carrier=True, cap=16384, defined_storage=True)
         assert gpu.poll(ids[i], capacity=16384) == ref, "stream %d" % i
         gpu.close_stream(ids[i])

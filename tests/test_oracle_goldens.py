@@ -97,24 +97,35 @@ def test_step_machine_matches_reference_on_fuzzed_streams(built, seed):
     if T.reference_lib() is None:
         pytest.skip("oracle/_ref not built")
     x = _fuzz_stream(seed)
-    ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384)
+    ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384, defined_storage=True)
     got = T.hostsim_decode(x, keep_carrier=True, cap=16384, lane=seed)
     assert got == ref
     assert len(ref) > 0
 
 
-def test_truncated_ats_is_classified_as_in_fresh_reference_storage(built):
-    """Found by profiles/tools/long_fuzz.py (seed 31337, capture 292): an ATS cut to `05 78 33` announces TA and TB but
-    ends before TB, and the reference takes FWI from frame[3] beyond the frame (NfcA.cpp:1736-1769), so the waiting time
-    of every later poll frame depends on what its recycled frame storage held. Bytes beyond a frame read as zero here,
-    which is the reference's own answer in a fresh process."""
+# captures found by profiles/tools/long_fuzz.py and cpu_fuzz.py on which the plain reference answers differently from run
+# to run: (seed of _fuzz_stream, length, the truncated frame, what the reference reads beyond it)
+_TRUNCATED = [
+    (31337 + 13 * 292, 250000, (0x103, "057833"), "ATS ending before TB: FWI from frame[3], NfcA.cpp:1736-1769"),
+    (225057, 395353, (0x103, "ab019955"), "4-byte answer taken as ATQB: FSDI/FWI from frame[10], frame[11], NfcB.cpp:1186-1187"),
+    (220294, 393913, (0x102, "0600ffff00"), "5-byte REQC: time slots from frame[5], NfcF.cpp:1151-1160"),
+    (209959, 277521, (0x102, "06"), "1-byte NFC-F poll: command from frame[1], NfcF.cpp:1151-1160"),
+]
+
+
+@pytest.mark.parametrize("seed,length,trigger,what", _TRUNCATED, ids=[t[3].split(":")[0] for t in _TRUNCATED])
+def test_truncated_frames_are_classified_as_with_cleared_reference_storage(built, seed, length, trigger, what):
+    """The reference classifies these frames from bytes beyond their length, i.e. from leftovers in recycled RawFrame
+    storage, and derives the waiting time of later frames from them; with that storage defined (cleared, not recycled:
+    oracle/ref_capi.cpp nfcref_decode_defined) it agrees frame for frame with the step machine, whose out-of-frame bytes
+    read as zero (nfc_byte)."""
     if T.reference_lib() is None:
         pytest.skip("oracle/_ref not built")
-    x = _fuzz_stream(31337 + 13 * 292, 250000)
-    ref = T.reference_decode_fresh(x, keep_carrier=True, cap=16384)
+    x = _fuzz_stream(seed, length)
+    ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384, defined_storage=True)
     got = T.hostsim_decode(x, keep_carrier=True, cap=16384, lane=3)
     assert got == ref
-    assert any(f[1] == 0x103 and f[-1] == bytes([0x05, 0x78, 0x33]) for f in ref)
+    assert any(f[1] == trigger[0] and f[-1] == bytes.fromhex(trigger[1]) for f in ref), what
 
 
 @pytest.mark.parametrize("rate,step", [(5000000, 2), (2500000, 4)])
