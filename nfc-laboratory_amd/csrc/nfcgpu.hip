@@ -43,6 +43,7 @@ struct StreamInfo
    bool open = false;
    bool initialized = false; /* device state valid */
    bool needInit = true;
+   bool listed = false; /* part of the batch being submitted */
    nfcgpu_params params {};
    float powerAtInit = 0.01f; /* carrier thresholds are derived when the decoder (re)initialises */
    uint32_t config = 0;
@@ -222,18 +223,21 @@ int adopt_sample_rate(nfcgpu_ctx *ctx, StreamInfo &si, uint32_t sampleRate)
    return NFCGPU_OK;
 }
 
-/* run nfc_init_kernel for every stream in [first, first+count) that needs it; contiguous runs with equal
+/* run nfc_init_kernel for every stream in [first, first+count) that needs it (listedOnly: and is part of the batch
+ * being submitted; a stream opened but not yet fed has no configuration resolved); contiguous runs with equal
  * (config, keep) share one launch */
-int initialize_pending(nfcgpu_ctx *ctx, uint32_t first, uint32_t count)
+int initialize_pending(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, bool listedOnly)
 {
    uint32_t i = first;
    const uint32_t end = first + count;
+
+   auto due = [&](const StreamInfo &si) { return si.open && si.needInit && (si.listed || !listedOnly); };
 
    while (i < end)
    {
       StreamInfo &si = ctx->streams[i];
 
-      if (!si.open || !si.needInit)
+      if (!due(si))
       {
          i++;
          continue;
@@ -243,8 +247,7 @@ int initialize_pending(nfcgpu_ctx *ctx, uint32_t first, uint32_t count)
       const bool keep = si.initialized;
       uint32_t j = i;
 
-      while (j < end && ctx->streams[j].open && ctx->streams[j].needInit && ctx->streams[j].config == cfg &&
-             ctx->streams[j].initialized == keep)
+      while (j < end && due(ctx->streams[j]) && ctx->streams[j].config == cfg && ctx->streams[j].initialized == keep)
          j++;
 
       NfcLaunch L = base_launch(ctx);
@@ -651,49 +654,62 @@ int nfcgpu_stream_close(nfcgpu_ctx *ctx, uint32_t id)
 
 int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
 {
-   if (!ctx || !b || !b->stream_ids || !b->data || !b->n_samples || (b->stride != 1 && b->stride != 2))
+   if (!ctx || !b || !b->stream_ids || !b->data || !b->n_samples || (b->stride != 1 && b->stride != 2) ||
+       (b->location != NFCGPU_LOC_HOST && b->location != NFCGPU_LOC_DEVICE))
       return NFCGPU_EINVAL;
    if (b->n_streams == 0)
       return NFCGPU_OK;
 
    HIP_TRY(ctx, hipSetDevice(ctx->device));
 
+   /* the per-slot work table and the batch marks are idle between calls: every exit path restores that */
+   auto clearWorks = [&]() {
+      for (uint32_t i = 0; i < b->n_streams; i++)
+      {
+         const uint32_t id = b->stream_ids[i];
+         if (id >= ctx->maxStreams)
+            continue;
+         NfcWork &w = ctx->hWorks[id];
+         w.data = nullptr;
+         w.count = 0;
+         w.stride = 1;
+         ctx->streams[id].listed = false;
+      }
+   };
+
    /* validate + adopt rate */
    size_t hostBytes = 0;
    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+   int rc = NFCGPU_OK;
 
-   for (uint32_t i = 0; i < b->n_streams; i++)
+   for (uint32_t i = 0; i < b->n_streams && rc == NFCGPU_OK; i++)
    {
       const uint32_t id = b->stream_ids[i];
 
       if (id >= ctx->maxStreams || !ctx->streams[id].open)
-         return fail(ctx, NFCGPU_ESTREAM, "unknown stream in batch");
-      if (ctx->hWorks[id].count)
-         return fail(ctx, NFCGPU_EINVAL, "stream listed twice in one batch");
-      if (b->n_samples[i] && !b->data[i])
-         return fail(ctx, NFCGPU_EINVAL, "null data pointer in batch");
+         rc = fail(ctx, NFCGPU_ESTREAM, "unknown stream in batch");
+      else if (ctx->streams[id].listed)
+         rc = fail(ctx, NFCGPU_EINVAL, "stream listed twice in one batch");
+      else if (b->n_samples[i] && !b->data[i])
+         rc = fail(ctx, NFCGPU_EINVAL, "null data pointer in batch");
+      else
+         rc = adopt_sample_rate(ctx, ctx->streams[id], b->sample_rate);
 
-      int rc = adopt_sample_rate(ctx, ctx->streams[id], b->sample_rate);
       if (rc)
-         return rc;
+         break;
 
-      ctx->hWorks[id].count = b->n_samples[i]; /* also marks the slot as taken for the duplicate check */
+      ctx->streams[id].listed = true;
+      ctx->hWorks[id].count = b->n_samples[i];
       hostBytes += (size_t)b->n_samples[i] * b->stride * 4;
       lo = id < lo ? id : lo;
       hi = id > hi ? id : hi;
    }
 
-   auto clearWorks = [&]() {
-      for (uint32_t i = 0; i < b->n_streams; i++)
-      {
-         NfcWork &w = ctx->hWorks[b->stream_ids[i]];
-         w.data = nullptr;
-         w.count = 0;
-         w.stride = 1;
-      }
-   };
-
-   int rc = NFCGPU_OK;
+   if (rc)
+   {
+      clearWorks();
+      return rc;
+   }
 
    if (b->location == NFCGPU_LOC_HOST)
    {
@@ -705,7 +721,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       }
    }
 
-   rc = initialize_pending(ctx, lo, hi - lo + 1);
+   rc = initialize_pending(ctx, lo, hi - lo + 1, true);
    if (rc)
    {
       clearWorks();
@@ -962,7 +978,8 @@ int nfcgpu_resample_radio(nfcgpu_ctx *ctx, const float *in, uint64_t inPitch, ui
 int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const void *base, uint64_t pitch, uint32_t n,
                           uint32_t stride, uint32_t location, uint32_t sampleRate)
 {
-   if (!ctx || !base || (stride != 1 && stride != 2) || count == 0)
+   if (!ctx || !base || (stride != 1 && stride != 2) || count == 0 ||
+       (location != NFCGPU_LOC_HOST && location != NFCGPU_LOC_DEVICE) || (count > 1 && pitch < (uint64_t)n * stride * 4))
       return NFCGPU_EINVAL;
    if ((uint64_t)first + count > ctx->maxStreams)
       return fail(ctx, NFCGPU_ESTREAM, "stream range out of bounds");
@@ -1001,7 +1018,7 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       devBase = ctx->dStage;
    }
 
-   int rc = initialize_pending(ctx, first, count);
+   int rc = initialize_pending(ctx, first, count, false);
    if (rc)
       return rc;
 

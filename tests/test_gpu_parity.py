@@ -387,3 +387,37 @@ def test_streams_joining_a_block_at_different_times(gpu):
         ref, _ = T.reference_decode(data[i], keep_carrier=True, cap=16384, defined_storage=True)
         assert gpu.poll(ids[i], capacity=16384) == ref, "stream %d" % i
         gpu.close_stream(ids[i])
+
+
+def test_streams_with_own_parameters_between_streams_already_running(gpu):
+    """Three neighbouring slots with three tech masks, opened with their sample rate set; the middle one is fed only
+    after its neighbours have run (a batch initialises only the streams it lists, each with its own configuration)."""
+    import nfclab_amd
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    x = T.load_fixture("test_POLL_ABF_001")
+    masks = (0x1, 0x4, 0x2)
+    sids = [gpu.open(nfclab_amd.default_params(sample_rate=FS, tech_mask=m)) for m in masks]
+    assert sids == list(range(sids[0], sids[0] + 3))
+    half = x.size // 2
+    outer = [np.ascontiguousarray(x[:half]), np.ascontiguousarray(x[:half])]
+    gpu.submit_batch([sids[0], sids[2]], [p.ctypes.data for p in outer], [half, half], FS)
+    rest = np.ascontiguousarray(x[half:])
+    gpu.submit_batch(sids, [rest.ctypes.data, x.ctypes.data, rest.ctypes.data], [rest.size, x.size, rest.size], FS)
+    for sid, mask in zip(sids, masks):
+        ref, _ = T.reference_decode(x, tech_mask=mask, keep_carrier=True)
+        assert gpu.poll(sid) == ref, hex(mask)
+        gpu.close_stream(sid)
+
+
+def test_rejected_batch_leaves_no_trace(gpu):
+    """A batch refused half way through validation (unknown stream, stream listed twice) must not mark its streams."""
+    import nfclab_amd
+    x = T.load_fixture("test_NFC-A_106kbps_001")
+    sid = gpu.open()
+    for ids in ([sid, 0x7FFFFFFF], [sid, sid]):
+        with pytest.raises(nfclab_amd.NfcGpuError):
+            gpu.submit_batch(ids, [x.ctypes.data] * 2, [x.size] * 2, FS)
+    gpu.submit_batch([sid], [x.ctypes.data], [x.size], FS)
+    assert data_frames(gpu.poll(sid)) == T.load_golden("test_NFC-A_106kbps_001")
+    gpu.close_stream(sid)
