@@ -8,13 +8,16 @@
  * it provides exactly the symbols that RadioDecoderTask.o, nfc-rx and test-sdr import from lab-radio
  * (SURVEY.md 8(b)), so those link and run unchanged; the per-sample work happens in HIP kernels behind the
  * C ABI of include/nfcgpu.h. One NfcDecoder instance == one nfcgpu stream; all instances of a process share
- * one nfcgpu context (one GPU). There is no CPU decoding path: if the GPU runtime cannot be initialised the
- * constructor throws.
+ * one nfcgpu context (one GPU), serialised by one lock (a decoder is still used by one thread at a time, like the
+ * reference's, but different decoders may live on different threads). There is no CPU decoding path: if the GPU
+ * runtime cannot be initialised the constructor throws, and a buffer the GPU side refuses (sample rate beyond the
+ * history depth, HIP error) makes nextFrames() throw instead of silently dropping samples.
  *
  * This file replaces src/nfc-lib/lib-lab/lab-radio/src/main/cpp/NfcDecoder.cpp (+ NfcTech.cpp, tech/*.cpp)
  * in the reference's lab-radio library; see INTEGRATION.md.
  */
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <stdexcept>
@@ -38,6 +41,7 @@ struct SharedContext
    nfcgpu_ctx *ctx = nullptr;
    bool closed = false;
    std::mutex mutex;
+   std::recursive_mutex use; /* the context is single-threaded: every call into it holds this */
 
    /* Decoders owned by long-lived objects (the RadioDecoderTask worker, static subjects) may be destroyed while the
     * process is exiting, after the GPU runtime has begun to unload. The context is therefore released by an atexit
@@ -80,6 +84,7 @@ SharedContext shared;
 
 void SharedContext::atExit()
 {
+   std::lock_guard<std::recursive_mutex> use(shared.use);
    std::lock_guard<std::mutex> lock(shared.mutex);
 
    if (shared.ctx)
@@ -101,6 +106,8 @@ struct NfcDecoder::Impl
 
    Impl() : ctx(shared.get())
    {
+      std::lock_guard<std::recursive_mutex> use(shared.use);
+
       nfcgpu_default_params(&params);
 
       int rc = nfcgpu_stream_open(ctx, &params, &stream);
@@ -111,15 +118,26 @@ struct NfcDecoder::Impl
 
    ~Impl()
    {
+      std::lock_guard<std::recursive_mutex> use(shared.use);
+
       if (shared.alive())
          nfcgpu_stream_close(ctx, stream);
+   }
+
+   /* the reference's interface has no error channel: refuse loudly rather than lose samples */
+   void check(int rc, const char *what)
+   {
+      if (rc == NFCGPU_EOVERFLOW)
+         std::fprintf(stderr, "nfcgpu: %s: %s\n", what, nfcgpu_last_error(ctx));
+      else if (rc != NFCGPU_OK)
+         throw std::runtime_error(std::string("nfcgpu: ") + what + ": " + nfcgpu_strerror(rc) + " (" + nfcgpu_last_error(ctx) + ")");
    }
 
    void push()
    {
       if (dirty)
       {
-         nfcgpu_stream_configure(ctx, stream, &params);
+         check(nfcgpu_stream_configure(ctx, stream, &params), "stream_configure");
          dirty = false;
       }
    }
@@ -154,8 +172,7 @@ struct NfcDecoder::Impl
 
       do
       {
-         if (nfcgpu_poll(ctx, stream, chunk.data(), (uint32_t)chunk.size(), &count) < 0 && count == 0)
-            break;
+         check(nfcgpu_poll(ctx, stream, chunk.data(), (uint32_t)chunk.size(), &count), "poll");
 
          for (uint32_t i = 0; i < count; i++)
          {
@@ -189,11 +206,13 @@ NfcDecoder::NfcDecoder() : impl(std::make_shared<Impl>())
 
 void NfcDecoder::initialize()
 {
+   std::lock_guard<std::recursive_mutex> use(shared.use);
+
    if (!shared.alive())
       return;
 
    impl->push();
-   nfcgpu_stream_reset(impl->ctx, impl->stream);
+   impl->check(nfcgpu_stream_reset(impl->ctx, impl->stream), "stream_reset");
 }
 
 void NfcDecoder::cleanup()
@@ -202,6 +221,8 @@ void NfcDecoder::cleanup()
 
 std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
 {
+   std::lock_guard<std::recursive_mutex> use(shared.use);
+
    if (!shared.alive())
       return {};
 
@@ -219,14 +240,14 @@ std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
          const unsigned int count = samples.remaining() / stride;
 
          if (count)
-            nfcgpu_submit(impl->ctx, impl->stream, samples.ptr(), count, stride, samples.sampleRate());
+            impl->check(nfcgpu_submit(impl->ctx, impl->stream, samples.ptr(), count, stride, samples.sampleRate()), "submit");
 
          impl->params.sample_rate = samples.sampleRate();
       }
    }
    else
    {
-      nfcgpu_flush(impl->ctx, impl->stream);
+      impl->check(nfcgpu_flush(impl->ctx, impl->stream), "flush");
    }
 
    return impl->collect();
