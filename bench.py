@@ -2,7 +2,7 @@
 """bench.py — IQ Msamples/s demodulated on MI355X (BASELINE.json metric), one process per GPU.
 
 A "step" is one pass of the demodulation hot path (IQ -> magnitude -> front end -> NFC-A/B/F/V detector bank ->
-symbol/bit/frame assembly) over one 16384-sample buffer of every stream of this rank, with the IQ already
+symbol/bit/frame assembly) over one 8192-sample buffer (default) of every stream of this rank, with the IQ already
 resident in HBM. Streams are independent capture streams (BASELINE config 5 shape, sharded by rank: weak
 scaling, no data-path collective); decoded frames are gathered at the end of the timed region (RCCL all_gather
 when N > 1, D2H when N == 1).

@@ -80,9 +80,17 @@ struct nfcref_params
    float max_depth[4];          // NaN => keep default
 };
 
+struct IdlePrefix
+{
+   const float *samples; /* one buffer, fed `repeats` times before the capture */
+   uint32_t count;
+   uint64_t repeats;
+};
+
 static long decode_capture(const float *samples, uint64_t count, uint32_t sample_rate, uint32_t chunk,
                            const nfcref_params *params, int keep_carrier, int send_eof,
-                           nfcref_frame *out, uint32_t cap, double *seconds, std::list<std::list<lab::RawFrame>> *kept)
+                           nfcref_frame *out, uint32_t cap, double *seconds, std::list<std::list<lab::RawFrame>> *kept,
+                           const IdlePrefix *idle = nullptr)
 {
    if (!chunk)
       chunk = 65536;
@@ -145,6 +153,13 @@ static long decode_capture(const float *samples, uint64_t count, uint32_t sample
       }
    };
 
+   for (uint64_t r = 0; idle && r < idle->repeats; r++)
+   {
+      hw::SignalBuffer buffer(idle->count, 1, 1, sample_rate, 0, 0, hw::SignalType::SIGNAL_TYPE_RADIO_SAMPLES, 0);
+      buffer.put(idle->samples, idle->count).flip();
+      emit(decoder.nextFrames(buffer));
+   }
+
    for (uint64_t pos = 0; pos < count; pos += chunk)
    {
       uint32_t n = (count - pos) < chunk ? (uint32_t)(count - pos) : chunk;
@@ -186,6 +201,16 @@ long nfcref_decode(const float *samples, uint64_t count, uint32_t sample_rate, u
                    nfcref_frame *out, uint32_t cap, double *seconds)
 {
    return decode_capture(samples, count, sample_rate, chunk, params, keep_carrier, send_eof, out, cap, seconds, nullptr);
+}
+
+/* the capture after `repeats` copies of an idle buffer: the only way to take the reference's 32-bit sample clock
+ * (NfcTech.h signalClock) to its wrap, which needs 2^32 samples (profiles/tools/clock_wrap.py) */
+long nfcref_decode_after_idle(const float *idle, uint32_t idle_count, uint64_t repeats, const float *samples, uint64_t count,
+                              uint32_t sample_rate, uint32_t chunk, const nfcref_params *params, int keep_carrier,
+                              nfcref_frame *out, uint32_t cap)
+{
+   IdlePrefix prefix {idle, idle_count, repeats};
+   return decode_capture(samples, count, sample_rate, chunk, params, keep_carrier, 0, out, cap, nullptr, nullptr, &prefix);
 }
 
 /* same, with defined frame storage (see the top of this file); not for timing, single caller at a time */

@@ -25,9 +25,10 @@ struct hostsim_frame
 };
 
 /* decode one stream placed in lane `lane` of a 64-wide stream block; returns frame count */
-long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint32_t sampleRate, uint32_t lane,
-                    uint32_t enabled, float powerThreshold, const float *corr, const float *minDepth, const float *maxDepth,
-                    hostsim_frame *out, uint32_t cap)
+/* the same after `repeats` copies of an idle buffer (stride 1): takes the 32-bit sample clock to its wrap */
+long hostsim_decode_after_idle(const float *idle, uint32_t idleCount, uint64_t repeats, const float *samples, uint64_t count,
+                               uint32_t stride, uint32_t sampleRate, uint32_t lane, uint32_t enabled, float powerThreshold,
+                               const float *corr, const float *minDepth, const float *maxDepth, hostsim_frame *out, uint32_t cap)
 {
    NfcHostParams p;
    p.sampleRate = sampleRate;
@@ -69,6 +70,12 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
    mem.tables = &cfg;
    nfc_state_init(cfg, s, cold, false);
 
+   for (uint64_t r = 0; r < repeats; r++)
+   {
+      for (uint32_t i = 0; i < idleCount; i++)
+         nfc_step(cfg, s, mem, idle[i], nfc_exact_zone(s.clock + 1u));
+   }
+
    for (uint64_t i = 0; i < count; i++)
    {
       float v;
@@ -107,6 +114,14 @@ long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint3
       pos += NFC_FRAME_HEADER_WORDS + ((len + 3) >> 2);
    }
    return n;
+}
+
+long hostsim_decode(const float *samples, uint64_t count, uint32_t stride, uint32_t sampleRate, uint32_t lane,
+                    uint32_t enabled, float powerThreshold, const float *corr, const float *minDepth, const float *maxDepth,
+                    hostsim_frame *out, uint32_t cap)
+{
+   return hostsim_decode_after_idle(nullptr, 0, 0, samples, count, stride, sampleRate, lane, enabled, powerThreshold, corr,
+                                    minDepth, maxDepth, out, cap);
 }
 
 }

@@ -421,3 +421,48 @@ def test_rejected_batch_leaves_no_trace(gpu):
     gpu.submit_batch([sid], [x.ctypes.data], [x.size], FS)
     assert data_frames(gpu.poll(sid)) == T.load_golden("test_NFC-A_106kbps_001")
     gpu.close_stream(sid)
+
+
+def test_one_batch_of_streams_with_different_thresholds(gpu):
+    """Eight fuzzed captures in one ragged batch, each stream with its own tech mask, power level, correlation and
+    modulation-depth thresholds: one launch per configuration inside the batch, each stream against the reference run
+    with the same parameters."""
+    import ctypes
+    import nfclab_amd
+    from test_oracle_goldens import _fuzz_stream
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    rng = np.random.default_rng(77)
+    captures, sids, refs = [], [], []
+    for i in range(8):
+        x = _fuzz_stream(900 + i, 200000)
+        p = nfclab_amd.default_params(tech_mask=int(rng.integers(1, 16)))
+        rp = T.RefParams(p.tech_mask, float("nan"), *[(ctypes.c_float * 4)(*([float("nan")] * 4)) for _ in range(3)])
+        if i % 2:
+            p.power_level_threshold = rp.power_level_threshold = float(np.float32(rng.uniform(0.004, 0.05)))
+        for t in range(4):
+            if rng.random() < 0.5:
+                p.corr_threshold[t] = rp.corr_threshold[t] = float(np.float32(rng.uniform(0.2, 0.9)))
+            if rng.random() < 0.5:
+                p.min_modulation_depth[t] = rp.min_depth[t] = float(np.float32(rng.uniform(0.05, 0.95)))
+            if rng.random() < 0.5:
+                p.max_modulation_depth[t] = rp.max_depth[t] = float(np.float32(rng.uniform(0.5, 1.0)))
+        ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384, params=rp, defined_storage=True)
+        captures.append(x)
+        refs.append(ref)
+        sids.append(gpu.open(p))
+    fed = [0] * 8
+    while any(f < 200000 for f in fed):
+        ids, parts = [], []
+        for i in range(8):
+            if fed[i] < 200000 and rng.random() < 0.8:
+                c = int(min(200000 - fed[i], rng.integers(1, 50000)))
+                parts.append(np.ascontiguousarray(captures[i][fed[i]:fed[i] + c]))
+                ids.append(sids[i])
+                fed[i] += c
+        if ids:
+            gpu.submit_batch(ids, [q.ctypes.data for q in parts], [q.size for q in parts], FS)
+    for i in range(8):
+        assert gpu.poll(sids[i], capacity=16384) == refs[i], i
+        gpu.close_stream(sids[i])
+    assert sum(len(r) for r in refs) > 40

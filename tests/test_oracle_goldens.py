@@ -103,6 +103,37 @@ def test_step_machine_matches_reference_on_fuzzed_streams(built, seed):
     assert len(ref) > 0
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_step_machine_matches_reference_with_random_parameters(built, seed):
+    """Random tech mask, power level, correlation and modulation-depth thresholds and sample rate (some of them only a
+    label: the capture is not resampled) on a fuzzed capture; profiles/tools/cpu_fuzz.py --params runs thousands."""
+    import ctypes
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(1000 + seed)
+    nan = float("nan")
+    x = _fuzz_stream(500 + seed, 250000)
+    rate = [10000000, 5000000, 2500000, 8000000, 6000000, 10500000][int(rng.integers(6))]
+    if rate in (5000000, 2500000):
+        x = np.ascontiguousarray(x[::10000000 // rate])
+    mask = int(rng.integers(1, 16))
+
+    def pick(a, b):
+        return nan if rng.random() < 0.4 else float(np.float32(rng.uniform(a, b)))
+
+    def f4(v):
+        return (ctypes.c_float * 4)(*v)
+    power = pick(0.002, 0.08)
+    corr, lo, hi = [pick(0.05, 1.0) for _ in range(4)], [pick(0.02, 1.0) for _ in range(4)], [pick(0.3, 1.0) for _ in range(4)]
+    out = (T.Frame * 16384)()
+    n = T.hostsim_lib().hostsim_decode(x.ctypes.data, len(x), 1, rate, seed, mask, power, f4(corr), f4(lo), f4(hi),
+                                       ctypes.byref(out), 16384)
+    assert 0 <= n <= 16384
+    ref, _ = T.reference_decode(x, sample_rate=rate, keep_carrier=True, cap=16384, defined_storage=True,
+                                params=T.RefParams(mask, power, f4(corr), f4(lo), f4(hi)))
+    assert T.frames_to_tuples(out, n, keep_carrier=True) == ref
+
+
 # captures found by profiles/tools/long_fuzz.py and cpu_fuzz.py on which the plain reference answers differently from run
 # to run: (seed of _fuzz_stream, length, the truncated frame, what the reference reads beyond it)
 _TRUNCATED = [
