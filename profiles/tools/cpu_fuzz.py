@@ -5,7 +5,10 @@ reference decoder, far beyond the test suite and without a GPU. Each capture is 
 The yardstick is the reference with defined frame storage (oracle/ref_capi.cpp, nfcref_decode_defined); the plain
 reference, whose answer for truncated frames depends on leftovers in recycled storage, is counted beside it.
 
-  cpu_fuzz.py FIRST LAST [--params]     prints one JSON line
+  cpu_fuzz.py FIRST LAST [--params] [--timescale]     prints one JSON line
+
+--timescale: pieces are also decimated or linearly interpolated by 2 or 4, which turns the fixtures into traffic at the
+rates no fixture covers (NFC-B 212 kbps, NFC-F 424 kbps listen frames, NFC-A 212/424 kbps polls from the 106 kbps ones).
 """
 import ctypes
 import json
@@ -25,6 +28,42 @@ NAN = float("nan")
 RATES = [10000000, 10000000, 10000000, 5000000, 2500000, 8000000, 6000000, 10500000]
 CAP = 32768
 PARAMS = "--params" in sys.argv
+TIMESCALE = "--timescale" in sys.argv
+
+
+def _up2(x):
+    y = np.empty(x.size * 2, np.float32)
+    y[0::2] = x
+    y[1::2] = np.concatenate([(x[:-1] + x[1:]) * np.float32(0.5), x[-1:]])
+    return y
+
+
+def _scaled_stream(seed, length):
+    """_fuzz_stream with each piece played at x1, x2, x4, /2 or /4 speed"""
+    rng = np.random.default_rng(seed)
+    names = T.fixture_names()
+    out = np.empty(length, np.float32)
+    pos = 0
+    while pos < length:
+        x = T.load_fixture(names[rng.integers(len(names))])
+        n = int(rng.integers(20000, 200000))
+        a = int(rng.integers(0, max(1, x.size - n)))
+        piece = x[a:a + n]
+        how = int(rng.integers(0, 6))
+        if how == 1:
+            piece = piece[::2]
+        elif how == 2:
+            piece = piece[::4]
+        elif how == 3:
+            piece = _up2(piece)
+        elif how == 4:
+            piece = _up2(_up2(piece[:n // 2]))
+        piece = piece * np.float32(rng.uniform(0.5, 1.5)) + np.float32(rng.uniform(-0.003, 0.003))
+        piece = piece + rng.normal(0, rng.uniform(0, 0.002), piece.size).astype(np.float32)
+        m = min(length - pos, piece.size)
+        out[pos:pos + m] = piece[:m]
+        pos += m
+    return out
 
 
 def _f4(v):
@@ -33,7 +72,7 @@ def _f4(v):
 
 def one(seed):
     rng = np.random.default_rng(seed * 7 + 1)
-    x = _fuzz_stream(seed, int(rng.integers(100000, 400000)))
+    x = (_scaled_stream if TIMESCALE else _fuzz_stream)(seed, int(rng.integers(100000, 400000)))
     rate, mask, power = 10000000, 0xF, NAN
     corr, lo, hi = [NAN] * 4, [NAN] * 4, [NAN] * 4
     if PARAMS:
@@ -77,7 +116,7 @@ if __name__ == "__main__":
             if r[2] == "MISMATCH":
                 print(r, file=sys.stderr, flush=True)
     done = [r for r in res if r[3] is not None]
-    print(json.dumps({"tool": "profiles/tools/cpu_fuzz.py", "seeds": [first, last], "random_parameters": PARAMS,
+    print(json.dumps({"tool": "profiles/tools/cpu_fuzz.py", "seeds": [first, last], "random_parameters": PARAMS, "time_scaled_pieces": TIMESCALE,
                       "captures": len(done), "rate_not_decodable": len(res) - len(done),
                       "reference_frames": sum(r[1] for r in done),
                       "mismatching_defined_storage_reference": sum(r[2] == "MISMATCH" for r in done),

@@ -259,3 +259,40 @@ def synthetic_stream_i16(stream, length, names=None):
         out[pos:pos + n] = piece[:n]
         pos += n
     return out
+
+
+def crc_iso15693(data):
+    """CRC of ISO/IEC 15693 frames (ISO/IEC 13239: reflected 0x1021, preset 0xFFFF, inverted), low byte first"""
+    crc = 0xFFFF
+    for b in data:
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ 0x8408 if crc & 1 else crc >> 1
+    crc ^= 0xFFFF
+    return bytes([crc & 0xFF, crc >> 8])
+
+
+def synth_nfcv_poll(payload, mode, lead=30000, tail=60000, level=0.5, depth=0.97, noise=0.0005, seed=1, sample_rate=10000000):
+    """Synthetic ISO 15693 reader frame (pulse-position coding, 9.44 us pauses): SOF, `payload` in 1-of-4 (mode 4) or
+    1-of-256 (mode 256) coding, EOF, on an unmodulated carrier. No fixture of the reference uses 1-of-256."""
+    unit = 9.44e-6 * sample_rate           # one half slot
+    pauses = [(0, 1), (7, 8)] if mode == 256 else [(0, 1), (5, 6)]
+    t = 8
+    for b in payload:
+        if mode == 256:
+            pauses.append((t + 2 * b + 1, t + 2 * b + 2))
+            t += 512
+        else:
+            for k in range(4):
+                v = (b >> (2 * k)) & 3
+                pauses.append((t + 2 * v + 1, t + 2 * v + 2))
+                t += 8
+    pauses.append((t + 2, t + 3))
+    t += 4
+    x = np.full(int(lead + t * unit + tail), level, np.float32)
+    for a, b in pauses:
+        x[int(round(lead + a * unit)):int(round(lead + b * unit))] = level * (1 - depth)
+    x = np.convolve(x, np.array([0.25, 0.5, 0.25], np.float32), mode="same").astype(np.float32)
+    x += np.random.default_rng(seed).normal(0, noise, x.size).astype(np.float32)
+    x[:200] *= np.linspace(0, 1, 200, dtype=np.float32)
+    return x

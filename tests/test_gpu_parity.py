@@ -466,3 +466,15 @@ def test_one_batch_of_streams_with_different_thresholds(gpu):
         assert gpu.poll(sids[i], capacity=16384) == refs[i], i
         gpu.close_stream(sids[i])
     assert sum(len(r) for r in refs) > 40
+
+
+def test_synthetic_nfcv_one_of_256_frames(gpu):
+    """NFC-V 1-of-256 pulse-position frames (no capture of the reference uses that coding) next to 1-of-4 ones."""
+    from test_oracle_goldens import _nfcv_capture
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    x, want = _nfcv_capture(2)
+    ref, _ = T.reference_decode(x, keep_carrier=True, cap=4096, defined_storage=True)
+    got = decode_chunked(gpu, x, 65536)
+    assert got == ref
+    assert [(256 if f[4] == 1655 else 4, f[-1]) for f in got if f[0] == 0x104 and f[1] == 0x102] == want

@@ -103,6 +103,35 @@ def test_step_machine_matches_reference_on_fuzzed_streams(built, seed):
     assert len(ref) > 0
 
 
+def _nfcv_capture(seed):
+    """several synthetic NFC-V reader frames, 1-of-4 and 1-of-256 mixed, random payloads, levels and depths"""
+    rng = np.random.default_rng(seed)
+    parts, want = [], []
+    for k in range(4):
+        body = bytes(rng.integers(0, 256, int(rng.integers(2, 6)), dtype=np.uint8))
+        if k % 2 == 0:
+            body += T.crc_iso15693(body)
+        mode = 256 if (k + seed) % 2 else 4
+        parts.append(T.synth_nfcv_poll(body, mode, lead=20000 if k else 30000, tail=int(rng.integers(20000, 60000)), level=0.4,
+                                       depth=float(rng.uniform(0.93, 1.0)), noise=float(rng.uniform(0, 0.001)), seed=seed * 8 + k))
+        want.append((mode, body))
+    return np.ascontiguousarray(np.concatenate(parts)), want
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_synthetic_nfcv_one_of_256_frames(built, seed):
+    """NFC-V pulse-position frames in 1-of-256 coding (symbol rate / 32), which none of the reference's captures uses,
+    next to 1-of-4 ones: the reference decodes the synthetic frames to their payloads and the step machine agrees."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    x, want = _nfcv_capture(seed)
+    ref, _ = T.reference_decode(x, keep_carrier=True, cap=4096, defined_storage=True)
+    got = T.hostsim_decode(x, keep_carrier=True, cap=4096, lane=seed)
+    assert got == ref
+    polls = [f for f in ref if f[0] == 0x104 and f[1] == 0x102]
+    assert [(256 if f[4] == 1655 else 4, f[-1]) for f in polls] == want
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_step_machine_matches_reference_with_random_parameters(built, seed):
     """Random tech mask, power level, correlation and modulation-depth thresholds and sample rate (some of them only a
