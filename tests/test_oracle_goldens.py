@@ -201,6 +201,23 @@ def test_step_machine_matches_reference_at_other_sample_rates(built, name, rate,
     assert any(f[1] in (0x102, 0x103) for f in ref)
 
 
+@pytest.mark.parametrize("rate", [8000000, 6000000, 3200000, 2400000, 10500000])
+def test_step_machine_matches_reference_on_resampled_captures(built, rate):
+    """Captures resampled (linear interpolation) to the rates of the other receivers the reference supports (RTL-SDR 2.4 and
+    3.2 MS/s, Airspy 6 MS/s) and to the edge of the history depth: periods, delays and windows all round differently."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    frames = 0
+    for name in ("test_NFC-A_424kbps_002", "test_NFC-B_106kbps_002", "test_NFC-F_212kbps_003", "test_NFC-V_26kbps_001"):
+        x = T.load_fixture(name)
+        t = np.arange(int(x.size * rate / 10e6), dtype=np.float64) * (10e6 / rate)
+        y = np.interp(t, np.arange(x.size), x).astype(np.float32)
+        ref, _ = T.reference_decode(y, sample_rate=rate, keep_carrier=True, cap=16384, defined_storage=True)
+        assert T.hostsim_decode(y, sample_rate=rate, keep_carrier=True, cap=16384, lane=7) == ref, name
+        frames += sum(f[1] in (0x102, 0x103) for f in ref)
+    assert frames > 60
+
+
 def test_reference_radio_decoder_task_plumbing(tmp_path):
     """BASELINE configs[0]: a fixture through the reference's own RadioDecoderTask (subjects + executor, reference CPU
     decoder underneath, oracle/_ref/task-ref) yields the golden frames; the GPU twin of this test is in
