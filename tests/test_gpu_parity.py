@@ -495,3 +495,22 @@ def test_synthetic_nfcv_one_of_256_frames(gpu):
     got = decode_chunked(gpu, x, 65536)
     assert got == ref
     assert [(256 if f[4] == 1655 else 4, f[-1]) for f in got if f[0] == 0x104 and f[1] == 0x102] == want
+
+
+def test_special_sample_values(gpu):
+    """Negative and zero runs, denormals, huge values and sign flips in a float capture (finite values only here; the
+    CPU suite also covers NaN and infinities on the step machine): one ragged batch of six captures."""
+    from test_oracle_goldens import _special_values_capture
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    captures = [_special_values_capture(20 + i, finite_only=True) for i in range(6)]
+    first = gpu.open(count=6)
+    for pos in range(0, 200000, 50000):
+        parts = [np.ascontiguousarray(c[pos:pos + 50000 - 7 * i]) for i, c in enumerate(captures)]
+        gpu.submit_batch([first + i for i in range(6)], [p.ctypes.data for p in parts], [p.size for p in parts], FS)
+        rest = [np.ascontiguousarray(c[pos + 50000 - 7 * i:pos + 50000]) for i, c in enumerate(captures)]
+        gpu.submit_batch([first + i for i in range(6)], [p.ctypes.data for p in rest], [p.size for p in rest], FS)
+    for i, c in enumerate(captures):
+        ref, _ = T.reference_decode(c, keep_carrier=True, cap=16384, defined_storage=True)
+        assert gpu.poll(first + i, capacity=16384) == ref, i
+        gpu.close_stream(first + i)

@@ -103,6 +103,37 @@ def test_step_machine_matches_reference_on_fuzzed_streams(built, seed):
     assert len(ref) > 0
 
 
+_SPECIAL = np.array([-0.25, 0.0, -0.0, 1e-40, -1e-40, 3e38, 1e-30, 65504.0, -1.0, np.nan, np.inf, -np.inf], np.float32)
+
+
+def _special_values_capture(seed, finite_only=False):
+    """a fuzzed capture with samples no receiver delivers but a float WAV may hold: negative and zero runs, denormals,
+    huge values, sign flips, NaN and infinities"""
+    rng = np.random.default_rng(seed)
+    x = _fuzz_stream(seed, 200000).copy()
+    pos = rng.integers(0, x.size, int(rng.integers(4, 40)))
+    kind = seed % (3 if finite_only else 4)
+    if kind == 0:
+        x[pos] = _SPECIAL[rng.integers(0, 9, pos.size)]
+    elif kind == 1:
+        for p in pos[:6]:
+            x[p:p + int(rng.integers(1, 3000))] = _SPECIAL[rng.integers(0, 9)]
+    elif kind == 2:
+        x[pos[0]:] = -x[pos[0]:]
+    else:
+        x[pos[:3]] = _SPECIAL[rng.integers(9, 12, 3)]
+    return x
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_step_machine_follows_reference_on_special_sample_values(built, seed):
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    x = _special_values_capture(seed)
+    ref, _ = T.reference_decode(x, keep_carrier=True, cap=16384, defined_storage=True)
+    assert T.hostsim_decode(x, keep_carrier=True, cap=16384, lane=seed) == ref
+
+
 def _nfcv_capture(seed):
     """several synthetic NFC-V reader frames, 1-of-4 and 1-of-256 mixed, random payloads, levels and depths"""
     rng = np.random.default_rng(seed)
