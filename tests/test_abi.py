@@ -62,3 +62,20 @@ def test_product_sources_do_not_reference_the_oracle():
                 continue
             text = open(os.path.join(dirpath, fn), errors="ignore").read()
             assert "oracle/" not in text and "libnfcref" not in text and "hostsim" not in text.replace("tests/hostsim", ""), fn
+
+
+def test_decoder_shim_refuses_loudly_without_gpu(built, tmp_path):
+    """The reference's own test-sdr harness linked against the lab::NfcDecoder shim: on a box without a GPU it must
+    not decode anything by other means; the constructor throws (no CPU fallback behind the reference's interface)."""
+    import subprocess
+    import torch
+    exe = os.path.join(T.ROOT, "oracle", "_ref", "test-sdr-gpu")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    if not os.path.exists(exe):
+        pytest.skip("test-sdr-gpu not built (needs the reference tree at build time)")
+    T.write_wav(str(tmp_path / "test_NFC-A_106kbps_001.wav"), T.load_fixture_i16("test_NFC-A_106kbps_001"))
+    run = subprocess.run([exe, str(tmp_path) + "/"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert run.returncode != 0
+    assert "PASS" not in run.stdout
+    assert "no usable HIP device" in run.stdout
