@@ -1297,7 +1297,11 @@ const char *nfcgpu_last_error(nfcgpu_ctx *ctx)
 
 const char *nfcgpu_version(void)
 {
+#ifdef NFCGPU_EMULATED_TEST_BUILD
+   return "nfcgpu 0.1 (test build of the host runtime on an emulated HIP: not a product library)";
+#else
    return "nfcgpu 0.1 (gfx950)";
+#endif
 }
 
 }

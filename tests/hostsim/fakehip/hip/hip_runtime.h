@@ -1,0 +1,73 @@
+/*
+ * TEST INFRASTRUCTURE ONLY - a stand-in for <hip/hip_runtime.h> with which the host runtime of the product
+ * (nfc-laboratory_amd/csrc/nfcgpu.hip, unchanged) compiles for a box without a GPU: device memory is host memory,
+ * the stream is synchronous, a kernel launch is a call of the CPU twin of that kernel (tests/hostsim/emu_kernels.cpp).
+ * Only tests/hostsim/build_emulated.sh uses it; see there for what the resulting library is for.
+ */
+#ifndef NFC_FAKE_HIP_RUNTIME_H
+#define NFC_FAKE_HIP_RUNTIME_H
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorUnknown 999
+
+typedef struct fakeHipStream *hipStream_t;
+typedef struct fakeHipEvent *hipEvent_t;
+
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+#define hipStreamNonBlocking 1u
+#define hipHostMallocDefault 0u
+
+struct dim3
+{
+   uint32_t x, y, z;
+   dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+struct float2
+{
+   float x, y;
+};
+
+namespace fakehip {
+extern dim3 launchGrid, launchBlock;
+}
+
+static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *count) { *count = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)std::malloc(1); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::malloc(1); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+
+/* a launch is a call: the CPU twin walks the grid itself */
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+   do                                                              \
+   {                                                               \
+      fakehip::launchGrid = (grid);                                \
+      fakehip::launchBlock = (block);                              \
+      (kernel)(__VA_ARGS__);                                       \
+   } while (0)
+
+#endif
