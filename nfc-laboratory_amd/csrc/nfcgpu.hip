@@ -43,10 +43,12 @@ struct StreamInfo
    bool open = false;
    bool initialized = false; /* device state valid */
    bool needInit = true;
+   bool explicitInit = false; /* the pending initialisation was asked for (initialize()), not caused by a buffer */
    bool listed = false; /* part of the batch being submitted */
    nfcgpu_params params {};
    float powerAtInit = 0.01f; /* carrier thresholds are derived when the decoder (re)initialises */
    uint32_t config = 0;
+   uint32_t derivedRate = 0; /* sample rate the running configuration was derived from (params.sample_rate is the stored one) */
    uint32_t clock = 0xFFFFFFFFu; /* mirror of the device sample clock (NfcStreamState::clock) */
    std::deque<nfcgpu_frame> queue;
 };
@@ -163,7 +165,7 @@ bool matches_fixed_table(const NfcConfig &cfg)
 int resolve_config(nfcgpu_ctx *ctx, StreamInfo &si)
 {
    NfcHostParams hp;
-   hp.sampleRate = si.params.sample_rate;
+   hp.sampleRate = si.derivedRate;
    hp.enabled = si.params.tech_mask & 0xF;
    hp.powerLevelThreshold = si.params.power_level_threshold;
    for (int t = 0; t < 4; t++)
@@ -202,21 +204,41 @@ int resolve_config(nfcgpu_ctx *ctx, StreamInfo &si)
    return NFCGPU_OK;
 }
 
-/* apply a new sample rate the way NfcDecoder::nextFrames does (NfcDecoder.cpp:383-388) */
+/* The reference keeps two things apart: the sample rate it stores (setSampleRate(), or taken from a buffer whose rate
+ * differs from the stored one, NfcDecoder.cpp:383-388) and the parameters initialize() derived from the rate stored at
+ * that moment (NfcDecoder.cpp:295-360). A buffer only re-initialises the decoder when its rate differs from the stored
+ * one, so after setSampleRate(x) buffers labelled x are decoded with the parameters of the previous rate. The one thing
+ * not reproduced: parameters derived while the stored rate was still 0 (initialize() before any rate is known, then the
+ * rate given through the setter) leave the reference with NaN filter weights and no output; here they are derived when
+ * the first buffer arrives. */
 int adopt_sample_rate(nfcgpu_ctx *ctx, StreamInfo &si, uint32_t sampleRate)
 {
    if (sampleRate == 0)
       return fail(ctx, NFCGPU_EINVAL, "sample rate must be non-zero");
 
-   if (si.params.sample_rate != sampleRate || !si.initialized)
+   if (si.params.sample_rate != sampleRate)
    {
       si.params.sample_rate = sampleRate;
+      si.derivedRate = sampleRate;
+      si.needInit = true;
+      si.explicitInit = false; /* the reference initialises again, with what is set now */
+   }
+   else if (!si.initialized || si.derivedRate == 0)
+   {
       si.needInit = true;
    }
 
    if (si.needInit)
    {
-      si.powerAtInit = si.params.power_level_threshold;
+      if (si.derivedRate == 0)
+         si.derivedRate = sampleRate;
+
+      /* the carrier thresholds follow the power level of the moment of the initialisation (NfcDecoder.cpp:327-329):
+       * the moment of initialize() if that is what is pending, now otherwise */
+      if (!si.explicitInit)
+         si.powerAtInit = si.params.power_level_threshold;
+
+      si.explicitInit = false;
       return resolve_config(ctx, si);
    }
 
@@ -614,16 +636,13 @@ int nfcgpu_stream_configure(nfcgpu_ctx *ctx, uint32_t id, const nfcgpu_params *p
 
    si.params = *params;
 
-   /* setSampleRate() only stores the value; the decoder re-initialises when a buffer arrives whose rate differs
-    * from it. Keeping the old rate here until then reproduces that. */
+   /* setSampleRate() only stores the value (0 = leave it alone); nothing is re-derived from it until the decoder
+    * (re)initialises, see adopt_sample_rate */
    if (params->sample_rate == 0)
       si.params.sample_rate = oldRate;
 
-   if (si.initialized && !si.needInit && si.params.sample_rate == oldRate)
-      return resolve_config(ctx, si); /* thresholds take effect immediately */
-
-   if (si.params.sample_rate != oldRate)
-      si.needInit = true;
+   if (si.initialized && !si.needInit)
+      return resolve_config(ctx, si); /* thresholds and the enable mask take effect immediately */
 
    return NFCGPU_OK;
 }
@@ -635,7 +654,12 @@ int nfcgpu_stream_reset(nfcgpu_ctx *ctx, uint32_t id)
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
-   ctx->streams[id].needInit = true;
+   /* initialize(): everything is derived again from what is stored now (applied when the next buffer arrives) */
+   StreamInfo &si = ctx->streams[id];
+   si.needInit = true;
+   si.explicitInit = true;
+   si.derivedRate = si.params.sample_rate;
+   si.powerAtInit = si.params.power_level_threshold;
    return NFCGPU_OK;
 }
 
@@ -1129,7 +1153,7 @@ int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t id)
    {
       NfcStreamState s;
       HIP_TRY(ctx, hipMemcpy(&s, ctx->dStates + id, sizeof(s), hipMemcpyDeviceToHost));
-      clock = s.clock;
+      clock = si.needInit ? 0xFFFFFFFFu : s.clock; /* a pending initialize() has already reset the clock, not the carrier state */
       carrierOn = s.carrierOn;
    }
 

@@ -239,8 +239,9 @@ std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
       {
          const unsigned int count = samples.remaining() / stride;
 
-         if (count)
-            impl->check(nfcgpu_submit(impl->ctx, impl->stream, samples.ptr(), count, stride, samples.sampleRate()), "submit");
+         /* an empty buffer still counts: a sample rate that differs from the stored one re-initialises the decoder
+          * at this point (NfcDecoder.cpp:383-388), with the thresholds set at this point */
+         impl->check(nfcgpu_submit(impl->ctx, impl->stream, samples.ptr(), count, stride, samples.sampleRate()), "submit");
 
          impl->params.sample_rate = samples.sampleRate();
       }

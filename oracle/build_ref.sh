@@ -86,4 +86,6 @@ fi
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/resample_harness.cpp" "$RO" "$OUT/obj/Worker.o" "$OUT/obj/Executor.o" \
     "$OUT/libnfcref_support.a" -o "$OUT/resample-ref" -pthread
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/task_harness.cpp" "$OUT/libnfcref_task.a" $OBJS -o "$OUT/task-ref" -pthread
-echo "built $OUT/libnfcref.so $OUT/test-sdr-ref $OUT/task-ref $OUT/resample-ref"
+# the decoder interface driven by a script (tests/dropin/api_harness.cpp), reference decoder underneath
+g++ $CXXFLAGS $INC "$HERE/../tests/dropin/api_harness.cpp" $OBJS -o "$OUT/api-ref" -pthread
+echo "built $OUT/libnfcref.so $OUT/test-sdr-ref $OUT/task-ref $OUT/resample-ref $OUT/api-ref"

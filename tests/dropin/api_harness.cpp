@@ -1,0 +1,113 @@
+/*
+ * TEST INFRASTRUCTURE. Drives one lab::NfcDecoder through its public interface (the drop-in seam) with a
+ * scripted sequence of calls and prints what comes back. Linked twice from this one source: with the reference's
+ * decoder (oracle/_ref/api-ref) and with the lab::NfcDecoder shim on libnfcgpu.so (oracle/_ref/api-gpu); the outputs
+ * of the two on the same script must be identical (tests/test_decoder_api_sequences.py). Unlike a capture replay this
+ * exercises the interface semantics: setters between buffers, initialize() in mid-stream, sample-rate changes, invalid
+ * buffers, empty buffers, technologies switched off while locked.
+ *
+ *   api_harness samples.f32 script.txt
+ * script lines:  enable <A|B|F|V> <0|1> | power <f> | corr <A|B|F|V> <f> | depth <A|B|F|V> <min> <max> | rate <hz>
+ *                time <t> | init | feed <first> <count> <hz> | invalid
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <list>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <hw/SignalType.h>
+#include <hw/SignalBuffer.h>
+#include <lab/data/RawFrame.h>
+#include <lab/nfc/NfcDecoder.h>
+
+static void print(const char *tag, const std::list<lab::RawFrame> &frames)
+{
+   for (const lab::RawFrame &f: frames)
+   {
+      std::printf("%s %u %u %u %u %u %lu %lu %lu %.9f %.9f %.3f ", tag, f.techType(), f.frameType(), f.frameFlags(), f.framePhase(),
+                  f.frameRate(), (unsigned long)f.sampleStart(), (unsigned long)f.sampleEnd(), (unsigned long)f.sampleRate(), f.timeStart(),
+                  f.timeEnd(), f.dateTime());
+      for (unsigned int i = 0; i < f.limit(); i++)
+         std::printf("%02x", (unsigned)f[i]);
+      std::printf("\n");
+   }
+}
+
+int main(int argc, char *argv[])
+{
+   if (argc != 3)
+      return 2;
+
+   std::ifstream raw(argv[1], std::ios::binary);
+   std::vector<char> bytes((std::istreambuf_iterator<char>(raw)), std::istreambuf_iterator<char>());
+   const float *samples = reinterpret_cast<const float *>(bytes.data());
+   const size_t total = bytes.size() / sizeof(float);
+
+   lab::NfcDecoder decoder;
+   std::ifstream script(argv[2]);
+   std::string line;
+   int step = 0;
+
+   while (std::getline(script, line))
+   {
+      std::istringstream in(line);
+      std::string op, tech;
+      in >> op;
+      step++;
+
+      auto which = [&]() { in >> tech; return tech.empty() ? 'A' : tech[0]; };
+
+      if (op == "enable")
+      {
+         char t = which(); int on = 0; in >> on;
+         if (t == 'A') decoder.setEnableNfcA(on); if (t == 'B') decoder.setEnableNfcB(on);
+         if (t == 'F') decoder.setEnableNfcF(on); if (t == 'V') decoder.setEnableNfcV(on);
+      }
+      else if (op == "power") { float v = 0; in >> v; decoder.setPowerLevelThreshold(v); }
+      else if (op == "corr")
+      {
+         char t = which(); float v = 0; in >> v;
+         if (t == 'A') decoder.setCorrelationThresholdNfcA(v); if (t == 'B') decoder.setCorrelationThresholdNfcB(v);
+         if (t == 'F') decoder.setCorrelationThresholdNfcF(v); if (t == 'V') decoder.setCorrelationThresholdNfcV(v);
+      }
+      else if (op == "depth")
+      {
+         char t = which(); float lo = 0, hi = 0; in >> lo >> hi;
+         if (t == 'A') decoder.setModulationThresholdNfcA(lo, hi); if (t == 'B') decoder.setModulationThresholdNfcB(lo, hi);
+         if (t == 'F') decoder.setModulationThresholdNfcF(lo, hi); if (t == 'V') decoder.setModulationThresholdNfcV(lo, hi);
+      }
+      else if (op == "rate") { long hz = 0; in >> hz; decoder.setSampleRate(hz); }
+      else if (op == "time") { long t = 0; in >> t; decoder.setStreamTime(t); }
+      else if (op == "init") { decoder.initialize(); }
+      else if (op == "feed")
+      {
+         size_t first = 0, count = 0; long hz = 0;
+         in >> first >> count >> hz;
+         if (first > total) first = total;
+         if (first + count > total) count = total - first;
+         hw::SignalBuffer buffer(count ? count : 1, 1, 1, hz, 0, 0, hw::SignalType::SIGNAL_TYPE_RADIO_SAMPLES, 0);
+         buffer.put(samples + first, count).flip();
+         char tag[32];
+         std::snprintf(tag, sizeof(tag), "F%d", step);
+         print(tag, decoder.nextFrames(buffer));
+      }
+      else if (op == "invalid")
+      {
+         hw::SignalBuffer invalid;
+         char tag[32];
+         std::snprintf(tag, sizeof(tag), "I%d", step);
+         print(tag, decoder.nextFrames(invalid));
+      }
+
+      std::printf("S%d rate=%ld time=%ld power=%.6f A=%d B=%d F=%d V=%d\n", step, decoder.sampleRate(), decoder.streamTime(),
+                  decoder.powerLevelThreshold(), (int)decoder.isNfcAEnabled(), (int)decoder.isNfcBEnabled(), (int)decoder.isNfcFEnabled(),
+                  (int)decoder.isNfcVEnabled());
+   }
+
+   return 0;
+}
