@@ -7,8 +7,10 @@
  * buffers, empty buffers, technologies switched off while locked.
  *
  *   api_harness samples.f32 script.txt
- * script lines:  enable <A|B|F|V> <0|1> | power <f> | corr <A|B|F|V> <f> | depth <A|B|F|V> <min> <max> | rate <hz>
- *                time <t> | init | feed <first> <count> <hz> | invalid
+ * script lines:  [@k] enable <A|B|F|V> <0|1> | power <f> | corr <A|B|F|V> <f> | depth <A|B|F|V> <min> <max> | rate <hz>
+ *                     time <t> | init | feed <first> <count> <hz> | invalid | drop
+ * @k selects decoder k (created at its first line, default 0): several decoders live side by side, as several
+ * RadioDecoderTasks would (with the shim they share one GPU context); drop destroys decoder k.
  */
 #include <cmath>
 #include <cstdio>
@@ -16,6 +18,8 @@
 #include <fstream>
 #include <iostream>
 #include <list>
+#include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -48,7 +52,7 @@ int main(int argc, char *argv[])
    const float *samples = reinterpret_cast<const float *>(bytes.data());
    const size_t total = bytes.size() / sizeof(float);
 
-   lab::NfcDecoder decoder;
+   std::map<int, std::unique_ptr<lab::NfcDecoder>> decoders;
    std::ifstream script(argv[2]);
    std::string line;
    int step = 0;
@@ -59,6 +63,25 @@ int main(int argc, char *argv[])
       std::string op, tech;
       in >> op;
       step++;
+
+      int k = 0;
+      if (!op.empty() && op[0] == '@')
+      {
+         k = std::atoi(op.c_str() + 1);
+         in >> op;
+      }
+
+      if (op == "drop")
+      {
+         decoders.erase(k);
+         std::printf("S%d @%d dropped\n", step, k);
+         continue;
+      }
+
+      if (!decoders.count(k))
+         decoders[k].reset(new lab::NfcDecoder());
+
+      lab::NfcDecoder &decoder = *decoders[k];
 
       auto which = [&]() { in >> tech; return tech.empty() ? 'A' : tech[0]; };
 
@@ -104,7 +127,7 @@ int main(int argc, char *argv[])
          print(tag, decoder.nextFrames(invalid));
       }
 
-      std::printf("S%d rate=%ld time=%ld power=%.6f A=%d B=%d F=%d V=%d\n", step, decoder.sampleRate(), decoder.streamTime(),
+      std::printf("S%d @%d rate=%ld time=%ld power=%.6f A=%d B=%d F=%d V=%d\n", step, k, decoder.sampleRate(), decoder.streamTime(),
                   decoder.powerLevelThreshold(), (int)decoder.isNfcAEnabled(), (int)decoder.isNfcBEnabled(), (int)decoder.isNfcFEnabled(),
                   (int)decoder.isNfcVEnabled());
    }

@@ -17,10 +17,10 @@ GPU = os.path.join(T.ROOT, "oracle", "_ref", "api-gpu")
 EMU = os.path.join(T.ROOT, "tests", "hostsim", "libnfcgpu_emulated.so")
 
 
-def _script(seed, total):
+def _script(seed, total, prefix="", start=0):
     """a random but plausible life of a decoder: mostly buffers of the capture in order, now and then something else"""
     rng = np.random.default_rng(seed)
-    lines, pos, rate = [], 0, 10000000
+    lines, pos, rate = [], start, 10000000
     # the start as the reference's callers do it: either nothing (test-sdr: the first buffer brings the rate) or the rate
     # followed by initialize() (RadioDecoderTask: Configure, then Start). initialize() while the rate is still unknown,
     # or the rate without initialize(), leaves the reference with parameters derived from rate 0 (NaN filter weights,
@@ -56,6 +56,26 @@ def _script(seed, total):
         else:
             lines.append("time %d" % int(rng.integers(0, 2000000000)))
     lines.append("invalid")
+    if prefix:
+        return [prefix + " " + l for l in lines]
+    return "\n".join(lines) + "\n"
+
+
+def _interleaved_script(seed, total):
+    """three decoders side by side (with the shim: three streams of one GPU context, neighbours in one stream block), their
+    calls interleaved at random; one of them is destroyed and created again on the way"""
+    rng = np.random.default_rng(seed + 5000)
+    lives = [_script(seed * 3 + k, total, prefix="@%d" % k, start=int(rng.integers(0, total // 2))) for k in range(3)]
+    lines = []
+    while any(lives):
+        k = int(rng.integers(3))
+        if not lives[k]:
+            continue
+        take = int(rng.integers(1, 5))
+        lines += lives[k][:take]
+        lives[k] = lives[k][take:]
+        if rng.random() < 0.03:
+            lines.append("@%d drop" % k)
     return "\n".join(lines) + "\n"
 
 
@@ -65,13 +85,13 @@ def _run(exe, raw, script, env=None):
     return run.stdout.splitlines()
 
 
-def _check(seed, tmp_path, env):
+def _check(seed, tmp_path, env, interleaved=False):
     x = _fuzz_stream(7000 + seed, 400000)
     raw = str(tmp_path / "x.f32")
     x.tofile(raw)
     script = str(tmp_path / "script.txt")
     with open(script, "w") as f:
-        f.write(_script(seed, x.size))
+        f.write(_interleaved_script(seed, x.size) if interleaved else _script(seed, x.size))
     want = _run(REF, raw, script)
     got = _run(GPU, raw, script, env=env)
     assert len(got) == len(want)
@@ -93,7 +113,21 @@ def test_random_call_sequences_on_the_emulated_runtime(built, seed, tmp_path):
 
 
 @needs_harness
+@pytest.mark.parametrize("seed", range(4))
+def test_interleaved_decoders_on_the_emulated_runtime(built, seed, tmp_path):
+    if not os.path.exists(EMU):
+        subprocess.check_call(["bash", os.path.join(T.ROOT, "tests", "hostsim", "build_emulated.sh")])
+    _check(seed, tmp_path, dict(os.environ, LD_PRELOAD=EMU), interleaved=True)
+
+
+@needs_harness
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(3))
 def test_random_call_sequences_on_the_gpu(built, seed, tmp_path):
     _check(seed, tmp_path, None)
+
+
+@needs_harness
+@pytest.mark.gpu
+def test_interleaved_decoders_on_the_gpu(built, tmp_path):
+    _check(1, tmp_path, None, interleaved=True)
