@@ -25,14 +25,23 @@ def _script(seed, total, prefix="", start=0):
     # followed by initialize() (RadioDecoderTask: Configure, then Start). initialize() while the rate is still unknown,
     # or the rate without initialize(), leaves the reference with parameters derived from rate 0 (NaN filter weights,
     # no output): the one piece of its behaviour the shim does not reproduce
-    if rng.random() < 0.6:
-        lines.append("rate %d" % rate)
-        lines.append("init")
+    def start():
+        if rng.random() < 0.6:
+            lines.append("rate %d" % rate)
+            lines.append("init")
+
+    start()
+    fed = False   # the decoder has seen a buffer since it was created
     if rng.random() < 0.5:
         lines.append("time %d" % int(rng.integers(0, 2000000000)))
     while pos < total:
         r = rng.random()
-        if r < 0.70:
+        if prefix and r < 0.01:
+            lines.append("drop")   # destroyed; the next line creates a new decoder under the same number
+            start()
+            fed = False
+        elif r < 0.70:
+            fed = True
             n = int(rng.choice([65536, 65536, 16384, 4099, 1, 0, int(rng.integers(1, 100000))]))
             lines.append("feed %d %d %d" % (pos, n, rate))
             pos += n
@@ -51,8 +60,10 @@ def _script(seed, total, prefix="", start=0):
             lines.append("invalid")
         elif r < 0.96:
             rate = int(rng.choice([10000000, 5000000, 8000000, 10000000]))
-            if rng.random() < 0.5:
-                lines.append("rate %d" % rate)   # announced through the setter as well; otherwise the buffers just change
+            if rng.random() < 0.5 and fed:
+                # announced through the setter as well (otherwise the buffers just change); not before the decoder has been
+                # initialised by a first buffer: see the note on rate 0 above
+                lines.append("rate %d" % rate)
         else:
             lines.append("time %d" % int(rng.integers(0, 2000000000)))
     lines.append("invalid")
@@ -63,7 +74,7 @@ def _script(seed, total, prefix="", start=0):
 
 def _interleaved_script(seed, total):
     """three decoders side by side (with the shim: three streams of one GPU context, neighbours in one stream block), their
-    calls interleaved at random; one of them is destroyed and created again on the way"""
+    calls interleaved at random; now and then one is destroyed and created again"""
     rng = np.random.default_rng(seed + 5000)
     lives = [_script(seed * 3 + k, total, prefix="@%d" % k, start=int(rng.integers(0, total // 2))) for k in range(3)]
     lines = []
@@ -74,8 +85,6 @@ def _interleaved_script(seed, total):
         take = int(rng.integers(1, 5))
         lines += lives[k][:take]
         lives[k] = lives[k][take:]
-        if rng.random() < 0.03:
-            lines.append("@%d drop" % k)
     return "\n".join(lines) + "\n"
 
 
