@@ -192,11 +192,36 @@ int resolve_config(nfcgpu_ctx *ctx, StreamInfo &si)
       }
    }
 
-   if (ctx->configs.size() >= kMaxConfigs)
-      return fail(ctx, NFCGPU_ENOMEM, "too many distinct decoder configurations");
+   if (ctx->configs.size() < kMaxConfigs)
+   {
+      ctx->configs.push_back(cfg);
+      si.config = (uint32_t)ctx->configs.size() - 1;
+   }
+   else
+   {
+      /* the table is full: take the place of a configuration no open stream refers to any more (parameters changed
+       * since, streams closed). Launches that may still read it are waited for first. */
+      std::vector<bool> used(kMaxConfigs, false);
+      for (const StreamInfo &other: ctx->streams)
+      {
+         if (other.open && &other != &si && (other.initialized || other.needInit))
+            used[other.config] = true;
+      }
 
-   ctx->configs.push_back(cfg);
-   si.config = (uint32_t)ctx->configs.size() - 1;
+      uint32_t slot = kMaxConfigs;
+      for (uint32_t i = 0; i < kMaxConfigs && slot == kMaxConfigs; i++)
+      {
+         if (!used[i])
+            slot = i;
+      }
+
+      if (slot == kMaxConfigs)
+         return fail(ctx, NFCGPU_ENOMEM, "too many distinct decoder configurations in use at once");
+
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->configs[slot] = cfg;
+      si.config = slot;
+   }
 
    HIP_TRY(ctx, hipMemcpyAsync(ctx->dConfigs + si.config, &cfg, sizeof(cfg), hipMemcpyHostToDevice, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* cfg is a stack object */
@@ -218,6 +243,15 @@ int adopt_sample_rate(nfcgpu_ctx *ctx, StreamInfo &si, uint32_t sampleRate)
 
    if (si.params.sample_rate != sampleRate)
    {
+      /* frames are stamped with the rate stored when they were produced (NfcDecoder.cpp frame.setSampleRate): collect
+       * what the sink holds before the stored rate changes */
+      if (si.params.sample_rate != 0 && ctx->dirty && !ctx->hold)
+      {
+         int rc = nfcgpu_sync(ctx);
+         if (rc != NFCGPU_OK && rc != NFCGPU_EOVERFLOW)
+            return rc;
+      }
+
       si.params.sample_rate = sampleRate;
       si.derivedRate = sampleRate;
       si.needInit = true;
@@ -633,6 +667,14 @@ int nfcgpu_stream_configure(nfcgpu_ctx *ctx, uint32_t id, const nfcgpu_params *p
 
    StreamInfo &si = ctx->streams[id];
    const uint32_t oldRate = si.params.sample_rate;
+
+   if (params->sample_rate != 0 && params->sample_rate != oldRate && oldRate != 0 && ctx->dirty && !ctx->hold)
+   {
+      /* frames already produced keep the rate stored when they were produced */
+      int rc = nfcgpu_sync(ctx);
+      if (rc != NFCGPU_OK && rc != NFCGPU_EOVERFLOW)
+         return rc;
+   }
 
    si.params = *params;
 
