@@ -84,6 +84,7 @@ int main(int argc, char *argv[])
       lab::NfcDecoder &decoder = *decoders[k];
 
       auto which = [&]() { in >> tech; return tech.empty() ? 'A' : tech[0]; };
+      auto number = [&]() { std::string t; in >> t; return std::strtof(t.c_str(), nullptr); }; /* accepts nan */
 
       if (op == "enable")
       {
@@ -91,16 +92,16 @@ int main(int argc, char *argv[])
          if (t == 'A') decoder.setEnableNfcA(on); if (t == 'B') decoder.setEnableNfcB(on);
          if (t == 'F') decoder.setEnableNfcF(on); if (t == 'V') decoder.setEnableNfcV(on);
       }
-      else if (op == "power") { float v = 0; in >> v; decoder.setPowerLevelThreshold(v); }
+      else if (op == "power") { float v = number(); decoder.setPowerLevelThreshold(v); }
       else if (op == "corr")
       {
-         char t = which(); float v = 0; in >> v;
+         char t = which(); float v = number();
          if (t == 'A') decoder.setCorrelationThresholdNfcA(v); if (t == 'B') decoder.setCorrelationThresholdNfcB(v);
          if (t == 'F') decoder.setCorrelationThresholdNfcF(v); if (t == 'V') decoder.setCorrelationThresholdNfcV(v);
       }
       else if (op == "depth")
       {
-         char t = which(); float lo = 0, hi = 0; in >> lo >> hi;
+         char t = which(); float lo = number(), hi = number();
          if (t == 'A') decoder.setModulationThresholdNfcA(lo, hi); if (t == 'B') decoder.setModulationThresholdNfcB(lo, hi);
          if (t == 'F') decoder.setModulationThresholdNfcF(lo, hi); if (t == 'V') decoder.setModulationThresholdNfcV(lo, hi);
       }
@@ -127,9 +128,14 @@ int main(int argc, char *argv[])
          print(tag, decoder.nextFrames(invalid));
       }
 
-      std::printf("S%d @%d rate=%ld time=%ld power=%.6f A=%d B=%d F=%d V=%d\n", step, k, decoder.sampleRate(), decoder.streamTime(),
+      std::printf("S%d @%d rate=%ld time=%ld power=%.6f A=%d B=%d F=%d V=%d corr=%.6f/%.6f/%.6f/%.6f depth=%.6f-%.6f/%.6f-%.6f/%.6f-%.6f/%.6f-%.6f debug=%d\n",
+                  step, k, decoder.sampleRate(), decoder.streamTime(),
                   decoder.powerLevelThreshold(), (int)decoder.isNfcAEnabled(), (int)decoder.isNfcBEnabled(), (int)decoder.isNfcFEnabled(),
-                  (int)decoder.isNfcVEnabled());
+                  (int)decoder.isNfcVEnabled(), decoder.correlationThresholdNfcA(), decoder.correlationThresholdNfcB(),
+                  decoder.correlationThresholdNfcF(), decoder.correlationThresholdNfcV(), decoder.modulationThresholdNfcAMin(),
+                  decoder.modulationThresholdNfcAMax(), decoder.modulationThresholdNfcBMin(), decoder.modulationThresholdNfcBMax(),
+                  decoder.modulationThresholdNfcFMin(), decoder.modulationThresholdNfcFMax(), decoder.modulationThresholdNfcVMin(),
+                  decoder.modulationThresholdNfcVMax(), (int)decoder.isDebugEnabled());
    }
 
    return 0;

@@ -50,10 +50,13 @@ def _script(seed, total, prefix="", start=0):
         elif r < 0.78:
             lines.append("power %.6f" % rng.uniform(0.003, 0.05))
         elif r < 0.82:
-            lines.append("corr %s %.6f" % ("ABFV"[int(rng.integers(4))], rng.uniform(0.2, 0.9)))
+            lines.append("corr %s %s" % ("ABFV"[int(rng.integers(4))], "nan" if rng.random() < 0.15 else "%.6f" % rng.uniform(0.2, 0.9)))
         elif r < 0.86:
             lo = rng.uniform(0.05, 0.9)
-            lines.append("depth %s %.6f %.6f" % ("ABFV"[int(rng.integers(4))], lo, min(1.0, lo + rng.uniform(0.05, 0.6))))
+            pair = ["%.6f" % lo, "%.6f" % min(1.0, lo + rng.uniform(0.05, 0.6))]
+            if rng.random() < 0.2:
+                pair[int(rng.integers(2))] = "nan"   # NaN leaves that bound as it is (NfcDecoder.cpp setters)
+            lines.append("depth %s %s %s" % ("ABFV"[int(rng.integers(4))], pair[0], pair[1]))
         elif r < 0.90:
             lines.append("init")
         elif r < 0.93:
