@@ -1,5 +1,5 @@
 """The C ABI used the way a multi-receiver host would (nfcgpu_submit_batch): dozens of streams in neighbouring
-slots, each with its own parameters, ragged batches, and in between configure / reset / flush / close-and-reopen on single
+slots, each with its own parameters, ragged batches of magnitude or interleaved IQ samples, and in between configure / reset / flush / close-and-reopen on single
 streams. The yardstick is the reference class itself: every stream is one lab::NfcDecoder of oracle/_ref/api-ref, which is
 fed the equivalent call sequence (tests/dropin/api_harness.cpp), and the frames of each stream must be the same. Runs on
 the emulated host runtime here (tests/test_host_runtime_emulated.py) and on the GPU with -m gpu."""
@@ -41,10 +41,19 @@ with nfclab_amd.NfcGpu(device=0, max_streams=ops["slots"]) as gpu:
         kind = op[0]
         if kind == "batch":
             ids, parts = [], []
+            stride = op[3]
             for slot, pos, n in op[1]:
                 ids.append(first + slot)
-                parts.append(np.ascontiguousarray(x[pos:pos + n]))
-            gpu.submit_batch(ids, [p.ctypes.data for p in parts], [p.size for p in parts], op[2])
+                m = x[pos:pos + n]
+                if stride == 2:
+                    # interleaved IQ whose magnitude is exactly the capture: the phase turns by 90 degrees every 7 samples
+                    iq = np.zeros((n, 2), np.float32)
+                    q = (np.arange(pos, pos + n) // 7) % 4
+                    iq[:, 0] = np.where(q == 0, m, np.where(q == 2, -m, 0))
+                    iq[:, 1] = np.where(q == 1, m, np.where(q == 3, -m, 0))
+                    m = iq.reshape(-1)
+                parts.append(np.ascontiguousarray(m, dtype=np.float32))
+            gpu.submit_batch(ids, [p.ctypes.data for p in parts], [p.size // stride for p in parts], op[2], stride=stride)
         elif kind == "configure":
             slot, field, tech, a, b = op[1:]
             p = params[slot]
@@ -102,7 +111,7 @@ def _scenario(seed, total, slots=40, steps=60):
                 rate[slot] = batch_rate
                 fed[slot] = True
         if members:
-            ops.append(["batch", members, batch_rate])
+            ops.append(["batch", members, batch_rate, int(rng.choice([1, 1, 2]))])
         for _ in range(int(rng.integers(0, 4))):
             slot = int(rng.integers(slots))
             k = key_of[slot]
@@ -155,7 +164,7 @@ def _reference_frames(raw, script_path):
 
 def _check(seed, tmp_path, env):
     import json
-    x = _fuzz_stream(9000 + seed, 400000)
+    x = np.abs(_fuzz_stream(9000 + seed, 400000))   # a magnitude: the IQ batches carry it as |I + jQ|
     raw = str(tmp_path / "x.f32")
     x.tofile(raw)
     ops, script = _scenario(seed, x.size)
