@@ -77,3 +77,49 @@ def test_reference_radio_decoder_task_and_shim_on_the_emulated_runtime(emulated,
         got = T.run_task_harness(exe, names, tmp_path, iq=iq)
         for name in names:
             assert got[name] == T.load_golden(name), (name, iq)
+
+
+UNIFORM_DRIVER = r'''
+import sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np
+import nfc_testlib as T, nfclab_amd
+from test_oracle_goldens import _fuzz_stream
+S, L, K = 70, 8192, 5            # 70 streams: one full stream block and a partial one
+data = np.stack([np.abs(_fuzz_stream(4000 + s, L * K)) for s in range(S)]).astype(np.float32)
+iq = np.zeros((S, L * K, 2), np.float32)
+iq[:, :, 0] = data               # phase 0: |I + j0| is the magnitude itself
+bad = []
+with nfclab_amd.NfcGpu(device=0, max_streams=128) as gpu:
+    extra = gpu.open()           # a stream ahead of the range: the range starts in the middle of a block
+    first = gpu.open(count=S)
+    for k in range(K):
+        if k % 2:
+            gpu.submit_uniform(first, S, iq.ctypes.data + k * L * 8, L * K * 8, L, 10000000, stride=2, location=nfclab_amd.LOC_DEVICE)
+        else:
+            gpu.submit_uniform(first, S, data.ctypes.data + k * L * 4, L * K * 4, L, 10000000, stride=1, location=nfclab_amd.LOC_HOST)
+    frames = 0
+    for s in range(S):
+        ref, _ = T.reference_decode(data[s], chunk=L, keep_carrier=True, cap=8192, defined_storage=True)
+        frames += len(ref)
+        if gpu.poll(first + s, capacity=8192) != ref:
+            bad.append(s)
+print(json.dumps({"bad": bad, "frames": frames}))
+'''
+
+
+def test_uniform_layout_submissions_on_the_emulated_runtime(emulated, tmp_path):
+    """nfcgpu_submit_uniform ([stream][sample] layout, what bench.py uses with HBM-resident input): host-resident rows
+    and rows handed over as device memory (plain memory here), magnitude and IQ, a range that starts inside a stream
+    block; every stream against the reference."""
+    import json
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    with open(tmp_path / "driver.py", "w") as f:
+        f.write(UNIFORM_DRIVER)
+    run = subprocess.run([sys.executable, str(tmp_path / "driver.py"), os.path.join(T.ROOT, "nfc-laboratory_amd"), os.path.join(T.ROOT, "tests")],
+                         env=dict(os.environ, NFCGPU_LIB=emulated, NFCGPU_NO_TORCH="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    out = json.loads(run.stdout.splitlines()[-1])
+    assert out["bad"] == [] and out["frames"] > 200, out
