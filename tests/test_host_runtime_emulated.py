@@ -99,19 +99,40 @@ with nfclab_amd.NfcGpu(device=0, max_streams=128) as gpu:
         else:
             gpu.submit_uniform(first, S, data.ctypes.data + k * L * 4, L * K * 4, L, 10000000, stride=1, location=nfclab_amd.LOC_HOST)
     frames = 0
+    refs = []
     for s in range(S):
         ref, _ = T.reference_decode(data[s], chunk=L, keep_carrier=True, cap=8192, defined_storage=True)
+        refs.append(ref)
         frames += len(ref)
         if gpu.poll(first + s, capacity=8192) != ref:
             bad.append(s)
-print(json.dumps({"bad": bad, "frames": frames}))
+
+# the same once more the way bench.py collects frames: a caller-provided sink, held (never drained by the runtime),
+# parsed from the packed records
+import frames as framelib
+sink = np.zeros(1 << 22, np.int32)
+ctl = np.zeros(4, np.int32)
+bad_sink = []
+with nfclab_amd.NfcGpu(device=0, max_streams=128, frame_sink_bytes=1 << 20) as gpu:
+    gpu.sink_attach(sink.ctypes.data, sink.size, ctl.ctypes.data)
+    gpu.sink_hold(True)
+    first = gpu.open(count=S)
+    for k in range(K):
+        gpu.submit_uniform(first, S, data.ctypes.data + k * L * 4, L * K * 4, L, 10000000, stride=1, location=nfclab_amd.LOC_DEVICE)
+    gpu.sync()
+    parsed = framelib.parse_sink(sink, int(ctl[0]), 10000000)
+    for s in range(S):
+        if parsed.get(first + s, []) != refs[s]:
+            bad_sink.append(s)
+    dropped = int(ctl[1])
+print(json.dumps({"bad": bad, "frames": frames, "bad_sink": bad_sink, "dropped": dropped}))
 '''
 
 
 def test_uniform_layout_submissions_on_the_emulated_runtime(emulated, tmp_path):
     """nfcgpu_submit_uniform ([stream][sample] layout, what bench.py uses with HBM-resident input): host-resident rows
     and rows handed over as device memory (plain memory here), magnitude and IQ, a range that starts inside a stream
-    block; every stream against the reference."""
+    block; every stream against the reference, collected by polling and, as bench.py does, from a caller-provided held sink."""
     import json
     if T.reference_lib() is None:
         pytest.skip("oracle/_ref not built")
@@ -122,4 +143,4 @@ def test_uniform_layout_submissions_on_the_emulated_runtime(emulated, tmp_path):
                          text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
     out = json.loads(run.stdout.splitlines()[-1])
-    assert out["bad"] == [] and out["frames"] > 200, out
+    assert out["bad"] == [] and out["bad_sink"] == [] and out["dropped"] == 0 and out["frames"] > 200, out
