@@ -87,5 +87,5 @@ g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/resample_harness.cpp" "$RO" "$OUT/obj
     "$OUT/libnfcref_support.a" -o "$OUT/resample-ref" -pthread
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/task_harness.cpp" "$OUT/libnfcref_task.a" $OBJS -o "$OUT/task-ref" -pthread
 # the decoder interface driven by a script (tests/dropin/api_harness.cpp), reference decoder underneath
-g++ $CXXFLAGS $INC "$HERE/../tests/dropin/api_harness.cpp" $OBJS -o "$OUT/api-ref" -pthread
+g++ $CXXFLAGS $INC -DNFC_DEFINED_FRAME_STORAGE "$HERE/../tests/dropin/api_harness.cpp" $OBJS -o "$OUT/api-ref" -pthread -Wl,--wrap=posix_memalign
 echo "built $OUT/libnfcref.so $OUT/test-sdr-ref $OUT/task-ref $OUT/resample-ref $OUT/api-ref"

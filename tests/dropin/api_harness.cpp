@@ -29,6 +29,24 @@
 #include <lab/data/RawFrame.h>
 #include <lab/nfc/NfcDecoder.h>
 
+#ifdef NFC_DEFINED_FRAME_STORAGE
+/* Reference build only (oracle/build_ref.sh): frame storage cleared and never recycled, so that what the reference reads
+ * beyond truncated frames is defined (zero) instead of a leftover of an earlier frame; see oracle/ref_capi.cpp. */
+#include <cstring>
+extern "C" int __real_posix_memalign(void **ptr, size_t alignment, size_t size);
+extern "C" int __wrap_posix_memalign(void **ptr, size_t alignment, size_t size)
+{
+   int res = __real_posix_memalign(ptr, alignment, size);
+   if (res == 0)
+      std::memset(*ptr, 0, size);
+   return res;
+}
+static std::list<std::list<lab::RawFrame>> kept;
+#define KEEP(frames) kept.push_back(frames)
+#else
+#define KEEP(frames) (void)0
+#endif
+
 static void print(const char *tag, const std::list<lab::RawFrame> &frames)
 {
    for (const lab::RawFrame &f: frames)
@@ -118,14 +136,18 @@ int main(int argc, char *argv[])
          buffer.put(samples + first, count).flip();
          char tag[32];
          std::snprintf(tag, sizeof(tag), "F%d", step);
-         print(tag, decoder.nextFrames(buffer));
+         std::list<lab::RawFrame> frames = decoder.nextFrames(buffer);
+         print(tag, frames);
+         KEEP(frames);
       }
       else if (op == "invalid")
       {
          hw::SignalBuffer invalid;
          char tag[32];
          std::snprintf(tag, sizeof(tag), "I%d", step);
-         print(tag, decoder.nextFrames(invalid));
+         std::list<lab::RawFrame> frames = decoder.nextFrames(invalid);
+         print(tag, frames);
+         KEEP(frames);
       }
 
       std::printf("S%d @%d rate=%ld time=%ld power=%.6f A=%d B=%d F=%d V=%d corr=%.6f/%.6f/%.6f/%.6f depth=%.6f-%.6f/%.6f-%.6f/%.6f-%.6f/%.6f-%.6f debug=%d\n",
