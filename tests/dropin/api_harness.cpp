@@ -2,7 +2,7 @@
  * TEST INFRASTRUCTURE. Drives one lab::NfcDecoder through its public interface (the drop-in seam) with a
  * scripted sequence of calls and prints what comes back. Linked twice from this one source: with the reference's
  * decoder (oracle/_ref/api-ref) and with the lab::NfcDecoder shim on libnfcgpu.so (oracle/_ref/api-gpu); the outputs
- * of the two on the same script must be identical (tests/test_decoder_api_sequences.py). Unlike a capture replay this
+ * of the two on the same script must be identical (tests/test_interface_sequences.py). Unlike a capture replay this
  * exercises the interface semantics: setters between buffers, initialize() in mid-stream, sample-rate changes, invalid
  * buffers, empty buffers, technologies switched off while locked.
  *

@@ -316,23 +316,6 @@ def test_other_sample_rates_match_reference(gpu, rate, step):
         gpu.close_stream(sid)
 
 
-def test_resampled_capture_at_rtl_sdr_rate(gpu):
-    """3.2 MS/s (RTL-SDR, the slowest receiver class of the reference): captures resampled by linear interpolation, all
-    periods and windows rounded from a non-integer ratio to 10 MS/s; generic kernels."""
-    if T.reference_lib() is None:
-        pytest.skip("oracle/_ref not available")
-    rate = 3200000
-    for name in ["test_NFC-A_424kbps_002", "test_NFC-F_212kbps_003"]:
-        x = T.load_fixture(name)
-        t = np.arange(int(x.size * rate / 10e6), dtype=np.float64) * (10e6 / rate)
-        y = np.interp(t, np.arange(x.size), x).astype(np.float32)
-        ref, _ = T.reference_decode(y, sample_rate=rate, keep_carrier=True, cap=16384, defined_storage=True)
-        sid = gpu.open()
-        gpu.submit(sid, y, rate)
-        assert gpu.poll(sid, capacity=16384) == ref, name
-        gpu.close_stream(sid)
-
-
 def test_unsupported_sample_rate_is_rejected_loudly(gpu):
     import nfclab_amd
     sid = gpu.open()
@@ -514,3 +497,20 @@ def test_special_sample_values(gpu):
         ref, _ = T.reference_decode(c, keep_carrier=True, cap=16384, defined_storage=True)
         assert gpu.poll(first + i, capacity=16384) == ref, i
         gpu.close_stream(first + i)
+
+
+def test_resampled_capture_at_rtl_sdr_rate(gpu):
+    """3.2 MS/s (RTL-SDR, the slowest receiver class of the reference): captures resampled by linear interpolation, all
+    periods and windows rounded from a non-integer ratio to 10 MS/s; generic kernels."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    rate = 3200000
+    for name in ["test_NFC-A_424kbps_002", "test_NFC-F_212kbps_003"]:
+        x = T.load_fixture(name)
+        t = np.arange(int(x.size * rate / 10e6), dtype=np.float64) * (10e6 / rate)
+        y = np.interp(t, np.arange(x.size), x).astype(np.float32)
+        ref, _ = T.reference_decode(y, sample_rate=rate, keep_carrier=True, cap=16384, defined_storage=True)
+        sid = gpu.open()
+        gpu.submit(sid, y, rate)
+        assert gpu.poll(sid, capacity=16384) == ref, name
+        gpu.close_stream(sid)
