@@ -10,7 +10,8 @@
  * usage: task-harness [--iq] file.wav [file.wav ...]
  *    --iq   publish SIGNAL_TYPE_RADIO_IQ buffers (interleaved I/Q, |IQ| equal to the capture's magnitude) instead of
  *           magnitude buffers: what a receiver task would hand over if it skipped its host-side magnitude pass
- *           (SURVEY 8(f) rank 2). The GPU decoder demodulates them from IQ; the reference decoder ignores them.
+ *           (SURVEY 8(f) rank 2). The GPU decoder demodulates them from IQ; the reference decoder takes no sample from them and never returns
+ *           (NfcTech.cpp:30, NfcDecoder.cpp:441), so this mode is for the GPU build only.
  * prints one line per NFC poll/listen frame:
  *    FRAME <file> tech type flags phase rate sampleStart sampleEnd sampleRate hexdata
  * and "DONE <file> <frames> <seconds>" per file.
