@@ -86,6 +86,15 @@ fi
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/resample_harness.cpp" "$RO" "$OUT/obj/Worker.o" "$OUT/obj/Executor.o" \
     "$OUT/libnfcref_support.a" -o "$OUT/resample-ref" -pthread
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/task_harness.cpp" "$OUT/libnfcref_task.a" $OBJS -o "$OUT/task-ref" -pthread
+# the trace reader / writer of the application: the reference's TraceStorageTask behind its subjects,
+# with the reference's own tar + zlib package code; checks the .trz files nfc-laboratory_amd/trz.py writes
+if [ -f /usr/include/zlib.h ]; then
+  g++ $CXXFLAGS $TINC -I$R/lib-ext/microtar/src/main/c "$HERE/../tests/dropin/trace_harness.cpp" \
+      "$R/lib-lab/lab-tasks/src/main/cpp/tasks/TraceStorageTask.cpp" "$R/lib-rt/rt-lang/src/main/cpp/Package.cpp" \
+      -x c "$R/lib-ext/microtar/src/main/c/microtar.c" -x none "$OUT/obj/Worker.o" "$OUT/obj/Executor.o" \
+      "$OUT/libnfcref_support.a" -lz -o "$OUT/trace-ref" -pthread
+fi
+
 # the decoder interface driven by a script (tests/dropin/api_harness.cpp), reference decoder underneath
 g++ $CXXFLAGS $INC -DNFC_DEFINED_FRAME_STORAGE "$HERE/../tests/dropin/api_harness.cpp" $OBJS -o "$OUT/api-ref" -pthread -Wl,--wrap=posix_memalign
 echo "built $OUT/libnfcref.so $OUT/test-sdr-ref $OUT/task-ref $OUT/resample-ref $OUT/api-ref"

@@ -54,3 +54,52 @@ def test_trace_opens_with_the_reference_python_reader(tmp_path):
         assert (int(g.tech_type), int(g.frame_type), g.sample_start, g.sample_end, g.sample_rate, g.frame_rate) == \
                (f[0], f[1], f[5], f[6], f[7], f[4])
         assert bytes(g.data) == f[8]
+
+
+TRACE_REF = os.path.join(T.ROOT, "oracle", "_ref", "trace-ref")
+
+
+def _frame_lines(entries):
+    return ["%d %d %d %d %d %d %d %d %.17g %.17g %.17g %s" % (
+        e["techType"], e["frameType"], e["frameFlags"], e["framePhase"], e["frameRate"], e["sampleStart"], e["sampleEnd"],
+        e["sampleRate"], e["timeStart"], e["timeEnd"], e["dateTime"], e.get("frameData", "").replace(":", "") or "-") for e in entries]
+
+
+@pytest.mark.skipif(not os.path.exists(TRACE_REF), reason="trace-ref not built (needs the reference tree and zlib at build time)")
+def test_trace_against_the_reference_trace_storage_task(tmp_path):
+    """The task behind "open trace" / "save trace" of the application (lab-tasks TraceStorageTask.cpp, built in place with the
+    reference's own tar + zlib code, driven through its subjects by tests/dropin/trace_harness.cpp): it reads what trz.py
+    wrote and publishes the same frames, and what it writes itself for those frames is entry for entry what trz.py wrote."""
+    import subprocess
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    frames, _ = T.reference_decode(T.load_fixture("test_POLL_ABF_001"), keep_carrier=True)
+    more, _ = T.reference_decode(T.load_fixture("test_NFC-V_26kbps_001"), keep_carrier=True)
+    frames = frames + more
+    mine = str(tmp_path / "mine.trz")
+    trz.write_trz(mine, frames, stream_time=1700000000)
+    with tarfile.open(mine, "r:gz") as tar:
+        entries = json.load(tar.extractfile(tar.getmember("frame.json")))["frames"]
+    assert len(entries) == len(frames)
+
+    # read by the reference
+    run = subprocess.run([TRACE_REF, "read", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = run.stdout.splitlines()
+    assert len(got) == len(frames)
+    for line, f, e in zip(got, frames, entries):
+        w = line.split()
+        assert [int(v) for v in w[:8]] == list(f[:8])
+        assert (bytes.fromhex(w[11]) if w[11] != "-" else b"") == f[8]
+        assert float(w[8]) == pytest.approx(e["timeStart"], abs=1e-9) and float(w[10]) == pytest.approx(e["dateTime"], abs=1e-6)
+
+    # written by the reference
+    listing = tmp_path / "frames.txt"
+    listing.write_text("\n".join(_frame_lines(entries)) + "\n")
+    theirs = str(tmp_path / "theirs.trz")
+    run = subprocess.run([TRACE_REF, "write", theirs, str(listing)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    with tarfile.open(theirs, "r:gz") as tar:
+        assert tar.getnames() == ["frame.json"]
+        ref_entries = json.load(tar.extractfile(tar.getmember("frame.json")))["frames"]
+    assert ref_entries == entries
