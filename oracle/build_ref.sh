@@ -86,6 +86,15 @@ fi
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/resample_harness.cpp" "$RO" "$OUT/obj/Worker.o" "$OUT/obj/Executor.o" \
     "$OUT/libnfcref_support.a" -o "$OUT/resample-ref" -pthread
 g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/task_harness.cpp" "$OUT/libnfcref_task.a" $OBJS -o "$OUT/task-ref" -pthread
+# the application's replay pipeline: SignalStorageTask (WAV -> radio.signal.raw, IQ -> magnitude on the way, built with
+# the reference's -msse2 -DUSE_SSE2 of lab-tasks/CMakeLists.txt:18) feeding RadioDecoderTask, reference decoder underneath
+SS="$R/lib-lab/lab-tasks/src/main/cpp/tasks/SignalStorageTask.cpp"
+SO="$OUT/obj/SignalStorageTask.o"
+if [ ! -f "$SO" ] || [ "$SS" -nt "$SO" ]; then
+  g++ $CXXFLAGS -msse2 -DUSE_SSE2 $TINC -c "$SS" -o "$SO"
+fi
+g++ $CXXFLAGS $TINC "$HERE/../tests/dropin/replay_harness.cpp" "$SO" "$OUT/libnfcref_task.a" $OBJS -o "$OUT/replay-ref" -pthread
+
 # the trace reader / writer of the application: the reference's TraceStorageTask behind its subjects,
 # with the reference's own tar + zlib package code; checks the .trz files nfc-laboratory_amd/trz.py writes
 if [ -f /usr/include/zlib.h ]; then

@@ -30,6 +30,11 @@ TINC="$INC -I$R/lib-lab/lab-tasks/src/main/include -I$R/lib-lab/lab-tasks/src/ma
 g++ -std=c++17 -O2 -pthread -w $TINC "$HERE/task_harness.cpp" "$OUT/libnfcref_task.a" "$OUT/obj/NfcDecoder_gpu.o" \
     "$OUT/libnfcref_support.a" -L"$ROOT/nfc-laboratory_amd" -lnfcgpu -Wl,-rpath,'$ORIGIN/../../nfc-laboratory_amd' \
     -o "$OUT/task-gpu"
+# the application's replay pipeline (SignalStorageTask -> RadioDecoderTask), GPU decoder underneath
+[ -f "$OUT/obj/SignalStorageTask.o" ] && g++ -std=c++17 -O2 -pthread -w $TINC "$HERE/replay_harness.cpp" "$OUT/obj/SignalStorageTask.o" \
+    "$OUT/libnfcref_task.a" "$OUT/obj/NfcDecoder_gpu.o" "$OUT/libnfcref_support.a" -L"$ROOT/nfc-laboratory_amd" -lnfcgpu \
+    -Wl,-rpath,'$ORIGIN/../../nfc-laboratory_amd' -o "$OUT/replay-gpu"
+
 # the decoder interface driven by a script, GPU decoder underneath (same source as oracle/_ref/api-ref)
 g++ -std=c++17 -O2 -pthread -w $INC "$HERE/api_harness.cpp" "$OUT/obj/NfcDecoder_gpu.o" \
     "$OUT/libnfcref_support.a" -L"$ROOT/nfc-laboratory_amd" -lnfcgpu -Wl,-rpath,'$ORIGIN/../../nfc-laboratory_amd' \
