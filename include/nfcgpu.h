@@ -124,10 +124,20 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx);
 
 int nfcgpu_stream_open(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32_t *stream_id);
 int nfcgpu_stream_open_many(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32_t count, uint32_t *first_stream_id);
+/* The setters of lab::NfcDecoder (NfcDecoder.cpp:96-286). The enable mask and the per-technology thresholds take effect
+ * with the next sample; the power level moves the detectors' gate at once and the carrier thresholds at the next
+ * initialisation (NfcDecoder.cpp:327-329); sample_rate is only stored (0 leaves it as it is), exactly like
+ * setSampleRate(): nothing is derived from it until the stream (re)initialises. */
 int nfcgpu_stream_configure(nfcgpu_ctx *ctx, uint32_t stream_id, const nfcgpu_params *params);
+/* initialize() (NfcDecoder.cpp:295-360): clock, detectors, protocol state and everything derived from the sample rate and
+ * the power level stored at this moment start over; envelope, filter and carrier state carry on. Applied when the next
+ * buffer arrives; an nfcgpu_flush() in between already sees the reset clock. */
 int nfcgpu_stream_reset(nfcgpu_ctx *ctx, uint32_t stream_id);
 int nfcgpu_stream_close(nfcgpu_ctx *ctx, uint32_t stream_id);
 
+/* nextFrames(valid buffer) (NfcDecoder.cpp:374-447) without the frame collection (nfcgpu_poll). A buffer whose sample rate
+ * differs from the stored one stores it and re-initialises the stream first, also when it is empty (n_samples 0); a
+ * buffer at the stored rate does not, whatever the stored rate was derived-from last (see nfcgpu_stream_configure). */
 int nfcgpu_submit(nfcgpu_ctx *ctx, uint32_t stream_id, const float *data, uint32_t n_samples, uint32_t stride, uint32_t sample_rate);
 int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *batch);
 /* streams first..first+count-1; stream i reads n_samples*stride floats at base + i*pitch_bytes */
@@ -154,6 +164,7 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n_samples, float
 int nfcgpu_resample_radio(nfcgpu_ctx *ctx, const float *in, uint64_t in_pitch_bytes, uint32_t n_buffers, uint32_t n_samples,
                           float *out, uint64_t out_pitch_bytes, uint32_t capacity_pairs, uint32_t *counts, uint32_t location);
 
+/* nextFrames(invalid buffer) (NfcDecoder.cpp:449-463): queues one carrier-state frame stamped with the stream's clock */
 int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t stream_id);
 int nfcgpu_sync(nfcgpu_ctx *ctx);
 int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t stream_id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count);
