@@ -177,7 +177,9 @@ int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cu
  * `words` holds capacity_words 32-bit words, `ctl` holds 4 words ([0] cursor in words, [1] dropped frames).
  * Pass words == NULL to return to the context's own sink. Implies a sync + rewind. */
 int nfcgpu_sink_attach(nfcgpu_ctx *ctx, void *words, uint64_t capacity_words, void *ctl);
-/* when enabled, nfcgpu_sync leaves the sink untouched (no host drain) until nfcgpu_sink_rewind */
+/* when enabled, nfcgpu_sync leaves the sink untouched (no host drain) until nfcgpu_sink_rewind: the caller reads the
+ * packed records itself. nfcgpu_poll / nfcgpu_flush then only deal with the per-stream queues filled before; a held sink
+ * is meant for hosts that collect frames in bulk (bench.py, RCCL gathers), not to be mixed with polling. */
 int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold);
 int nfcgpu_sink_rewind(nfcgpu_ctx *ctx);
 
