@@ -48,6 +48,7 @@ struct StreamInfo
    nfcgpu_params params {};
    float powerAtInit = 0.01f; /* carrier thresholds are derived when the decoder (re)initialises */
    uint32_t config = 0;
+   bool hasConfig = false; /* `config` has been resolved (a stream opened but never fed refers to no table entry) */
    uint32_t derivedRate = 0; /* sample rate the running configuration was derived from (params.sample_rate is the stored one) */
    uint32_t clock = 0xFFFFFFFFu; /* mirror of the device sample clock (NfcStreamState::clock) */
    std::deque<nfcgpu_frame> queue;
@@ -188,6 +189,7 @@ int resolve_config(nfcgpu_ctx *ctx, StreamInfo &si)
       if (std::memcmp(&ctx->configs[i], &cfg, sizeof(cfg)) == 0)
       {
          si.config = i;
+         si.hasConfig = true;
          return NFCGPU_OK;
       }
    }
@@ -204,7 +206,7 @@ int resolve_config(nfcgpu_ctx *ctx, StreamInfo &si)
       std::vector<bool> used(kMaxConfigs, false);
       for (const StreamInfo &other: ctx->streams)
       {
-         if (other.open && &other != &si && (other.initialized || other.needInit))
+         if (other.open && &other != &si && other.hasConfig)
             used[other.config] = true;
       }
 
@@ -222,6 +224,8 @@ int resolve_config(nfcgpu_ctx *ctx, StreamInfo &si)
       ctx->configs[slot] = cfg;
       si.config = slot;
    }
+
+   si.hasConfig = true;
 
    HIP_TRY(ctx, hipMemcpyAsync(ctx->dConfigs + si.config, &cfg, sizeof(cfg), hipMemcpyHostToDevice, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* cfg is a stack object */
