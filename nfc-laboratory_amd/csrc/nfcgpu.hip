@@ -35,7 +35,7 @@ __global__ void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch 
 
 namespace {
 
-constexpr uint32_t kMaxConfigs = 64;
+constexpr uint32_t kMaxConfigs = 256; /* distinct decoder configurations in use at once (1.5 KB each on the device) */
 constexpr uint32_t kRingBlockFloats = (4 * NFC_HIST + NFC_PROD + NFC_CORR_MAX) * NFC_LANES;
 
 struct StreamInfo

@@ -151,25 +151,25 @@ import sys, json
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import numpy as np
 import nfc_testlib as T, nfclab_amd
-x = T.load_fixture("test_NFC-A_106kbps_001")[:20000]
+x = T.load_fixture("test_NFC-A_106kbps_001")[:18000]
 out = {}
-with nfclab_amd.NfcGpu(device=0, max_streams=128) as gpu:
-    # one stream whose thresholds change 200 times: every change is a new configuration, only one is in use at a time
+with nfclab_amd.NfcGpu(device=0, max_streams=320) as gpu:
+    # one stream whose thresholds change 300 times: every change is a new configuration, only one is in use at a time
     sid = gpu.open()
-    for k in range(200):
+    for k in range(300):
         p = nfclab_amd.default_params()
-        p.corr_threshold[1] = 0.2 + 0.003 * k          # NFC-B threshold: no effect on this NFC-A capture
+        p.corr_threshold[1] = 0.2 + 0.002 * k          # NFC-B threshold: no effect on this NFC-A capture
         gpu.configure(sid, p)
-        gpu.submit(sid, x[k * 100:(k + 1) * 100], 10000000)
+        gpu.submit(sid, x[k * 60:(k + 1) * 60], 10000000)
     ref, _ = T.reference_decode(x, keep_carrier=True)
     out["changing"] = gpu.poll(sid) == ref
     gpu.close_stream(sid)
-    # 70 streams with 70 distinct configurations at once: more than the table holds
-    first = gpu.open(count=70)
+    # 260 streams with 260 distinct configurations at once: more than the table holds
+    first = gpu.open(count=260)
     code = 0
-    for s in range(70):
+    for s in range(260):
         p = nfclab_amd.default_params()
-        p.corr_threshold[2] = 0.1 + 0.01 * s
+        p.corr_threshold[2] = 0.1 + 0.003 * s
         gpu.configure(first + s, p)
         try:
             gpu.submit(first + s, x[:64], 10000000)
@@ -182,7 +182,7 @@ with nfclab_amd.NfcGpu(device=0, max_streams=128) as gpu:
     for s in range(10):
         gpu.close_stream(first + s)
     try:
-        gpu.submit(first + out.get("failed_at", 69), x[:64], 10000000)
+        gpu.submit(first + out.get("failed_at", 259), x[:64], 10000000)
         out["after_close"] = True
     except nfclab_amd.NfcGpuError:
         out["after_close"] = False
@@ -191,8 +191,8 @@ print(json.dumps(out))
 
 
 def test_configuration_table_is_recycled(emulated, tmp_path):
-    """Every distinct set of thresholds is one entry of a 64-entry device table. Entries no stream refers to any more are
-    reused (a stream whose thresholds change 200 times keeps decoding), and more than 64 in use at once is refused loudly."""
+    """Every distinct set of thresholds is one entry of a 256-entry device table. Entries no stream refers to any more are
+    reused (a stream whose thresholds change 300 times keeps decoding), and more than 256 in use at once is refused loudly."""
     import json
     if T.reference_lib() is None:
         pytest.skip("oracle/_ref not built")
@@ -204,5 +204,5 @@ def test_configuration_table_is_recycled(emulated, tmp_path):
     assert run.returncode == 0, run.stderr[-3000:]
     out = json.loads(run.stdout.splitlines()[-1])
     assert out["changing"] is True
-    assert out["code"] == -3 and out["failed_at"] == 64, out     # NFCGPU_ENOMEM at the 65th configuration in use
+    assert out["code"] == -3 and out["failed_at"] == 256, out     # NFCGPU_ENOMEM at the 257th configuration in use
     assert out["after_close"] is True
