@@ -46,6 +46,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if args.gpus != world:
+        # one process per GPU: N > 1 is launched by torch.distributed.run (see the module docstring); a bare
+        # `python bench.py --gpus N` is a single-rank run and reports itself as such (n_gpus = 1)
+        print("bench.py: --gpus %d but WORLD_SIZE is %d: running %d rank(s); launch with python -m torch.distributed.run "
+              "--nproc-per-node %d bench.py --gpus %d for the multi-GPU figure" % (args.gpus, world, world, args.gpus, args.gpus),
+              file=sys.stderr)
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
