@@ -41,7 +41,7 @@ extern "C" {
 #define NFCGPU_OK 0
 #define NFCGPU_EINVAL (-1)    /* bad argument */
 #define NFCGPU_ENODEV (-2)    /* no usable HIP device / kernel image */
-#define NFCGPU_ENOMEM (-3)    /* device or host allocation failed */
+#define NFCGPU_ENOMEM (-3)    /* allocation failed, or more than 256 distinct decoder configurations in use at once */
 #define NFCGPU_ESTREAM (-4)   /* unknown or closed stream id */
 #define NFCGPU_ERATE (-5)     /* sample rate not decodable (history depth) */
 #define NFCGPU_EOVERFLOW (-6) /* frame sink overflowed, frames were dropped */
