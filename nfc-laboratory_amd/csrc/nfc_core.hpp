@@ -935,13 +935,11 @@ NFC_DEV void nfc_state_init(const NfcConfig &c, NfcStreamState &s, NfcStreamCold
    float env = s.env, n1 = s.n1, mdev = s.mdev, avg = s.avg, edgePeak = s.edgePeak;
    uint32_t pulse = s.pulseFilter, edgeTime = s.edgeTime, off = s.carrierOff, on = s.carrierOn;
 
-   uint32_t *w = (uint32_t *)&s;
-   for (uint32_t i = 0; i < sizeof(NfcStreamState) / 4; i++)
-      w[i] = 0;
-
-   uint32_t *k = (uint32_t *)&cold;
-   for (uint32_t i = 0; i < sizeof(NfcStreamCold) / 4; i++)
-      k[i] = 0;
+   /* memset, not stores through a uint32_t alias: with type-based alias analysis the compiler treated the float
+    * fields saved above as untouched by integer stores and dropped the `s.env = env` restores below as redundant,
+    * so a re-initialised stream lost its envelope / filter / average on the GPU (round-1 hardware-only failure) */
+   __builtin_memset(&s, 0, sizeof(NfcStreamState));
+   __builtin_memset(&cold, 0, sizeof(NfcStreamCold));
 
    if (keepFrontEnd)
    {

@@ -175,6 +175,11 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
 
    NfcStreamState s = L.states[slot];
 
+   /* the common kernel runs first and advances the clocks it decides on: a block it has taken must not be looked at
+    * again by the exact kernel of the same launch (its clock may have moved into the zone meanwhile) */
+   if (__any(mineCount != 0 && s.served == L.launchSeq) != 0)
+      return;
+
    if ((L.forceExact != 0 || __any(nfc_exact_span(s.clock, mineCount)) != 0) != EXACT)
       return;
 
@@ -248,7 +253,10 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
    }
 
    if (mineCount)
+   {
+      s.served = L.launchSeq;
       L.states[slot] = s;
+   }
 }
 
 #define NFC_DEMOD_KERNEL(name, exact, fixed, attrs)                                                        \

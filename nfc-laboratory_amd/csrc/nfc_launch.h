@@ -34,6 +34,7 @@ struct NfcLaunch
    uint32_t firstSlot;
    uint32_t slotCount;
    uint32_t ringBlockFloats;
+   uint32_t launchSeq;  /* non-zero, distinct for every demodulation launch of a context (see NfcStreamState::served) */
    uint32_t forceExact; /* the host launches only the exact-modulo kernel: it takes every block, whatever the clocks say */
 };
 

@@ -229,6 +229,8 @@ struct NfcStreamState
    uint32_t unlock;    /* technology that reset during this decode step (its unparking is done once, at the end of the step) */
    uint32_t bankClock; /* clock of the last sample at which the whole detector bank was stepped (search mode) */
    uint32_t chainedA;  /* NFC-A chained frame flags (Encrypted after AUTH) */
+   uint32_t served;    /* NfcLaunch::launchSeq of the last launch that advanced this stream: a block is taken by exactly
+                          one of the common / exact-modulo kernels of a launch, whichever sees it first */
 
    /* ---- ring positions (idx % period) of every correlator ---- */
    uint32_t posA[3];

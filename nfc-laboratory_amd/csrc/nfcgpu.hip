@@ -105,6 +105,7 @@ struct nfcgpu_ctx
    bool hold = false;
    bool profile = false;
    bool dirty = false; /* work submitted since last sync */
+   uint32_t launchSeq = 0; /* stamp of the last demodulation launch (NfcLaunch::launchSeq) */
    std::vector<ProfiledLaunch> timed;
    std::vector<hipEvent_t> eventPool;
    nfcgpu_stats stats {};
@@ -367,6 +368,10 @@ int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t sample
    /* every stream block picks its kernel from the device state; a launch in which every stream needs the exact
     * variant (the first buffer of freshly opened streams) does not need the common kernel at all */
    L.forceExact = exactOnly ? 1u : 0u;
+
+   if (++ctx->launchSeq == 0)
+      ctx->launchSeq = 1;
+   L.launchSeq = ctx->launchSeq;
 
    if (!exactOnly)
    {

@@ -64,6 +64,7 @@ void demod(const NfcConfig *cfgPtr, const NfcLaunch &L, bool exactKernel)
       const uint32_t block = L.firstBlock + b;
       uint32_t longest = 0;
       bool anyExact = false;
+      bool served = false;
 
       for (uint32_t lane = 0; lane < NFC_LANES; lane++)
       {
@@ -71,9 +72,10 @@ void demod(const NfcConfig *cfgPtr, const NfcLaunch &L, bool exactKernel)
          const Row r = row_of(L, slot);
          longest = r.count > longest ? r.count : longest;
          anyExact = anyExact || exact_span(L.states[slot].clock, r.count);
+         served = served || (r.count != 0 && L.states[slot].served == L.launchSeq);
       }
 
-      if (longest == 0)
+      if (longest == 0 || served)
          continue;
 
       if ((L.forceExact != 0 || anyExact) != exactKernel)
@@ -119,6 +121,7 @@ void demod(const NfcConfig *cfgPtr, const NfcLaunch &L, bool exactKernel)
             nfc_step(*cfgPtr, s, mem, v, exactKernel);
          }
 
+         s.served = L.launchSeq;
          L.states[slot] = s;
       }
    }
