@@ -279,8 +279,10 @@ struct NfcNow
    float depth; /* modulateDepth  */
 };
 
-/* the caller has already advanced s.clock and s.pulseFilter for this sample */
-NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+/* The front end without its history stores: envelope (conditional EMA), DC removal, mean deviation, average and the
+ * carrier-edge peak tracker. It depends on nothing but the samples (no detector or lock state), which is what lets the
+ * scan kernel (nfc_scan.hpp) run it ahead of the decoder. The caller has already advanced s.clock and s.pulseFilter. */
+NFC_DEV NfcNow nfc_front_end_core(const NfcConfig &c, NfcStreamState &s, float value)
 {
    float env = s.env;
 
@@ -315,20 +317,11 @@ NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLan
    s.mdev = s.mdev * c.mdevW0 + nfc_abs(filtered) * c.mdevW1;
    s.avg = s.avg * c.meanW0 + value * c.meanW1;
 
-   float clamped = (value < 0.0f) ? 0.0f : ((env < value) ? env : value);
-
    NfcNow now;
    now.x = value;
    now.filt = filtered;
    now.mdev = s.mdev;
-   now.depth = (env - clamped) / env;
-
-   const uint32_t slot = s.clock & NFC_HMASK;
-
-   NFC_AT(mem, NFC_R_X, slot) = now.x;
-   NFC_AT(mem, NFC_R_FILT, slot) = now.filt;
-   NFC_AT(mem, NFC_R_MDEV, slot) = now.mdev;
-   NFC_AT(mem, NFC_R_DEPTH, slot) = now.depth;
+   now.depth = 0.0f;
 
    float rectified = nfc_abs(filtered);
 
@@ -344,6 +337,26 @@ NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLan
    {
       s.edgePeak = 0;
    }
+
+   return now;
+}
+
+/* the caller has already advanced s.clock and s.pulseFilter for this sample */
+NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float value)
+{
+   NfcNow now = nfc_front_end_core(c, s, value);
+
+   const float env = s.env;
+   const float clamped = (value < 0.0f) ? 0.0f : ((env < value) ? env : value);
+
+   now.depth = (env - clamped) / env;
+
+   const uint32_t slot = s.clock & NFC_HMASK;
+
+   NFC_AT(mem, NFC_R_X, slot) = now.x;
+   NFC_AT(mem, NFC_R_FILT, slot) = now.filt;
+   NFC_AT(mem, NFC_R_MDEV, slot) = now.mdev;
+   NFC_AT(mem, NFC_R_DEPTH, slot) = now.depth;
 
    return now;
 }
