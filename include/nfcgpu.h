@@ -115,6 +115,15 @@ typedef struct nfcgpu_stats
    uint64_t frames;
    uint64_t dropped_frames;
    double kernel_ms;
+   /* time-parallel path: scan kernel time and samples (profiling on), windowed decode kernel time,
+    * windows decoded (lanes, repeats included), decode passes, streams of submissions that took it / fell back */
+   double scan_ms;
+   double window_ms;
+   uint64_t scan_samples;
+   uint64_t windows;
+   uint64_t window_passes;
+   uint64_t windowed_streams;
+   uint64_t fallback_streams;
 } nfcgpu_stats;
 
 void nfcgpu_default_params(nfcgpu_params *params);

@@ -78,6 +78,7 @@ struct NfcLaneMem
    uint32_t streamId;
    NfcStreamCold *cold;  /* protocol timing of this stream (HBM) */
    const NfcConfig *tables; /* configuration in memory, for its dynamically indexed tables (NFC-V pulse slots) */
+   bool linked;          /* frame records are chained per lane in a staging sink (time-parallel path) */
 };
 
 /* ring regions (in slots) inside a stream block */
@@ -236,8 +237,10 @@ NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, u
    if (len > NFC_STREAM_BYTES)
       len = NFC_STREAM_BYTES;
 
-   const uint32_t words = NFC_FRAME_HEADER_WORDS + ((len + 3u) >> 2);
-   const uint32_t at = NFC_ATOMIC_ADD(mem.sinkCursor, words);
+   /* a lane of the time-parallel path chains its records: one link word in front of each (see nfc_finish_frames) */
+   const uint32_t link = mem.linked ? 1u : 0u;
+   const uint32_t words = NFC_FRAME_HEADER_WORDS + ((len + 3u) >> 2) + link;
+   uint32_t at = NFC_ATOMIC_ADD(mem.sinkCursor, words);
 
    mem.cold->framesOut++;
 
@@ -247,6 +250,17 @@ NFC_DEV void nfc_emit(const NfcLaneMem &mem, NfcStreamState &s, uint32_t tech, u
    {
       NFC_ATOMIC_ADD(mem.sinkDropped, 1u);
       return;
+   }
+
+   if (link)
+   {
+      mem.sink[at] = 0;
+      if (mem.cold->frameTail)
+         mem.sink[mem.cold->frameTail - 1u] = at + 1u;
+      else
+         mem.cold->frameHead = at + 1u;
+      mem.cold->frameTail = at + 1u;
+      at++;
    }
 
    uint32_t *w = mem.sink + at;
@@ -279,12 +293,13 @@ struct NfcNow
    float depth; /* modulateDepth  */
 };
 
-/* The front end without its history stores: envelope (conditional EMA), DC removal, mean deviation, average and the
- * carrier-edge peak tracker. It depends on nothing but the samples (no detector or lock state), which is what lets the
- * scan kernel (nfc_scan.hpp) run it ahead of the decoder. The caller has already advanced s.clock and s.pulseFilter. */
-NFC_DEV NfcNow nfc_front_end_core(const NfcConfig &c, NfcStreamState &s, float value)
+/* The envelope tracker on its own (NfcTech.cpp:36-56): follows the signal while it stays within 5 % of the envelope,
+ * otherwise only once per ten symbols. Unlike the other recurrences of the front end it is not contractive (which
+ * samples update it depends on its own value), so the scan path cannot always reach its true state from a guess and
+ * has to be able to walk it alone (nfc_scan.hpp: nfc_envelope_fix). `pulseFilter` has already been incremented. */
+NFC_DEV void nfc_envelope_step(const NfcConfig &c, uint32_t clock, uint32_t &pulseFilter, float &envelope, float value)
 {
-   float env = s.env;
+   float env = envelope;
 
    /* reference: |x - env| / env < 0.05f. Decided without the division unless the ratio is within 0.2 % of the
     * limit (for env > 0: dev < 0.0499*env implies fl(dev/env) < 0.05f, dev > 0.0501*env implies the opposite) */
@@ -298,17 +313,25 @@ NFC_DEV NfcNow nfc_front_end_core(const NfcConfig &c, NfcStreamState &s, float v
    else
       tracking = (dev / env) < 0.05f;
 
-   if (tracking || s.pulseFilter > (uint32_t)(c.etu * 10))
+   if (tracking || pulseFilter > (uint32_t)(c.etu * 10))
    {
-      s.pulseFilter = 0;
+      pulseFilter = 0;
       env = env * c.envW0 + value * c.envW1;
    }
-   else if (s.clock < (uint32_t)c.etu)
+   else if (clock < (uint32_t)c.etu)
    {
       env = value;
    }
 
-   s.env = env;
+   envelope = env;
+}
+
+/* The front end without its history stores: envelope (conditional EMA), DC removal, mean deviation, average and the
+ * carrier-edge peak tracker. It depends on nothing but the samples (no detector or lock state), which is what lets the
+ * scan kernel (nfc_scan.hpp) run it ahead of the decoder. The caller has already advanced s.clock and s.pulseFilter. */
+NFC_DEV NfcNow nfc_front_end_core(const NfcConfig &c, NfcStreamState &s, float value)
+{
+   nfc_envelope_step(c, s.clock, s.pulseFilter, s.env, value);
 
    float n0 = value + s.n1 * c.iirA;
    float filtered = n0 - s.n1;
@@ -375,9 +398,26 @@ NFC_DEV uint32_t nfc_bump(uint32_t pos, uint32_t period)
    return pos >= period ? 0u : pos;
 }
 
-NFC_DEV uint32_t nfc_next_pos(uint32_t clock, bool exact, uint32_t pos, const NfcRate &rt, uint32_t period)
+NFC_DEV uint32_t nfc_next_pos(uint32_t clock, bool exact, uint32_t pos, const NfcRate &rt, uint32_t period, uint32_t label)
 {
-   return exact ? (uint32_t)(1024u - rt.delay + clock) % period : nfc_bump(pos, period);
+   return exact ? ((uint32_t)(1024u - rt.delay + clock) % period + label) % period : nfc_bump(pos, period);
+}
+
+/* Ring phase label of the correlation ring that starts at `base` (NfcStreamCold::label): zero for a stream that has
+ * only ever been decoded sequentially; a lane of the time-parallel path numbers its rings from its own first sample.
+ * Only the exact-modulo variants need it (the common ones advance whatever positions they are given). */
+NFC_DEV uint32_t nfc_ring_label(const NfcLaneMem &mem, uint32_t base, uint32_t period)
+{
+   const NfcConfig &c = *mem.tables;
+   uint32_t k = 0;
+
+   for (uint32_t i = 1; i < 6; i++)
+      k = base >= c.corrOffset[i] ? i : k;
+
+   if (k == 5 && period == c.v.p0)
+      k = 6;
+
+   return mem.cold->label[k];
 }
 
 NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem)
@@ -385,13 +425,15 @@ NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s, const 
    const bool exact = mem.exact;
 
    /* written out per correlator: every state field keeps a compile-time address, so the record stays in VGPRs */
-   s.posA[0] = nfc_next_pos(s.clock, exact, s.posA[0], c.a[0], c.a[0].p1);
-   s.posA[1] = nfc_next_pos(s.clock, exact, s.posA[1], c.a[1], c.a[1].p1);
-   s.posA[2] = nfc_next_pos(s.clock, exact, s.posA[2], c.a[2], c.a[2].p1);
-   s.posF[0] = nfc_next_pos(s.clock, exact, s.posF[0], c.f[1], c.f[1].p1);
-   s.posF[1] = nfc_next_pos(s.clock, exact, s.posF[1], c.f[2], c.f[2].p1);
-   s.posV1 = nfc_next_pos(s.clock, exact, s.posV1, c.v, c.v.p1);
-   s.posV0 = nfc_next_pos(s.clock, exact, s.posV0, c.v, c.v.p0);
+   const uint32_t *label = mem.cold->label; /* read by the exact variants only */
+
+   s.posA[0] = nfc_next_pos(s.clock, exact, s.posA[0], c.a[0], c.a[0].p1, exact ? label[0] : 0u);
+   s.posA[1] = nfc_next_pos(s.clock, exact, s.posA[1], c.a[1], c.a[1].p1, exact ? label[1] : 0u);
+   s.posA[2] = nfc_next_pos(s.clock, exact, s.posA[2], c.a[2], c.a[2].p1, exact ? label[2] : 0u);
+   s.posF[0] = nfc_next_pos(s.clock, exact, s.posF[0], c.f[1], c.f[1].p1, exact ? label[3] : 0u);
+   s.posF[1] = nfc_next_pos(s.clock, exact, s.posF[1], c.f[2], c.f[2].p1, exact ? label[4] : 0u);
+   s.posV1 = nfc_next_pos(s.clock, exact, s.posV1, c.v, c.v.p1, exact ? label[5] : 0u);
+   s.posV0 = nfc_next_pos(s.clock, exact, s.posV0, c.v, c.v.p0, exact ? label[6] : 0u);
 }
 
 /* ring position of the locked correlator: a private copy taken at lock time and advanced alongside the others
@@ -399,7 +441,8 @@ NFC_DEV void nfc_advance_positions(const NfcConfig &c, NfcStreamState &s, const 
 NFC_DEV void nfc_advance_lock_pos(NfcStreamState &s, const NfcLaneMem &mem)
 {
    if (mem.exact)
-      s.u.decode.lockPos = (uint32_t)(1024u - s.u.decode.rt.delay + s.clock) % s.u.decode.rt.p1;
+      s.u.decode.lockPos = ((uint32_t)(1024u - s.u.decode.rt.delay + s.clock) % s.u.decode.rt.p1 +
+                            nfc_ring_label(mem, s.u.decode.lockBase, s.u.decode.rt.p1)) % s.u.decode.rt.p1;
    else
       s.u.decode.lockPos = nfc_bump(s.u.decode.lockPos, s.u.decode.rt.p1);
 }
@@ -410,10 +453,10 @@ NFC_DEV uint32_t nfc_lock_pos(const NfcStreamState &s)
 }
 
 /* (idx + add) % period given pos = idx % period; exact modulo near the clock wrap */
-NFC_DEV uint32_t nfc_point(const NfcLaneMem &mem, uint32_t clock, uint32_t delay, uint32_t pos, uint32_t add, uint32_t period)
+NFC_DEV uint32_t nfc_point(const NfcLaneMem &mem, uint32_t clock, uint32_t delay, uint32_t pos, uint32_t add, uint32_t period, uint32_t base)
 {
    if (mem.exact)
-      return (uint32_t)(1024u - delay + clock + add) % period;
+      return ((uint32_t)(1024u - delay + clock + add) % period + nfc_ring_label(mem, base, period)) % period;
 
    uint32_t p = pos + add;
    return p >= period ? p - period : p;
@@ -430,6 +473,8 @@ NFC_DEV void nfc_detect_carrier(const NfcConfig &c, NfcStreamState &s, const Nfc
          nfc_emit(mem, s, NFC_TECH_ANY, NFC_FRAME_CARRIER_ON, 0, NFC_PHASE_CARRIER, 0, s.carrierOn, s.carrierOn, nullptr, 0);
          s.carrierOff = 0;
          s.edgeTime = 0;
+         mem.cold->emitClock = s.clock;
+         mem.cold->emitValid = 1;
       }
    }
    else if (s.avg < c.lowThreshold)
@@ -440,6 +485,8 @@ NFC_DEV void nfc_detect_carrier(const NfcConfig &c, NfcStreamState &s, const Nfc
          nfc_emit(mem, s, NFC_TECH_ANY, NFC_FRAME_CARRIER_OFF, 0, NFC_PHASE_CARRIER, 0, s.carrierOff, s.carrierOff, nullptr, 0);
          s.carrierOn = 0;
          s.edgeTime = 0;
+         mem.cold->emitClock = s.clock;
+         mem.cold->emitValid = 1;
       }
    }
 }
@@ -470,8 +517,8 @@ NFC_DEV NfcTap nfc_tap_raw(const NfcLaneMem &mem, uint32_t clock, const NfcRate 
    const uint32_t cur = clock - rt.delay;
    t.in = NFC_AT(mem, NFC_R_X, cur & NFC_HMASK);
    t.out = NFC_AT(mem, NFC_R_X, (cur - rt.p2) & NFC_HMASK);
-   t.c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p2, rt.p1));
-   t.c3 = needC3 ? NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p1 - 1u, rt.p1)) : 0.0f;
+   t.c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p2, rt.p1, base));
+   t.c3 = needC3 ? NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p1 - 1u, rt.p1, base)) : 0.0f;
    return t;
 }
 
@@ -488,7 +535,7 @@ NFC_DEV float nfc_previous_sum(const NfcLaneMem &mem, const NfcStreamState &s, c
     * this branch: otherwise the compiler waits where the two paths meet, on every sample, and with an in-order memory
     * counter that wait also covers the ring store of the detector before this one (a full store round trip per
     * correlator per sample: it was 40 % of the idle step) */
-   float previous = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1));
+   float previous = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, s.clock, rt.delay, pos, rt.p1 - 1u, rt.p1, base));
    NFC_ARRIVED(previous);
    return previous;
 }
@@ -636,9 +683,9 @@ NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamSt
    const bool filt = valid && !raw;
    const bool stored = valid && rt.delay != 0; /* the decode point lies in the past: its values are in the rings */
 
-   const uint32_t p2 = vListen ? nfc_point(mem, s.clock, rt.delay, s.posV0, rt.p1, rt.p0)
-                               : nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p2, rt.p1);
-   const uint32_t p3 = nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p1 - 1u, rt.p1);
+   const uint32_t p2 = vListen ? nfc_point(mem, s.clock, rt.delay, s.posV0, rt.p1, rt.p0, d.lockBase)
+                               : nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p2, rt.p1, d.lockBase);
+   const uint32_t p3 = nfc_point(mem, s.clock, rt.delay, d.lockPos, rt.p1 - 1u, rt.p1, d.lockBase);
 
    /* slot index (within the stream block) of the row every lane reads anyway */
    const uint32_t common = NFC_R_CORR + (valid ? d.lockBase + p2 : 0u);
@@ -792,6 +839,7 @@ NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcL
 
    s.unlock = 0;
    s.u.search = mem.cold->parked;
+   mem.cold->lastUnlock = s.clock;
 
    uint32_t isA = tech, isB = tech, isF = tech, isV = tech;
    NFC_OPAQUE(isA);
@@ -818,6 +866,8 @@ NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcL
    {
       nfc_mod_clear(s.u.search.detF[0]);
       nfc_mod_clear(s.u.search.detF[1]);
+      mem.cold->clearedF[0] = 1;
+      mem.cold->clearedF[1] = 1;
       /* the two rings are adjacent */
       nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
    }
@@ -930,6 +980,109 @@ NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
 
    if (s.unlock)
       nfc_finish_unlock(c, s, mem);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* lanes of the time-parallel path (nfc_scan.h): warm-up steps and the "at rest" test           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Front end only: the first part of a window lane's warm-up refills the sample history (x, filtered, deviation, depth)
+ * its detectors and decoders look back into. */
+template <bool EXACT>
+NFC_DEV void nfc_step_front(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
+{
+   NfcLaneMem mem = lane;
+   mem.exact = EXACT;
+
+   ++s.clock;
+   ++s.pulseFilter;
+
+   nfc_advance_positions(c, s, mem);
+   (void)nfc_front_end(c, s, mem, value);
+}
+
+/* Front end + upkeep of the six search correlators (running box sum and ring entry), no decisions: the second part of
+ * the warm-up. The sums start from zero instead of from the reference's value at that sample; every use of them is a
+ * difference of two ring entries or of an entry and the running sum (S0, S1, nfc_corr_apply), and on the int16 grid all
+ * of these are exact, so a constant offset never shows (nfc_scan.h). */
+template <bool EXACT>
+NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
+{
+   NfcLaneMem mem = lane;
+   mem.exact = EXACT;
+
+   ++s.clock;
+   ++s.pulseFilter;
+
+   nfc_advance_positions(c, s, mem);
+
+   NfcTapsA ta;
+   NfcTapsF tf;
+   NfcTapsV tv;
+
+   nfca_load_taps(c, s, mem, ta);
+   nfcf_load_taps(c, s, mem, tf);
+   nfcv_load_taps(c, s, mem, tv);
+
+   const NfcNow now = nfc_front_end(c, s, mem, value);
+
+   NfcSearchRegs &r = s.u.search;
+
+   r.detA[0].acc += c.a[0].delay ? ta.t[0].in : now.x;
+   r.detA[0].acc -= ta.t[0].out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[0] + s.posA[0]) = r.detA[0].acc;
+
+   r.detA[1].acc += c.a[1].delay ? ta.t[1].in : now.x;
+   r.detA[1].acc -= ta.t[1].out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[1] + s.posA[1]) = r.detA[1].acc;
+
+   r.detA[2].acc += c.a[2].delay ? ta.t[2].in : now.x;
+   r.detA[2].acc -= ta.t[2].out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[2] + s.posA[2]) = r.detA[2].acc;
+
+   r.detF[0].acc += now.x;
+   r.detF[0].acc -= tf.t[1].out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[3] + s.posF[0]) = r.detF[0].acc;
+
+   r.detF[1].acc += now.x;
+   r.detF[1].acc -= tf.t[2].out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[4] + s.posF[1]) = r.detF[1].acc;
+
+   r.detV.acc += tv.t.in;
+   r.detV.acc -= tv.t.out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[5] + s.posV1) = r.detV.acc;
+
+   s.bankClock = s.clock;
+}
+
+NFC_DEV uint32_t nfc_bits(float v)
+{
+   return __builtin_bit_cast(uint32_t, v);
+}
+
+/* True when the decoder is searching and every detector record is what a cleared record is, apart from the running
+ * sums, from fields that are rewritten before they are next read (NFC-B: thr, recomputed on every sample of the idle
+ * detector; NFC-F: syncValue, c0, lastValue, lastPhase, set by the first pulse of the next preamble before they can
+ * decide anything) and from the two NFC-F fields a partial reset leaves behind, which travel with the lane's carry
+ * (NfcCarry::pulsesF / thrF). From such a state the next thing a detector does is decided by the signal alone. */
+NFC_DEV bool nfc_at_rest(const NfcStreamState &s)
+{
+   const NfcSearchRegs &r = s.u.search;
+   uint32_t busy = s.lockTech | s.unlock;
+
+   for (int i = 0; i < 3; i++)
+      busy |= r.detA[i].winStart | r.detA[i].winEnd | r.detA[i].symStart | r.detA[i].peakTime | nfc_bits(r.detA[i].peak) | nfc_bits(r.detA[i].aux);
+
+   for (int i = 0; i < 2; i++)
+      busy |= r.detB[i].winStart | r.detB[i].winEnd | r.detB[i].symStart | r.detB[i].symEnd | r.detB[i].auxTime | nfc_bits(r.detB[i].aux);
+
+   for (int i = 0; i < 2; i++)
+      busy |= r.detF[i].winStart | r.detF[i].winEnd | r.detF[i].sync | r.detF[i].symStart | r.detF[i].symEnd | nfc_bits(r.detF[i].peak) |
+              r.detF[i].peakTime;
+
+   busy |= r.detV.winStart | r.detV.winEnd | r.detV.symStart | r.detV.peakTime | nfc_bits(r.detV.peak) | nfc_bits(r.detV.aux);
+
+   return busy == 0;
 }
 
 /* run-time selection of the variant (CPU test build of this text; the kernels instantiate one variant each) */

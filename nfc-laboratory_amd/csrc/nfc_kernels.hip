@@ -21,7 +21,28 @@
 #define NFC_ANY(predicate) (__any(predicate) != 0)
 
 #include "nfc_core.hpp"
+
+/* magnitude of one IQ sample, the reference's scalar formula (RadioDeviceTask.cpp:626-642): products and sum rounded
+ * separately (no contraction), correctly rounded square root */
+__device__ __forceinline__ float nfc_iq_magnitude(float i, float q)
+{
+   return __builtin_sqrtf(__fadd_rn(__fmul_rn(i, i), __fmul_rn(q, q)));
+}
+
+__device__ __forceinline__ float nfc_sample_at(const uint8_t *data, uint32_t stride, uint32_t index)
+{
+   if (stride == 2)
+   {
+      const float2 iq = reinterpret_cast<const float2 *>(data)[index];
+      return nfc_iq_magnitude(iq.x, iq.y);
+   }
+   return reinterpret_cast<const float *>(data)[index];
+}
+
+#define NFC_SAMPLE_AT(data, stride, index) nfc_sample_at((data), (stride), (index))
+#include "nfc_scan.hpp"
 #include "nfc_launch.h"
+#include "nfc_scan_launch.h"
 
 /* sample-rate-derived constants of the most common configuration as literals (generated at build time) */
 #define NFC_FIXED_FN __device__ __forceinline__
@@ -52,13 +73,6 @@ __device__ __forceinline__ bool nfc_exact_span(uint32_t clock, uint32_t count)
    const uint32_t start = clock + 1u + 1024u; /* first sample clock of the launch, zone = [0, 2048) after the shift */
    const uint32_t untilWrap = 0u - start;
    return count != 0 && (start < 2048u || untilWrap < count);
-}
-
-/* magnitude of one IQ sample, the reference's scalar formula (RadioDeviceTask.cpp:626-642): products and sum rounded
- * separately (no contraction), correctly rounded square root */
-__device__ __forceinline__ float nfc_iq_magnitude(float i, float q)
-{
-   return __builtin_sqrtf(__fadd_rn(__fmul_rn(i, i), __fmul_rn(q, q)));
 }
 
 /* input row of one stream slot for this launch; every field is wave-uniform (the slot is) */
@@ -187,6 +201,7 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
    mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats;
    mem.lane = lane;
    mem.exact = false;
+   mem.linked = false;
    mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
    mem.sink = L.sink;
    mem.sinkCursor = L.sinkCtl;
@@ -440,4 +455,517 @@ __global__ __launch_bounds__(64) void nfc_init_kernel(const NfcConfig *__restric
 
    for (uint32_t i = from; i < total; i++)
       ring[i * NFC_LANES] = 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* time-parallel path (nfc_scan.h): scan -> seams -> windows -> lanes -> windowed decode -> chain -> finish */
+/* ------------------------------------------------------------------------------------------ */
+
+/* run-time part of the configuration on top of the compiled-in table (the path is only taken at that sample rate) */
+__device__ __forceinline__ void nfc_fixed_runtime_config(const NfcConfig *cfgPtr, NfcConfig &cc)
+{
+   const NfcConfigConst *cp = (const NfcConfigConst *)cfgPtr;
+
+   nfc_fixed_config(cc);
+   cc.enabled = cp->enabled;
+   cc.powerThreshold = cp->powerThreshold;
+   cc.lowThreshold = cp->lowThreshold;
+   cc.highThreshold = cp->highThreshold;
+   for (int t = 0; t < 4; t++)
+   {
+      cc.corrThreshold[t] = cp->corrThreshold[t];
+      cc.minDepth[t] = cp->minDepth[t];
+      cc.maxDepth[t] = cp->maxDepth[t];
+   }
+}
+
+/* The scan kernel: one lane per chunk of a stream, 64 chunks per wave. Per pass the wave fetches 64 consecutive samples
+ * of each of its 64 chunks with one coalesced row load each (512 B of IQ / 256 B of magnitude), converts to magnitude
+ * and parks the tile transposed in LDS; every lane then walks its own row through the exact front end and the tile
+ * tests. Nothing is written per sample: a 4-byte flag word per 64 samples, a 32-byte front-end state per 512.
+ * Bound: HBM read (8 B per IQ sample, plus the warm-up overlap warmSamples / chunkSamples). */
+#define NFC_SCAN_ROWS 16
+
+__global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
+{
+   __shared__ float tile[NFC_LANES * (NFC_SCAN_TILE + 1)];
+
+   const uint32_t lane = threadIdx.x;
+   const uint32_t g = blockIdx.x * NFC_LANES + lane;
+   const bool mine = g < A.nChunks;
+
+   NfcScanChunk ch;
+   ch.job = 0;
+   ch.index = 0;
+   if (mine)
+      ch = A.chunks[g];
+
+   const NfcScanJob *job = A.jobs + ch.job;
+
+   const uint8_t *data = mine ? job->data : nullptr;
+   const uint32_t count = mine ? job->count : 0u;
+   const uint32_t L = A.params.chunkSamples, WU = A.params.warmSamples;
+
+   const uint32_t start = ch.index * L;
+   const uint32_t end = mine ? (start + L < count ? start + L : count) : 0u;
+   const uint32_t walkFrom = ch.index == 0 ? 0u : start - WU;
+   const int32_t origin = (int32_t)start - (int32_t)WU; /* position of this lane's row at relative step 0 */
+
+   NfcConfig cc;
+   nfc_fixed_runtime_config(cfgPtr, cc);
+
+   const NfcStreamState *from = nullptr;
+   uint32_t clockBase = 0;
+   if (mine)
+   {
+      const NfcStreamState *st = A.states + job->slot;
+      clockBase = st->clock;
+      if (ch.index == 0)
+         from = st;
+   }
+
+   NfcScanLane w;
+   bool begun = false;
+
+   NfcScanSeam seam;
+   __builtin_memset(&seam, 0, sizeof(seam));
+
+   for (uint32_t rel = 0; rel < WU + L; rel += NFC_SCAN_TILE)
+   {
+      /* stage: row q = the 64 samples of lane q's chunk at this step */
+#pragma clang loop unroll(disable)
+      for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_SCAN_ROWS)
+      {
+         float re[NFC_SCAN_ROWS], im[NFC_SCAN_ROWS];
+
+#pragma unroll
+         for (uint32_t j = 0; j < NFC_SCAN_ROWS; j++)
+         {
+            const uint32_t q = r0 + j;
+            const uint64_t rowData = ((uint64_t)(uint32_t)__shfl((int)((uint64_t)data >> 32), (int)q, 64) << 32) |
+                                     (uint32_t)__shfl((int)(uint32_t)(uint64_t)data, (int)q, 64);
+            const int32_t rowPos = __shfl(origin, (int)q, 64) + (int32_t)rel;
+            const uint32_t rowFrom = (uint32_t)__shfl((int)walkFrom, (int)q, 64);
+            const uint32_t rowEnd = (uint32_t)__shfl((int)end, (int)q, 64);
+
+            const int32_t at = rowPos + (int32_t)lane;
+            const bool ok = rowPos + (int32_t)NFC_SCAN_TILE > (int32_t)rowFrom && at >= 0 && (uint32_t)at < rowEnd;
+
+            re[j] = 0.0f;
+            im[j] = 0.0f;
+
+            if (ok)
+            {
+               if (A.stride == 2)
+               {
+                  const float2 iq = reinterpret_cast<const float2 *>(rowData)[at];
+                  re[j] = iq.x;
+                  im[j] = iq.y;
+               }
+               else
+                  re[j] = reinterpret_cast<const float *>(rowData)[at];
+            }
+         }
+
+#pragma unroll
+         for (uint32_t j = 0; j < NFC_SCAN_ROWS; j++)
+            tile[(r0 + j) * (NFC_SCAN_TILE + 1) + lane] = A.stride == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
+      }
+
+      __syncthreads();
+
+      const int32_t pos = origin + (int32_t)rel;
+
+      if (mine && pos + (int32_t)NFC_SCAN_TILE > (int32_t)walkFrom && pos < (int32_t)end)
+      {
+         for (uint32_t k = 0; k < NFC_SCAN_TILE; k++)
+         {
+            const int32_t sp = pos + (int32_t)k;
+
+            if (sp < (int32_t)walkFrom || sp >= (int32_t)end)
+               continue;
+
+            const float x = tile[lane * (NFC_SCAN_TILE + 1) + k];
+
+            if (!begun)
+            {
+               /* guess for the envelope and the average: mean of what this tile holds of the walk */
+               float first = 0.0f;
+               uint32_t span = 0;
+               for (uint32_t m = k; m < NFC_SCAN_TILE && pos + (int32_t)m < (int32_t)end; m++, span++)
+                  first += tile[lane * (NFC_SCAN_TILE + 1) + m];
+               first = first / (float)span;
+
+               nfc_scan_begin(w, from, clockBase + (uint32_t)sp, first);
+               begun = true;
+            }
+
+            if (ch.index != 0 && (uint32_t)sp == walkFrom + WU / 3)
+               nfc_scan_reseed(w);
+
+            if ((uint32_t)sp == start)
+               nfc_scan_point(w, seam.start);
+
+            if ((uint32_t)sp >= start && ((uint32_t)sp % NFC_SCAN_POINT) == 0)
+               nfc_scan_point(w, A.points[job->firstPoint + (uint32_t)sp / NFC_SCAN_POINT]);
+
+            nfc_scan_sample(cc, w, x);
+
+            if (((uint32_t)sp % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || (uint32_t)sp == end - 1)
+            {
+               NfcScanTile stat;
+               nfc_scan_tile_end(w, stat);
+               if ((uint32_t)sp >= start)
+                  A.tileStats[job->firstTile + (uint32_t)sp / NFC_SCAN_TILE] = stat;
+            }
+         }
+      }
+
+      __syncthreads();
+   }
+
+   if (mine)
+   {
+      if (begun)
+         nfc_scan_point(w, seam.end);
+      A.seams[g] = seam;
+   }
+}
+
+/* one thread per job: seams, then windows (the two are cheap and sequential per stream) */
+__global__ __launch_bounds__(64) void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams)
+{
+   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (j >= A.nJobs)
+      return;
+
+   NfcScanJob job = A.jobs[j];
+
+   NfcConfig cc;
+   nfc_fixed_runtime_config(cfgPtr, cc);
+
+   if (checkSeams)
+   {
+      job.status = 0;
+      job.passes = 0;
+      nfc_seams_check(cc, A.params, job, A.seams, A.points, A.tileStats, A.stride, A.chunkEdge, A.states[job.slot].edgeTime, A.states[job.slot].clock);
+   }
+
+   job.status &= ~NFC_JOB_OVERFLOW;
+
+   const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+   for (uint32_t i = 0; i < nTiles; i++)
+   {
+      const uint32_t flags = nfc_tile_flags(cc, A.params, A.tileStats + job.firstTile, i);
+      A.tiles[job.firstTile + i] = flags;
+      if (flags & NFC_TILE_OFFGRID)
+         job.status |= NFC_JOB_OFFGRID;
+   }
+
+   /* count, reserve, fill: the speculative windows of a job are contiguous and ordered */
+   const uint32_t need = nfc_windows_build(job, j, A.tiles, nullptr, 0);
+   const uint32_t first = atomicAdd(A.windowCount, need);
+
+   job.firstWindow = A.firstWindowSlot + first;
+   job.windows = need;
+
+   if (first + need > A.windowRoom)
+   {
+      job.status |= NFC_JOB_OVERFLOW;
+      job.windows = 0;
+   }
+   else
+      nfc_windows_build(job, j, A.tiles, A.windows + job.firstWindow, need);
+
+   A.jobs[j] = job;
+}
+
+/* Prepare lanes. Carry lanes (window index == job index, one wave per job): a copy of the stream's slot, so that the
+ * stream itself stays untouched until the submission is settled. Speculative lanes: scanned front end + assumed carry. */
+__global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
+{
+   const uint32_t j = blockIdx.x;
+   const uint32_t t = threadIdx.x;
+
+   if (j >= A.nJobs)
+      return;
+
+   const NfcScanJob *job = A.jobs + j;
+   const uint32_t from = job->slot, to = j;
+
+   const float *src = real.rings + (uint64_t)(from / NFC_LANES) * real.ringBlockFloats + (from % NFC_LANES);
+   float *dst = lanes.rings + (uint64_t)(to / NFC_LANES) * lanes.ringBlockFloats + (to % NFC_LANES);
+
+   for (uint32_t i = t; i < real.ringBlockFloats / NFC_LANES; i += NFC_LANES)
+      dst[(uint64_t)i * NFC_LANES] = src[(uint64_t)i * NFC_LANES];
+
+   for (uint32_t i = t; i < NFC_STREAM_BYTES / 4; i += NFC_LANES)
+      ((uint32_t *)(lanes.bytes + (uint64_t)to * NFC_STREAM_BYTES))[i] = ((const uint32_t *)(real.bytes + (uint64_t)from * NFC_STREAM_BYTES))[i];
+
+   if (t == 0)
+   {
+      NfcStreamState s = real.states[from];
+      NfcStreamCold cold = real.cold[from];
+
+      cold.frameHead = 0;
+      cold.frameTail = 0;
+
+      lanes.states[to] = s;
+      lanes.cold[to] = cold;
+
+      NfcWindow w;
+      __builtin_memset(&w, 0, sizeof(w));
+      w.job = j;
+      nfc_carry_take(w.carry, s, cold);
+      w.want = w.carry;
+      A.windows[to] = w;
+
+      NfcWork work;
+      work.data = job->data;
+      work.count = (job->status & NFC_JOB_INVALID) ? 0u : job->count;
+      work.stride = A.stride;
+      work.tiles = A.tiles + job->firstTile;
+      A.works[to] = work;
+   }
+}
+
+/* speculative lanes: all of them (pass 0: every window assumes what the stream's state holds now), or those marked */
+__global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass)
+{
+   const uint32_t wi = A.firstWindowSlot + blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (wi >= A.firstWindowSlot + *A.windowCount || wi >= A.firstWindowSlot + A.windowRoom)
+      return;
+
+   NfcWindow w = A.windows[wi];
+   const NfcScanJob *job = A.jobs + w.job;
+
+   NfcWork work;
+   work.data = job->data + (uint64_t)w.start * A.stride * 4u;
+   work.count = 0;
+   work.stride = A.stride;
+   work.tiles = A.tiles + job->firstTile + w.start / NFC_SCAN_TILE;
+
+   const bool run = !(job->status & NFC_JOB_INVALID) && (pass == 0 || w.rerun);
+
+   if (run)
+   {
+      if (pass == 0)
+         w.carry = A.windows[w.job].carry; /* the carry lane's: the stream's state as the submission finds it */
+      else
+         w.carry = w.want;
+
+      w.want = w.carry;
+      w.rerun = 0;
+      w.stop = 0;
+      w.retired = 0;
+
+      NfcConfig cc;
+      nfc_fixed_runtime_config(cfgPtr, cc);
+
+      const uint32_t chunk = job->firstChunk + w.start / A.params.chunkSamples;
+
+      NfcStreamState s;
+      NfcStreamCold cold;
+      nfc_window_lane(cc, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+
+      lanes.states[wi] = s;
+      lanes.cold[wi] = cold;
+      A.windows[wi] = w;
+
+      work.count = job->count - w.start;
+   }
+
+   A.works[wi] = work;
+}
+
+/* The windowed decode: nfc_demod_body with lanes that stop on their own. A lane consumes its row tile by tile: front
+ * end only, then correlator upkeep (both lengths are the launch's), then the full step machine; at a tile boundary it
+ * retires when the decoder is at rest, the rings hold nothing from before its last unlock and the scan found nothing
+ * ahead (NFC_TILE_RETIRE_OK). CARRY lanes continue a stream from its own state (no warm-up, exact-modulo ring positions
+ * where the clock asks for them). */
+template <bool CARRY>
+__device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, float *tile)
+{
+   const uint32_t lane = threadIdx.x;
+   const uint32_t block = L.firstBlock + blockIdx.x;
+   const uint32_t slot = block * NFC_LANES + lane;
+
+   uint32_t mineCount = 0;
+   const uint32_t *flags = nullptr;
+
+   if (slot >= L.firstSlot && slot < L.firstSlot + L.slotCount)
+   {
+      mineCount = L.works[slot].count;
+      flags = L.works[slot].tiles;
+   }
+
+   uint32_t longest = mineCount;
+   for (int off = 32; off > 0; off >>= 1)
+   {
+      uint32_t other = __shfl_xor(longest, off, 64);
+      longest = other > longest ? other : longest;
+   }
+
+   longest = __builtin_amdgcn_readfirstlane(longest);
+
+   if (longest == 0)
+      return;
+
+   NfcStreamState s = L.states[slot];
+
+   NfcLaneMem mem;
+   mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats;
+   mem.lane = lane;
+   mem.exact = false;
+   mem.linked = true;
+   mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
+   mem.sink = L.sink;
+   mem.sinkCursor = L.sinkCtl;
+   mem.sinkDropped = L.sinkCtl + 1;
+   mem.sinkWords = L.sinkWords;
+   mem.streamId = slot;
+   mem.cold = L.cold + slot;
+   mem.tables = cfgPtr;
+
+   NFC_DRAIN();
+
+   NfcConfig cc;
+   nfc_fixed_runtime_config(cfgPtr, cc);
+
+   const uint32_t warm = L.warmFront + L.warmCorr;
+   bool stopped = mineCount == 0;
+   uint32_t consumed = 0;
+
+   for (uint32_t base = 0; base < longest; base += TILE)
+   {
+      if (!stopped && base >= mineCount)
+         stopped = true;
+
+      /* retire? (tile boundary: TILE == NFC_SCAN_TILE and every lane starts on a tile boundary of its stream) */
+      if (!stopped && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
+          (uint32_t)(s.clock - mem.cold->lastUnlock) >= NFC_WINDOW_SETTLE)
+         stopped = true;
+
+      if (__any(!stopped) == 0)
+         break;
+
+      if (L.uniformStride == 2)
+         nfc_stage_tile<2>(L, block, base, lane, tile);
+      else
+         nfc_stage_tile<1>(L, block, base, lane, tile);
+
+      __syncthreads();
+
+      if (!stopped)
+      {
+         const uint32_t left = mineCount - base;
+         const uint32_t n = left < TILE ? left : TILE;
+
+         if (base < L.warmFront)
+         {
+            for (uint32_t k = 0; k < n; k++)
+               nfc_step_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+         }
+         else if (base < warm)
+         {
+            for (uint32_t k = 0; k < n; k++)
+               nfc_step_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+         }
+         else if (CARRY && __any(nfc_exact_span(s.clock, n)) != 0)
+         {
+            for (uint32_t k = 0; k < n; k++)
+               nfc_step_as<true>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+         }
+         else
+         {
+            for (uint32_t k = 0; k < n; k++)
+               nfc_step_as<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+         }
+
+         consumed = base + n;
+      }
+
+      __syncthreads();
+   }
+
+   if (mineCount)
+   {
+      L.states[slot] = s;
+      L.windows[slot].stop = L.windows[slot].start + consumed;
+      L.windows[slot].retired = consumed < mineCount ? 1u : 0u;
+   }
+}
+
+__global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+{
+   __shared__ float tile[NFC_LANES * TILE_PITCH];
+   nfc_window_body<false>(cfgPtr, L, tile);
+}
+
+__global__ __launch_bounds__(64) void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+{
+   __shared__ float tile[NFC_LANES * TILE_PITCH];
+   nfc_window_body<true>(cfgPtr, L, tile);
+}
+
+/* one thread per job after a decode pass; counts the jobs that need another pass */
+__global__ __launch_bounds__(64) void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses)
+{
+   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (j >= A.nJobs)
+      return;
+
+   NfcScanJob job = A.jobs[j];
+
+   if (job.status & NFC_JOB_INVALID)
+      return;
+
+   if (nfc_chain_follow(job, j, A.windows, lanes.states, lanes.cold, maxPasses))
+      atomicAdd(A.rerunCount, 1u);
+
+   A.jobs[j] = job;
+}
+
+/* one wave per job once the chain is settled: frames in stream order into the sink, last lane's state into the stream */
+__global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
+{
+   const uint32_t j = blockIdx.x;
+   const uint32_t t = threadIdx.x;
+
+   if (j >= A.nJobs)
+      return;
+
+   const NfcScanJob *job = A.jobs + j;
+
+   if (job->status & NFC_JOB_INVALID)
+      return;
+
+   if (t == 0)
+      nfc_finish_frames(*job, j, A.windows, lanes.cold, lanes.sink, real.sink, real.sinkCtl, real.sinkWords);
+
+   const uint32_t from = job->finalLane, to = job->slot;
+
+   const float *src = lanes.rings + (uint64_t)(from / NFC_LANES) * lanes.ringBlockFloats + (from % NFC_LANES);
+   float *dst = real.rings + (uint64_t)(to / NFC_LANES) * real.ringBlockFloats + (to % NFC_LANES);
+
+   for (uint32_t i = t; i < real.ringBlockFloats / NFC_LANES; i += NFC_LANES)
+      dst[(uint64_t)i * NFC_LANES] = src[(uint64_t)i * NFC_LANES];
+
+   for (uint32_t i = t; i < NFC_STREAM_BYTES / 4; i += NFC_LANES)
+      ((uint32_t *)(real.bytes + (uint64_t)to * NFC_STREAM_BYTES))[i] = ((const uint32_t *)(lanes.bytes + (uint64_t)from * NFC_STREAM_BYTES))[i];
+
+   if (t == 0)
+   {
+      NfcStreamState s = lanes.states[from];
+      NfcStreamCold cold = lanes.cold[from];
+
+      cold.frameHead = 0;
+      cold.frameTail = 0;
+
+      real.states[to] = s;
+      real.cold[to] = cold;
+   }
 }

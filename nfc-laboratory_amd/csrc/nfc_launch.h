@@ -14,6 +14,7 @@ struct NfcWork
    const uint8_t *data; /* device pointer: count*stride floats */
    uint32_t count;      /* samples */
    uint32_t stride;     /* 1 magnitude, 2 interleaved IQ (host bookkeeping; a launch has one format, NfcLaunch::uniformStride) */
+   const uint32_t *tiles; /* windowed launches: tile flag words (nfc_scan.h) from the lane's first sample on */
 };
 
 struct NfcLaunch
@@ -34,6 +35,9 @@ struct NfcLaunch
    uint32_t firstSlot;
    uint32_t slotCount;
    uint32_t ringBlockFloats;
+   uint32_t warmFront;  /* windowed launches: leading samples of every lane that only run the front end ... */
+   uint32_t warmCorr;   /* ... then samples that also keep the search correlators up, before the decoder goes live */
+   struct NfcWindow *windows; /* windowed launches: per-slot records (stop / retired are written back) */
    uint32_t launchSeq;  /* non-zero, distinct for every demodulation launch of a context (see NfcStreamState::served) */
    uint32_t forceExact; /* the host launches only the exact-modulo kernel: it takes every block, whatever the clocks say */
 };

@@ -1,0 +1,631 @@
+/*
+ * nfc_scan.hpp — device code of the time-parallel path (see nfc_scan.h for the idea and the records).
+ *
+ *   nfc_scan_*      the chunk walker: exact front end (the very nfc_front_end_core the decoder runs) plus the per-tile
+ *                   "can a detector at rest move here?" tests; one lane per chunk.
+ *   nfc_seams_*     verifies every chunk seam bit for bit and resolves the edge-tracker time across chunks.
+ *   nfc_windows_*   turns tile flags into windows (clusters of busy tiles) and marks where a lane may retire.
+ *   nfc_window_*    prepares the lane of a window: scanned front-end state + assumed carry, everything else at rest.
+ *   nfc_chain_*     after a decode pass: which lanes' frames are the stream's frames, were their assumptions right.
+ *   nfc_finish_*    copies the live frames, in stream order, to the frame sink and the last lane's state to the stream.
+ *
+ * Included by nfc_kernels.hip after nfc_core.hpp (and by the CPU twins of tests/hostsim, test infrastructure).
+ * Reference behaviour: NfcTech.cpp:28-105 (front end), NfcDecoder.cpp:394-418,472-523 (search loop, carrier detector),
+ * detectModulation of NfcA.cpp:217-411, NfcB.cpp:238-432, NfcF.cpp:206-408, NfcV.cpp:236-435 (what moves a detector
+ * at rest).
+ */
+#ifndef NFC_AMD_SCAN_HPP
+#define NFC_AMD_SCAN_HPP
+
+#include "nfc_scan.h"
+
+/* constants of a scan launch, derived on the host from the configuration of the streams it covers */
+struct NfcScanParams
+{
+   float rangeK;   /* 0.49 * smallest correlation threshold of the enabled raw-signal detectors (A, F, V); +inf when none */
+   float edgeK;    /* 0.99 * NFC-B minimum modulation depth; +inf when NFC-B is disabled */
+   uint32_t chunkSamples;  /* samples per chunk (multiple of NFC_SCAN_POINT) */
+   uint32_t warmSamples;   /* samples walked before a chunk to reach the true front-end state (multiple of NFC_SCAN_POINT) */
+};
+
+/* walker state of one chunk */
+struct NfcScanLane
+{
+   NfcStreamState fe; /* only the front-end fields are used */
+   uint32_t zone;
+   uint32_t edgeSynced; /* the edge-peak tracker has been reset since the walk began: its peak is the true one */
+   uint32_t edgeKnown;  /* ... and it has set a time since: fe.edgeTime is the true one */
+   float xmin, xmax, envmin, fmin; /* of the tile being walked */
+   uint32_t bits;
+};
+
+#define NFC_SCAN_BIG 3.0e38f
+#define NFC_ZONE_MASK 0xFFu
+#define NFC_ZONE_EDGE_KNOWN 0x100u
+
+NFC_DEV void nfc_scan_tile_reset(NfcScanLane &w)
+{
+   w.xmin = NFC_SCAN_BIG;
+   w.xmax = -NFC_SCAN_BIG;
+   w.envmin = NFC_SCAN_BIG;
+   w.fmin = NFC_SCAN_BIG;
+   w.bits = 0;
+}
+
+/* start of a walk: `exact` = from the stream's own state (first chunk of a submission), else from a guess that the
+ * warm-up turns into the true state */
+NFC_DEV void nfc_scan_begin(NfcScanLane &w, const NfcStreamState *from, uint32_t clock, float first)
+{
+   __builtin_memset(&w.fe, 0, sizeof(w.fe));
+
+   if (from)
+   {
+      w.fe.clock = from->clock;
+      w.fe.pulseFilter = from->pulseFilter;
+      w.fe.env = from->env;
+      w.fe.n1 = from->n1;
+      w.fe.mdev = from->mdev;
+      w.fe.avg = from->avg;
+      w.fe.edgePeak = from->edgePeak;
+      w.fe.edgeTime = from->edgeTime;
+      w.zone = from->carrierOn ? 1u : (from->carrierOff ? 2u : 0u);
+      w.edgeSynced = 1;
+      w.edgeKnown = 0; /* the decoder's copy may have been zeroed by a carrier frame: resolved through NfcCarry */
+   }
+   else
+   {
+      w.fe.clock = clock;
+      w.fe.env = first;
+      w.fe.n1 = first * 10.0f; /* fixed point of n = x + 0.9 n */
+      w.fe.avg = first;
+      w.zone = 0;
+      w.edgeSynced = 0;
+      w.edgeKnown = 0;
+   }
+
+   nfc_scan_tile_reset(w);
+}
+
+NFC_DEV void nfc_scan_point(const NfcScanLane &w, NfcScanPoint &p)
+{
+   p.env = w.fe.env;
+   p.n1 = w.fe.n1;
+   p.mdev = w.fe.mdev;
+   p.avg = w.fe.avg;
+   p.edgePeak = w.fe.edgePeak;
+   p.pulseFilter = w.fe.pulseFilter;
+   p.edgeTime = w.fe.edgeTime;
+   p.zone = w.zone | (w.edgeKnown ? NFC_ZONE_EDGE_KNOWN : 0u);
+}
+
+/* A third of the way into the warm-up the guessed envelope is replaced by the average, which has converged by then
+ * whatever it started from (a plain EMA): on unmodulated carrier the two agree within the noise, so the envelope
+ * tracker starts inside its 5 % capture range. (Started further away it only moves once per ten symbols and can take
+ * a whole chunk to find the carrier level.) */
+NFC_DEV void nfc_scan_reseed(NfcScanLane &w)
+{
+   w.fe.env = w.fe.avg;
+   w.fe.pulseFilter = 0;
+}
+
+/* one sample: the decoder's own front end, then what the tile tests need */
+NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
+{
+   ++w.fe.clock;
+   ++w.fe.pulseFilter;
+
+   const float peakBefore = w.fe.edgePeak;
+   const uint32_t timeBefore = w.fe.edgeTime;
+
+   const NfcNow now = nfc_front_end_core(c, w.fe, x);
+
+   /* edge tracker bookkeeping: a reset (peak back to zero) makes the peak the true one whatever the walk started from;
+    * a time set after that is the true time */
+   if (w.fe.edgePeak == 0.0f && !(nfc_abs(now.filt) > c.highThreshold))
+      w.edgeSynced = w.edgeSynced | (nfc_abs(now.filt) < c.lowThreshold ? 1u : 0u);
+   if (w.fe.edgeTime != timeBefore || w.fe.edgePeak != peakBefore)
+      w.edgeKnown = (w.fe.edgeTime != timeBefore && w.edgeSynced) ? 1u : w.edgeKnown;
+
+   w.xmin = x < w.xmin ? x : w.xmin;
+   w.xmax = x > w.xmax ? x : w.xmax;
+   w.envmin = w.fe.env < w.envmin ? w.fe.env : w.envmin;
+   w.fmin = now.filt < w.fmin ? now.filt : w.fmin;
+
+   /* on the int16 grid of the captures (k / 32768, |k| small enough for every box sum to stay exact)? */
+   const float scaled = x * 32768.0f;
+   if (!(scaled == __builtin_truncf(scaled)) || !(nfc_abs(x) <= 4.0f))
+      w.bits |= NFC_TILE_OFFGRID;
+
+   /* NaNs make both comparisons false, exactly as in nfc_detect_carrier */
+   if (w.fe.avg > c.highThreshold)
+   {
+      if (w.zone != 1u)
+      {
+         w.zone = 1u;
+         w.bits |= NFC_TILE_CARRIER;
+      }
+   }
+   else if (w.fe.avg < c.lowThreshold)
+   {
+      if (w.zone != 2u)
+      {
+         w.zone = 2u;
+         w.bits |= NFC_TILE_CARRIER;
+      }
+   }
+
+   if (w.fe.clock < 1024u)
+      w.bits |= NFC_TILE_UNARMED;
+}
+
+/* end of a tile */
+NFC_DEV void nfc_scan_tile_end(NfcScanLane &w, NfcScanTile &out)
+{
+   out.xmin = w.xmin;
+   out.xmax = w.xmax;
+   out.fmin = w.fmin;
+   out.envmin = w.envmin;
+   out.bits = w.bits;
+   nfc_scan_tile_reset(w);
+}
+
+/* The tile tests (nfc_scan.h): flag word of tile i of a job from the recorded extremes of the tile and of the tiles a
+ * detector can still look back into. Written so that NaNs (and an envelope of zero or less) come out busy. */
+NFC_DEV uint32_t nfc_tile_flags(const NfcConfig &c, const NfcScanParams &sp, const NfcScanTile *t, uint32_t i)
+{
+   uint32_t flags = t[i].bits;
+
+   if (i < NFC_SCAN_LOOKBACK)
+      flags |= NFC_TILE_NOHISTORY;
+   else
+   {
+      float lo = t[i].xmin, hi = t[i].xmax;
+
+      for (uint32_t k = 1; k <= NFC_SCAN_LOOKBACK; k++)
+      {
+         lo = t[i - k].xmin < lo ? t[i - k].xmin : lo;
+         hi = t[i - k].xmax > hi ? t[i - k].xmax : hi;
+      }
+
+      if (!((hi - lo) <= sp.rangeK * t[i].envmin))
+         flags |= NFC_TILE_RANGE;
+
+      float fm = t[i].fmin;
+      for (uint32_t k = 1; k <= NFC_SCAN_EDGEBACK; k++)
+         fm = t[i - k].fmin < fm ? t[i - k].fmin : fm;
+
+      if (!(fm >= -(sp.edgeK * t[i].envmin)))
+         flags |= NFC_TILE_EDGE;
+   }
+
+   if (!(t[i].envmin >= c.powerThreshold))
+      flags |= NFC_TILE_UNARMED;
+
+   return flags;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* seams: one thread per job, chunks in order                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The includer says how to read sample i of a stream as a magnitude: NFC_SAMPLE_AT(data, stride, i). */
+#ifndef NFC_SAMPLE_AT
+#error "define NFC_SAMPLE_AT(data, stride, index) before including nfc_scan.hpp"
+#endif
+
+/* Everything of a point but the envelope tracker (those recurrences are contractive: a mismatch there is not repaired) */
+NFC_DEV bool nfc_point_same_but_envelope(const NfcScanPoint &a, const NfcScanPoint &b)
+{
+   const uint32_t *x = (const uint32_t *)&a, *y = (const uint32_t *)&b;
+   return x[1] == y[1] && x[2] == y[2] && x[3] == y[3] && x[4] == y[4] && ((a.zone ^ b.zone) & NFC_ZONE_MASK) == 0;
+}
+
+/* Seams of a job, chunks in order. Where the chunk before ends with another envelope / pulse filter than the chunk
+ * started from, the envelope is walked again from the true value (alone: nothing else of the front end depends on it)
+ * until it meets the scanned one at a stored point, or to the end of the chunk; the points and tile minima on the way are
+ * corrected and the tiles marked NFC_TILE_REWALKED (their other flags may have been decided with a wrong envelope only
+ * in the sense that the tests have not been evaluated yet: nfc_tile_flags runs afterwards).
+ * chunkEdge[k] = true edgeTime of the autonomous tracker at the start of chunk k. */
+NFC_DEV void nfc_seams_check(const NfcConfig &c, const NfcScanParams &sp, NfcScanJob &job, NfcScanSeam *seams, NfcScanPoint *points,
+                             NfcScanTile *tiles, uint32_t stride, uint32_t *chunkEdge, uint32_t startEdge, uint32_t startClock)
+{
+   uint32_t edge = startEdge;
+
+   for (uint32_t k = 0; k < job.chunks; k++)
+   {
+      NfcScanSeam &s = seams[job.firstChunk + k];
+
+      if (k > 0)
+      {
+         const NfcScanPoint &before = seams[job.firstChunk + k - 1].end;
+
+         if (!nfc_point_same_but_envelope(s.start, before))
+            job.status |= NFC_JOB_SEAM;
+
+         if ((s.start.zone & NFC_ZONE_EDGE_KNOWN) && s.start.edgeTime != edge)
+            job.status |= NFC_JOB_SEAM;
+
+         if (nfc_bits(s.start.env) != nfc_bits(before.env) || s.start.pulseFilter != before.pulseFilter)
+         {
+            float env = before.env;
+            uint32_t pulse = before.pulseFilter;
+
+            const uint32_t from = k * sp.chunkSamples;
+            const uint32_t to = from + sp.chunkSamples < job.count ? from + sp.chunkSamples : job.count;
+            bool met = false;
+            float envmin = NFC_SCAN_BIG;
+
+            for (uint32_t i = from; i < to; i++)
+            {
+               if ((i % NFC_SCAN_POINT) == 0)
+               {
+                  NfcScanPoint &p = points[job.firstPoint + i / NFC_SCAN_POINT];
+
+                  if (nfc_bits(p.env) == nfc_bits(env) && p.pulseFilter == pulse)
+                  {
+                     met = true;
+                     break;
+                  }
+
+                  p.env = env;
+                  p.pulseFilter = pulse;
+               }
+
+               ++pulse;
+               nfc_envelope_step(c, startClock + 1u + i, pulse, env, NFC_SAMPLE_AT(job.data, stride, i));
+
+               envmin = env < envmin ? env : envmin;
+
+               if ((i % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || i == to - 1)
+               {
+                  NfcScanTile &t = tiles[job.firstTile + i / NFC_SCAN_TILE];
+                  t.envmin = envmin;
+                  t.bits |= NFC_TILE_REWALKED;
+                  envmin = NFC_SCAN_BIG;
+               }
+            }
+
+            if (!met)
+            {
+               s.end.env = env;
+               s.end.pulseFilter = pulse;
+            }
+         }
+      }
+
+      chunkEdge[job.firstChunk + k] = edge;
+
+      if (s.end.zone & NFC_ZONE_EDGE_KNOWN)
+         edge = s.end.edgeTime;
+   }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* windows: one thread per job                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Marks the tiles from which on at least NFC_WINDOW_GAP tiles are quiet (a lane may retire there: whatever comes next
+ * is far enough for the following lane's warm-up to lie in quiet signal) and lists the speculative windows of the job:
+ * one per busy tile that follows such a gap, plus a closing one that activates at the end of the submission (it decodes
+ * nothing: it rebuilds the rings a stream at rest has there, for the case that the last lane retired before the end).
+ * The end of the submission does not count as a gap: a lane still running in the last quiet stretch runs to the end.
+ * `room` windows may be written at `out`; returns the number the job needs. */
+NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uint32_t *flags, NfcWindow *out, uint32_t room)
+{
+   const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+   uint32_t *t = flags + job.firstTile;
+
+   uint32_t quietAhead = 0;
+
+   for (uint32_t i = nTiles; i-- > 0;)
+   {
+      if (t[i] & NFC_TILE_BUSY)
+         quietAhead = 0;
+      else if (quietAhead < NFC_WINDOW_GAP)
+         quietAhead++;
+
+      if (quietAhead >= NFC_WINDOW_GAP)
+         t[i] |= NFC_TILE_RETIRE_OK;
+      else
+         t[i] &= ~NFC_TILE_RETIRE_OK;
+   }
+
+   uint32_t n = 0;
+
+   auto put = [&](uint32_t start, uint32_t activate) {
+      if (n < room)
+      {
+         NfcWindow &w = out[n];
+         __builtin_memset(&w, 0, sizeof(w));
+         w.job = jobIndex;
+         w.start = start;
+         w.activate = activate;
+      }
+      n++;
+   };
+
+   const uint32_t warm = NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
+
+   uint32_t quietBehind = 0;
+
+   for (uint32_t i = 0; i < nTiles; i++)
+   {
+      if (!(t[i] & NFC_TILE_BUSY))
+      {
+         quietBehind++;
+         continue;
+      }
+
+      /* a busy tile after a gap a lane may have retired in */
+      if (quietBehind >= NFC_WINDOW_GAP)
+      {
+         const uint32_t act = i * NFC_SCAN_TILE;
+         if (act >= warm + NFC_SCAN_POINT)
+            put((act - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, act);
+      }
+
+      quietBehind = 0;
+   }
+
+   if (job.count >= warm + NFC_SCAN_POINT)
+      put((job.count - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, job.count);
+
+   return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* carry: what a lane inherits / leaves                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+NFC_DEV void nfc_carry_take(NfcCarry &x, const NfcStreamState &s, const NfcStreamCold &cold)
+{
+   for (int t = 0; t < 4; t++)
+      x.tim[t] = cold.tim[t];
+   x.chainedA = s.chainedA;
+   x.carrierOn = s.carrierOn;
+   x.carrierOff = s.carrierOff;
+   x.emitClock = cold.emitClock;
+   x.emitValid = cold.emitValid;
+
+   /* only meaningful (and only looked at) for a lane that stopped at rest: the detector records share their storage
+    * with the decode registers */
+   for (int i = 0; i < 2; i++)
+   {
+      x.pulsesF[i] = s.lockTech ? 0u : s.u.search.detF[i].pulses;
+      x.thrF[i] = s.lockTech ? 0.0f : s.u.search.detF[i].thr;
+      x.clearedF[i] = cold.clearedF[i];
+   }
+}
+
+/* The fields a later decode can depend on. guardTime / waitingTime are rewritten by every poll frame's processing before
+ * they are read (nfc*_process), the carrier times only matter as "set or not" (NfcDecoder.cpp:449-463,472-523). */
+NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b)
+{
+   bool same = a.chainedA == b.chainedA && (a.carrierOn != 0) == (b.carrierOn != 0) && (a.carrierOff != 0) == (b.carrierOff != 0) &&
+               a.emitValid == b.emitValid && (!a.emitValid || a.emitClock == b.emitClock);
+
+   for (int t = 0; t < 4; t++)
+      same = same && a.tim[t].lastCommand == b.tim[t].lastCommand && a.tim[t].maxFrameSize == b.tim[t].maxFrameSize &&
+             a.tim[t].protoGuardTime == b.tim[t].protoGuardTime && a.tim[t].protoWaitingTime == b.tim[t].protoWaitingTime;
+
+   for (int i = 0; i < 2; i++)
+      same = same && a.pulsesF[i] == b.pulsesF[i] && nfc_bits(a.thrF[i]) == nfc_bits(b.thrF[i]);
+
+   return same;
+}
+
+/* Prediction of what a lane will leave when it is run again with `given` instead of `assumed`, from what it `left`
+ * last time: every field it left as it had found it is taken to be passed through, every other to be set by the lane
+ * whatever it is given. Only used to choose what to run next; results are always checked. */
+NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const NfcCarry &given)
+{
+#define NFC_CARRY_FIELD(f) left.f = (left.f == assumed.f) ? given.f : left.f
+   NFC_CARRY_FIELD(chainedA);
+   NFC_CARRY_FIELD(carrierOn);
+   NFC_CARRY_FIELD(carrierOff);
+   NFC_CARRY_FIELD(emitClock);
+   NFC_CARRY_FIELD(emitValid);
+
+   for (int t = 0; t < 4; t++)
+   {
+      NFC_CARRY_FIELD(tim[t].lastCommand);
+      NFC_CARRY_FIELD(tim[t].guardTime);
+      NFC_CARRY_FIELD(tim[t].waitingTime);
+      NFC_CARRY_FIELD(tim[t].maxFrameSize);
+      NFC_CARRY_FIELD(tim[t].protoGuardTime);
+      NFC_CARRY_FIELD(tim[t].protoWaitingTime);
+   }
+
+   for (int i = 0; i < 2; i++)
+   {
+      /* the pulse counter is counted on: a lane adds what it added before, unless it cleared the counter on the way */
+      if (!left.clearedF[i])
+         left.pulsesF[i] = given.pulsesF[i] + (left.pulsesF[i] - assumed.pulsesF[i]);
+      left.thrF[i] = nfc_bits(left.thrF[i]) == nfc_bits(assumed.thrF[i]) ? given.thrF[i] : left.thrF[i];
+   }
+#undef NFC_CARRY_FIELD
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* lane of a window                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* ring phase labels: a lane numbers its correlation rings from zero at its first sample, whatever its clock, so that
+ * the lanes of a wave walk the same ring rows (nfc_types.h: NfcStreamCold::label) */
+NFC_DEV uint32_t nfc_label(uint32_t clock, uint32_t delay, uint32_t period, uint32_t pos)
+{
+   /* label = (pos - true position) mod period, true position = (1024 - delay + clock) % period in 32-bit arithmetic */
+   const uint32_t truePos = (uint32_t)(1024u - delay + clock) % period;
+   return (pos + period - truePos) % period;
+}
+
+NFC_DEV void nfc_window_lane(const NfcConfig &c, const NfcWindow &w, const NfcScanPoint &p, uint32_t chunkEdge, uint32_t startClock,
+                             NfcStreamState &s, NfcStreamCold &cold)
+{
+   __builtin_memset(&s, 0, sizeof(s));
+   __builtin_memset(&cold, 0, sizeof(cold));
+
+   /* state after the sample before w.start */
+   s.clock = startClock + w.start;
+   s.pulseFilter = p.pulseFilter;
+   s.env = p.env;
+   s.n1 = p.n1;
+   s.mdev = p.mdev;
+   s.avg = p.avg;
+   s.edgePeak = p.edgePeak;
+
+   /* the decoder's edge time: the tracker's, unless a carrier frame zeroed it since */
+   const uint32_t tracked = (p.zone & NFC_ZONE_EDGE_KNOWN) ? p.edgeTime : chunkEdge;
+   s.edgeTime = (w.carry.emitValid && (int32_t)(tracked - w.carry.emitClock) <= 0) ? 0u : tracked;
+
+   s.carrierOn = w.carry.carrierOn;
+   s.carrierOff = w.carry.carrierOff;
+   s.chainedA = w.carry.chainedA;
+
+   for (int t = 0; t < 4; t++)
+      cold.tim[t] = w.carry.tim[t];
+
+   cold.emitClock = w.carry.emitClock;
+   cold.emitValid = w.carry.emitValid;
+   cold.lastUnlock = s.clock;
+
+   for (int i = 0; i < 2; i++)
+   {
+      s.u.search.detF[i].pulses = w.carry.pulsesF[i];
+      s.u.search.detF[i].thr = w.carry.thrF[i];
+   }
+
+   /* every ring position starts at zero (the detector records are at rest, the rings are rebuilt by the warm-up) */
+   cold.label[0] = nfc_label(s.clock, c.a[0].delay, c.a[0].p1, 0);
+   cold.label[1] = nfc_label(s.clock, c.a[1].delay, c.a[1].p1, 0);
+   cold.label[2] = nfc_label(s.clock, c.a[2].delay, c.a[2].p1, 0);
+   cold.label[3] = nfc_label(s.clock, c.f[1].delay, c.f[1].p1, 0);
+   cold.label[4] = nfc_label(s.clock, c.f[2].delay, c.f[2].p1, 0);
+   cold.label[5] = nfc_label(s.clock, c.v.delay, c.v.p1, 0);
+   cold.label[6] = nfc_label(s.clock, c.v.delay, c.v.p0, 0);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* chain: one thread per job, after every decode pass                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Follows the stream through its lanes: lane 0 carries the state in; a lane that retired at sample r hands over to the
+ * first window that activates at or after r. A hand-over is sound when the window had assumed exactly what the lane
+ * left (nfc_carry_same). Otherwise the window is marked to run again with what was left; from there on the walk goes by
+ * prediction - a lane that left what it had assumed will pass through whatever it is given, any other lane leaves
+ * what it left before, and every lane stops where it stopped before - so that one more pass usually settles the whole
+ * stream. Predictions are only used to choose what to run; a job is done when a walk meets results only.
+ * Returns true when the job needs another pass. lanes[] / colds[] are the virtual slots (index = window index). */
+NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *windows, const NfcStreamState *lanes, const NfcStreamCold *colds,
+                              uint32_t maxPasses)
+{
+   NfcWindow *w = windows + job.firstWindow; /* speculative windows, ordered by activation */
+   const uint32_t n = job.windows;
+
+   for (uint32_t i = 0; i < n; i++)
+   {
+      w[i].live = 0;
+      w[i].rerun = 0;
+   }
+
+   bool again = false;
+   uint32_t lane = jobIndex; /* the carry lane comes first */
+   uint32_t next = 0;        /* first speculative window not yet passed */
+   NfcCarry have;
+
+   for (;;)
+   {
+      NfcWindow &x = windows[lane];
+
+      NfcCarry left;
+      nfc_carry_take(left, lanes[lane], colds[lane]);
+
+      if (lane != jobIndex && !nfc_carry_same(x.carry, have))
+      {
+         /* ran on a wrong assumption: again, and predict what it will leave */
+#ifdef NFC_CHAIN_TRACE
+         NFC_CHAIN_TRACE(lane, x.carry, have, left);
+#endif
+         nfc_carry_predict(left, x.carry, have);
+         x.want = have;
+         x.rerun = 1;
+         again = true;
+      }
+
+      x.live = 1;
+      job.finalLane = lane;
+
+      if (!x.retired || x.stop >= job.count)
+         break;
+
+      have = left;
+
+      /* next lane: first window activating at or after the sample this one stopped at (the closing window at the latest) */
+      while (next < n && w[next].activate < x.stop)
+         next++;
+
+      if (next >= n)
+         break;
+
+      lane = job.firstWindow + next;
+      next++;
+   }
+
+   job.passes++;
+
+   if (again && job.passes >= maxPasses)
+   {
+      job.status |= NFC_JOB_GIVEUP;
+      again = false;
+   }
+
+   if (again)
+      job.status |= NFC_JOB_RERUN;
+   else
+      job.status &= ~NFC_JOB_RERUN;
+
+   return again;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* finish: one thread per job, once the chain is settled                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* A lane of a windowed launch chains its frame records in the staging sink: [next][record as nfc_emit writes it];
+ * NfcStreamCold::frameHead is the word offset + 1 of the lane's first record. Copies the records of the live lanes,
+ * in stream order, to the frame sink under the stream's own id. */
+NFC_DEV void nfc_finish_frames(const NfcScanJob &job, uint32_t jobIndex, const NfcWindow *windows, const NfcStreamCold *colds,
+                               const uint32_t *staging, uint32_t *sink, uint32_t *sinkCtl, uint32_t sinkWords)
+{
+   for (uint32_t i = 0; i <= job.windows; i++)
+   {
+      const uint32_t lane = i == 0 ? jobIndex : job.firstWindow + i - 1u;
+
+      if (!windows[lane].live)
+         continue;
+
+      uint32_t at = colds[lane].frameHead;
+
+      while (at)
+      {
+         const uint32_t *rec = staging + (at - 1u);
+         const uint32_t len = rec[9] > NFC_STREAM_BYTES ? NFC_STREAM_BYTES : rec[9];
+         const uint32_t words = NFC_FRAME_HEADER_WORDS + ((len + 3u) >> 2);
+
+         const uint32_t to = NFC_ATOMIC_ADD(sinkCtl, words);
+
+         if (to + NFC_FRAME_MAX_WORDS > sinkWords)
+            NFC_ATOMIC_ADD(sinkCtl + 1, 1u);
+         else
+         {
+            sink[to] = job.slot;
+            for (uint32_t k = 1; k < words; k++)
+               sink[to + k] = rec[1 + k];
+         }
+
+         at = rec[0];
+      }
+   }
+}
+
+#endif

@@ -1,0 +1,43 @@
+/*
+ * nfc_scan_launch.h — argument block of the kernels of the time-parallel path (nfc_scan.h), shared by
+ * nfc_kernels.hip and the host runtime.
+ */
+#ifndef NFC_AMD_SCAN_LAUNCH_H
+#define NFC_AMD_SCAN_LAUNCH_H
+
+#include "nfc_launch.h"
+#include "nfc_scan.h"
+
+#ifndef NFC_AMD_SCAN_HPP
+struct NfcScanParams
+{
+   float rangeK;
+   float edgeK;
+   uint32_t chunkSamples;
+   uint32_t warmSamples;
+};
+#endif
+
+struct NfcScanArgs
+{
+   NfcScanJob *jobs;
+   uint32_t nJobs;
+   const NfcScanChunk *chunks;
+   uint32_t nChunks;
+   uint32_t stride;            /* floats per sample of every job: 1 magnitude, 2 IQ */
+   NfcScanParams params;
+   const NfcStreamState *states; /* the streams' own slots (state a submission starts from) */
+   NfcScanPoint *points;
+   NfcScanSeam *seams;         /* [nChunks] */
+   uint32_t *chunkEdge;        /* [nChunks] */
+   NfcScanTile *tileStats;     /* per tile: what the walk recorded */
+   uint32_t *tiles;            /* per tile: flag word (nfc_tile_flags, then NFC_TILE_RETIRE_OK) */
+   NfcWindow *windows;         /* [firstWindowSlot + windowRoom]: entry i describes lane i of the lane arrays */
+   NfcWork *works;             /* same indexing */
+   uint32_t firstWindowSlot;   /* carry lanes occupy [0, nJobs), speculative lanes start here (multiple of 64) */
+   uint32_t windowRoom;        /* speculative lanes there is room for */
+   uint32_t *windowCount;      /* speculative lanes in use (device counter) */
+   uint32_t *rerunCount;       /* jobs that need another decode pass (device counter) */
+};
+
+#endif

@@ -104,7 +104,7 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 /* the preamble tracker shared by search (NfcF.cpp:267-405) and listen-SOF (NfcF.cpp:815-933);
  * returns true when a complete, length-checked preamble has just ended */
 template <class M>
-NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, float sd, float s0, bool above, uint32_t &polarity)
+NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, float sd, float s0, bool above, uint32_t &polarity, uint32_t *cleared)
 {
    if (above)
    {
@@ -137,6 +137,10 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, flo
       {
          m.symStart = 0; m.symEnd = 0; m.sync = 0; m.syncValue = 0; m.winStart = 0; m.winEnd = 0;
          m.pulses = 0; m.thr = 0; m.peak = 0; m.peakTime = 0;
+      if (cleared)
+         *cleared = 1;
+         if (cleared)
+            *cleared = 1; /* the pulse counter starts over (NfcStreamCold::clearedF) */
          return false;
       }
    }
@@ -168,6 +172,8 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, flo
    {
       m.symStart = 0; m.symEnd = 0; m.sync = 0; m.syncValue = 0; m.winStart = 0; m.winEnd = 0;
       m.pulses = 0; m.thr = 0; m.peak = 0; m.peakTime = 0;
+      if (cleared)
+         *cleared = 1;
       return false;
    }
 
@@ -235,7 +241,7 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
 
    uint32_t polarity = 0;
 
-   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity))
+   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1]))
       return false;
 
    /* preamble complete: lock this bitrate, the sync bytes follow (copy the detector record before it is parked) */
@@ -370,7 +376,7 @@ NFC_DEV uint32_t nfcf_listen_start(const NfcConfig &c, NfcStreamState &s, const 
 
    uint32_t polarity = 0;
 
-   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd >= m.thr, polarity))
+   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd >= m.thr, polarity, nullptr))
       return SYM_NONE;
 
    m.stage = polarity;

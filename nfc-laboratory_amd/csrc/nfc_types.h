@@ -252,7 +252,20 @@ struct NfcStreamCold
    NfcSearchRegs parked; /* detector records while a technology is locked */
    NfcDecodeRegs init;   /* decode register set prepared by the detector that locked, installed by nfc_enter_lock */
    uint32_t framesOut;
-   uint32_t reserved[4];
+   uint32_t lastUnlock; /* clock of the last return to search mode (a lane of the time-parallel path may only retire
+                           once the correlation rings hold nothing older than that) */
+   uint32_t emitClock;  /* clock of the last carrier frame (the decoder zeroes edgeTime when it emits one) */
+   uint32_t emitValid;
+   uint32_t frameHead;  /* chained frame records of this lane in the staging sink: word offset + 1 of the first / last */
+   uint32_t frameTail;
+   /* Ring phase labels of the seven correlation ring positions (A106 A212 A424 F212 F424 V(p1) V(p0)):
+    * position = (reference position + label) % period. Zero for a stream decoded sequentially from its start. A lane of
+    * the time-parallel path numbers its rings from zero at its first sample so that the lanes of a wave, whatever their
+    * clocks, touch the same ring rows; the state it leaves keeps that numbering. Only the exact-modulo kernel variants
+    * (stream start, 32-bit clock wrap) compute positions from the clock and have to add it. */
+   uint32_t label[7];
+   uint32_t clearedF[2]; /* an NFC-F preamble detector cleared its pulse counter since the lane started (NfcCarry::pulsesF) */
+   uint32_t reserved;
 };
 
 /* header of one frame in the frame sink, followed by (length+3)/4 payload words */

@@ -18,6 +18,7 @@
 #include "../../include/nfcgpu.h"
 #include "nfc_config.hpp"
 #include "nfc_launch.h"
+#include "nfc_scan_launch.h"
 
 __global__ void nfc_demod_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_demod_exact_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
@@ -32,6 +33,14 @@ __global__ void nfc_demod_fixed_exact_kernel(const NfcConfig *__restrict__ cfgPt
 #define NFC_FIXED_FN static inline
 #include "nfc_config_fixed.inc"
 __global__ void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd);
+__global__ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
+__global__ void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams);
+__global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
+__global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass);
+__global__ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses);
+__global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
 
 namespace {
 
@@ -106,6 +115,21 @@ struct nfcgpu_ctx
    bool profile = false;
    bool dirty = false; /* work submitted since last sync */
    uint32_t launchSeq = 0; /* stamp of the last demodulation launch (NfcLaunch::launchSeq) */
+
+   /* ---- time-parallel path (nfc_scan.h): device buffers, grown on demand and kept ---- */
+   bool windowed = true;           /* NFCGPU_WINDOWED=0 switches the path off */
+   uint32_t windowedMinSamples = 32768; /* shortest submission (per stream) worth cutting into windows */
+   uint32_t scanChunk = 65536;     /* samples per scan chunk */
+   uint32_t scanWarm = 6144;       /* samples walked ahead of a chunk */
+   uint32_t maxPasses = 8;
+   struct DevBuf
+   {
+      void *ptr = nullptr;
+      size_t bytes = 0;
+   };
+   DevBuf wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters;
+   DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
+   std::vector<ProfiledLaunch> timedScan, timedWindow;
    std::vector<ProfiledLaunch> timed;
    std::vector<hipEvent_t> eventPool;
    nfcgpu_stats stats {};
@@ -401,6 +425,387 @@ int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t sample
    return NFCGPU_OK;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* time-parallel path (nfc_scan.h)                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+struct WindowedItem
+{
+   uint32_t slot;
+   const uint8_t *data; /* device */
+   uint32_t count;
+};
+
+int grow(nfcgpu_ctx *ctx, nfcgpu_ctx::DevBuf &b, size_t bytes)
+{
+   if (bytes <= b.bytes)
+      return NFCGPU_OK;
+
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   if (b.ptr)
+      (void)hipFree(b.ptr);
+
+   b.ptr = nullptr;
+   b.bytes = 0;
+
+   const size_t want = bytes + bytes / 4 + 256;
+
+   if (hipMalloc(&b.ptr, want) != hipSuccess)
+      return fail(ctx, NFCGPU_ENOMEM, "device allocation for the time-parallel path failed");
+
+   b.bytes = want;
+   return NFCGPU_OK;
+}
+
+/* the sequential kernels over a subset of slots (fallback of the time-parallel path) */
+int launch_sequential(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride)
+{
+   if (items.empty())
+      return NFCGPU_OK;
+
+   uint32_t first = 0xFFFFFFFFu, last = 0;
+   uint64_t samples = 0;
+   bool exactPossible = false, exactOnly = true;
+
+   for (const WindowedItem &it: items)
+   {
+      first = it.slot < first ? it.slot : first;
+      last = it.slot > last ? it.slot : last;
+   }
+
+   std::vector<NfcWork> table(last - first + 1);
+   for (NfcWork &w: table)
+   {
+      w.data = nullptr;
+      w.count = 0;
+      w.stride = 1;
+      w.tiles = nullptr;
+   }
+
+   for (const WindowedItem &it: items)
+   {
+      NfcWork &w = table[it.slot - first];
+      w.data = it.data;
+      w.count = it.count;
+      w.stride = stride;
+      samples += it.count;
+      const bool exact = advance_clock(ctx->streams[it.slot], it.count);
+      exactPossible = exactPossible || exact;
+      exactOnly = exactOnly && (exact || it.count == 0);
+   }
+
+   HIP_TRY(ctx, hipMemcpyAsync(ctx->dWorks + first, table.data(), sizeof(NfcWork) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* `table` is a local */
+
+   NfcLaunch L = base_launch(ctx);
+   L.works = ctx->dWorks;
+   L.uniformStride = stride;
+   L.firstSlot = first;
+   L.slotCount = last - first + 1;
+
+   return launch_demod(ctx, config, L, samples, exactPossible, exactOnly);
+}
+
+/* may these streams take the time-parallel path for this submission? (one configuration, one sample format) */
+bool windowed_eligible(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items)
+{
+   if (!ctx->windowed || ctx->genericOnly || items.empty() || !matches_fixed_table(ctx->configs[config]))
+      return false;
+
+   for (const WindowedItem &it: items)
+   {
+      if (it.count < ctx->windowedMinSamples)
+         return false;
+
+      /* stay clear of the 32-bit wrap of the sample clock: the lanes number their rings from their own first sample
+       * and never take the exact-modulo route (a fresh stream, clock 0xFFFFFFFF, is handled by its carry lane) */
+      const uint32_t clock = ctx->streams[it.slot].clock;
+      if (clock != 0xFFFFFFFFu && (uint64_t)clock + it.count + 4096u >= 0xFFFFFFFFull)
+         return false;
+   }
+
+   return true;
+}
+
+void record_span(nfcgpu_ctx *ctx, std::vector<ProfiledLaunch> &into, ProfiledLaunch &pl, bool begin)
+{
+   if (!ctx->profile)
+      return;
+
+   if (begin)
+   {
+      pl.start = take_event(ctx);
+      pl.stop = take_event(ctx);
+      (void)hipEventRecord(pl.start, ctx->stream);
+   }
+   else
+   {
+      (void)hipEventRecord(pl.stop, ctx->stream);
+      into.push_back(pl);
+   }
+}
+
+/* One submission of `items` (all of configuration `config`, `stride` floats per sample, data resident on the device)
+ * through scan -> windows -> windowed decode -> chain -> finish; streams the path cannot vouch for (samples off the
+ * int16 grid, a seam that did not verify, no settled chain) are then decoded sequentially from their untouched state. */
+int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride)
+{
+   const uint32_t nJobs = (uint32_t)items.size();
+   const NfcConfig &cfg = ctx->configs[config];
+
+   NfcScanParams sp;
+   {
+      float corr = 3.0e38f;
+      if (cfg.enabled & 1u) corr = cfg.corrThreshold[0] < corr ? cfg.corrThreshold[0] : corr;
+      if (cfg.enabled & 4u) corr = cfg.corrThreshold[2] < corr ? cfg.corrThreshold[2] : corr;
+      if (cfg.enabled & 8u) corr = cfg.corrThreshold[3] < corr ? cfg.corrThreshold[3] : corr;
+      sp.rangeK = corr < 1.0e30f ? 0.49f * corr : 3.0e38f;
+      sp.edgeK = (cfg.enabled & 2u) ? 0.99f * cfg.minDepth[1] : 3.0e38f;
+      sp.chunkSamples = ctx->scanChunk;
+      sp.warmSamples = ctx->scanWarm;
+   }
+
+   /* job and chunk tables */
+   std::vector<NfcScanJob> jobs(nJobs);
+   std::vector<NfcScanChunk> chunks;
+   uint32_t tiles = 0, points = 0;
+   uint64_t totalSamples = 0;
+
+   for (uint32_t j = 0; j < nJobs; j++)
+   {
+      NfcScanJob &job = jobs[j];
+      std::memset(&job, 0, sizeof(job));
+      job.data = items[j].data;
+      job.count = items[j].count;
+      job.slot = items[j].slot;
+      job.firstChunk = (uint32_t)chunks.size();
+      job.chunks = (job.count + sp.chunkSamples - 1) / sp.chunkSamples;
+      job.firstTile = tiles;
+      job.firstPoint = points;
+      tiles += (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+      points += job.count / NFC_SCAN_POINT + 1;
+      totalSamples += job.count;
+
+      for (uint32_t k = 0; k < job.chunks; k++)
+         chunks.push_back(NfcScanChunk {j, k});
+   }
+
+   const uint32_t nChunks = (uint32_t)chunks.size();
+   const uint32_t firstWindowSlot = (nJobs + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
+
+   int rc;
+   if ((rc = grow(ctx, ctx->wJobs, sizeof(NfcScanJob) * nJobs)) || (rc = grow(ctx, ctx->wChunks, sizeof(NfcScanChunk) * nChunks)) ||
+       (rc = grow(ctx, ctx->wPoints, sizeof(NfcScanPoint) * (size_t)points)) || (rc = grow(ctx, ctx->wSeams, sizeof(NfcScanSeam) * nChunks)) ||
+       (rc = grow(ctx, ctx->wChunkEdge, 4 * (size_t)nChunks)) || (rc = grow(ctx, ctx->wTiles, 4 * (size_t)tiles)) ||
+       (rc = grow(ctx, ctx->wTileStats, sizeof(NfcScanTile) * (size_t)tiles)) ||
+       (rc = grow(ctx, ctx->wCounters, 64)))
+      return rc;
+
+   /* lanes: a first guess (one window per 8192 samples); the window kernel reports what it needs */
+   uint32_t room = (uint32_t)(totalSamples / 8192) + 2 * nJobs + 64;
+
+   auto growLanes = [&](uint32_t lanesWanted) -> int {
+      const size_t lanes = ((size_t)lanesWanted + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
+      int r;
+      if ((r = grow(ctx, ctx->wWindows, sizeof(NfcWindow) * lanes)) || (r = grow(ctx, ctx->wWorks, sizeof(NfcWork) * lanes)) ||
+          (r = grow(ctx, ctx->vStates, sizeof(NfcStreamState) * lanes)) || (r = grow(ctx, ctx->vCold, sizeof(NfcStreamCold) * lanes)) ||
+          (r = grow(ctx, ctx->vRings, sizeof(float) * (size_t)kRingBlockFloats * (lanes / NFC_LANES))) ||
+          (r = grow(ctx, ctx->vBytes, (size_t)NFC_STREAM_BYTES * lanes)))
+         return r;
+      return NFCGPU_OK;
+   };
+
+   /* is there room already from an earlier, larger submission? */
+   {
+      const size_t have = ctx->wWindows.bytes / sizeof(NfcWindow);
+      if (have > (size_t)firstWindowSlot + room)
+         room = (uint32_t)(have - firstWindowSlot - NFC_LANES);
+   }
+
+   if ((rc = growLanes(firstWindowSlot + room)))
+      return rc;
+
+   /* staging sink for the lanes' chained frame records: as large as the frame sink */
+   if ((rc = grow(ctx, ctx->vSink, (size_t)ctx->ownSinkWords * 4)) || (rc = grow(ctx, ctx->vSinkCtl, 16)))
+      return rc;
+
+   uint32_t *counters = (uint32_t *)ctx->wCounters.ptr;
+
+   HIP_TRY(ctx, hipMemcpyAsync(ctx->wJobs.ptr, jobs.data(), sizeof(NfcScanJob) * nJobs, hipMemcpyHostToDevice, ctx->stream));
+   HIP_TRY(ctx, hipMemcpyAsync(ctx->wChunks.ptr, chunks.data(), sizeof(NfcScanChunk) * nChunks, hipMemcpyHostToDevice, ctx->stream));
+   HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, ctx->stream));
+   HIP_TRY(ctx, hipMemsetAsync(ctx->vSinkCtl.ptr, 0, 16, ctx->stream));
+
+   NfcScanArgs A;
+   std::memset(&A, 0, sizeof(A));
+   A.jobs = (NfcScanJob *)ctx->wJobs.ptr;
+   A.nJobs = nJobs;
+   A.chunks = (const NfcScanChunk *)ctx->wChunks.ptr;
+   A.nChunks = nChunks;
+   A.stride = stride;
+   A.params = sp;
+   A.states = ctx->dStates;
+   A.points = (NfcScanPoint *)ctx->wPoints.ptr;
+   A.seams = (NfcScanSeam *)ctx->wSeams.ptr;
+   A.chunkEdge = (uint32_t *)ctx->wChunkEdge.ptr;
+   A.tiles = (uint32_t *)ctx->wTiles.ptr;
+   A.tileStats = (NfcScanTile *)ctx->wTileStats.ptr;
+   A.windows = (NfcWindow *)ctx->wWindows.ptr;
+   A.works = (NfcWork *)ctx->wWorks.ptr;
+   A.firstWindowSlot = firstWindowSlot;
+   A.windowRoom = room;
+   A.windowCount = counters;
+   A.rerunCount = counters + 1;
+
+   const NfcConfig *dCfg = ctx->dConfigs + config;
+
+   /* scan */
+   ProfiledLaunch pl {nullptr, nullptr};
+   record_span(ctx, ctx->timedScan, pl, true);
+   hipLaunchKernelGGL(nfc_scan_kernel, dim3((nChunks + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, A);
+   HIP_TRY(ctx, hipGetLastError());
+   record_span(ctx, ctx->timedScan, pl, false);
+   ctx->stats.scan_samples += totalSamples;
+
+   /* windows (again with more room when the guess was short) */
+   uint32_t nWindows = 0;
+
+   for (int attempt = 0; attempt < 2; attempt++)
+   {
+      hipLaunchKernelGGL(nfc_windows_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, dCfg, A, attempt == 0 ? 1u : 0u);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemcpyAsync(&nWindows, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+      if (nWindows <= room)
+         break;
+
+      room = nWindows + NFC_LANES;
+      if ((rc = growLanes(firstWindowSlot + room)))
+         return rc;
+
+      A.windows = (NfcWindow *)ctx->wWindows.ptr;
+      A.works = (NfcWork *)ctx->wWorks.ptr;
+      A.windowRoom = room;
+      HIP_TRY(ctx, hipMemsetAsync(counters, 0, 4, ctx->stream));
+   }
+
+   NfcLaunch real = base_launch(ctx);
+
+   NfcLaunch lanes;
+   std::memset(&lanes, 0, sizeof(lanes));
+   lanes.states = (NfcStreamState *)ctx->vStates.ptr;
+   lanes.cold = (NfcStreamCold *)ctx->vCold.ptr;
+   lanes.rings = (float *)ctx->vRings.ptr;
+   lanes.bytes = (uint8_t *)ctx->vBytes.ptr;
+   lanes.sink = (uint32_t *)ctx->vSink.ptr;
+   lanes.sinkCtl = (uint32_t *)ctx->vSinkCtl.ptr;
+   lanes.sinkWords = (uint32_t)(ctx->vSink.bytes / 4 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ctx->vSink.bytes / 4);
+   lanes.ringBlockFloats = kRingBlockFloats;
+   lanes.works = (const NfcWork *)ctx->wWorks.ptr;
+   lanes.windows = (NfcWindow *)ctx->wWindows.ptr;
+   lanes.uniformStride = stride;
+
+   /* lanes */
+   hipLaunchKernelGGL(nfc_carry_lanes_kernel, dim3(nJobs), dim3(NFC_LANES), 0, ctx->stream, A, real, lanes);
+   HIP_TRY(ctx, hipGetLastError());
+
+   const uint32_t windowBlocks = (nWindows + NFC_LANES - 1) / NFC_LANES;
+
+   auto decode = [&](bool carry, uint32_t firstSlot, uint32_t slotCount) -> int {
+      if (slotCount == 0)
+         return NFCGPU_OK;
+
+      NfcLaunch L = lanes;
+      L.firstSlot = firstSlot;
+      L.slotCount = slotCount;
+      L.firstBlock = firstSlot / NFC_LANES;
+      L.warmFront = carry ? 0u : NFC_WINDOW_WARM_FRONT;
+      L.warmCorr = carry ? 0u : NFC_WINDOW_WARM_CORR;
+
+      const uint32_t blocks = (firstSlot % NFC_LANES + slotCount + NFC_LANES - 1) / NFC_LANES;
+
+      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_kernel, dim3(blocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, L);
+      HIP_TRY(ctx, hipGetLastError());
+      ctx->stats.launches++;
+      return NFCGPU_OK;
+   };
+
+   ProfiledLaunch pw {nullptr, nullptr};
+   record_span(ctx, ctx->timedWindow, pw, true);
+
+   if ((rc = decode(true, 0, nJobs)))
+      return rc;
+
+   uint32_t pass = 0;
+
+   for (;;)
+   {
+      if (nWindows)
+      {
+         hipLaunchKernelGGL(nfc_window_lanes_kernel, dim3(windowBlocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, A, lanes, pass);
+         HIP_TRY(ctx, hipGetLastError());
+
+         if ((rc = decode(false, firstWindowSlot, nWindows)))
+            return rc;
+      }
+
+      HIP_TRY(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));
+      hipLaunchKernelGGL(nfc_chain_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, lanes, ctx->maxPasses);
+      HIP_TRY(ctx, hipGetLastError());
+
+      uint32_t again = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(&again, counters + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+      ctx->stats.window_passes++;
+      pass++;
+
+      if (!again || !nWindows)
+         break;
+   }
+
+   record_span(ctx, ctx->timedWindow, pw, false);
+
+   hipLaunchKernelGGL(nfc_finish_kernel, dim3(nJobs), dim3(NFC_LANES), 0, ctx->stream, A, real, lanes);
+   HIP_TRY(ctx, hipGetLastError());
+
+   HIP_TRY(ctx, hipMemcpyAsync(jobs.data(), ctx->wJobs.ptr, sizeof(NfcScanJob) * nJobs, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   ctx->stats.windows += nWindows + nJobs;
+   ctx->stats.samples += totalSamples;
+   ctx->dirty = true;
+
+   std::vector<WindowedItem> fallback;
+
+   for (uint32_t j = 0; j < nJobs; j++)
+   {
+      if (jobs[j].status & NFC_JOB_INVALID)
+         fallback.push_back(items[j]);
+      else
+      {
+         ctx->streams[items[j].slot].clock += items[j].count;
+         ctx->stats.windowed_streams++;
+      }
+   }
+
+   ctx->stats.fallback_streams += fallback.size();
+
+   if (!fallback.empty())
+   {
+      ctx->stats.samples -= 0; /* launch_demod counts the samples of the streams it decodes */
+      uint64_t again = 0;
+      for (const WindowedItem &it: fallback)
+         again += it.count;
+      ctx->stats.samples -= again;
+      return launch_sequential(ctx, config, fallback, stride);
+   }
+
+   return NFCGPU_OK;
+}
+
 int ensure_stage(nfcgpu_ctx *ctx, size_t bytes)
 {
    if (bytes <= ctx->stageBytes)
@@ -520,6 +925,23 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    const char *generic = std::getenv("NFCGPU_GENERIC_KERNELS");
    ctx->genericOnly = generic && generic[0] == '1';
 
+   /* knobs of the time-parallel path (testing and tuning; the defaults are what DESIGN.md describes) */
+   auto knob = [](const char *name, uint32_t fallback) -> uint32_t {
+      const char *v = std::getenv(name);
+      return v && v[0] ? (uint32_t)std::strtoul(v, nullptr, 10) : fallback;
+   };
+
+   ctx->windowed = knob("NFCGPU_WINDOWED", 1) != 0;
+   ctx->windowedMinSamples = knob("NFCGPU_WINDOWED_MIN", ctx->windowedMinSamples);
+   ctx->scanChunk = knob("NFCGPU_SCAN_CHUNK", ctx->scanChunk) / NFC_SCAN_POINT * NFC_SCAN_POINT;
+   ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
+   ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
+
+   if (ctx->scanWarm < NFC_SCAN_POINT)
+      ctx->scanWarm = NFC_SCAN_POINT;
+   if (ctx->scanChunk < ctx->scanWarm + NFC_SCAN_POINT)
+      ctx->scanChunk = ctx->scanWarm + NFC_SCAN_POINT;
+
    uint32_t maxStreams = options && options->max_streams ? options->max_streams : 1024;
    uint64_t sinkBytes = options && options->frame_sink_bytes ? options->frame_sink_bytes : (64ull << 20);
 
@@ -607,6 +1029,22 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    (void)hipFree(ctx->dStage);
    if (ctx->hStage)
       (void)hipHostFree(ctx->hStage);
+
+   for (nfcgpu_ctx::DevBuf *b: {&ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows,
+                                &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl})
+   {
+      if (b->ptr)
+         (void)hipFree(b->ptr);
+   }
+
+   for (auto *list: {&ctx->timedScan, &ctx->timedWindow})
+   {
+      for (auto &pl: *list)
+      {
+         (void)hipEventDestroy(pl.start);
+         (void)hipEventDestroy(pl.stop);
+      }
+   }
 
    if (ctx->stream)
       (void)hipStreamDestroy(ctx->stream);
@@ -853,6 +1291,27 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
 
    for (uint32_t c: cfgs)
    {
+      {
+         std::vector<WindowedItem> items;
+         for (uint32_t i = 0; i < b->n_streams; i++)
+         {
+            const uint32_t id = b->stream_ids[i];
+            if (ctx->streams[id].config == c)
+               items.push_back(WindowedItem {id, ctx->hWorks[id].data, b->n_samples[i]});
+         }
+
+         if (windowed_eligible(ctx, c, items))
+         {
+            rc = run_windowed(ctx, c, items, b->stride);
+            if (rc)
+            {
+               clearWorks();
+               return rc;
+            }
+            continue;
+         }
+      }
+
       uint32_t first = 0xFFFFFFFFu, last = 0;
       uint64_t groupSamples = 0;
       bool exactPossible = false, exactOnly = true;
@@ -1108,6 +1567,22 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       while (j < first + count && ctx->streams[j].config == c)
          j++;
 
+      {
+         std::vector<WindowedItem> items(j - i);
+         for (uint32_t k = i; k < j; k++)
+            items[k - i] = WindowedItem {k, devBase + (uint64_t)(k - first) * devPitch, n};
+
+         if (windowed_eligible(ctx, c, items))
+         {
+            rc = run_windowed(ctx, c, items, stride);
+            if (rc)
+               return rc;
+
+            i = j;
+            continue;
+         }
+      }
+
       NfcLaunch L = base_launch(ctx);
       L.works = nullptr;
       L.uniformBase = devBase + (uint64_t)(i - first) * devPitch;
@@ -1156,6 +1631,26 @@ int nfcgpu_sync(nfcgpu_ctx *ctx)
       ctx->eventPool.push_back(pl.stop);
    }
    ctx->timed.clear();
+
+   for (auto &pl: ctx->timedScan)
+   {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
+         ctx->stats.scan_ms += ms;
+      ctx->eventPool.push_back(pl.start);
+      ctx->eventPool.push_back(pl.stop);
+   }
+   ctx->timedScan.clear();
+
+   for (auto &pl: ctx->timedWindow)
+   {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
+         ctx->stats.window_ms += ms;
+      ctx->eventPool.push_back(pl.start);
+      ctx->eventPool.push_back(pl.stop);
+   }
+   ctx->timedWindow.clear();
 
    if (!ctx->dirty || ctx->hold)
       return NFCGPU_OK;

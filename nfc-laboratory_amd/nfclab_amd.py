@@ -78,6 +78,13 @@ class Stats(ctypes.Structure):
         ("frames", ctypes.c_uint64),
         ("dropped_frames", ctypes.c_uint64),
         ("kernel_ms", ctypes.c_double),
+        ("scan_ms", ctypes.c_double),
+        ("window_ms", ctypes.c_double),
+        ("scan_samples", ctypes.c_uint64),
+        ("windows", ctypes.c_uint64),
+        ("window_passes", ctypes.c_uint64),
+        ("windowed_streams", ctypes.c_uint64),
+        ("fallback_streams", ctypes.c_uint64),
     ]
 
 

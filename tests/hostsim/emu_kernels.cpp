@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define NFC_DEV static inline
@@ -15,7 +17,36 @@ static inline uint32_t emu_add(uint32_t *p, uint32_t v) { uint32_t old = *p; *p 
 #define NFC_ATOMIC_ADD(ptr, value) emu_add((ptr), (value))
 #define NFC_ANY(predicate) (predicate)
 #include "../../nfc-laboratory_amd/csrc/nfc_core.hpp"
+static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t i)
+{
+   const float *p = reinterpret_cast<const float *>(data);
+   if (stride == 2)
+   {
+      volatile float ii = p[2 * i] * p[2 * i];
+      volatile float qq = p[2 * i + 1] * p[2 * i + 1];
+      return __builtin_sqrtf(ii + qq);
+   }
+   return p[i];
+}
+#define NFC_SAMPLE_AT(data, stride, index) emu_sample_at((data), (stride), (index))
+#include "../../nfc-laboratory_amd/csrc/nfc_scan.h"
+static void emu_chain_trace(uint32_t lane, const NfcCarry &assumed, const NfcCarry &have, const NfcCarry &left)
+{
+   if (!std::getenv("NFC_EMU_DEBUG3"))
+      return;
+   std::fprintf(stderr, "[emu] lane %u assumed!=have:", lane);
+#define F(f) if (assumed.f != have.f) std::fprintf(stderr, " " #f " %u->%u (left %u)", (unsigned)assumed.f, (unsigned)have.f, (unsigned)left.f)
+   F(chainedA); F(carrierOn); F(carrierOff); F(emitClock); F(emitValid); F(pulsesF[0]); F(pulsesF[1]);
+   for (int t = 0; t < 4; t++) { F(tim[t].lastCommand); F(tim[t].maxFrameSize); F(tim[t].protoGuardTime); F(tim[t].protoWaitingTime); }
+#undef F
+   if (assumed.thrF[0] != have.thrF[0]) std::fprintf(stderr, " thrF0 %g->%g (left %g)", assumed.thrF[0], have.thrF[0], left.thrF[0]);
+   if (assumed.thrF[1] != have.thrF[1]) std::fprintf(stderr, " thrF1 %g->%g (left %g)", assumed.thrF[1], have.thrF[1], left.thrF[1]);
+   std::fprintf(stderr, "\n");
+}
+#define NFC_CHAIN_TRACE(lane, a, b, c) emu_chain_trace((lane), (a), (b), (c))
+#include "../../nfc-laboratory_amd/csrc/nfc_scan.hpp"
 #include "../../nfc-laboratory_amd/csrc/nfc_launch.h"
+#include "../../nfc-laboratory_amd/csrc/nfc_scan_launch.h"
 
 namespace fakehip {
 dim3 launchGrid, launchBlock;
@@ -95,6 +126,7 @@ void demod(const NfcConfig *cfgPtr, const NfcLaunch &L, bool exactKernel)
          mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats;
          mem.lane = lane;
          mem.exact = false;
+         mem.linked = false;
          mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
          mem.sink = L.sink;
          mem.sinkCursor = L.sinkCtl;
@@ -226,5 +258,368 @@ void nfc_resample_radio_kernel(const float *__restrict__ in, uint64_t pitchFloat
          put(last, (float)p);
 
       counts[buffer] = count;
+   }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* time-parallel path: the same device functions (nfc_scan.hpp), chunk after chunk / lane after lane */
+/* ------------------------------------------------------------------------------------------ */
+
+namespace {
+
+float sample_of(const uint8_t *data, uint32_t stride, uint32_t i)
+{
+   return emu_sample_at(data, stride, i);
+}
+
+void copy_lane(const NfcLaunch &from, uint32_t a, const NfcLaunch &to, uint32_t b)
+{
+   const float *src = from.rings + (uint64_t)(a / NFC_LANES) * from.ringBlockFloats + (a % NFC_LANES);
+   float *dst = to.rings + (uint64_t)(b / NFC_LANES) * to.ringBlockFloats + (b % NFC_LANES);
+
+   for (uint32_t i = 0; i < from.ringBlockFloats / NFC_LANES; i++)
+      dst[(uint64_t)i * NFC_LANES] = src[(uint64_t)i * NFC_LANES];
+
+   std::memcpy(to.bytes + (uint64_t)b * NFC_STREAM_BYTES, from.bytes + (uint64_t)a * NFC_STREAM_BYTES, NFC_STREAM_BYTES);
+}
+
+void window_decode(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry)
+{
+   for (uint32_t slot = L.firstSlot; slot < L.firstSlot + L.slotCount; slot++)
+   {
+      const uint32_t mineCount = L.works[slot].count;
+
+      if (!mineCount)
+         continue;
+
+      const uint32_t *flags = L.works[slot].tiles;
+      const uint8_t *data = L.works[slot].data;
+
+      NfcStreamState s = L.states[slot];
+
+      NfcLaneMem mem;
+      mem.ring = L.rings + (uint64_t)(slot / NFC_LANES) * L.ringBlockFloats;
+      mem.lane = slot % NFC_LANES;
+      mem.exact = false;
+      mem.linked = true;
+      mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
+      mem.sink = L.sink;
+      mem.sinkCursor = L.sinkCtl;
+      mem.sinkDropped = L.sinkCtl + 1;
+      mem.sinkWords = L.sinkWords;
+      mem.streamId = slot;
+      mem.cold = L.cold + slot;
+      mem.tables = cfgPtr;
+
+      const uint32_t warm = L.warmFront + L.warmCorr;
+      uint32_t consumed = 0;
+
+      for (uint32_t base = 0; base < mineCount; base += NFC_SCAN_TILE)
+      {
+         if (base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
+             (uint32_t)(s.clock - mem.cold->lastUnlock) >= NFC_WINDOW_SETTLE)
+            break;
+
+         if (std::getenv("NFC_EMU_DEBUG2") && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK))
+         {
+            static uint64_t shown = 0;
+            if (shown++ % 500 == 0)
+            {
+               const NfcSearchRegs &r = s.u.search;
+               std::fprintf(stderr, "[emu] lane %u base %u cannot retire: lock %x unlock %x settle %u | A %u %u %u %u | B %u %u | F ws %u we %u sync %u pulses %u thr %g ss %u se %u peak %g pt %u | F2 pulses %u thr %g ws %u | V %u %u\n",
+                            slot, base, s.lockTech, s.unlock, (uint32_t)(s.clock - mem.cold->lastUnlock),
+                            r.detA[0].winStart, r.detA[0].peakTime, r.detA[1].winStart, r.detA[2].winStart, r.detB[0].symStart, r.detB[1].symStart,
+                            r.detF[0].winStart, r.detF[0].winEnd, r.detF[0].sync, r.detF[0].pulses, r.detF[0].thr, r.detF[0].symStart, r.detF[0].symEnd, r.detF[0].peak, r.detF[0].peakTime,
+                            r.detF[1].pulses, r.detF[1].thr, r.detF[1].winStart, r.detV.winStart, r.detV.peakTime);
+            }
+         }
+
+         const uint32_t left = mineCount - base;
+         const uint32_t n = left < NFC_SCAN_TILE ? left : NFC_SCAN_TILE;
+         const bool exact = carry && exact_span(s.clock, n);
+
+         for (uint32_t k = 0; k < n; k++)
+         {
+            const float v = sample_of(data, L.uniformStride, base + k);
+
+            if (base < L.warmFront)
+               nfc_step_front<false>(*cfgPtr, s, mem, v);
+            else if (base < warm)
+               nfc_step_upkeep<false>(*cfgPtr, s, mem, v);
+            else if (exact)
+               nfc_step_as<true>(*cfgPtr, s, mem, v);
+            else
+               nfc_step_as<false>(*cfgPtr, s, mem, v);
+         }
+
+         consumed = base + n;
+      }
+
+      L.states[slot] = s;
+      L.windows[slot].stop = L.windows[slot].start + consumed;
+      L.windows[slot].retired = consumed < mineCount ? 1u : 0u;
+   }
+}
+
+}
+
+void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
+{
+   const uint32_t L = A.params.chunkSamples, WU = A.params.warmSamples;
+
+   for (uint32_t g = 0; g < A.nChunks; g++)
+   {
+      const NfcScanChunk ch = A.chunks[g];
+      const NfcScanJob *job = A.jobs + ch.job;
+      const uint32_t start = ch.index * L;
+      const uint32_t end = start + L < job->count ? start + L : job->count;
+      const uint32_t walkFrom = ch.index == 0 ? 0u : start - WU;
+      const NfcStreamState *st = A.states + job->slot;
+
+      NfcScanLane w;
+      NfcScanSeam seam;
+      std::memset(&seam, 0, sizeof(seam));
+      bool begun = false;
+
+      for (uint32_t sp = walkFrom; sp < end; sp++)
+      {
+         const float x = sample_of(job->data, A.stride, sp);
+
+         if (!begun)
+         {
+            /* guess for the envelope: mean of the first tile of the walk (nfc_scan_kernel does the same) */
+            float first = 0.0f;
+            const uint32_t span = end - sp < NFC_SCAN_TILE ? end - sp : NFC_SCAN_TILE;
+            for (uint32_t k = 0; k < span; k++)
+               first += sample_of(job->data, A.stride, sp + k);
+            first = first / (float)span;
+
+            nfc_scan_begin(w, ch.index == 0 ? st : nullptr, st->clock + sp, first);
+            begun = true;
+         }
+
+         if (ch.index != 0 && sp == walkFrom + WU / 3)
+            nfc_scan_reseed(w);
+
+         if (sp == start)
+            nfc_scan_point(w, seam.start);
+
+         if (sp >= start && (sp % NFC_SCAN_POINT) == 0)
+            nfc_scan_point(w, A.points[job->firstPoint + sp / NFC_SCAN_POINT]);
+
+         nfc_scan_sample(*cfgPtr, w, x);
+
+         if ((sp % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || sp == end - 1)
+         {
+            NfcScanTile stat;
+            nfc_scan_tile_end(w, stat);
+            if (sp >= start)
+               A.tileStats[job->firstTile + sp / NFC_SCAN_TILE] = stat;
+         }
+      }
+
+      if (begun)
+         nfc_scan_point(w, seam.end);
+      A.seams[g] = seam;
+   }
+}
+
+void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams)
+{
+   for (uint32_t j = 0; j < A.nJobs; j++)
+   {
+      NfcScanJob job = A.jobs[j];
+
+      if (checkSeams)
+      {
+         job.status = 0;
+         job.passes = 0;
+         nfc_seams_check(*cfgPtr, A.params, job, A.seams, A.points, A.tileStats, A.stride, A.chunkEdge, A.states[job.slot].edgeTime, A.states[job.slot].clock);
+      }
+
+      job.status &= ~NFC_JOB_OVERFLOW;
+
+      const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+      uint32_t rewalked = 0;
+      for (uint32_t i = 0; i < nTiles; i++)
+      {
+         const uint32_t flags = nfc_tile_flags(*cfgPtr, A.params, A.tileStats + job.firstTile, i);
+         A.tiles[job.firstTile + i] = flags;
+         if (flags & NFC_TILE_OFFGRID)
+            job.status |= NFC_JOB_OFFGRID;
+         rewalked += (flags & NFC_TILE_REWALKED) ? 1 : 0;
+      }
+      if (std::getenv("NFC_EMU_DEBUG"))
+         std::fprintf(stderr, "[emu] job %u: %u of %u tiles had their envelope walked again\n", j, rewalked, nTiles);
+
+      const uint32_t need = nfc_windows_build(job, j, A.tiles, nullptr, 0);
+      const uint32_t first = emu_add(A.windowCount, need);
+
+      job.firstWindow = A.firstWindowSlot + first;
+      job.windows = need;
+
+      if (first + need > A.windowRoom)
+      {
+         job.status |= NFC_JOB_OVERFLOW;
+         job.windows = 0;
+      }
+      else
+         nfc_windows_build(job, j, A.tiles, A.windows + job.firstWindow, need);
+
+      A.jobs[j] = job;
+
+      if (std::getenv("NFC_EMU_DEBUG"))
+      {
+         uint32_t kinds[8] = {0};
+         uint32_t busy = 0, ok = 0;
+         for (uint32_t i = 0; i < nTiles; i++)
+         {
+            const uint32_t f = A.tiles[job.firstTile + i];
+            for (int b = 0; b < 6; b++)
+               kinds[b] += (f >> b) & 1u;
+            busy += (f & NFC_TILE_BUSY) ? 1 : 0;
+            ok += (f & NFC_TILE_RETIRE_OK) ? 1 : 0;
+         }
+         std::fprintf(stderr, "[emu] job %u slot %u count %u tiles %u busy %u (range %u edge %u unarmed %u carrier %u offgrid %u nohist %u) retireOK %u status %x windows %u\n",
+                      j, job.slot, job.count, nTiles, busy, kinds[0], kinds[1], kinds[2], kinds[3], kinds[4], kinds[5], ok, job.status, job.windows);
+         for (uint32_t i = 0; i < job.windows && i < 40; i++)
+            std::fprintf(stderr, "[emu]   window %u start %u activate %u\n", job.firstWindow + i, A.windows[job.firstWindow + i].start, A.windows[job.firstWindow + i].activate);
+      }
+   }
+}
+
+void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
+{
+   for (uint32_t j = 0; j < A.nJobs; j++)
+   {
+      const NfcScanJob *job = A.jobs + j;
+
+      copy_lane(real, job->slot, lanes, j);
+
+      NfcStreamState s = real.states[job->slot];
+      NfcStreamCold cold = real.cold[job->slot];
+      cold.frameHead = 0;
+      cold.frameTail = 0;
+      lanes.states[j] = s;
+      lanes.cold[j] = cold;
+
+      NfcWindow w;
+      std::memset(&w, 0, sizeof(w));
+      w.job = j;
+      nfc_carry_take(w.carry, s, cold);
+      w.want = w.carry;
+      A.windows[j] = w;
+
+      NfcWork work;
+      work.data = job->data;
+      work.count = (job->status & NFC_JOB_INVALID) ? 0u : job->count;
+      work.stride = A.stride;
+      work.tiles = A.tiles + job->firstTile;
+      A.works[j] = work;
+   }
+}
+
+void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass)
+{
+   const uint32_t n = *A.windowCount < A.windowRoom ? *A.windowCount : A.windowRoom;
+
+   for (uint32_t wi = A.firstWindowSlot; wi < A.firstWindowSlot + n; wi++)
+   {
+      NfcWindow w = A.windows[wi];
+      const NfcScanJob *job = A.jobs + w.job;
+
+      NfcWork work;
+      work.data = job->data + (uint64_t)w.start * A.stride * 4u;
+      work.count = 0;
+      work.stride = A.stride;
+      work.tiles = A.tiles + job->firstTile + w.start / NFC_SCAN_TILE;
+
+      const bool run = !(job->status & NFC_JOB_INVALID) && (pass == 0 || w.rerun);
+
+      if (run)
+      {
+         w.carry = pass == 0 ? A.windows[w.job].carry : w.want;
+         w.want = w.carry;
+         w.rerun = 0;
+         w.stop = 0;
+         w.retired = 0;
+
+         const uint32_t chunk = job->firstChunk + w.start / A.params.chunkSamples;
+
+         NfcStreamState s;
+         NfcStreamCold cold;
+         nfc_window_lane(*cfgPtr, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+
+         lanes.states[wi] = s;
+         lanes.cold[wi] = cold;
+         A.windows[wi] = w;
+
+         work.count = job->count - w.start;
+      }
+
+      A.works[wi] = work;
+   }
+}
+
+void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) { window_decode(cfgPtr, L, false); }
+void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) { window_decode(cfgPtr, L, true); }
+
+void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses)
+{
+   for (uint32_t j = 0; j < A.nJobs; j++)
+   {
+      NfcScanJob job = A.jobs[j];
+
+      if (job.status & NFC_JOB_INVALID)
+         continue;
+
+      const bool again = nfc_chain_follow(job, j, A.windows, lanes.states, lanes.cold, maxPasses);
+      if (again)
+         emu_add(A.rerunCount, 1u);
+
+      A.jobs[j] = job;
+
+      if (std::getenv("NFC_EMU_DEBUG"))
+      {
+         uint64_t steps = 0, liveSteps = 0;
+         for (uint32_t i = 0; i <= job.windows; i++)
+         {
+            const uint32_t lane = i == 0 ? j : job.firstWindow + i - 1;
+            const NfcWindow &w = A.windows[lane];
+            steps += w.stop - w.start;
+            liveSteps += w.live ? w.stop - w.start : 0;
+         }
+         std::fprintf(stderr, "[emu] chain job %u pass %u again %d final %u status %x lanes %u lane-steps %llu (live %llu) of %u samples\n", j, job.passes, (int)again,
+                      job.finalLane, job.status, job.windows + 1, (unsigned long long)steps, (unsigned long long)liveSteps, job.count);
+         for (uint32_t i = 0; i <= job.windows && i < 60; i++)
+         {
+            const uint32_t lane = i == 0 ? j : job.firstWindow + i - 1;
+            const NfcWindow &w = A.windows[lane];
+            std::fprintf(stderr, "[emu]   lane %u start %u act %u stop %u retired %u live %u rerun %u frames %u\n", lane, w.start, w.activate, w.stop, w.retired,
+                         w.live, w.rerun, lanes.cold[lane].framesOut);
+         }
+      }
+   }
+}
+
+void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
+{
+   for (uint32_t j = 0; j < A.nJobs; j++)
+   {
+      const NfcScanJob *job = A.jobs + j;
+
+      if (job->status & NFC_JOB_INVALID)
+         continue;
+
+      nfc_finish_frames(*job, j, A.windows, lanes.cold, lanes.sink, real.sink, real.sinkCtl, real.sinkWords);
+
+      copy_lane(lanes, job->finalLane, real, job->slot);
+
+      NfcStreamState s = lanes.states[job->finalLane];
+      NfcStreamCold cold = lanes.cold[job->finalLane];
+      cold.frameHead = 0;
+      cold.frameTail = 0;
+      real.states[job->slot] = s;
+      real.cold[job->slot] = cold;
    }
 }
