@@ -940,6 +940,10 @@ __global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch
 
    const NfcScanJob *job = A.jobs + j;
 
+   /* records the staging sink had no room for are lost frames like any other */
+   if (j == 0 && t == 0 && lanes.sinkCtl[1])
+      atomicAdd(real.sinkCtl + 1, lanes.sinkCtl[1]);
+
    if (job->status & NFC_JOB_INVALID)
       return;
 

@@ -626,9 +626,17 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    if ((rc = growLanes(firstWindowSlot + room)))
       return rc;
 
-   /* staging sink for the lanes' chained frame records: as large as the frame sink */
-   if ((rc = grow(ctx, ctx->vSink, (size_t)ctx->ownSinkWords * 4)) || (rc = grow(ctx, ctx->vSinkCtl, 16)))
-      return rc;
+   /* staging sink for the lanes' chained frame records (lanes that turn out not to be live write theirs too): room
+    * for four times the frame sink, at least 64 MiB; what does not fit is reported as dropped like any overflow */
+   {
+      size_t staging = (size_t)ctx->ownSinkWords * 16;
+      if (staging < (64u << 20))
+         staging = 64u << 20;
+      if (staging > 0xFFFFFFF0ull * 4ull)
+         staging = 0xFFFFFFF0ull * 4ull;
+      if ((rc = grow(ctx, ctx->vSink, staging)) || (rc = grow(ctx, ctx->vSinkCtl, 16)))
+         return rc;
+   }
 
    uint32_t *counters = (uint32_t *)ctx->wCounters.ptr;
 

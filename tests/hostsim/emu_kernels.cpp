@@ -604,6 +604,9 @@ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses)
 
 void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
 {
+   if (lanes.sinkCtl[1])
+      emu_add(real.sinkCtl + 1, lanes.sinkCtl[1]);
+
    for (uint32_t j = 0; j < A.nJobs; j++)
    {
       const NfcScanJob *job = A.jobs + j;
