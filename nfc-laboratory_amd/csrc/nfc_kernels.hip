@@ -775,6 +775,8 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
       A.windows[wi] = w;
 
       work.count = job->count - w.start;
+
+      A.runList[atomicAdd(A.runCount, 1u)] = wi;
    }
 
    A.works[wi] = work;
@@ -898,16 +900,273 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
    }
 }
 
-__global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+/* one lane per job, warm-up as a window: regenerates the state (rings included) of a job's last lane in the job's own
+ * lane slot once the chain is settled (the persistent waves below do not keep a finished lane's rings) */
+__global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
    nfc_window_body<false>(cfgPtr, L, tile);
+}
+
+/* The windowed decode of the speculative lanes: persistent waves that refill their lanes. A wave keeps 64 windows in
+ * flight, one per lane, all stepping one sample per step; a lane that finishes (retired at rest, or out of samples)
+ * stores its result and, at the next multiple of 512 steps, takes the next window off the run list. Joining only there,
+ * and numbering the joining lane's correlation rings from the wave's current common positions (the ring phase labels
+ * say how that relates to the reference's numbering), keeps every ring access of the wave on one row: window starts are
+ * multiples of 512 samples, so clock & 511 is the same for all lanes of a wave as long as the submissions are. The ring
+ * storage belongs to the (wave, lane), not to the window: a lane's rings are rebuilt by its warm-up. */
+__global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
+{
+   __shared__ float tile[NFC_LANES * TILE_PITCH];
+
+   const uint32_t lane = threadIdx.x;
+   const uint32_t ringBlock = A.firstWindowSlot / NFC_LANES + blockIdx.x;
+
+   NfcLaneMem mem;
+   mem.ring = L.rings + (uint64_t)ringBlock * L.ringBlockFloats;
+   mem.lane = lane;
+   mem.exact = false;
+   mem.linked = true;
+   mem.bytes = L.bytes + ((uint64_t)ringBlock * NFC_LANES + lane) * NFC_STREAM_BYTES;
+   mem.sink = L.sink;
+   mem.sinkCursor = L.sinkCtl;
+   mem.sinkDropped = L.sinkCtl + 1;
+   mem.sinkWords = L.sinkWords;
+   mem.streamId = 0;
+   mem.cold = L.cold;
+   mem.tables = cfgPtr;
+
+   NfcConfig cc;
+   nfc_fixed_runtime_config(cfgPtr, cc);
+
+   const uint32_t warm = L.warmFront + L.warmCorr;
+   const uint32_t total = *A.runCount;
+
+   NfcStreamState s;
+   __builtin_memset(&s, 0, sizeof(s));
+
+   bool active = false;
+   uint32_t w = 0, consumed = 0, mineCount = 0;
+   const uint8_t *data = nullptr;
+   const uint32_t *flags = nullptr;
+   uint32_t steps = 0; /* steps of this wave since its lanes last all started together (multiple of 512 at a join) */
+
+   for (;;)
+   {
+      /* ---- join: free lanes take the next windows off the run list ---- */
+      const uint64_t freeMask = __ballot(!active);
+
+      if (freeMask == ~0ull)
+         steps = 0; /* nobody to stay in step with */
+
+      if (freeMask)
+      {
+         const uint32_t leader = (uint32_t)__builtin_ctzll(freeMask);
+         uint32_t base = 0;
+
+         if (lane == leader)
+            base = atomicAdd(A.runNext, (uint32_t)__builtin_popcountll(freeMask));
+
+         base = (uint32_t)__shfl((int)base, (int)leader, 64);
+
+         const uint32_t mine = base + (uint32_t)__builtin_popcountll(freeMask & ((1ull << lane) - 1ull));
+
+         if (!active && mine < total)
+         {
+            w = A.runList[mine];
+            s = L.states[w];
+            NFC_DRAIN();
+
+            const NfcWork work = L.works[w];
+            data = work.data;
+            mineCount = work.count;
+            flags = work.tiles;
+            consumed = 0;
+            active = mineCount != 0;
+
+            mem.cold = L.cold + w;
+            mem.streamId = w;
+
+            /* number the rings from where the wave's other lanes are */
+            s.posA[0] = steps % cc.a[0].p1;
+            s.posA[1] = steps % cc.a[1].p1;
+            s.posA[2] = steps % cc.a[2].p1;
+            s.posF[0] = steps % cc.f[1].p1;
+            s.posF[1] = steps % cc.f[2].p1;
+            s.posV1 = steps % cc.v.p1;
+            s.posV0 = steps % cc.v.p0;
+
+            mem.cold->label[0] = nfc_label(s.clock, cc.a[0].delay, cc.a[0].p1, s.posA[0]);
+            mem.cold->label[1] = nfc_label(s.clock, cc.a[1].delay, cc.a[1].p1, s.posA[1]);
+            mem.cold->label[2] = nfc_label(s.clock, cc.a[2].delay, cc.a[2].p1, s.posA[2]);
+            mem.cold->label[3] = nfc_label(s.clock, cc.f[1].delay, cc.f[1].p1, s.posF[0]);
+            mem.cold->label[4] = nfc_label(s.clock, cc.f[2].delay, cc.f[2].p1, s.posF[1]);
+            mem.cold->label[5] = nfc_label(s.clock, cc.v.delay, cc.v.p1, s.posV1);
+            mem.cold->label[6] = nfc_label(s.clock, cc.v.delay, cc.v.p0, s.posV0);
+         }
+      }
+
+      if (__any(active) == 0)
+         break; /* run list exhausted and every lane done */
+
+      /* ---- one epoch: 512 steps, lanes may finish at any tile boundary ---- */
+      for (uint32_t t = 0; t < NFC_SCAN_POINT / TILE; t++)
+      {
+         if (active)
+         {
+            bool done = consumed >= mineCount;
+
+            if (!done && consumed >= warm && (flags[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
+                (uint32_t)(s.clock - mem.cold->lastUnlock) >= NFC_WINDOW_SETTLE)
+               done = true;
+
+            if (done)
+            {
+               L.states[w] = s;
+               L.windows[w].stop = L.windows[w].start + consumed;
+               L.windows[w].retired = consumed < mineCount ? 1u : 0u;
+               active = false;
+            }
+         }
+
+         /* stage: row r = the next 64 samples of lane r's window */
+         {
+            const uint32_t left = active ? mineCount - consumed : 0u;
+            const uint8_t *rowBase = active ? data + (uint64_t)consumed * L.uniformStride * 4u : (const uint8_t *)L.rings;
+
+#pragma clang loop unroll(disable)
+            for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_STAGE_ROWS)
+            {
+               float re[NFC_STAGE_ROWS], im[NFC_STAGE_ROWS];
+               uint32_t count[NFC_STAGE_ROWS];
+
+#pragma unroll
+               for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
+               {
+                  const int q = (int)(r0 + j);
+                  const uint64_t p = ((uint64_t)(uint32_t)__shfl((int)((uint64_t)rowBase >> 32), q, 64) << 32) |
+                                     (uint32_t)__shfl((int)(uint32_t)(uint64_t)rowBase, q, 64);
+                  const uint32_t n = (uint32_t)__shfl((int)left, q, 64);
+                  const uint32_t at = n ? (lane < n ? lane : n - 1u) : 0u;
+
+                  count[j] = n;
+
+                  if (L.uniformStride == 2)
+                  {
+                     const float2 iq = reinterpret_cast<const float2 *>(p)[at];
+                     re[j] = iq.x;
+                     im[j] = iq.y;
+                  }
+                  else
+                  {
+                     re[j] = reinterpret_cast<const float *>(p)[at];
+                     im[j] = 0.0f;
+                  }
+               }
+
+#pragma unroll
+               for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
+               {
+                  const float v = L.uniformStride == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
+                  tile[(r0 + j) * TILE_PITCH + lane] = lane < count[j] ? v : 0.0f;
+               }
+            }
+         }
+
+         __syncthreads();
+
+         {
+            const uint32_t left = active ? mineCount - consumed : 0u;
+            const uint32_t n = left < TILE ? left : TILE;
+
+            const bool front = active && consumed < L.warmFront;
+            const bool upkeep = active && !front && consumed < warm;
+            const bool full = active && !front && !upkeep;
+
+            if (__any(front))
+            {
+               for (uint32_t k = 0; k < TILE; k++)
+               {
+                  if (front && k < n)
+                     nfc_step_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+               }
+            }
+
+            if (__any(upkeep))
+            {
+               for (uint32_t k = 0; k < TILE; k++)
+               {
+                  if (upkeep && k < n)
+                     nfc_step_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+               }
+            }
+
+            if (__any(full))
+            {
+               for (uint32_t k = 0; k < TILE; k++)
+               {
+                  if (full && k < n)
+                     nfc_step_as<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+               }
+            }
+
+            consumed += n;
+         }
+
+         __syncthreads();
+      }
+
+      steps += NFC_SCAN_POINT;
+   }
 }
 
 __global__ __launch_bounds__(64) void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
    nfc_window_body<true>(cfgPtr, L, tile);
+}
+
+/* once the chain is settled: jobs whose last lane is a speculative window get that window set up again in their own
+ * final-lane slot (A.finalLaneSlot + job), to be run by nfc_window_final_kernel */
+__global__ __launch_bounds__(64) void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes)
+{
+   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (j >= A.nJobs)
+      return;
+
+   const NfcScanJob *job = A.jobs + j;
+   const uint32_t to = A.finalLaneSlot + j;
+
+   NfcWork work;
+   work.data = nullptr;
+   work.count = 0;
+   work.stride = A.stride;
+   work.tiles = nullptr;
+
+   if (!(job->status & NFC_JOB_INVALID) && job->finalLane != j)
+   {
+      NfcWindow w = A.windows[job->finalLane];
+
+      NfcConfig cc;
+      nfc_fixed_runtime_config(cfgPtr, cc);
+
+      const uint32_t chunk = job->firstChunk + w.start / A.params.chunkSamples;
+
+      NfcStreamState s;
+      NfcStreamCold cold;
+      nfc_window_lane(cc, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+
+      lanes.states[to] = s;
+      lanes.cold[to] = cold;
+      A.windows[to] = w;
+
+      work.data = job->data + (uint64_t)w.start * A.stride * 4u;
+      work.count = job->count - w.start;
+      work.tiles = A.tiles + job->firstTile + w.start / NFC_SCAN_TILE;
+   }
+
+   A.works[to] = work;
 }
 
 /* one thread per job after a decode pass; counts the jobs that need another pass */
@@ -950,7 +1209,7 @@ __global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch
    if (t == 0)
       nfc_finish_frames(*job, j, A.windows, lanes.cold, lanes.sink, real.sink, real.sinkCtl, real.sinkWords);
 
-   const uint32_t from = job->finalLane, to = job->slot;
+   const uint32_t from = job->finalLane == j ? j : A.finalLaneSlot + j, to = job->slot;
 
    const float *src = lanes.rings + (uint64_t)(from / NFC_LANES) * lanes.ringBlockFloats + (from % NFC_LANES);
    float *dst = real.rings + (uint64_t)(to / NFC_LANES) * real.ringBlockFloats + (to % NFC_LANES);

@@ -42,6 +42,7 @@ struct NfcScanLane
 #define NFC_SCAN_BIG 3.0e38f
 #define NFC_ZONE_MASK 0xFFu
 #define NFC_ZONE_EDGE_KNOWN 0x100u
+#define NFC_ZONE_EDGE_SYNCED 0x200u
 
 NFC_DEV void nfc_scan_tile_reset(NfcScanLane &w)
 {
@@ -95,7 +96,7 @@ NFC_DEV void nfc_scan_point(const NfcScanLane &w, NfcScanPoint &p)
    p.edgePeak = w.fe.edgePeak;
    p.pulseFilter = w.fe.pulseFilter;
    p.edgeTime = w.fe.edgeTime;
-   p.zone = w.zone | (w.edgeKnown ? NFC_ZONE_EDGE_KNOWN : 0u);
+   p.zone = w.zone | (w.edgeKnown ? NFC_ZONE_EDGE_KNOWN : 0u) | (w.edgeSynced ? NFC_ZONE_EDGE_SYNCED : 0u);
 }
 
 /* A third of the way into the warm-up the guessed envelope is replaced by the average, which has converged by then
@@ -213,90 +214,108 @@ NFC_DEV uint32_t nfc_tile_flags(const NfcConfig &c, const NfcScanParams &sp, con
 #error "define NFC_SAMPLE_AT(data, stride, index) before including nfc_scan.hpp"
 #endif
 
-/* Everything of a point but the envelope tracker (those recurrences are contractive: a mismatch there is not repaired) */
-NFC_DEV bool nfc_point_same_but_envelope(const NfcScanPoint &a, const NfcScanPoint &b)
+/* the recurrences of a point, bit for bit (not the edge time, which a walk may not know: see NFC_ZONE_EDGE_KNOWN) */
+NFC_DEV bool nfc_point_same(const NfcScanPoint &a, const NfcScanPoint &b)
 {
    const uint32_t *x = (const uint32_t *)&a, *y = (const uint32_t *)&b;
-   return x[1] == y[1] && x[2] == y[2] && x[3] == y[3] && x[4] == y[4] && ((a.zone ^ b.zone) & NFC_ZONE_MASK) == 0;
+   bool same = true;
+   for (uint32_t i = 0; i < 6; i++) /* env n1 mdev avg edgePeak pulseFilter */
+      same = same && x[i] == y[i];
+   return same && ((a.zone ^ b.zone) & NFC_ZONE_MASK) == 0;
 }
 
-/* Seams of a job, chunks in order. Where the chunk before ends with another envelope / pulse filter than the chunk
- * started from, the envelope is walked again from the true value (alone: nothing else of the front end depends on it)
- * until it meets the scanned one at a stored point, or to the end of the chunk; the points and tile minima on the way are
- * corrected and the tiles marked NFC_TILE_REWALKED (their other flags may have been decided with a wrong envelope only
- * in the sense that the tests have not been evaluated yet: nfc_tile_flags runs afterwards).
- * chunkEdge[k] = true edgeTime of the autonomous tracker at the start of chunk k. */
+/* continue a walk from a known state */
+NFC_DEV void nfc_scan_resume(NfcScanLane &w, const NfcScanPoint &p, uint32_t edgeTime, uint32_t clock)
+{
+   __builtin_memset(&w.fe, 0, sizeof(w.fe));
+   w.fe.clock = clock;
+   w.fe.pulseFilter = p.pulseFilter;
+   w.fe.env = p.env;
+   w.fe.n1 = p.n1;
+   w.fe.mdev = p.mdev;
+   w.fe.avg = p.avg;
+   w.fe.edgePeak = p.edgePeak;
+   w.fe.edgeTime = edgeTime;
+   w.zone = p.zone & NFC_ZONE_MASK;
+   w.edgeSynced = 1;
+   w.edgeKnown = 1;
+   nfc_scan_tile_reset(w);
+}
+
+/* Seams of a job, chunks in order (one thread). A chunk whose walk did not start from the state the chunk before ends
+ * with - the envelope tracker is not contractive, the other recurrences sometimes need longer than the warm-up - is
+ * walked again from that state, sequentially, until the new walk meets the recorded one at a stored point (from there
+ * on the record is the truth) or the chunk ends; points and tile records on the way are replaced. The result is exact
+ * whatever the warm-up achieved; what the warm-up buys is that this happens rarely.
+ * chunkEdge[k] = edge-tracker time that points of chunk k without a time of their own inherit. */
 NFC_DEV void nfc_seams_check(const NfcConfig &c, const NfcScanParams &sp, NfcScanJob &job, NfcScanSeam *seams, NfcScanPoint *points,
                              NfcScanTile *tiles, uint32_t stride, uint32_t *chunkEdge, uint32_t startEdge, uint32_t startClock)
 {
-   uint32_t edge = startEdge;
+   uint32_t edge = startEdge; /* true edge time at the start of the chunk at hand */
 
    for (uint32_t k = 0; k < job.chunks; k++)
    {
       NfcScanSeam &s = seams[job.firstChunk + k];
+      uint32_t inherit = edge;
 
-      if (k > 0)
+      const bool sound = k == 0 || (nfc_point_same(s.start, seams[job.firstChunk + k - 1].end) &&
+                                    (!(s.start.zone & NFC_ZONE_EDGE_KNOWN) || s.start.edgeTime == edge));
+
+      if (!sound)
       {
-         const NfcScanPoint &before = seams[job.firstChunk + k - 1].end;
+         const uint32_t from = k * sp.chunkSamples;
+         const uint32_t to = from + sp.chunkSamples < job.count ? from + sp.chunkSamples : job.count;
 
-         if (!nfc_point_same_but_envelope(s.start, before))
-            job.status |= NFC_JOB_SEAM;
+         NfcScanLane w;
+         nfc_scan_resume(w, seams[job.firstChunk + k - 1].end, edge, startClock + from);
 
-         if ((s.start.zone & NFC_ZONE_EDGE_KNOWN) && s.start.edgeTime != edge)
-            job.status |= NFC_JOB_SEAM;
+         bool met = false;
 
-         if (nfc_bits(s.start.env) != nfc_bits(before.env) || s.start.pulseFilter != before.pulseFilter)
+         for (uint32_t i = from; i < to; i++)
          {
-            float env = before.env;
-            uint32_t pulse = before.pulseFilter;
-
-            const uint32_t from = k * sp.chunkSamples;
-            const uint32_t to = from + sp.chunkSamples < job.count ? from + sp.chunkSamples : job.count;
-            bool met = false;
-            float envmin = NFC_SCAN_BIG;
-
-            for (uint32_t i = from; i < to; i++)
+            if ((i % NFC_SCAN_POINT) == 0)
             {
-               if ((i % NFC_SCAN_POINT) == 0)
+               NfcScanPoint &p = points[job.firstPoint + i / NFC_SCAN_POINT];
+               NfcScanPoint mine;
+               nfc_scan_point(w, mine);
+
+               /* met: same recurrences, and the recorded walk's edge tracker is in step from here on */
+               if (i > from && nfc_point_same(p, mine) && (p.zone & NFC_ZONE_EDGE_SYNCED) &&
+                   (!(p.zone & NFC_ZONE_EDGE_KNOWN) || p.edgeTime == mine.edgeTime))
                {
-                  NfcScanPoint &p = points[job.firstPoint + i / NFC_SCAN_POINT];
-
-                  if (nfc_bits(p.env) == nfc_bits(env) && p.pulseFilter == pulse)
-                  {
-                     met = true;
-                     break;
-                  }
-
-                  p.env = env;
-                  p.pulseFilter = pulse;
+                  met = true;
+                  inherit = mine.edgeTime;
+                  break;
                }
 
-               ++pulse;
-               nfc_envelope_step(c, startClock + 1u + i, pulse, env, NFC_SAMPLE_AT(job.data, stride, i));
-
-               envmin = env < envmin ? env : envmin;
-
-               if ((i % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || i == to - 1)
-               {
-                  NfcScanTile &t = tiles[job.firstTile + i / NFC_SCAN_TILE];
-                  t.envmin = envmin;
-                  t.bits |= NFC_TILE_REWALKED;
-                  envmin = NFC_SCAN_BIG;
-               }
+               p = mine;
             }
 
-            if (!met)
+            nfc_scan_sample(c, w, NFC_SAMPLE_AT(job.data, stride, i));
+
+            if ((i % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || i == to - 1)
             {
-               s.end.env = env;
-               s.end.pulseFilter = pulse;
+               NfcScanTile stat;
+               nfc_scan_tile_end(w, stat);
+               stat.bits |= NFC_TILE_REWALKED;
+               tiles[job.firstTile + i / NFC_SCAN_TILE] = stat;
             }
+         }
+
+         if (!met)
+         {
+            nfc_scan_point(w, s.end);
+            inherit = edge; /* every point of the chunk has been rewritten with its own time */
          }
       }
 
-      chunkEdge[job.firstChunk + k] = edge;
+      chunkEdge[job.firstChunk + k] = inherit;
 
+      /* true edge time at the end of the chunk */
       if (s.end.zone & NFC_ZONE_EDGE_KNOWN)
          edge = s.end.edgeTime;
+      else
+         edge = inherit;
    }
 }
 

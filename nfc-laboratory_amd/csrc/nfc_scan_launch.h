@@ -34,10 +34,14 @@ struct NfcScanArgs
    uint32_t *tiles;            /* per tile: flag word (nfc_tile_flags, then NFC_TILE_RETIRE_OK) */
    NfcWindow *windows;         /* [firstWindowSlot + windowRoom]: entry i describes lane i of the lane arrays */
    NfcWork *works;             /* same indexing */
-   uint32_t firstWindowSlot;   /* carry lanes occupy [0, nJobs), speculative lanes start here (multiple of 64) */
+   uint32_t finalLaneSlot;     /* carry lanes occupy [0, nJobs), the lanes that regenerate a job's final state [finalLaneSlot, + nJobs) */
+   uint32_t firstWindowSlot;   /* speculative lanes start here (multiple of 64) */
    uint32_t windowRoom;        /* speculative lanes there is room for */
    uint32_t *windowCount;      /* speculative lanes in use (device counter) */
    uint32_t *rerunCount;       /* jobs that need another decode pass (device counter) */
+   uint32_t *runList;          /* speculative lanes to run in the coming pass (indices into the lane arrays) */
+   uint32_t *runCount;         /* entries of runList (device counter) */
+   uint32_t *runNext;          /* next entry a persistent wave takes (device counter) */
 };
 
 #endif

@@ -137,8 +137,6 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, flo
       {
          m.symStart = 0; m.symEnd = 0; m.sync = 0; m.syncValue = 0; m.winStart = 0; m.winEnd = 0;
          m.pulses = 0; m.thr = 0; m.peak = 0; m.peakTime = 0;
-      if (cleared)
-         *cleared = 1;
          if (cleared)
             *cleared = 1; /* the pulse counter starts over (NfcStreamCold::clearedF) */
          return false;

@@ -37,7 +37,9 @@ __global__ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArg
 __global__ void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams);
 __global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
 __global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass);
-__global__ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
+__global__ void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes);
 __global__ void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
 __global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses);
 __global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
@@ -127,7 +129,8 @@ struct nfcgpu_ctx
       void *ptr = nullptr;
       size_t bytes = 0;
    };
-   DevBuf wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters;
+   DevBuf wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
+   uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
    std::vector<ProfiledLaunch> timed;
@@ -592,7 +595,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    }
 
    const uint32_t nChunks = (uint32_t)chunks.size();
-   const uint32_t firstWindowSlot = (nJobs + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
+   const uint32_t finalLaneSlot = (nJobs + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
+   const uint32_t firstWindowSlot = 2 * finalLaneSlot;
 
    int rc;
    if ((rc = grow(ctx, ctx->wJobs, sizeof(NfcScanJob) * nJobs)) || (rc = grow(ctx, ctx->wChunks, sizeof(NfcScanChunk) * nChunks)) ||
@@ -605,13 +609,18 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    /* lanes: a first guess (one window per 8192 samples); the window kernel reports what it needs */
    uint32_t room = (uint32_t)(totalSamples / 8192) + 2 * nJobs + 64;
 
+   /* records per lane slot (carry lanes, final lanes, one per window); ring and frame-assembly storage per carry lane,
+    * final lane and per lane of the persistent waves that run the windows */
+   const size_t storageLanes = (size_t)firstWindowSlot + (size_t)ctx->windowWaves * NFC_LANES;
+
    auto growLanes = [&](uint32_t lanesWanted) -> int {
       const size_t lanes = ((size_t)lanesWanted + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
       int r;
       if ((r = grow(ctx, ctx->wWindows, sizeof(NfcWindow) * lanes)) || (r = grow(ctx, ctx->wWorks, sizeof(NfcWork) * lanes)) ||
           (r = grow(ctx, ctx->vStates, sizeof(NfcStreamState) * lanes)) || (r = grow(ctx, ctx->vCold, sizeof(NfcStreamCold) * lanes)) ||
-          (r = grow(ctx, ctx->vRings, sizeof(float) * (size_t)kRingBlockFloats * (lanes / NFC_LANES))) ||
-          (r = grow(ctx, ctx->vBytes, (size_t)NFC_STREAM_BYTES * lanes)))
+          (r = grow(ctx, ctx->wRunList, 4 * lanes)) ||
+          (r = grow(ctx, ctx->vRings, sizeof(float) * (size_t)kRingBlockFloats * (storageLanes / NFC_LANES))) ||
+          (r = grow(ctx, ctx->vBytes, (size_t)NFC_STREAM_BYTES * storageLanes)))
          return r;
       return NFCGPU_OK;
    };
@@ -661,10 +670,14 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.tileStats = (NfcScanTile *)ctx->wTileStats.ptr;
    A.windows = (NfcWindow *)ctx->wWindows.ptr;
    A.works = (NfcWork *)ctx->wWorks.ptr;
+   A.finalLaneSlot = finalLaneSlot;
    A.firstWindowSlot = firstWindowSlot;
    A.windowRoom = room;
    A.windowCount = counters;
    A.rerunCount = counters + 1;
+   A.runCount = counters + 2;
+   A.runNext = counters + 3;
+   A.runList = (uint32_t *)ctx->wRunList.ptr;
 
    const NfcConfig *dCfg = ctx->dConfigs + config;
 
@@ -695,6 +708,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       A.windows = (NfcWindow *)ctx->wWindows.ptr;
       A.works = (NfcWork *)ctx->wWorks.ptr;
+      A.runList = (uint32_t *)ctx->wRunList.ptr;
       A.windowRoom = room;
       HIP_TRY(ctx, hipMemsetAsync(counters, 0, 4, ctx->stream));
    }
@@ -721,7 +735,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    const uint32_t windowBlocks = (nWindows + NFC_LANES - 1) / NFC_LANES;
 
-   auto decode = [&](bool carry, uint32_t firstSlot, uint32_t slotCount) -> int {
+   /* one lane per slot: the carry lanes (and, at the end, the lanes that regenerate a job's final state) */
+   auto decodeSlots = [&](bool carry, uint32_t firstSlot, uint32_t slotCount) -> int {
       if (slotCount == 0)
          return NFCGPU_OK;
 
@@ -734,7 +749,23 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       const uint32_t blocks = (firstSlot % NFC_LANES + slotCount + NFC_LANES - 1) / NFC_LANES;
 
-      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_kernel, dim3(blocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, L);
+      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, L);
+      HIP_TRY(ctx, hipGetLastError());
+      ctx->stats.launches++;
+      return NFCGPU_OK;
+   };
+
+   /* the speculative windows on the run list: persistent waves */
+   auto decodeWindows = [&]() -> int {
+      NfcLaunch L = lanes;
+      L.warmFront = NFC_WINDOW_WARM_FRONT;
+      L.warmCorr = NFC_WINDOW_WARM_CORR;
+
+      uint32_t waves = (nWindows + NFC_LANES - 1) / NFC_LANES;
+      if (waves > ctx->windowWaves)
+         waves = ctx->windowWaves;
+
+      hipLaunchKernelGGL(nfc_window_kernel, dim3(waves), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
       return NFCGPU_OK;
@@ -743,7 +774,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    ProfiledLaunch pw {nullptr, nullptr};
    record_span(ctx, ctx->timedWindow, pw, true);
 
-   if ((rc = decode(true, 0, nJobs)))
+   if ((rc = decodeSlots(true, 0, nJobs)))
       return rc;
 
    uint32_t pass = 0;
@@ -752,10 +783,11 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    {
       if (nWindows)
       {
+         HIP_TRY(ctx, hipMemsetAsync(counters + 2, 0, 8, ctx->stream)); /* run list: count and next */
          hipLaunchKernelGGL(nfc_window_lanes_kernel, dim3(windowBlocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, A, lanes, pass);
          HIP_TRY(ctx, hipGetLastError());
 
-         if ((rc = decode(false, firstWindowSlot, nWindows)))
+         if ((rc = decodeWindows()))
             return rc;
       }
 
@@ -773,6 +805,13 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (!again || !nWindows)
          break;
    }
+
+   /* the state a stream is left in: its last lane's, run once more with storage of its own */
+   hipLaunchKernelGGL(nfc_final_lanes_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, dCfg, A, lanes);
+   HIP_TRY(ctx, hipGetLastError());
+
+   if ((rc = decodeSlots(false, finalLaneSlot, nJobs)))
+      return rc;
 
    record_span(ctx, ctx->timedWindow, pw, false);
 
@@ -944,6 +983,9 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->scanChunk = knob("NFCGPU_SCAN_CHUNK", ctx->scanChunk) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
+   ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
+   if (ctx->windowWaves == 0)
+      ctx->windowWaves = 1;
 
    if (ctx->scanWarm < NFC_SCAN_POINT)
       ctx->scanWarm = NFC_SCAN_POINT;
@@ -1038,7 +1080,7 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    if (ctx->hStage)
       (void)hipHostFree(ctx->hStage);
 
-   for (nfcgpu_ctx::DevBuf *b: {&ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows,
+   for (nfcgpu_ctx::DevBuf *b: {&ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
                                 &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl})
    {
       if (b->ptr)

@@ -283,14 +283,22 @@ void copy_lane(const NfcLaunch &from, uint32_t a, const NfcLaunch &to, uint32_t 
    std::memcpy(to.bytes + (uint64_t)b * NFC_STREAM_BYTES, from.bytes + (uint64_t)a * NFC_STREAM_BYTES, NFC_STREAM_BYTES);
 }
 
+/* one lane: record slot `slot` (state, cold, work, window), ring / frame-assembly storage of lane slot `storage` */
+void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32_t slot, uint32_t storage);
+
 void window_decode(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry)
 {
    for (uint32_t slot = L.firstSlot; slot < L.firstSlot + L.slotCount; slot++)
+      window_lane(cfgPtr, L, carry, slot, slot);
+}
+
+void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32_t slot, uint32_t storage)
+{
    {
       const uint32_t mineCount = L.works[slot].count;
 
       if (!mineCount)
-         continue;
+         return;
 
       const uint32_t *flags = L.works[slot].tiles;
       const uint8_t *data = L.works[slot].data;
@@ -298,11 +306,11 @@ void window_decode(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry)
       NfcStreamState s = L.states[slot];
 
       NfcLaneMem mem;
-      mem.ring = L.rings + (uint64_t)(slot / NFC_LANES) * L.ringBlockFloats;
-      mem.lane = slot % NFC_LANES;
+      mem.ring = L.rings + (uint64_t)(storage / NFC_LANES) * L.ringBlockFloats;
+      mem.lane = storage % NFC_LANES;
       mem.exact = false;
       mem.linked = true;
-      mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
+      mem.bytes = L.bytes + (uint64_t)storage * NFC_STREAM_BYTES;
       mem.sink = L.sink;
       mem.sinkCursor = L.sinkCtl;
       mem.sinkDropped = L.sinkCtl + 1;
@@ -555,14 +563,60 @@ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A
          A.windows[wi] = w;
 
          work.count = job->count - w.start;
+
+         A.runList[emu_add(A.runCount, 1u)] = wi;
       }
 
       A.works[wi] = work;
    }
 }
 
-void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) { window_decode(cfgPtr, L, false); }
+/* the persistent waves: here one lane after the other, every window in the ring storage of the first wave's first lane
+ * (as on the device, a window does not own ring storage: its warm-up rebuilds what it needs) */
+void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
+{
+   for (uint32_t i = 0; i < *A.runCount; i++)
+      window_lane(cfgPtr, L, false, A.runList[i], A.firstWindowSlot + (i % NFC_LANES));
+   *A.runNext = *A.runCount;
+}
+
+void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) { window_decode(cfgPtr, L, false); }
 void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) { window_decode(cfgPtr, L, true); }
+
+void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes)
+{
+   for (uint32_t j = 0; j < A.nJobs; j++)
+   {
+      const NfcScanJob *job = A.jobs + j;
+      const uint32_t to = A.finalLaneSlot + j;
+
+      NfcWork work;
+      work.data = nullptr;
+      work.count = 0;
+      work.stride = A.stride;
+      work.tiles = nullptr;
+
+      if (!(job->status & NFC_JOB_INVALID) && job->finalLane != j)
+      {
+         NfcWindow w = A.windows[job->finalLane];
+         const uint32_t chunk = job->firstChunk + w.start / A.params.chunkSamples;
+
+         NfcStreamState s;
+         NfcStreamCold cold;
+         nfc_window_lane(*cfgPtr, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+
+         lanes.states[to] = s;
+         lanes.cold[to] = cold;
+         A.windows[to] = w;
+
+         work.data = job->data + (uint64_t)w.start * A.stride * 4u;
+         work.count = job->count - w.start;
+         work.tiles = A.tiles + job->firstTile + w.start / NFC_SCAN_TILE;
+      }
+
+      A.works[to] = work;
+   }
+}
 
 void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses)
 {
@@ -616,10 +670,12 @@ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
 
       nfc_finish_frames(*job, j, A.windows, lanes.cold, lanes.sink, real.sink, real.sinkCtl, real.sinkWords);
 
-      copy_lane(lanes, job->finalLane, real, job->slot);
+      const uint32_t from = job->finalLane == j ? j : A.finalLaneSlot + j;
 
-      NfcStreamState s = lanes.states[job->finalLane];
-      NfcStreamCold cold = lanes.cold[job->finalLane];
+      copy_lane(lanes, from, real, job->slot);
+
+      NfcStreamState s = lanes.states[from];
+      NfcStreamCold cold = lanes.cold[from];
       cold.frameHead = 0;
       cold.frameTail = 0;
       real.states[job->slot] = s;
