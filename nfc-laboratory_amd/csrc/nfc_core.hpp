@@ -761,7 +761,11 @@ NFC_DEV void nfc_search_detect(const NfcConfig &c, NfcStreamState &s, const NfcL
       /* every detector that is enabled stepped its correlator on this sample: on the next sample
        * ring[(idx - 1) % p1] is known to equal the running sum and need not be read back */
       if (!locked)
+      {
+         if (s.bankClock != s.clock - 1u)
+            mem.cold->bankRun = s.clock; /* first step after a gap (rare): where the unbroken run of the bank begins */
          s.bankClock = s.clock;
+      }
    }
 
    if (locked)
@@ -1052,6 +1056,8 @@ NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLan
    r.detV.acc -= tv.t.out;
    NFC_AT(mem, NFC_R_CORR, c.corrOffset[5] + s.posV1) = r.detV.acc;
 
+   if (s.bankClock != s.clock - 1u)
+      mem.cold->bankRun = s.clock;
    s.bankClock = s.clock;
 }
 

@@ -40,6 +40,7 @@ __device__ __forceinline__ float nfc_sample_at(const uint8_t *data, uint32_t str
 }
 
 #define NFC_SAMPLE_AT(data, stride, index) nfc_sample_at((data), (stride), (index))
+#define NFC_FENCE() __threadfence()
 #include "nfc_scan.hpp"
 #include "nfc_launch.h"
 #include "nfc_scan_launch.h"
@@ -717,6 +718,7 @@ __global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcL
       NfcWindow w;
       __builtin_memset(&w, 0, sizeof(w));
       w.job = j;
+      w.verify = 0xFFFFFFFFu;
       nfc_carry_take(w.carry, s, cold);
       w.want = w.carry;
       A.windows[to] = w;
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
    if (run)
    {
       if (pass == 0)
-         w.carry = A.windows[w.job].carry; /* the carry lane's: the stream's state as the submission finds it */
+         nfc_carry_guess(w.carry, A.windows[w.job].carry, A.points[job->firstPoint + w.start / NFC_SCAN_POINT]);
       else
          w.carry = w.want;
 
@@ -760,6 +762,11 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
       w.rerun = 0;
       w.stop = 0;
       w.retired = 0;
+      w.handTo = 0;
+      w.pubState = 0;
+      w.pubTail = 0;
+      if (pass == 0)
+         w.noHand = 0;
 
       NfcConfig cc;
       nfc_fixed_runtime_config(cfgPtr, cc);
@@ -768,7 +775,11 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
 
       NfcStreamState s;
       NfcStreamCold cold;
-      nfc_window_lane(cc, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+      {
+         const NfcScanPoint &pt = A.points[job->firstPoint + w.start / NFC_SCAN_POINT];
+         w.tracked = (pt.zone & NFC_ZONE_EDGE_KNOWN) ? pt.edgeTime : A.chunkEdge[chunk];
+         nfc_window_lane(cc, w, pt, A.states[job->slot].clock, s, cold);
+      }
 
       lanes.states[wi] = s;
       lanes.cold[wi] = cold;
@@ -839,16 +850,41 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
    const uint32_t warm = L.warmFront + L.warmCorr;
    bool stopped = mineCount == 0;
    uint32_t consumed = 0;
+   uint32_t handed = 0;
+
+   /* the lanes after this one on the same stream (nfc_lane_handover) */
+   uint32_t startPos = 0, verifyPos = 0xFFFFFFFFu, succ = 0, succEnd = 0;
+
+   if (mineCount)
+   {
+      const NfcWindow &me = L.windows[slot];
+      const NfcScanJob &job = L.jobs[me.job];
+      startPos = me.start;
+      verifyPos = me.verify;
+      succ = CARRY ? job.firstWindow : slot + 1u;
+      succEnd = job.firstWindow + job.windows;
+      if (!CARRY && (slot < job.firstWindow || slot >= succEnd))
+         succ = succEnd; /* a final lane (regenerates a state): runs on its own */
+   }
 
    for (uint32_t base = 0; base < longest; base += TILE)
    {
       if (!stopped && base >= mineCount)
          stopped = true;
 
+      if (!stopped && startPos + base == verifyPos)
+         nfc_lane_publish(L.windows[slot], s, *mem.cold);
+
       /* retire? (tile boundary: TILE == NFC_SCAN_TILE and every lane starts on a tile boundary of its stream) */
       if (!stopped && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
-          (uint32_t)(s.clock - mem.cold->lastUnlock) >= NFC_WINDOW_SETTLE)
+          s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
          stopped = true;
+
+      if (!stopped && base >= warm && base > 0 && nfc_lane_handover(L.windows, L.windows[slot], succ, succEnd, startPos + base, s, *mem.cold))
+      {
+         stopped = true;
+         handed = 1;
+      }
 
       if (__any(!stopped) == 0)
          break;
@@ -896,7 +932,7 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
    {
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
-      L.windows[slot].retired = consumed < mineCount ? 1u : 0u;
+      L.windows[slot].retired = handed ? 2u : (consumed < mineCount ? 1u : 0u);
    }
 }
 
@@ -947,6 +983,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
 
    bool active = false;
    uint32_t w = 0, consumed = 0, mineCount = 0;
+   uint32_t startPos = 0, verifyPos = 0xFFFFFFFFu, succ = 0, succEnd = 0;
    const uint8_t *data = nullptr;
    const uint32_t *flags = nullptr;
    uint32_t steps = 0; /* steps of this wave since its lanes last all started together (multiple of 512 at a join) */
@@ -987,6 +1024,15 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
             mem.cold = L.cold + w;
             mem.streamId = w;
 
+            {
+               const NfcWindow &me = L.windows[w];
+               const NfcScanJob &job = A.jobs[me.job];
+               startPos = me.start;
+               verifyPos = me.verify;
+               succ = w + 1u;
+               succEnd = job.firstWindow + job.windows;
+            }
+
             /* number the rings from where the wave's other lanes are */
             s.posA[0] = steps % cc.a[0].p1;
             s.posA[1] = steps % cc.a[1].p1;
@@ -1015,16 +1061,26 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
          if (active)
          {
             bool done = consumed >= mineCount;
+            uint32_t how = done ? 0u : 1u;
+
+            if (!done && startPos + consumed == verifyPos)
+               nfc_lane_publish(L.windows[w], s, *mem.cold);
 
             if (!done && consumed >= warm && (flags[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
-                (uint32_t)(s.clock - mem.cold->lastUnlock) >= NFC_WINDOW_SETTLE)
+                s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
                done = true;
+
+            if (!done && consumed >= warm && nfc_lane_handover(L.windows, L.windows[w], succ, succEnd, startPos + consumed, s, *mem.cold))
+            {
+               done = true;
+               how = 2u;
+            }
 
             if (done)
             {
                L.states[w] = s;
-               L.windows[w].stop = L.windows[w].start + consumed;
-               L.windows[w].retired = consumed < mineCount ? 1u : 0u;
+               L.windows[w].stop = startPos + consumed;
+               L.windows[w].retired = how;
                active = false;
             }
          }
@@ -1155,7 +1211,11 @@ __global__ __launch_bounds__(64) void nfc_final_lanes_kernel(const NfcConfig *__
 
       NfcStreamState s;
       NfcStreamCold cold;
-      nfc_window_lane(cc, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+      {
+         const NfcScanPoint &pt = A.points[job->firstPoint + w.start / NFC_SCAN_POINT];
+         w.tracked = (pt.zone & NFC_ZONE_EDGE_KNOWN) ? pt.edgeTime : A.chunkEdge[chunk];
+         nfc_window_lane(cc, w, pt, A.states[job->slot].clock, s, cold);
+      }
 
       lanes.states[to] = s;
       lanes.cold[to] = cold;

@@ -38,6 +38,7 @@ struct NfcLaunch
    uint32_t warmFront;  /* windowed launches: leading samples of every lane that only run the front end ... */
    uint32_t warmCorr;   /* ... then samples that also keep the search correlators up, before the decoder goes live */
    struct NfcWindow *windows; /* windowed launches: per-slot records (stop / retired are written back) */
+   const struct NfcScanJob *jobs; /* windowed launches: the submission's streams */
    uint32_t launchSeq;  /* non-zero, distinct for every demodulation launch of a context (see NfcStreamState::served) */
    uint32_t forceExact; /* the host launches only the exact-modulo kernel: it takes every block, whatever the clocks say */
 };

@@ -49,7 +49,11 @@
 #define NFC_WINDOW_GAP 16u        /* quiet tiles that separate two windows (1024 samples) */
 #define NFC_WINDOW_WARM_FRONT 512u /* samples of front end only at the start of a window lane: refills the sample history */
 #define NFC_WINDOW_WARM_CORR 256u  /* then samples of correlator upkeep only: refills every search correlation ring (p1 <= 189) */
-#define NFC_WINDOW_SETTLE 256u     /* samples of plain search after an unlock before a lane may retire (stale ring entries) */
+#define NFC_WINDOW_SETTLE 256u     /* unbroken detector-bank steps before a lane may retire at rest (stale ring entries) */
+#define NFC_WINDOW_CUT 16384u      /* inside busy signal a new lane starts this often ... */
+#define NFC_WINDOW_VERIFY 2048u    /* ... and this long after going live it publishes its state: a lane before it whose
+                                      state is then the same hands over to it (both need NFC_WINDOW_STEADY steady steps) */
+#define NFC_WINDOW_STEADY 1024u    /* unbroken detector-bank steps that make the correlation rings a function of the samples alone */
 
 /* front-end state before sample `NFC_SCAN_POINT * k` of a submission (after the sample before it) */
 struct NfcScanPoint
@@ -118,6 +122,7 @@ struct NfcCarry
    uint32_t carrierOff;
    uint32_t emitClock; /* clock of the last carrier frame the decoder emitted (it zeroes edgeTime then) */
    uint32_t emitValid;
+   uint32_t edgeTime;  /* the decoder's edge time (compared when two lanes meet at the same sample) */
    /* what an NFC-F preamble detector at rest still remembers: its partial resets (modulation deeper than the NFC-F
     * maximum, peak timeout: NfcF.cpp:262-283) leave the pulse counter and the threshold of the last pulse in place, and
     * every 100 % ASK pause of an NFC-A / NFC-V frame goes through one; both are read again when the next pulse ends */
@@ -132,13 +137,22 @@ struct NfcWindow
    uint32_t job;
    uint32_t start;    /* first sample the lane consumes (multiple of NFC_SCAN_POINT; 0 for the lane that carries the stream's state in) */
    uint32_t activate; /* sample at which the lane's decoder goes live (multiple of NFC_SCAN_TILE) */
+   uint32_t verify;   /* sample at which the lane publishes its state (activate + NFC_WINDOW_VERIFY), 0xFFFFFFFF: never */
    uint32_t stop;     /* out: first sample the lane did not consume */
-   uint32_t retired;  /* out: 1 when the lane stopped at rest, 0 when it ran to the end of the submission */
-   uint32_t rerun;    /* chain kernel: run this window again with `carry` */
-   uint32_t live;     /* chain kernel: its frames are the stream's frames */
-   uint32_t reserved;
+   uint32_t retired;  /* out: 0 ran to the end of the submission, 1 stopped at rest, 2 handed over at `stop` to lane handTo */
+   uint32_t handTo;
+   uint32_t noHand;   /* chain kernel: when run again, do not hand over to lanes up to this index */
+   uint32_t rerun;    /* chain kernel: run this window again (with `want`) */
+   uint32_t live;     /* chain kernel: its frames (after liveFrom) are the stream's frames */
+   uint32_t liveFrom; /* chain kernel: 0 all its frames, else frameTail marker: only the records chained after that one */
+   uint32_t pubState; /* 0 nothing published (yet), 1 state published, 2 reached `verify` in a state that cannot be compared */
+   uint32_t pubTail;  /* the lane's frameTail when it published */
+   uint32_t pubDigest[2];
+   uint32_t stopDigest[2]; /* digest of the lane's own state where it handed over */
+   uint32_t tracked;  /* edge-tracker time at the lane's first sample (scanned): with the carry's last carrier frame it gives the decoder's edge time */
    NfcCarry carry;    /* what the lane assumed when it last ran */
    NfcCarry want;     /* chain kernel: what it has to assume in the next pass (rerun) */
+   NfcCarry pubCarry; /* the lane's carry when it published */
 };
 
 #endif

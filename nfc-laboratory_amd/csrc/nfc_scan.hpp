@@ -359,6 +359,7 @@ NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uin
          w.job = jobIndex;
          w.start = start;
          w.activate = activate;
+         w.verify = activate + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= job.count ? activate + NFC_WINDOW_VERIFY : 0xFFFFFFFFu;
       }
       n++;
    };
@@ -366,27 +367,37 @@ NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uin
    const uint32_t warm = NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
 
    uint32_t quietBehind = 0;
+   uint32_t lastAct = 0; /* activation of the most recent window (the carry lane goes live at 0) */
 
    for (uint32_t i = 0; i < nTiles; i++)
    {
+      const uint32_t act = i * NFC_SCAN_TILE;
+
       if (!(t[i] & NFC_TILE_BUSY))
-      {
          quietBehind++;
-         continue;
-      }
-
-      /* a busy tile after a gap a lane may have retired in */
-      if (quietBehind >= NFC_WINDOW_GAP)
+      else
       {
-         const uint32_t act = i * NFC_SCAN_TILE;
-         if (act >= warm + NFC_SCAN_POINT)
+         /* a busy tile after a gap a lane may have retired in */
+         if (quietBehind >= NFC_WINDOW_GAP && act >= warm + NFC_SCAN_POINT)
+         {
             put((act - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, act);
+            lastAct = act;
+         }
+
+         quietBehind = 0;
       }
 
-      quietBehind = 0;
+      /* where lanes cannot retire (busy signal, or not enough quiet signal ahead) a new lane starts every
+       * NFC_WINDOW_CUT samples: whoever is running there hands over to it if their states agree (nfc_lane_handover) */
+      if (!(t[i] & NFC_TILE_RETIRE_OK) && act >= lastAct + NFC_WINDOW_CUT && act >= warm + NFC_SCAN_POINT &&
+          act + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= job.count)
+      {
+         put((act - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, act);
+         lastAct = act;
+      }
    }
 
-   if (job.count >= warm + NFC_SCAN_POINT)
+   if (job.count >= warm + NFC_SCAN_POINT && job.count > lastAct)
       put((job.count - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, job.count);
 
    return n;
@@ -405,6 +416,7 @@ NFC_DEV void nfc_carry_take(NfcCarry &x, const NfcStreamState &s, const NfcStrea
    x.carrierOff = s.carrierOff;
    x.emitClock = cold.emitClock;
    x.emitValid = cold.emitValid;
+   x.edgeTime = s.edgeTime;
 
    /* only meaningful (and only looked at) for a lane that stopped at rest: the detector records share their storage
     * with the decode registers */
@@ -418,10 +430,19 @@ NFC_DEV void nfc_carry_take(NfcCarry &x, const NfcStreamState &s, const NfcStrea
 
 /* The fields a later decode can depend on. guardTime / waitingTime are rewritten by every poll frame's processing before
  * they are read (nfc*_process), the carrier times only matter as "set or not" (NfcDecoder.cpp:449-463,472-523). */
-NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b)
+/* the decoder's edge time at a lane's first sample: the tracker's, unless a carrier frame has zeroed it since */
+NFC_DEV uint32_t nfc_edge_time(const NfcCarry &x, uint32_t tracked)
+{
+   return (x.emitValid && (int32_t)(tracked - x.emitClock) <= 0) ? 0u : tracked;
+}
+
+/* Two carries of lanes meeting at the same sample (`meeting`: their decoders' edge times are compared as they are), or
+ * an assumption against what the stream holds at a lane's first sample (`tracked`: edge-tracker time there; the last
+ * carrier frame only matters through the edge time it leaves the lane with). */
+NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked)
 {
    bool same = a.chainedA == b.chainedA && (a.carrierOn != 0) == (b.carrierOn != 0) && (a.carrierOff != 0) == (b.carrierOff != 0) &&
-               a.emitValid == b.emitValid && (!a.emitValid || a.emitClock == b.emitClock);
+               (meeting ? a.edgeTime == b.edgeTime : nfc_edge_time(a, tracked) == nfc_edge_time(b, tracked));
 
    for (int t = 0; t < 4; t++)
       same = same && a.tim[t].lastCommand == b.tim[t].lastCommand && a.tim[t].maxFrameSize == b.tim[t].maxFrameSize &&
@@ -440,10 +461,15 @@ NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const Nf
 {
 #define NFC_CARRY_FIELD(f) left.f = (left.f == assumed.f) ? given.f : left.f
    NFC_CARRY_FIELD(chainedA);
-   NFC_CARRY_FIELD(carrierOn);
-   NFC_CARRY_FIELD(carrierOff);
-   NFC_CARRY_FIELD(emitClock);
-   NFC_CARRY_FIELD(emitValid);
+
+   /* carrier state: only "set or not" is ever read; a lane that emitted no carrier frame passes everything through */
+   if (left.emitClock == assumed.emitClock && left.emitValid == assumed.emitValid)
+   {
+      left.carrierOn = given.carrierOn;
+      left.carrierOff = given.carrierOff;
+      left.emitClock = given.emitClock;
+      left.emitValid = given.emitValid;
+   }
 
    for (int t = 0; t < 4; t++)
    {
@@ -478,7 +504,27 @@ NFC_DEV uint32_t nfc_label(uint32_t clock, uint32_t delay, uint32_t period, uint
    return (pos + period - truePos) % period;
 }
 
-NFC_DEV void nfc_window_lane(const NfcConfig &c, const NfcWindow &w, const NfcScanPoint &p, uint32_t chunkEdge, uint32_t startClock,
+/* first guess of a lane's carry: what the stream's state holds as the submission finds it, with the carrier state the
+ * scan saw at the lane's first sample (a decoder that has been searching knows the carrier is on when the average is) */
+NFC_DEV void nfc_carry_guess(NfcCarry &x, const NfcCarry &stream, const NfcScanPoint &p)
+{
+   x = stream;
+
+   const uint32_t zone = p.zone & NFC_ZONE_MASK;
+
+   if (zone == 1u && !x.carrierOn)
+   {
+      x.carrierOn = 1u;
+      x.carrierOff = 0u;
+   }
+   else if (zone == 2u && !x.carrierOff)
+   {
+      x.carrierOff = 1u;
+      x.carrierOn = 0u;
+   }
+}
+
+NFC_DEV void nfc_window_lane(const NfcConfig &c, const NfcWindow &w, const NfcScanPoint &p, uint32_t startClock,
                              NfcStreamState &s, NfcStreamCold &cold)
 {
    __builtin_memset(&s, 0, sizeof(s));
@@ -494,8 +540,7 @@ NFC_DEV void nfc_window_lane(const NfcConfig &c, const NfcWindow &w, const NfcSc
    s.edgePeak = p.edgePeak;
 
    /* the decoder's edge time: the tracker's, unless a carrier frame zeroed it since */
-   const uint32_t tracked = (p.zone & NFC_ZONE_EDGE_KNOWN) ? p.edgeTime : chunkEdge;
-   s.edgeTime = (w.carry.emitValid && (int32_t)(tracked - w.carry.emitClock) <= 0) ? 0u : tracked;
+   s.edgeTime = nfc_edge_time(w.carry, w.tracked);
 
    s.carrierOn = w.carry.carrierOn;
    s.carrierOff = w.carry.carrierOff;
@@ -525,6 +570,121 @@ NFC_DEV void nfc_window_lane(const NfcConfig &c, const NfcWindow &w, const NfcSc
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* handing over between lanes                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+#ifndef NFC_FENCE
+#error "define NFC_FENCE() (device-wide memory fence) before including nfc_scan.hpp"
+#endif
+
+/* Can this lane's state be compared with another lane's at the same clock? Searching, and the detector bank has been
+ * stepped without a break for NFC_WINDOW_STEADY samples (no lock, no sample below the power threshold): then every
+ * history and correlation ring entry a detector can still read was written during that run and is a function of the
+ * samples alone (up to the constant offset of the box sums, which never shows: nfc_step_upkeep). */
+NFC_DEV bool nfc_lane_comparable(const NfcStreamState &s, const NfcStreamCold &cold)
+{
+   return s.lockTech == 0 && s.unlock == 0 && s.bankClock == s.clock && (uint32_t)(s.clock - cold.bankRun) >= NFC_WINDOW_STEADY;
+}
+
+NFC_DEV void nfc_mix(uint32_t h[2], uint32_t v)
+{
+   h[0] = (h[0] ^ v) * 0x01000193u;
+   h[1] = (h[1] + v) * 0x9E3779B1u + (h[1] >> 15);
+}
+
+/* What decides the future of a searching decoder apart from the samples: the detector records (without the running
+ * sums, whose offset never shows, and without what travels as NfcCarry) and the front end (equal anyway: scanned). */
+NFC_DEV void nfc_lane_digest(const NfcStreamState &s, uint32_t h[2])
+{
+   const NfcSearchRegs &r = s.u.search;
+
+   h[0] = 0x811C9DC5u;
+   h[1] = 0x7F4A7C15u;
+
+   nfc_mix(h, nfc_bits(s.env)); nfc_mix(h, nfc_bits(s.n1)); nfc_mix(h, nfc_bits(s.mdev)); nfc_mix(h, nfc_bits(s.avg));
+   nfc_mix(h, nfc_bits(s.edgePeak)); nfc_mix(h, s.pulseFilter);
+
+   for (int i = 0; i < 3; i++)
+   {
+      nfc_mix(h, r.detA[i].winStart); nfc_mix(h, r.detA[i].winEnd); nfc_mix(h, r.detA[i].symStart);
+      nfc_mix(h, nfc_bits(r.detA[i].peak)); nfc_mix(h, nfc_bits(r.detA[i].aux)); nfc_mix(h, r.detA[i].peakTime);
+   }
+
+   for (int i = 0; i < 2; i++)
+   {
+      const NfcDetB &b = r.detB[i];
+      const bool tracking = (b.symStart | b.symEnd | b.winStart | b.winEnd | b.auxTime | nfc_bits(b.aux)) != 0;
+      nfc_mix(h, b.winStart); nfc_mix(h, b.winEnd); nfc_mix(h, b.symStart); nfc_mix(h, b.symEnd);
+      nfc_mix(h, nfc_bits(b.aux)); nfc_mix(h, b.auxTime);
+      nfc_mix(h, tracking ? nfc_bits(b.thr) : 0u); /* recomputed on every sample of an idle detector */
+   }
+
+   for (int i = 0; i < 2; i++)
+   {
+      const NfcDetF &f = r.detF[i];
+      const bool tracking = (f.winStart | f.winEnd | f.sync | f.symStart | f.symEnd | f.peakTime | nfc_bits(f.peak)) != 0;
+      nfc_mix(h, f.winStart); nfc_mix(h, f.winEnd); nfc_mix(h, f.sync); nfc_mix(h, f.symStart); nfc_mix(h, f.symEnd);
+      nfc_mix(h, nfc_bits(f.peak)); nfc_mix(h, f.peakTime);
+      /* rewritten by the first pulse of a preamble before they are read */
+      nfc_mix(h, tracking ? nfc_bits(f.lastPhase) : 0u); nfc_mix(h, tracking ? nfc_bits(f.lastValue) : 0u);
+      nfc_mix(h, tracking ? nfc_bits(f.syncValue) : 0u); nfc_mix(h, tracking ? nfc_bits(f.c0) : 0u);
+      /* pulses and thr travel with the carry */
+   }
+
+   nfc_mix(h, r.detV.winStart); nfc_mix(h, r.detV.winEnd); nfc_mix(h, r.detV.symStart);
+   nfc_mix(h, nfc_bits(r.detV.peak)); nfc_mix(h, nfc_bits(r.detV.aux)); nfc_mix(h, r.detV.peakTime);
+}
+
+/* a lane has reached its `verify` sample */
+NFC_DEV void nfc_lane_publish(NfcWindow &w, const NfcStreamState &s, const NfcStreamCold &cold)
+{
+   if (nfc_lane_comparable(s, cold))
+   {
+      uint32_t h[2];
+      nfc_lane_digest(s, h);
+      w.pubDigest[0] = h[0];
+      w.pubDigest[1] = h[1];
+      nfc_carry_take(w.pubCarry, s, cold);
+      w.pubTail = cold.frameTail;
+      NFC_FENCE();
+      *(volatile uint32_t *)&w.pubState = 1u;
+   }
+   else
+      *(volatile uint32_t *)&w.pubState = 2u;
+}
+
+/* A lane at sample `pos` (a tile boundary): is there a later lane of the same stream that published its state for this
+ * very sample, and is it the state this lane is in? Then the two will decode the rest identically and this one stops.
+ * `succ` walks the job's windows [.., succEnd). */
+NFC_DEV bool nfc_lane_handover(NfcWindow *windows, NfcWindow &me, uint32_t &succ, uint32_t succEnd, uint32_t pos, const NfcStreamState &s,
+                               const NfcStreamCold &cold)
+{
+   while (succ < succEnd && (windows[succ].verify < pos || succ <= me.noHand))
+      succ++;
+
+   if (succ >= succEnd || windows[succ].verify != pos)
+      return false;
+
+   NfcWindow &next = windows[succ];
+
+   if (*(volatile uint32_t *)&next.pubState != 1u || !nfc_lane_comparable(s, cold))
+      return false;
+
+   NFC_FENCE();
+
+   uint32_t h[2];
+   nfc_lane_digest(s, h);
+
+   if (h[0] != *(volatile uint32_t *)&next.pubDigest[0] || h[1] != *(volatile uint32_t *)&next.pubDigest[1])
+      return false;
+
+   me.handTo = succ;
+   me.stopDigest[0] = h[0];
+   me.stopDigest[1] = h[1];
+   return true;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* chain: one thread per job, after every decode pass                                          */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -544,13 +704,18 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
    for (uint32_t i = 0; i < n; i++)
    {
       w[i].live = 0;
+      w[i].liveFrom = 0;
       w[i].rerun = 0;
    }
 
    bool again = false;
    uint32_t lane = jobIndex; /* the carry lane comes first */
    uint32_t next = 0;        /* first speculative window not yet passed */
-   NfcCarry have;
+   NfcCarry have;            /* what the stream's state holds where `lane` takes over */
+   bool handed = false;      /* `lane` took over at its verify sample (else at its start) */
+
+   windows[jobIndex].live = 1;
+   windows[jobIndex].liveFrom = 0;
 
    for (;;)
    {
@@ -559,27 +724,67 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
       NfcCarry left;
       nfc_carry_take(left, lanes[lane], colds[lane]);
 
-      if (lane != jobIndex && !nfc_carry_same(x.carry, have))
+      if (lane != jobIndex)
       {
-         /* ran on a wrong assumption: again, and predict what it will leave */
+         /* what the lane had where it took over: its assumption at its start, or what it published */
+         const NfcCarry &had = handed ? x.pubCarry : x.carry;
+
+         if (!nfc_carry_same(had, have, handed, x.tracked))
+         {
+            /* ran on a wrong assumption: again. At its start it has to assume `have`, corrected by what it did itself
+             * between its start and the sample it took over at; then predict what it will leave */
+            NfcCarry want = have;
+            if (handed)
+            {
+               want = x.carry;
+               nfc_carry_predict(want, x.pubCarry, have); /* fields it had not touched by then follow `have` */
+               for (int i = 0; i < 2; i++)
+               {
+                  if (!x.pubCarry.clearedF[i])
+                     want.pulsesF[i] = have.pulsesF[i] - (x.pubCarry.pulsesF[i] - x.carry.pulsesF[i]);
+               }
+            }
 #ifdef NFC_CHAIN_TRACE
-         NFC_CHAIN_TRACE(lane, x.carry, have, left);
+            NFC_CHAIN_TRACE(lane, had, have, left);
 #endif
-         nfc_carry_predict(left, x.carry, have);
-         x.want = have;
-         x.rerun = 1;
-         again = true;
+            nfc_carry_predict(left, x.carry, want);
+            x.want = want;
+            x.rerun = 1;
+            again = true;
+         }
       }
 
       x.live = 1;
       job.finalLane = lane;
 
-      if (!x.retired || x.stop >= job.count)
+      if (x.retired == 0 || x.stop >= job.count)
          break;
 
       have = left;
 
-      /* next lane: first window activating at or after the sample this one stopped at (the closing window at the latest) */
+      if (x.retired == 2)
+      {
+         /* handed over at x.stop to a lane that had published the same state; after a rerun of that lane the two may no
+          * longer agree: then this lane has to go on instead */
+         NfcWindow &y = windows[x.handTo];
+
+         if (y.pubState != 1u || y.pubDigest[0] != x.stopDigest[0] || y.pubDigest[1] != x.stopDigest[1] || y.verify != x.stop)
+         {
+            x.noHand = x.handTo;
+            x.want = x.carry;
+            x.rerun = 1;
+            again = true;
+            break; /* nothing after this lane is known */
+         }
+
+         lane = x.handTo;
+         next = lane - job.firstWindow + 1;
+         handed = true;
+         y.liveFrom = y.pubTail ? y.pubTail : 0xFFFFFFFFu; /* 0xFFFFFFFF: from its first record */
+         continue;
+      }
+
+      /* stopped at rest: the first window activating at or after that sample takes over (the closing window at the latest) */
       while (next < n && w[next].activate < x.stop)
          next++;
 
@@ -588,6 +793,7 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
 
       lane = job.firstWindow + next;
       next++;
+      handed = false;
    }
 
    job.passes++;
@@ -623,7 +829,11 @@ NFC_DEV void nfc_finish_frames(const NfcScanJob &job, uint32_t jobIndex, const N
       if (!windows[lane].live)
          continue;
 
+      /* a lane that took over at its verify sample: only what it chained after the record that was its last then */
       uint32_t at = colds[lane].frameHead;
+
+      if (windows[lane].liveFrom != 0 && windows[lane].liveFrom != 0xFFFFFFFFu)
+         at = staging[windows[lane].liveFrom - 1u];
 
       while (at)
       {

@@ -252,8 +252,10 @@ struct NfcStreamCold
    NfcSearchRegs parked; /* detector records while a technology is locked */
    NfcDecodeRegs init;   /* decode register set prepared by the detector that locked, installed by nfc_enter_lock */
    uint32_t framesOut;
-   uint32_t lastUnlock; /* clock of the last return to search mode (a lane of the time-parallel path may only retire
-                           once the correlation rings hold nothing older than that) */
+   uint32_t lastUnlock; /* clock of the last return to search mode */
+   uint32_t bankRun;    /* clock at which the detector bank began its current unbroken run of steps (no lock, no sample
+                           below the power threshold since): a lane of the time-parallel path may only stop once the
+                           correlation rings hold nothing older than that */
    uint32_t emitClock;  /* clock of the last carrier frame (the decoder zeroes edgeTime when it emits one) */
    uint32_t emitValid;
    uint32_t frameHead;  /* chained frame records of this lane in the staging sink: word offset + 1 of the first / last */

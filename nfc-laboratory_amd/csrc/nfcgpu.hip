@@ -123,7 +123,7 @@ struct nfcgpu_ctx
    uint32_t windowedMinSamples = 32768; /* shortest submission (per stream) worth cutting into windows */
    uint32_t scanChunk = 65536;     /* samples per scan chunk */
    uint32_t scanWarm = 6144;       /* samples walked ahead of a chunk */
-   uint32_t maxPasses = 8;
+   uint32_t maxPasses = 12;
    struct DevBuf
    {
       void *ptr = nullptr;
@@ -727,6 +727,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    lanes.ringBlockFloats = kRingBlockFloats;
    lanes.works = (const NfcWork *)ctx->wWorks.ptr;
    lanes.windows = (NfcWindow *)ctx->wWindows.ptr;
+   lanes.jobs = (const NfcScanJob *)ctx->wJobs.ptr;
    lanes.uniformStride = stride;
 
    /* lanes */
@@ -774,9 +775,6 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    ProfiledLaunch pw {nullptr, nullptr};
    record_span(ctx, ctx->timedWindow, pw, true);
 
-   if ((rc = decodeSlots(true, 0, nJobs)))
-      return rc;
-
    uint32_t pass = 0;
 
    for (;;)
@@ -790,6 +788,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          if ((rc = decodeWindows()))
             return rc;
       }
+
+      /* the carry lanes after the windows: they hand over to a window that has published the state they reach */
+      if (pass == 0 && (rc = decodeSlots(true, 0, nJobs)))
+         return rc;
 
       HIP_TRY(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));
       hipLaunchKernelGGL(nfc_chain_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, lanes, ctx->maxPasses);

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #define NFC_DEV static inline
@@ -29,6 +30,7 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
    return p[i];
 }
 #define NFC_SAMPLE_AT(data, stride, index) emu_sample_at((data), (stride), (index))
+#define NFC_FENCE() ((void)0)
 #include "../../nfc-laboratory_amd/csrc/nfc_scan.h"
 static void emu_chain_trace(uint32_t lane, const NfcCarry &assumed, const NfcCarry &have, const NfcCarry &left)
 {
@@ -321,12 +323,29 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
 
       const uint32_t warm = L.warmFront + L.warmCorr;
       uint32_t consumed = 0;
+      uint32_t handed = 0;
+
+      NfcWindow &me = L.windows[slot];
+      const NfcScanJob &job = L.jobs[me.job];
+      uint32_t succ = carry ? job.firstWindow : slot + 1u;
+      const uint32_t succEnd = job.firstWindow + job.windows;
+      if (!carry && (slot < job.firstWindow || slot >= succEnd))
+         succ = succEnd;
 
       for (uint32_t base = 0; base < mineCount; base += NFC_SCAN_TILE)
       {
+         if (me.start + base == me.verify)
+            nfc_lane_publish(me, s, *mem.cold);
+
          if (base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
-             (uint32_t)(s.clock - mem.cold->lastUnlock) >= NFC_WINDOW_SETTLE)
+             s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
             break;
+
+         if (base >= warm && base > 0 && nfc_lane_handover(L.windows, me, succ, succEnd, me.start + base, s, *mem.cold))
+         {
+            handed = 1;
+            break;
+         }
 
          if (std::getenv("NFC_EMU_DEBUG2") && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK))
          {
@@ -335,7 +354,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
             {
                const NfcSearchRegs &r = s.u.search;
                std::fprintf(stderr, "[emu] lane %u base %u cannot retire: lock %x unlock %x settle %u | A %u %u %u %u | B %u %u | F ws %u we %u sync %u pulses %u thr %g ss %u se %u peak %g pt %u | F2 pulses %u thr %g ws %u | V %u %u\n",
-                            slot, base, s.lockTech, s.unlock, (uint32_t)(s.clock - mem.cold->lastUnlock),
+                            slot, base, s.lockTech, s.unlock, (uint32_t)(s.clock - mem.cold->bankRun),
                             r.detA[0].winStart, r.detA[0].peakTime, r.detA[1].winStart, r.detA[2].winStart, r.detB[0].symStart, r.detB[1].symStart,
                             r.detF[0].winStart, r.detF[0].winEnd, r.detF[0].sync, r.detF[0].pulses, r.detF[0].thr, r.detF[0].symStart, r.detF[0].symEnd, r.detF[0].peak, r.detF[0].peakTime,
                             r.detF[1].pulses, r.detF[1].thr, r.detF[1].winStart, r.detV.winStart, r.detV.peakTime);
@@ -365,7 +384,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
 
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
-      L.windows[slot].retired = consumed < mineCount ? 1u : 0u;
+      L.windows[slot].retired = handed ? 2u : (consumed < mineCount ? 1u : 0u);
    }
 }
 
@@ -514,6 +533,7 @@ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
       NfcWindow w;
       std::memset(&w, 0, sizeof(w));
       w.job = j;
+      w.verify = 0xFFFFFFFFu;
       nfc_carry_take(w.carry, s, cold);
       w.want = w.carry;
       A.windows[j] = w;
@@ -546,17 +566,29 @@ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A
 
       if (run)
       {
-         w.carry = pass == 0 ? A.windows[w.job].carry : w.want;
+         if (pass == 0)
+            nfc_carry_guess(w.carry, A.windows[w.job].carry, A.points[job->firstPoint + w.start / NFC_SCAN_POINT]);
+         else
+            w.carry = w.want;
          w.want = w.carry;
          w.rerun = 0;
          w.stop = 0;
          w.retired = 0;
+         w.handTo = 0;
+         w.pubState = 0;
+         w.pubTail = 0;
+         if (pass == 0)
+            w.noHand = 0;
 
          const uint32_t chunk = job->firstChunk + w.start / A.params.chunkSamples;
 
          NfcStreamState s;
          NfcStreamCold cold;
-         nfc_window_lane(*cfgPtr, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+         {
+            const NfcScanPoint &pt = A.points[job->firstPoint + w.start / NFC_SCAN_POINT];
+            w.tracked = (pt.zone & NFC_ZONE_EDGE_KNOWN) ? pt.edgeTime : A.chunkEdge[chunk];
+            nfc_window_lane(*cfgPtr, w, pt, A.states[job->slot].clock, s, cold);
+         }
 
          lanes.states[wi] = s;
          lanes.cold[wi] = cold;
@@ -575,8 +607,12 @@ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A
  * (as on the device, a window does not own ring storage: its warm-up rebuilds what it needs) */
 void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
-   for (uint32_t i = 0; i < *A.runCount; i++)
-      window_lane(cfgPtr, L, false, A.runList[i], A.firstWindowSlot + (i % NFC_LANES));
+   /* later windows first: on the device the lanes of a stream run side by side and a lane reaches the sample its successor
+    * published for long after the successor did; one after the other, that order has to be arranged */
+   std::vector<uint32_t> order(A.runList, A.runList + *A.runCount);
+   std::sort(order.begin(), order.end());
+   for (uint32_t i = (uint32_t)order.size(); i-- > 0;)
+      window_lane(cfgPtr, L, false, order[i], A.firstWindowSlot + (i % NFC_LANES));
    *A.runNext = *A.runCount;
 }
 
@@ -603,7 +639,11 @@ void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A,
 
          NfcStreamState s;
          NfcStreamCold cold;
-         nfc_window_lane(*cfgPtr, w, A.points[job->firstPoint + w.start / NFC_SCAN_POINT], A.chunkEdge[chunk], A.states[job->slot].clock, s, cold);
+         {
+            const NfcScanPoint &pt = A.points[job->firstPoint + w.start / NFC_SCAN_POINT];
+            w.tracked = (pt.zone & NFC_ZONE_EDGE_KNOWN) ? pt.edgeTime : A.chunkEdge[chunk];
+            nfc_window_lane(*cfgPtr, w, pt, A.states[job->slot].clock, s, cold);
+         }
 
          lanes.states[to] = s;
          lanes.cold[to] = cold;
