@@ -129,6 +129,10 @@ struct NfcCarry
    uint32_t pulsesF[2];
    float thrF[2];
    uint32_t clearedF[2]; /* result only: the lane's detector started its pulse count over (not compared) */
+   /* The detector records (running sums apart). A lane starts with all of them at rest; one that was tracking something
+    * when another technology locked comes back from the lock with its window in the past and stays like that until the
+    * next strong pulse (NfcF.cpp:262-283 and the like): a state no amount of warm-up reproduces, so it travels here. */
+   NfcSearchRegs search;
 };
 
 /* one window: a lane of the windowed decode launch */

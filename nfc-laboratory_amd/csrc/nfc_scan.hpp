@@ -426,6 +426,57 @@ NFC_DEV void nfc_carry_take(NfcCarry &x, const NfcStreamState &s, const NfcStrea
       x.thrF[i] = s.lockTech ? 0.0f : s.u.search.detF[i].thr;
       x.clearedF[i] = cold.clearedF[i];
    }
+
+   if (s.lockTech)
+      __builtin_memset(&x.search, 0, sizeof(x.search));
+   else
+      x.search = s.u.search;
+}
+
+/* detector records as far as they decide anything: without the running sums (their offset never shows), without the
+ * two NFC-F leftovers that are compared on their own (pulsesF / thrF), and without fields an idle detector rewrites
+ * before it reads them (nfc_at_rest) */
+NFC_DEV void nfc_records_canonical(NfcSearchRegs &r)
+{
+   for (int i = 0; i < 3; i++)
+      r.detA[i].acc = 0.0f;
+
+   for (int i = 0; i < 2; i++)
+   {
+      NfcDetB &b = r.detB[i];
+      if ((b.symStart | b.symEnd | b.winStart | b.winEnd | b.auxTime | nfc_bits(b.aux)) == 0)
+         b.thr = 0.0f;
+   }
+
+   for (int i = 0; i < 2; i++)
+   {
+      NfcDetF &f = r.detF[i];
+      f.acc = 0.0f;
+      f.pulses = 0;
+      f.thr = 0.0f;
+      if ((f.winStart | f.winEnd | f.sync | f.symStart | f.symEnd | f.peakTime | nfc_bits(f.peak)) == 0)
+      {
+         f.lastPhase = 0.0f;
+         f.lastValue = 0.0f;
+         f.syncValue = 0.0f;
+         f.c0 = 0.0f;
+      }
+   }
+
+   r.detV.acc = 0.0f;
+}
+
+NFC_DEV bool nfc_records_same(const NfcSearchRegs &a, const NfcSearchRegs &b)
+{
+   NfcSearchRegs x = a, y = b;
+   nfc_records_canonical(x);
+   nfc_records_canonical(y);
+
+   const uint32_t *p = (const uint32_t *)&x, *q = (const uint32_t *)&y;
+   bool same = true;
+   for (uint32_t i = 0; i < sizeof(NfcSearchRegs) / 4; i++)
+      same = same && p[i] == q[i];
+   return same;
 }
 
 /* The fields a later decode can depend on. guardTime / waitingTime are rewritten by every poll frame's processing before
@@ -450,6 +501,8 @@ NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, 
 
    for (int i = 0; i < 2; i++)
       same = same && a.pulsesF[i] == b.pulsesF[i] && nfc_bits(a.thrF[i]) == nfc_bits(b.thrF[i]);
+
+   same = same && nfc_records_same(a.search, b.search);
 
    return same;
 }
@@ -488,6 +541,28 @@ NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const Nf
          left.pulsesF[i] = given.pulsesF[i] + (left.pulsesF[i] - assumed.pulsesF[i]);
       left.thrF[i] = nfc_bits(left.thrF[i]) == nfc_bits(assumed.thrF[i]) ? given.thrF[i] : left.thrF[i];
    }
+
+   /* detector records, one by one: left as found -> whatever it is given */
+   {
+      NfcSearchRegs l = left.search, a = assumed.search;
+      nfc_records_canonical(l);
+      nfc_records_canonical(a);
+
+#define NFC_CARRY_RECORD(f)                                                         \
+      {                                                                             \
+         const uint32_t *p = (const uint32_t *)&l.f, *q = (const uint32_t *)&a.f;   \
+         bool untouched = true;                                                     \
+         for (uint32_t k = 0; k < sizeof(l.f) / 4; k++)                             \
+            untouched = untouched && p[k] == q[k];                                  \
+         if (untouched)                                                             \
+            left.search.f = given.search.f;                                         \
+      }
+      NFC_CARRY_RECORD(detA[0]) NFC_CARRY_RECORD(detA[1]) NFC_CARRY_RECORD(detA[2])
+      NFC_CARRY_RECORD(detB[0]) NFC_CARRY_RECORD(detB[1])
+      NFC_CARRY_RECORD(detF[0]) NFC_CARRY_RECORD(detF[1])
+      NFC_CARRY_RECORD(detV)
+#undef NFC_CARRY_RECORD
+   }
 #undef NFC_CARRY_FIELD
 }
 
@@ -509,6 +584,9 @@ NFC_DEV uint32_t nfc_label(uint32_t clock, uint32_t delay, uint32_t period, uint
 NFC_DEV void nfc_carry_guess(NfcCarry &x, const NfcCarry &stream, const NfcScanPoint &p)
 {
    x = stream;
+
+   /* detectors at rest (what the stream's state holds belongs to the sample before the submission, not to this lane's) */
+   __builtin_memset(&x.search, 0, sizeof(x.search));
 
    const uint32_t zone = p.zone & NFC_ZONE_MASK;
 
@@ -553,8 +631,16 @@ NFC_DEV void nfc_window_lane(const NfcConfig &c, const NfcWindow &w, const NfcSc
    cold.emitValid = w.carry.emitValid;
    cold.lastUnlock = s.clock;
 
+   /* detector records as assumed (at rest unless the chain kernel knows better); the running sums start from zero */
+   s.u.search = w.carry.search;
+
+   for (int i = 0; i < 3; i++)
+      s.u.search.detA[i].acc = 0.0f;
+   s.u.search.detV.acc = 0.0f;
+
    for (int i = 0; i < 2; i++)
    {
+      s.u.search.detF[i].acc = 0.0f;
       s.u.search.detF[i].pulses = w.carry.pulsesF[i];
       s.u.search.detF[i].thr = w.carry.thrF[i];
    }
@@ -604,35 +690,7 @@ NFC_DEV void nfc_lane_digest(const NfcStreamState &s, uint32_t h[2])
    nfc_mix(h, nfc_bits(s.env)); nfc_mix(h, nfc_bits(s.n1)); nfc_mix(h, nfc_bits(s.mdev)); nfc_mix(h, nfc_bits(s.avg));
    nfc_mix(h, nfc_bits(s.edgePeak)); nfc_mix(h, s.pulseFilter);
 
-   for (int i = 0; i < 3; i++)
-   {
-      nfc_mix(h, r.detA[i].winStart); nfc_mix(h, r.detA[i].winEnd); nfc_mix(h, r.detA[i].symStart);
-      nfc_mix(h, nfc_bits(r.detA[i].peak)); nfc_mix(h, nfc_bits(r.detA[i].aux)); nfc_mix(h, r.detA[i].peakTime);
-   }
-
-   for (int i = 0; i < 2; i++)
-   {
-      const NfcDetB &b = r.detB[i];
-      const bool tracking = (b.symStart | b.symEnd | b.winStart | b.winEnd | b.auxTime | nfc_bits(b.aux)) != 0;
-      nfc_mix(h, b.winStart); nfc_mix(h, b.winEnd); nfc_mix(h, b.symStart); nfc_mix(h, b.symEnd);
-      nfc_mix(h, nfc_bits(b.aux)); nfc_mix(h, b.auxTime);
-      nfc_mix(h, tracking ? nfc_bits(b.thr) : 0u); /* recomputed on every sample of an idle detector */
-   }
-
-   for (int i = 0; i < 2; i++)
-   {
-      const NfcDetF &f = r.detF[i];
-      const bool tracking = (f.winStart | f.winEnd | f.sync | f.symStart | f.symEnd | f.peakTime | nfc_bits(f.peak)) != 0;
-      nfc_mix(h, f.winStart); nfc_mix(h, f.winEnd); nfc_mix(h, f.sync); nfc_mix(h, f.symStart); nfc_mix(h, f.symEnd);
-      nfc_mix(h, nfc_bits(f.peak)); nfc_mix(h, f.peakTime);
-      /* rewritten by the first pulse of a preamble before they are read */
-      nfc_mix(h, tracking ? nfc_bits(f.lastPhase) : 0u); nfc_mix(h, tracking ? nfc_bits(f.lastValue) : 0u);
-      nfc_mix(h, tracking ? nfc_bits(f.syncValue) : 0u); nfc_mix(h, tracking ? nfc_bits(f.c0) : 0u);
-      /* pulses and thr travel with the carry */
-   }
-
-   nfc_mix(h, r.detV.winStart); nfc_mix(h, r.detV.winEnd); nfc_mix(h, r.detV.symStart);
-   nfc_mix(h, nfc_bits(r.detV.peak)); nfc_mix(h, nfc_bits(r.detV.aux)); nfc_mix(h, r.detV.peakTime);
+   (void)r; /* the detector records are compared as part of the carry (NfcCarry::search) */
 }
 
 /* a lane has reached its `verify` sample */
@@ -646,37 +704,28 @@ NFC_DEV void nfc_lane_publish(NfcWindow &w, const NfcStreamState &s, const NfcSt
       w.pubDigest[1] = h[1];
       nfc_carry_take(w.pubCarry, s, cold);
       w.pubTail = cold.frameTail;
-      NFC_FENCE();
-      *(volatile uint32_t *)&w.pubState = 1u;
+      w.pubState = 1u;
    }
    else
-      *(volatile uint32_t *)&w.pubState = 2u;
+      w.pubState = 2u;
 }
 
-/* A lane at sample `pos` (a tile boundary): is there a later lane of the same stream that published its state for this
- * very sample, and is it the state this lane is in? Then the two will decode the rest identically and this one stops.
- * `succ` walks the job's windows [.., succEnd). */
+/* A lane at sample `pos` (a tile boundary): is this the sample a later lane of the same stream publishes its state for,
+ * and is this lane in a state that can be compared? Then it stops here and leaves its digest; whether the two states
+ * were the same (the later lane then decodes the rest exactly as this one would have) is settled by the chain kernel,
+ * which sends this lane on if they were not. The decision does not look at what the other lane has published so far:
+ * which lane runs first must not change what a lane does. `succ` walks the job's windows [.., succEnd). */
 NFC_DEV bool nfc_lane_handover(NfcWindow *windows, NfcWindow &me, uint32_t &succ, uint32_t succEnd, uint32_t pos, const NfcStreamState &s,
                                const NfcStreamCold &cold)
 {
    while (succ < succEnd && (windows[succ].verify < pos || succ <= me.noHand))
       succ++;
 
-   if (succ >= succEnd || windows[succ].verify != pos)
+   if (succ >= succEnd || windows[succ].verify != pos || !nfc_lane_comparable(s, cold))
       return false;
-
-   NfcWindow &next = windows[succ];
-
-   if (*(volatile uint32_t *)&next.pubState != 1u || !nfc_lane_comparable(s, cold))
-      return false;
-
-   NFC_FENCE();
 
    uint32_t h[2];
    nfc_lane_digest(s, h);
-
-   if (h[0] != *(volatile uint32_t *)&next.pubDigest[0] || h[1] != *(volatile uint32_t *)&next.pubDigest[1])
-      return false;
 
    me.handTo = succ;
    me.stopDigest[0] = h[0];

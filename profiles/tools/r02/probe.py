@@ -53,7 +53,7 @@ out["frames"] = sum(len(v) for v in frames.values())
 lib = TL.reference_lib()
 if lib is not None and CHECK:
     bad = 0
-    pick = sorted(set([0, 1, S // 2, S - 1] + list(range(min(S, CHECK)))))[:max(CHECK, 1)]
+    pick = sorted(set(i for i in [0, 1, S // 2, S - 1] + list(range(min(S, CHECK))) if 0 <= i < S))[:max(CHECK, 1)]
     for s in pick:
         mag = torch.sqrt(data[s, :, 0] ** 2 + data[s, :, 1] ** 2).cpu().numpy().astype(np.float32)
         fr, _ = TL.reference_decode(mag, sample_rate=FS, chunk=65536, keep_carrier=True, cap=65536, defined_storage=True)

@@ -334,8 +334,26 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
 
       for (uint32_t base = 0; base < mineCount; base += NFC_SCAN_TILE)
       {
+         auto dump = [&](const char *what) {
+            if (!std::getenv("NFC_EMU_DEBUG4"))
+               return;
+            const NfcSearchRegs &r = s.u.search;
+            std::fprintf(stderr, "[emu] %s lane %u pos %u clock %u lock %x comparable %d bankRun %u | A0 %u %u %u %g %g %u | A1 %u %u %u | A2 %u %u %u | B0 %u %u %u %u %g %u thr %g | B1 %u %u %u %u %g %u | F0 ws %u we %u sy %u ss %u se %u pk %g pt %u pulses %u thr %g | F1 ws %u we %u sy %u ss %u se %u pk %g pt %u pulses %u thr %g | V %u %u %u %g %g %u\n",
+                         what, slot, me.start + base, s.clock, s.lockTech, (int)nfc_lane_comparable(s, *mem.cold), mem.cold->bankRun,
+                         r.detA[0].winStart, r.detA[0].winEnd, r.detA[0].symStart, r.detA[0].peak, r.detA[0].aux, r.detA[0].peakTime,
+                         r.detA[1].winStart, r.detA[1].winEnd, r.detA[1].symStart, r.detA[2].winStart, r.detA[2].winEnd, r.detA[2].symStart,
+                         r.detB[0].winStart, r.detB[0].winEnd, r.detB[0].symStart, r.detB[0].symEnd, r.detB[0].aux, r.detB[0].auxTime, r.detB[0].thr,
+                         r.detB[1].winStart, r.detB[1].winEnd, r.detB[1].symStart, r.detB[1].symEnd, r.detB[1].aux, r.detB[1].auxTime,
+                         r.detF[0].winStart, r.detF[0].winEnd, r.detF[0].sync, r.detF[0].symStart, r.detF[0].symEnd, r.detF[0].peak, r.detF[0].peakTime, r.detF[0].pulses, r.detF[0].thr,
+                         r.detF[1].winStart, r.detF[1].winEnd, r.detF[1].sync, r.detF[1].symStart, r.detF[1].symEnd, r.detF[1].peak, r.detF[1].peakTime, r.detF[1].pulses, r.detF[1].thr,
+                         r.detV.winStart, r.detV.winEnd, r.detV.symStart, r.detV.peak, r.detV.aux, r.detV.peakTime);
+         };
+
          if (me.start + base == me.verify)
+         {
             nfc_lane_publish(me, s, *mem.cold);
+            dump("publish");
+         }
 
          if (base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
              s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
@@ -343,6 +361,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
 
          if (base >= warm && base > 0 && nfc_lane_handover(L.windows, me, succ, succEnd, me.start + base, s, *mem.cold))
          {
+            dump("handover");
             handed = 1;
             break;
          }
