@@ -684,7 +684,7 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(const NfcConfig *__rest
 
 /* Prepare lanes. Carry lanes (window index == job index, one wave per job): a copy of the stream's slot, so that the
  * stream itself stays untouched until the submission is settled. Speculative lanes: scanned front end + assumed carry. */
-__global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
+__global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint32_t pass)
 {
    const uint32_t j = blockIdx.x;
    const uint32_t t = threadIdx.x;
@@ -693,6 +693,16 @@ __global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcL
       return;
 
    const NfcScanJob *job = A.jobs + j;
+
+   /* later passes: only the carry lanes the chain kernel sent on past a lane they had handed over to */
+   const uint32_t noHand = pass ? A.windows[j].noHand : 0u;
+
+   if (pass && !A.windows[j].rerun)
+   {
+      if (t == 0)
+         A.works[j].count = 0;
+      return;
+   }
    const uint32_t from = job->slot, to = j;
 
    const float *src = real.rings + (uint64_t)(from / NFC_LANES) * real.ringBlockFloats + (from % NFC_LANES);
@@ -719,6 +729,7 @@ __global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcL
       __builtin_memset(&w, 0, sizeof(w));
       w.job = j;
       w.verify = 0xFFFFFFFFu;
+      w.noHand = noHand;
       nfc_carry_take(w.carry, s, cold);
       w.want = w.carry;
       A.windows[to] = w;

@@ -28,6 +28,24 @@ struct NfcScanParams
    uint32_t warmSamples;   /* samples walked before a chunk to reach the true front-end state (multiple of NFC_SCAN_POINT) */
 };
 
+/* bit-for-bit equality of two records (word by word through memcpy: no library call on the device, and no loads through
+ * an integer alias of float fields, which type-based alias analysis may move across the stores that produced them) */
+NFC_DEV bool nfc_same_words(const void *a, const void *b, uint32_t bytes)
+{
+   const unsigned char *p = (const unsigned char *)a, *q = (const unsigned char *)b;
+   bool same = true;
+
+   for (uint32_t i = 0; i + 4 <= bytes; i += 4)
+   {
+      uint32_t u, v;
+      __builtin_memcpy(&u, p + i, 4);
+      __builtin_memcpy(&v, q + i, 4);
+      same = same && u == v;
+   }
+
+   return same;
+}
+
 /* walker state of one chunk */
 struct NfcScanLane
 {
@@ -217,11 +235,8 @@ NFC_DEV uint32_t nfc_tile_flags(const NfcConfig &c, const NfcScanParams &sp, con
 /* the recurrences of a point, bit for bit (not the edge time, which a walk may not know: see NFC_ZONE_EDGE_KNOWN) */
 NFC_DEV bool nfc_point_same(const NfcScanPoint &a, const NfcScanPoint &b)
 {
-   const uint32_t *x = (const uint32_t *)&a, *y = (const uint32_t *)&b;
-   bool same = true;
-   for (uint32_t i = 0; i < 6; i++) /* env n1 mdev avg edgePeak pulseFilter */
-      same = same && x[i] == y[i];
-   return same && ((a.zone ^ b.zone) & NFC_ZONE_MASK) == 0;
+   /* bit patterns: env n1 mdev avg edgePeak pulseFilter are the first six words of a point */
+   return nfc_same_words(&a, &b, 6 * sizeof(uint32_t)) && ((a.zone ^ b.zone) & NFC_ZONE_MASK) == 0;
 }
 
 /* continue a walk from a known state */
@@ -472,11 +487,9 @@ NFC_DEV bool nfc_records_same(const NfcSearchRegs &a, const NfcSearchRegs &b)
    nfc_records_canonical(x);
    nfc_records_canonical(y);
 
-   const uint32_t *p = (const uint32_t *)&x, *q = (const uint32_t *)&y;
-   bool same = true;
-   for (uint32_t i = 0; i < sizeof(NfcSearchRegs) / 4; i++)
-      same = same && p[i] == q[i];
-   return same;
+   /* memcmp, not words through an integer alias of the float fields (type-based alias analysis would let the loads
+    * pass the stores of the canonical form) */
+   return nfc_same_words(&x, &y, sizeof(NfcSearchRegs));
 }
 
 /* The fields a later decode can depend on. guardTime / waitingTime are rewritten by every poll frame's processing before
@@ -503,6 +516,11 @@ NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, 
       same = same && a.pulsesF[i] == b.pulsesF[i] && nfc_bits(a.thrF[i]) == nfc_bits(b.thrF[i]);
 
    same = same && nfc_records_same(a.search, b.search);
+
+#ifdef NFC_CARRY_DEBUG
+   if (!same)
+      NFC_CARRY_DEBUG(a, b, meeting, tracked);
+#endif
 
    return same;
 }
@@ -550,11 +568,7 @@ NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const Nf
 
 #define NFC_CARRY_RECORD(f)                                                         \
       {                                                                             \
-         const uint32_t *p = (const uint32_t *)&l.f, *q = (const uint32_t *)&a.f;   \
-         bool untouched = true;                                                     \
-         for (uint32_t k = 0; k < sizeof(l.f) / 4; k++)                             \
-            untouched = untouched && p[k] == q[k];                                  \
-         if (untouched)                                                             \
+         if (nfc_same_words(&l.f, &a.f, sizeof(l.f)))                               \
             left.search.f = given.search.f;                                         \
       }
       NFC_CARRY_RECORD(detA[0]) NFC_CARRY_RECORD(detA[1]) NFC_CARRY_RECORD(detA[2])
@@ -757,8 +771,11 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
       w[i].rerun = 0;
    }
 
+   windows[jobIndex].rerun = 0;
+
    bool again = false;
    uint32_t lane = jobIndex; /* the carry lane comes first */
+   uint32_t prev = jobIndex; /* the lane that handed over to `lane` */
    uint32_t next = 0;        /* first speculative window not yet passed */
    NfcCarry have;            /* what the stream's state holds where `lane` takes over */
    bool handed = false;      /* `lane` took over at its verify sample (else at its start) */
@@ -780,22 +797,31 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
 
          if (!nfc_carry_same(had, have, handed, x.tracked))
          {
-            /* ran on a wrong assumption: again. At its start it has to assume `have`, corrected by what it did itself
-             * between its start and the sample it took over at; then predict what it will leave */
+            /* ran on a wrong assumption. At its start it has to assume `have`, corrected by what it did itself between
+             * its start and the sample it took over at */
             NfcCarry want = have;
             if (handed)
             {
                want = x.carry;
-               nfc_carry_predict(want, x.pubCarry, have); /* fields it had not touched by then follow `have` */
-               for (int i = 0; i < 2; i++)
-               {
-                  if (!x.pubCarry.clearedF[i])
-                     want.pulsesF[i] = have.pulsesF[i] - (x.pubCarry.pulsesF[i] - x.carry.pulsesF[i]);
-               }
+               nfc_carry_predict(want, x.pubCarry, have); /* what it had not touched by then follows `have` */
             }
 #ifdef NFC_CHAIN_TRACE
             NFC_CHAIN_TRACE(lane, had, have, left);
 #endif
+            if (handed && nfc_carry_same(want, x.carry, false, x.tracked))
+            {
+               /* nothing it could assume differently would make the two lanes agree at that sample (both were busy
+                * with the same thing from different beginnings): the lane before has to go on past it */
+               NfcWindow &before = windows[prev];
+               before.noHand = lane;
+               before.want = before.carry;
+               before.rerun = 1;
+               again = true;
+               job.finalLane = prev;
+               break;
+            }
+
+            /* again, and predict what it will leave */
             nfc_carry_predict(left, x.carry, want);
             x.want = want;
             x.rerun = 1;
@@ -826,6 +852,7 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
             break; /* nothing after this lane is known */
          }
 
+         prev = lane;
          lane = x.handTo;
          next = lane - job.firstWindow + 1;
          handed = true;
@@ -840,6 +867,7 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
       if (next >= n)
          break;
 
+      prev = lane;
       lane = job.firstWindow + next;
       next++;
       handed = false;

@@ -35,7 +35,7 @@ __global__ void nfc_demod_fixed_exact_kernel(const NfcConfig *__restrict__ cfgPt
 __global__ void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd);
 __global__ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams);
-__global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
+__global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint32_t pass);
 __global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass);
 __global__ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
 __global__ void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
@@ -731,7 +731,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    lanes.uniformStride = stride;
 
    /* lanes */
-   hipLaunchKernelGGL(nfc_carry_lanes_kernel, dim3(nJobs), dim3(NFC_LANES), 0, ctx->stream, A, real, lanes);
+   hipLaunchKernelGGL(nfc_carry_lanes_kernel, dim3(nJobs), dim3(NFC_LANES), 0, ctx->stream, A, real, lanes, 0u);
    HIP_TRY(ctx, hipGetLastError());
 
    const uint32_t windowBlocks = (nWindows + NFC_LANES - 1) / NFC_LANES;
@@ -789,8 +789,15 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
             return rc;
       }
 
-      /* the carry lanes after the windows: they hand over to a window that has published the state they reach */
-      if (pass == 0 && (rc = decodeSlots(true, 0, nJobs)))
+      /* the carry lanes (later passes: those the chain kernel sent on): from the stream's own state, which has not
+       * been touched */
+      if (pass > 0)
+      {
+         hipLaunchKernelGGL(nfc_carry_lanes_kernel, dim3(nJobs), dim3(NFC_LANES), 0, ctx->stream, A, real, lanes, pass);
+         HIP_TRY(ctx, hipGetLastError());
+      }
+
+      if ((rc = decodeSlots(true, 0, nJobs)))
          return rc;
 
       HIP_TRY(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));

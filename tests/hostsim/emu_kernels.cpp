@@ -43,15 +43,34 @@ static void emu_chain_trace(uint32_t lane, const NfcCarry &assumed, const NfcCar
 #undef F
    if (assumed.thrF[0] != have.thrF[0]) std::fprintf(stderr, " thrF0 %g->%g (left %g)", assumed.thrF[0], have.thrF[0], left.thrF[0]);
    if (assumed.thrF[1] != have.thrF[1]) std::fprintf(stderr, " thrF1 %g->%g (left %g)", assumed.thrF[1], have.thrF[1], left.thrF[1]);
+   if (assumed.edgeTime != have.edgeTime) std::fprintf(stderr, " edgeTime %u->%u", assumed.edgeTime, have.edgeTime);
+   std::fprintf(stderr, " [emit %u/%u vs %u/%u]", assumed.emitValid, assumed.emitClock, have.emitValid, have.emitClock);
+   {
+      const uint32_t *p = (const uint32_t *)&assumed.search, *q = (const uint32_t *)&have.search;
+      for (uint32_t i = 0; i < sizeof(NfcSearchRegs) / 4; i++)
+         if (p[i] != q[i]) std::fprintf(stderr, " search[%u] %x->%x", i, p[i], q[i]);
+   }
    std::fprintf(stderr, "\n");
 }
 #define NFC_CHAIN_TRACE(lane, a, b, c) emu_chain_trace((lane), (a), (b), (c))
+static void emu_carry_debug(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked);
+#define NFC_CARRY_DEBUG(a, b, m, t) emu_carry_debug((a), (b), (m), (t))
 #include "../../nfc-laboratory_amd/csrc/nfc_scan.hpp"
 #include "../../nfc-laboratory_amd/csrc/nfc_launch.h"
 #include "../../nfc-laboratory_amd/csrc/nfc_scan_launch.h"
 
 namespace fakehip {
 dim3 launchGrid, launchBlock;
+}
+
+static void emu_carry_debug(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked)
+{
+   if (!std::getenv("NFC_EMU_DEBUG3"))
+      return;
+   std::fprintf(stderr, "[emu] carry_same fails: chained %d on %d off %d edge %d (meeting %d tracked %u: %u vs %u | %u vs %u) records %d\n",
+                a.chainedA == b.chainedA, (a.carrierOn != 0) == (b.carrierOn != 0), (a.carrierOff != 0) == (b.carrierOff != 0),
+                meeting ? a.edgeTime == b.edgeTime : nfc_edge_time(a, tracked) == nfc_edge_time(b, tracked), (int)meeting, tracked, a.edgeTime, b.edgeTime,
+                nfc_edge_time(a, tracked), nfc_edge_time(b, tracked), (int)nfc_records_same(a.search, b.search));
 }
 
 namespace {
@@ -534,11 +553,18 @@ void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uin
    }
 }
 
-void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
+void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint32_t pass)
 {
    for (uint32_t j = 0; j < A.nJobs; j++)
    {
       const NfcScanJob *job = A.jobs + j;
+      const uint32_t noHand = pass ? A.windows[j].noHand : 0u;
+
+      if (pass && !A.windows[j].rerun)
+      {
+         A.works[j].count = 0;
+         continue;
+      }
 
       copy_lane(real, job->slot, lanes, j);
 
@@ -553,6 +579,7 @@ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
       std::memset(&w, 0, sizeof(w));
       w.job = j;
       w.verify = 0xFFFFFFFFu;
+      w.noHand = noHand;
       nfc_carry_take(w.carry, s, cold);
       w.want = w.carry;
       A.windows[j] = w;
