@@ -804,13 +804,60 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
    A.works[wi] = work;
 }
 
+/* Stage the next 64 samples of every lane's own row (rowBase: where the lane's next sample is, left: samples it has
+ * left, 0 for a lane that takes none) into LDS as magnitudes, transposed: tile row r = lane r. One wave-wide load
+ * fetches 64 consecutive samples of one lane (512 B of IQ, 256 B of magnitude), NFC_STAGE_ROWS loads in flight. */
+__device__ __forceinline__ void nfc_stage_lanes(const NfcLaunch &L, const uint8_t *rowBase, uint32_t left, uint32_t lane, float *tile)
+{
+   if (!left)
+      rowBase = (const uint8_t *)L.rings; /* read (and discard) something that is always there */
+
+#pragma clang loop unroll(disable)
+   for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_STAGE_ROWS)
+   {
+      float re[NFC_STAGE_ROWS], im[NFC_STAGE_ROWS];
+      uint32_t count[NFC_STAGE_ROWS];
+
+#pragma unroll
+      for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
+      {
+         const int q = (int)(r0 + j);
+         const uint64_t p = ((uint64_t)(uint32_t)__shfl((int)((uint64_t)rowBase >> 32), q, 64) << 32) |
+                            (uint32_t)__shfl((int)(uint32_t)(uint64_t)rowBase, q, 64);
+         const uint32_t n = (uint32_t)__shfl((int)left, q, 64);
+         const uint32_t at = n ? (lane < n ? lane : n - 1u) : 0u;
+
+         count[j] = n;
+
+         if (L.uniformStride == 2)
+         {
+            const float2 iq = reinterpret_cast<const float2 *>(p)[at];
+            re[j] = iq.x;
+            im[j] = iq.y;
+         }
+         else
+         {
+            re[j] = reinterpret_cast<const float *>(p)[at];
+            im[j] = 0.0f;
+         }
+      }
+
+#pragma unroll
+      for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
+      {
+         const float v = L.uniformStride == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
+         tile[(r0 + j) * TILE_PITCH + lane] = lane < count[j] ? v : 0.0f;
+      }
+   }
+}
+
 /* The windowed decode: nfc_demod_body with lanes that stop on their own. A lane consumes its row tile by tile: front
  * end only, then correlator upkeep (both lengths are the launch's), then the full step machine; at a tile boundary it
  * retires when the decoder is at rest, the rings hold nothing from before its last unlock and the scan found nothing
  * ahead (NFC_TILE_RETIRE_OK). CARRY lanes continue a stream from its own state (no warm-up, exact-modulo ring positions
  * where the clock asks for them). */
 template <bool CARRY>
-__device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, float *tile)
+__device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, float *tile)
 {
    const uint32_t lane = threadIdx.x;
    const uint32_t block = L.firstBlock + blockIdx.x;
@@ -861,6 +908,7 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
    const uint32_t warm = L.warmFront + L.warmCorr;
    bool stopped = mineCount == 0;
    uint32_t consumed = 0;
+   uint32_t stepped = 0;
    uint32_t handed = 0;
 
    /* the lanes after this one on the same stream (nfc_lane_handover) */
@@ -878,10 +926,16 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
          succ = succEnd; /* a final lane (regenerates a state): runs on its own */
    }
 
-   for (uint32_t base = 0; base < longest; base += TILE)
+   /* `base`: samples of the row this lane has consumed (lanes may jump ahead through dark signal: nfc_lane_dark_jump) */
+   uint32_t base = 0;
+
+   for (;;)
    {
       if (!stopped && base >= mineCount)
          stopped = true;
+
+      if (__any(!stopped) == 0)
+         break;
 
       if (!stopped && startPos + base == verifyPos)
          nfc_lane_publish(L.windows[slot], s, *mem.cold);
@@ -897,13 +951,17 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
          handed = 1;
       }
 
+      if (!stopped && base >= warm && (flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT) >= NFC_DARK_JUMP)
+      {
+         const NfcScanJob &job = L.jobs[L.windows[slot].job];
+         base = nfc_lane_dark_jump(cc, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, startPos + base,
+                                   flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - startPos;
+      }
+
       if (__any(!stopped) == 0)
          break;
 
-      if (L.uniformStride == 2)
-         nfc_stage_tile<2>(L, block, base, lane, tile);
-      else
-         nfc_stage_tile<1>(L, block, base, lane, tile);
+      nfc_stage_lanes(L, stopped ? nullptr : L.works[slot].data + (uint64_t)base * L.uniformStride * 4u, stopped ? 0u : mineCount - base, lane, tile);
 
       __syncthreads();
 
@@ -933,7 +991,9 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
                nfc_step_as<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
          }
 
-         consumed = base + n;
+         base += n;
+         consumed = base;
+         stepped += n;
       }
 
       __syncthreads();
@@ -944,15 +1004,19 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
       L.windows[slot].retired = handed ? 2u : (consumed < mineCount ? 1u : 0u);
+
+      atomicAdd(L.laneStats, (stepped + TILE - 1) / TILE);
+      atomicMax(L.laneStats + 1, (stepped + TILE - 1) / TILE);
+      atomicAdd(L.laneStats + 2, 1u);
    }
 }
 
 /* one lane per job, warm-up as a window: regenerates the state (rings included) of a job's last lane in the job's own
  * lane slot once the chain is settled (the persistent waves below do not keep a finished lane's rings) */
-__global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+__global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
-   nfc_window_body<false>(cfgPtr, L, tile);
+   nfc_window_body<false>(cfgPtr, L, A, tile);
 }
 
 /* The windowed decode of the speculative lanes: persistent waves that refill their lanes. A wave keeps 64 windows in
@@ -993,7 +1057,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
    __builtin_memset(&s, 0, sizeof(s));
 
    bool active = false;
-   uint32_t w = 0, consumed = 0, mineCount = 0;
+   uint32_t w = 0, consumed = 0, mineCount = 0, stepped = 0;
    uint32_t startPos = 0, verifyPos = 0xFFFFFFFFu, succ = 0, succEnd = 0;
    const uint8_t *data = nullptr;
    const uint32_t *flags = nullptr;
@@ -1030,6 +1094,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
             mineCount = work.count;
             flags = work.tiles;
             consumed = 0;
+            stepped = 0;
             active = mineCount != 0;
 
             mem.cold = L.cold + w;
@@ -1093,52 +1158,23 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
                L.windows[w].stop = startPos + consumed;
                L.windows[w].retired = how;
                active = false;
+
+               atomicAdd(L.laneStats, (stepped + TILE - 1) / TILE);
+               atomicMax(L.laneStats + 1, (stepped + TILE - 1) / TILE);
+               atomicAdd(L.laneStats + 2, 1u);
             }
+         }
+
+         /* dark signal ahead: jump */
+         if (active && consumed >= warm && (flags[consumed / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT) >= NFC_DARK_JUMP)
+         {
+            const NfcScanJob &job = A.jobs[L.windows[w].job];
+            consumed = nfc_lane_dark_jump(cc, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, startPos + consumed,
+                                          flags[consumed / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - startPos;
          }
 
          /* stage: row r = the next 64 samples of lane r's window */
-         {
-            const uint32_t left = active ? mineCount - consumed : 0u;
-            const uint8_t *rowBase = active ? data + (uint64_t)consumed * L.uniformStride * 4u : (const uint8_t *)L.rings;
-
-#pragma clang loop unroll(disable)
-            for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_STAGE_ROWS)
-            {
-               float re[NFC_STAGE_ROWS], im[NFC_STAGE_ROWS];
-               uint32_t count[NFC_STAGE_ROWS];
-
-#pragma unroll
-               for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
-               {
-                  const int q = (int)(r0 + j);
-                  const uint64_t p = ((uint64_t)(uint32_t)__shfl((int)((uint64_t)rowBase >> 32), q, 64) << 32) |
-                                     (uint32_t)__shfl((int)(uint32_t)(uint64_t)rowBase, q, 64);
-                  const uint32_t n = (uint32_t)__shfl((int)left, q, 64);
-                  const uint32_t at = n ? (lane < n ? lane : n - 1u) : 0u;
-
-                  count[j] = n;
-
-                  if (L.uniformStride == 2)
-                  {
-                     const float2 iq = reinterpret_cast<const float2 *>(p)[at];
-                     re[j] = iq.x;
-                     im[j] = iq.y;
-                  }
-                  else
-                  {
-                     re[j] = reinterpret_cast<const float *>(p)[at];
-                     im[j] = 0.0f;
-                  }
-               }
-
-#pragma unroll
-               for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
-               {
-                  const float v = L.uniformStride == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
-                  tile[(r0 + j) * TILE_PITCH + lane] = lane < count[j] ? v : 0.0f;
-               }
-            }
-         }
+         nfc_stage_lanes(L, active ? data + (uint64_t)consumed * L.uniformStride * 4u : nullptr, active ? mineCount - consumed : 0u, lane, tile);
 
          __syncthreads();
 
@@ -1178,6 +1214,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
             }
 
             consumed += n;
+            stepped += n;
          }
 
          __syncthreads();
@@ -1187,10 +1224,10 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
    }
 }
 
-__global__ __launch_bounds__(64) void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L)
+__global__ __launch_bounds__(64) void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
-   nfc_window_body<true>(cfgPtr, L, tile);
+   nfc_window_body<true>(cfgPtr, L, A, tile);
 }
 
 /* once the chain is settled: jobs whose last lane is a speculative window get that window set up again in their own
@@ -1251,6 +1288,10 @@ __global__ __launch_bounds__(64) void nfc_chain_kernel(NfcScanArgs A, NfcLaunch 
    NfcScanJob job = A.jobs[j];
 
    if (job.status & NFC_JOB_INVALID)
+      return;
+
+   /* settled in an earlier pass: none of its lanes has run since */
+   if (job.passes > 0 && !(job.status & NFC_JOB_RERUN))
       return;
 
    if (nfc_chain_follow(job, j, A.windows, lanes.states, lanes.cold, maxPasses))

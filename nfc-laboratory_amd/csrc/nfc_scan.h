@@ -45,6 +45,9 @@
 #define NFC_TILE_REWALKED 0x40u /* the scanned envelope was wrong here (seam did not verify) and has been walked again */
 #define NFC_TILE_BUSY 0x3Fu
 #define NFC_TILE_RETIRE_OK 0x100u /* set by the window builder: no busy tile for at least NFC_WINDOW_GAP tiles from here */
+#define NFC_TILE_DARK 0x200u      /* every sample below the power threshold and no carrier event: the decoder only runs its front end */
+#define NFC_TILE_DARK_RUN_SHIFT 16 /* bits 16..31: number of dark tiles in a row from this one on (saturating) */
+#define NFC_DARK_JUMP 24u         /* dark tiles ahead that make a searching lane jump (it lands NFC_SCAN_POINT samples before they end) */
 
 #define NFC_WINDOW_GAP 16u        /* quiet tiles that separate two windows (1024 samples) */
 #define NFC_WINDOW_WARM_FRONT 512u /* samples of front end only at the start of a window lane: refills the sample history */
@@ -71,6 +74,7 @@ struct NfcScanTile
    float xmin, xmax; /* raw signal */
    float fmin;       /* DC-removed signal */
    float envmin;     /* envelope */
+   float envmax;
    uint32_t bits;    /* NFC_TILE_UNARMED (young decoder) | NFC_TILE_CARRIER | NFC_TILE_OFFGRID seen by the walk */
 };
 

@@ -53,7 +53,7 @@ struct NfcScanLane
    uint32_t zone;
    uint32_t edgeSynced; /* the edge-peak tracker has been reset since the walk began: its peak is the true one */
    uint32_t edgeKnown;  /* ... and it has set a time since: fe.edgeTime is the true one */
-   float xmin, xmax, envmin, fmin; /* of the tile being walked */
+   float xmin, xmax, envmin, envmax, fmin; /* of the tile being walked */
    uint32_t bits;
 };
 
@@ -67,6 +67,7 @@ NFC_DEV void nfc_scan_tile_reset(NfcScanLane &w)
    w.xmin = NFC_SCAN_BIG;
    w.xmax = -NFC_SCAN_BIG;
    w.envmin = NFC_SCAN_BIG;
+   w.envmax = -NFC_SCAN_BIG;
    w.fmin = NFC_SCAN_BIG;
    w.bits = 0;
 }
@@ -148,6 +149,7 @@ NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
    w.xmin = x < w.xmin ? x : w.xmin;
    w.xmax = x > w.xmax ? x : w.xmax;
    w.envmin = w.fe.env < w.envmin ? w.fe.env : w.envmin;
+   w.envmax = w.fe.env > w.envmax ? w.fe.env : w.envmax;
    w.fmin = now.filt < w.fmin ? now.filt : w.fmin;
 
    /* on the int16 grid of the captures (k / 32768, |k| small enough for every box sum to stay exact)? */
@@ -184,6 +186,7 @@ NFC_DEV void nfc_scan_tile_end(NfcScanLane &w, NfcScanTile &out)
    out.xmax = w.xmax;
    out.fmin = w.fmin;
    out.envmin = w.envmin;
+   out.envmax = w.envmax;
    out.bits = w.bits;
    nfc_scan_tile_reset(w);
 }
@@ -219,6 +222,10 @@ NFC_DEV uint32_t nfc_tile_flags(const NfcConfig &c, const NfcScanParams &sp, con
 
    if (!(t[i].envmin >= c.powerThreshold))
       flags |= NFC_TILE_UNARMED;
+
+   /* dark: the detector bank is not stepped on any sample of the tile and the carrier detector has nothing to do */
+   if (t[i].envmax < c.powerThreshold && !(t[i].bits & (NFC_TILE_CARRIER | NFC_TILE_OFFGRID)))
+      flags |= NFC_TILE_DARK;
 
    return flags;
 }
@@ -350,9 +357,13 @@ NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uin
    uint32_t *t = flags + job.firstTile;
 
    uint32_t quietAhead = 0;
+   uint32_t darkAhead = 0;
 
    for (uint32_t i = nTiles; i-- > 0;)
    {
+      darkAhead = (t[i] & NFC_TILE_DARK) ? (darkAhead < 0xFFFFu ? darkAhead + 1u : darkAhead) : 0u;
+      t[i] = (t[i] & 0xFFFFu) | (darkAhead << NFC_TILE_DARK_RUN_SHIFT);
+
       if (t[i] & NFC_TILE_BUSY)
          quietAhead = 0;
       else if (quietAhead < NFC_WINDOW_GAP)
@@ -404,7 +415,7 @@ NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uin
 
       /* where lanes cannot retire (busy signal, or not enough quiet signal ahead) a new lane starts every
        * NFC_WINDOW_CUT samples: whoever is running there hands over to it if their states agree (nfc_lane_handover) */
-      if (!(t[i] & NFC_TILE_RETIRE_OK) && act >= lastAct + NFC_WINDOW_CUT && act >= warm + NFC_SCAN_POINT &&
+      if (!(t[i] & (NFC_TILE_RETIRE_OK | NFC_TILE_DARK)) && act >= lastAct + NFC_WINDOW_CUT && act >= warm + NFC_SCAN_POINT &&
           act + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= job.count)
       {
          put((act - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, act);
@@ -745,6 +756,47 @@ NFC_DEV bool nfc_lane_handover(NfcWindow *windows, NfcWindow &me, uint32_t &succ
    me.stopDigest[0] = h[0];
    me.stopDigest[1] = h[1];
    return true;
+}
+
+/* A searching lane at tile boundary `pos` with `run` dark tiles ahead: through them the decoder does nothing but its front
+ * end (no detector is stepped, the carrier detector has nothing to do: NFC_TILE_DARK), and the front end has been
+ * scanned. The lane lands NFC_SCAN_POINT samples (rounded up to a stored point) before the dark tiles end, with the
+ * scanned front end; detector records, running sums and correlation rings stay as they are (the reference's are frozen
+ * too), the ring positions move on by the samples skipped, and the samples left before the dark ends refill the
+ * history rings. Returns the sample the lane continues at (== pos: no jump). */
+NFC_DEV uint32_t nfc_lane_dark_jump(const NfcConfig &c, const NfcScanJob &job, const NfcScanPoint *points, const uint32_t *chunkEdge, uint32_t chunkSamples,
+                                    uint32_t clockBase, uint32_t pos, uint32_t run, NfcStreamState &s, const NfcStreamCold &cold)
+{
+   if (s.lockTech || s.unlock || run < NFC_DARK_JUMP)
+      return pos;
+
+   const uint32_t land = (pos + run * NFC_SCAN_TILE - NFC_SCAN_POINT) / NFC_SCAN_POINT * NFC_SCAN_POINT;
+
+   if (land <= pos + NFC_SCAN_POINT || land >= job.count)
+      return pos;
+
+   const NfcScanPoint &p = points[job.firstPoint + land / NFC_SCAN_POINT];
+   const uint32_t tracked = (p.zone & NFC_ZONE_EDGE_KNOWN) ? p.edgeTime : chunkEdge[job.firstChunk + land / chunkSamples];
+   const uint32_t skipped = land - pos;
+
+   s.clock = clockBase + land;
+   s.pulseFilter = p.pulseFilter;
+   s.env = p.env;
+   s.n1 = p.n1;
+   s.mdev = p.mdev;
+   s.avg = p.avg;
+   s.edgePeak = p.edgePeak;
+   s.edgeTime = (cold.emitValid && (int32_t)(tracked - cold.emitClock) <= 0) ? 0u : tracked;
+
+   s.posA[0] = (s.posA[0] + skipped) % c.a[0].p1;
+   s.posA[1] = (s.posA[1] + skipped) % c.a[1].p1;
+   s.posA[2] = (s.posA[2] + skipped) % c.a[2].p1;
+   s.posF[0] = (s.posF[0] + skipped) % c.f[1].p1;
+   s.posF[1] = (s.posF[1] + skipped) % c.f[2].p1;
+   s.posV1 = (s.posV1 + skipped) % c.v.p1;
+   s.posV0 = (s.posV0 + skipped) % c.v.p0;
+
+   return land;
 }
 
 /* ------------------------------------------------------------------------------------------ */

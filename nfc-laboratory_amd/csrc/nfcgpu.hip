@@ -38,9 +38,9 @@ __global__ void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScan
 __global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint32_t pass);
 __global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass);
 __global__ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
-__global__ void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
 __global__ void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes);
-__global__ void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L);
+__global__ void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
 __global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses);
 __global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
 
@@ -728,6 +728,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    lanes.works = (const NfcWork *)ctx->wWorks.ptr;
    lanes.windows = (NfcWindow *)ctx->wWindows.ptr;
    lanes.jobs = (const NfcScanJob *)ctx->wJobs.ptr;
+   lanes.laneStats = counters + 4;
    lanes.uniformStride = stride;
 
    /* lanes */
@@ -750,7 +751,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       const uint32_t blocks = (firstSlot % NFC_LANES + slotCount + NFC_LANES - 1) / NFC_LANES;
 
-      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, L);
+      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
       return NFCGPU_OK;
@@ -807,6 +808,16 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       uint32_t again = 0;
       HIP_TRY(ctx, hipMemcpyAsync(&again, counters + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+      if (std::getenv("NFCGPU_WINDOW_DEBUG"))
+      {
+         uint32_t ls[3] = {0, 0, 0};
+         HIP_TRY(ctx, hipMemcpy(ls, counters + 4, 12, hipMemcpyDeviceToHost));
+         HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, 12, ctx->stream));
+         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+         std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled\n", pass, ls[2],
+                      (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again);
+      }
 
       ctx->stats.window_passes++;
       pass++;

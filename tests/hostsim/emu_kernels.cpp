@@ -305,15 +305,15 @@ void copy_lane(const NfcLaunch &from, uint32_t a, const NfcLaunch &to, uint32_t 
 }
 
 /* one lane: record slot `slot` (state, cold, work, window), ring / frame-assembly storage of lane slot `storage` */
-void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32_t slot, uint32_t storage);
+void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, bool carry, uint32_t slot, uint32_t storage);
 
-void window_decode(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry)
+void window_decode(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, bool carry)
 {
    for (uint32_t slot = L.firstSlot; slot < L.firstSlot + L.slotCount; slot++)
-      window_lane(cfgPtr, L, carry, slot, slot);
+      window_lane(cfgPtr, L, A, carry, slot, slot);
 }
 
-void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32_t slot, uint32_t storage)
+void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, bool carry, uint32_t slot, uint32_t storage)
 {
    {
       const uint32_t mineCount = L.works[slot].count;
@@ -342,6 +342,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
 
       const uint32_t warm = L.warmFront + L.warmCorr;
       uint32_t consumed = 0;
+      uint32_t stepped = 0;
       uint32_t handed = 0;
 
       NfcWindow &me = L.windows[slot];
@@ -351,7 +352,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
       if (!carry && (slot < job.firstWindow || slot >= succEnd))
          succ = succEnd;
 
-      for (uint32_t base = 0; base < mineCount; base += NFC_SCAN_TILE)
+      for (uint32_t base = 0; base < mineCount;)
       {
          auto dump = [&](const char *what) {
             if (!std::getenv("NFC_EMU_DEBUG4"))
@@ -378,6 +379,16 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
              s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
             break;
 
+         if (std::getenv("NFC_EMU_DEBUG5") && base >= warm && base > 0 && base > 60000)
+         {
+            uint32_t k = succ;
+            while (k < succEnd && L.windows[k].verify < me.start + base)
+               k++;
+            if (k < succEnd && L.windows[k].verify == me.start + base && !nfc_lane_comparable(s, *mem.cold))
+               std::fprintf(stderr, "[emu] lane %u (start %u) at %u (after %u steps) not comparable: lock %x unlock %x bank %d run %u env %g\n", slot, me.start,
+                            me.start + base, base, s.lockTech, s.unlock, (int)(s.bankClock == s.clock), (uint32_t)(s.clock - mem.cold->bankRun), s.env);
+         }
+
          if (base >= warm && base > 0 && nfc_lane_handover(L.windows, me, succ, succEnd, me.start + base, s, *mem.cold))
          {
             dump("handover");
@@ -399,6 +410,10 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
             }
          }
 
+         if (base >= warm && (flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT) >= NFC_DARK_JUMP)
+            base = nfc_lane_dark_jump(*cfgPtr, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, me.start + base,
+                                      flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - me.start;
+
          const uint32_t left = mineCount - base;
          const uint32_t n = left < NFC_SCAN_TILE ? left : NFC_SCAN_TILE;
          const bool exact = carry && exact_span(s.clock, n);
@@ -418,11 +433,18 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, bool carry, uint32
          }
 
          consumed = base + n;
+         base += n;
+         stepped += n;
       }
 
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
       L.windows[slot].retired = handed ? 2u : (consumed < mineCount ? 1u : 0u);
+
+      emu_add(L.laneStats, (stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE);
+      if ((stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE > L.laneStats[1])
+         L.laneStats[1] = (stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+      emu_add(L.laneStats + 2, 1u);
    }
 }
 
@@ -658,12 +680,12 @@ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcSca
    std::vector<uint32_t> order(A.runList, A.runList + *A.runCount);
    std::sort(order.begin(), order.end());
    for (uint32_t i = (uint32_t)order.size(); i-- > 0;)
-      window_lane(cfgPtr, L, false, order[i], A.firstWindowSlot + (i % NFC_LANES));
+      window_lane(cfgPtr, L, A, false, order[i], A.firstWindowSlot + (i % NFC_LANES));
    *A.runNext = *A.runCount;
 }
 
-void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) { window_decode(cfgPtr, L, false); }
-void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L) { window_decode(cfgPtr, L, true); }
+void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A) { window_decode(cfgPtr, L, A, false); }
+void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A) { window_decode(cfgPtr, L, A, true); }
 
 void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes)
 {
@@ -711,6 +733,9 @@ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses)
       NfcScanJob job = A.jobs[j];
 
       if (job.status & NFC_JOB_INVALID)
+         continue;
+
+      if (job.passes > 0 && !(job.status & NFC_JOB_RERUN))
          continue;
 
       const bool again = nfc_chain_follow(job, j, A.windows, lanes.states, lanes.cold, maxPasses);
