@@ -863,21 +863,23 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
             if (handed && nfc_carry_same(want, x.carry, false, x.tracked))
             {
                /* nothing it could assume differently would make the two lanes agree at that sample (both were busy
-                * with the same thing from different beginnings): the lane before has to go on past it */
+                * with the same thing from different beginnings): the lane before has to go on past it. The walk goes
+                * on from this lane all the same, on the guess that what it leaves does not depend on the difference:
+                * whatever else is wrong further down is then put right in the same pass */
                NfcWindow &before = windows[prev];
                before.noHand = lane;
                before.want = before.carry;
                before.rerun = 1;
                again = true;
-               job.finalLane = prev;
-               break;
             }
-
-            /* again, and predict what it will leave */
-            nfc_carry_predict(left, x.carry, want);
-            x.want = want;
-            x.rerun = 1;
-            again = true;
+            else
+            {
+               /* again, and predict what it will leave */
+               nfc_carry_predict(left, x.carry, want);
+               x.want = want;
+               x.rerun = 1;
+               again = true;
+            }
          }
       }
 
@@ -901,7 +903,9 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
             x.want = x.carry;
             x.rerun = 1;
             again = true;
-            break; /* nothing after this lane is known */
+
+            if (y.pubState != 1u)
+               break; /* that lane never reached a state to take over in: nothing after this lane is known */
          }
 
          prev = lane;
