@@ -124,6 +124,7 @@ typedef struct nfcgpu_stats
    uint64_t window_passes;
    uint64_t windowed_streams;
    uint64_t fallback_streams;
+   uint64_t scan_repairs; /* scan chunks walked a second time because their warm-up had not reached the true state */
 } nfcgpu_stats;
 
 void nfcgpu_default_params(nfcgpu_params *params);

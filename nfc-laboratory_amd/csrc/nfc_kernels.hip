@@ -480,37 +480,55 @@ __device__ __forceinline__ void nfc_fixed_runtime_config(const NfcConfig *cfgPtr
    }
 }
 
-/* The scan kernel: one lane per chunk of a stream, 64 chunks per wave. Per pass the wave fetches 64 consecutive samples
- * of each of its 64 chunks with one coalesced row load each (512 B of IQ / 256 B of magnitude), converts to magnitude
- * and parks the tile transposed in LDS; every lane then walks its own row through the exact front end and the tile
- * tests. Nothing is written per sample: a 4-byte flag word per 64 samples, a 32-byte front-end state per 512.
+/* The scan kernel: one lane per chunk of a stream, 64 chunks per wave. Per step the wave fetches 64 consecutive samples
+ * of each of its 64 chunks with one coalesced row load each (512 B of IQ / 256 B of magnitude; row descriptors are
+ * parked in LDS once and read back through the scalar unit), converts to magnitude and parks the tile transposed in LDS;
+ * every lane then walks its own row through the exact front end and the tile records. Nothing is written per sample:
+ * a 24-byte record per 64 samples, a 32-byte front-end state per 512.
  * Bound: HBM read (8 B per IQ sample, plus the warm-up overlap warmSamples / chunkSamples). */
 #define NFC_SCAN_ROWS 16
+#define NFC_SCAN_PITCH (NFC_SCAN_TILE + 1)
 
-__global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
+/* S = floats per sample (2 IQ, 1 magnitude) */
+template <uint32_t S>
+__device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgPtr, const NfcScanArgs &A, float *tile, uint32_t *rows)
 {
-   __shared__ float tile[NFC_LANES * (NFC_SCAN_TILE + 1)];
-
    const uint32_t lane = threadIdx.x;
-   const uint32_t g = blockIdx.x * NFC_LANES + lane;
-   const bool mine = g < A.nChunks;
+   const uint32_t listed = blockIdx.x * NFC_LANES + lane;
+   const bool mine = listed < A.nChunks;
 
    NfcScanChunk ch;
    ch.job = 0;
    ch.index = 0;
    if (mine)
-      ch = A.chunks[g];
+      ch = A.chunks[listed];
+
+   /* a chunk on the repair list is walked from the true end state of the chunk before, without warm-up */
+   const bool repair = (ch.index & NFC_CHUNK_REPAIR) != 0;
+   ch.index &= ~NFC_CHUNK_REPAIR;
 
    const NfcScanJob *job = A.jobs + ch.job;
+   const uint32_t g = job->firstChunk + ch.index; /* seam / chunk record */
 
-   const uint8_t *data = mine ? job->data : nullptr;
    const uint32_t count = mine ? job->count : 0u;
    const uint32_t L = A.params.chunkSamples, WU = A.params.warmSamples;
 
    const uint32_t start = ch.index * L;
    const uint32_t end = mine ? (start + L < count ? start + L : count) : 0u;
-   const uint32_t walkFrom = ch.index == 0 ? 0u : start - WU;
-   const int32_t origin = (int32_t)start - (int32_t)WU; /* position of this lane's row at relative step 0 */
+   const uint32_t walkFrom = (ch.index == 0 || repair) ? start : start - WU;
+   const int32_t origin = (int32_t)start - (int32_t)WU; /* stream position of this lane's row at step 0 (may be negative) */
+   const uint32_t reseedAt = walkFrom + WU / 3 / NFC_SCAN_TILE * NFC_SCAN_TILE;
+
+   /* row descriptor: where the row is at step 0, and the steps' sample range the walk covers: [fromRel, endRel) */
+   {
+      const uint64_t base = (uint64_t)(mine ? job->data : (const uint8_t *)A.tileStats) + (int64_t)origin * (int64_t)(S * 4u);
+      rows[lane * 4 + 0] = (uint32_t)base;
+      rows[lane * 4 + 1] = (uint32_t)(base >> 32);
+      rows[lane * 4 + 2] = walkFrom - (uint32_t)origin; /* origin <= walkFrom */
+      rows[lane * 4 + 3] = mine ? end - (uint32_t)origin : 0u;
+   }
+
+   __syncthreads();
 
    NfcConfig cc;
    nfc_fixed_runtime_config(cfgPtr, cc);
@@ -526,14 +544,17 @@ __global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restric
    }
 
    NfcScanLane w;
+   __builtin_memset(&w, 0, sizeof(w));
    bool begun = false;
 
    NfcScanSeam seam;
    __builtin_memset(&seam, 0, sizeof(seam));
 
+   const uint32_t myFrom = walkFrom - (uint32_t)origin, myEnd = mine ? end - (uint32_t)origin : 0u;
+
    for (uint32_t rel = 0; rel < WU + L; rel += NFC_SCAN_TILE)
    {
-      /* stage: row q = the 64 samples of lane q's chunk at this step */
+      /* ---- stage: tile row q = the 64 samples of lane q's chunk at this step ---- */
 #pragma clang loop unroll(disable)
       for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_SCAN_ROWS)
       {
@@ -543,83 +564,86 @@ __global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restric
          for (uint32_t j = 0; j < NFC_SCAN_ROWS; j++)
          {
             const uint32_t q = r0 + j;
-            const uint64_t rowData = ((uint64_t)(uint32_t)__shfl((int)((uint64_t)data >> 32), (int)q, 64) << 32) |
-                                     (uint32_t)__shfl((int)(uint32_t)(uint64_t)data, (int)q, 64);
-            const int32_t rowPos = __shfl(origin, (int)q, 64) + (int32_t)rel;
-            const uint32_t rowFrom = (uint32_t)__shfl((int)walkFrom, (int)q, 64);
-            const uint32_t rowEnd = (uint32_t)__shfl((int)end, (int)q, 64);
 
-            const int32_t at = rowPos + (int32_t)lane;
-            const bool ok = rowPos + (int32_t)NFC_SCAN_TILE > (int32_t)rowFrom && at >= 0 && (uint32_t)at < rowEnd;
+            /* the descriptor is the same for every lane: through the scalar unit */
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(rows[q * 4 + 0]);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane(rows[q * 4 + 1]);
+            const uint32_t fromRel = __builtin_amdgcn_readfirstlane(rows[q * 4 + 2]);
+            const uint32_t endRel = __builtin_amdgcn_readfirstlane(rows[q * 4 + 3]);
 
             re[j] = 0.0f;
             im[j] = 0.0f;
 
-            if (ok)
+            /* uniform: does the row have anything at this step? */
+            if (rel + NFC_SCAN_TILE > fromRel && rel < endRel)
             {
-               if (A.stride == 2)
+               const uint8_t *p = (const uint8_t *)(((uint64_t)hi << 32) | lo);
+               uint32_t at = rel + lane;
+               at = at < fromRel ? fromRel : at;
+               at = at >= endRel ? endRel - 1u : at;
+
+               if (S == 2)
                {
-                  const float2 iq = reinterpret_cast<const float2 *>(rowData)[at];
+                  const float2 iq = reinterpret_cast<const float2 *>(p)[at];
                   re[j] = iq.x;
                   im[j] = iq.y;
                }
                else
-                  re[j] = reinterpret_cast<const float *>(rowData)[at];
+                  re[j] = reinterpret_cast<const float *>(p)[at];
             }
          }
 
 #pragma unroll
          for (uint32_t j = 0; j < NFC_SCAN_ROWS; j++)
-            tile[(r0 + j) * (NFC_SCAN_TILE + 1) + lane] = A.stride == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
+            tile[(r0 + j) * NFC_SCAN_PITCH + lane] = S == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
       }
 
       __syncthreads();
 
-      const int32_t pos = origin + (int32_t)rel;
-
-      if (mine && pos + (int32_t)NFC_SCAN_TILE > (int32_t)walkFrom && pos < (int32_t)end)
+      /* ---- walk: this lane's 64 samples ---- */
+      if (rel + NFC_SCAN_TILE > myFrom && rel < myEnd)
       {
-         for (uint32_t k = 0; k < NFC_SCAN_TILE; k++)
+         const uint32_t pos = (uint32_t)(origin + (int32_t)rel); /* stream position of the tile's first sample (>= 0 here) */
+         const uint32_t n = myEnd - rel < NFC_SCAN_TILE ? myEnd - rel : NFC_SCAN_TILE;
+         const float *row = tile + lane * NFC_SCAN_PITCH;
+
+         if (!begun)
          {
-            const int32_t sp = pos + (int32_t)k;
-
-            if (sp < (int32_t)walkFrom || sp >= (int32_t)end)
-               continue;
-
-            const float x = tile[lane * (NFC_SCAN_TILE + 1) + k];
-
-            if (!begun)
+            if (repair)
+               nfc_scan_resume(w, A.seams[g].start, A.seams[g].start.edgeTime, clockBase + pos);
+            else
             {
-               /* guess for the envelope and the average: mean of what this tile holds of the walk */
+               /* guess for the envelope and the average: mean of the first tile of the walk */
                float first = 0.0f;
-               uint32_t span = 0;
-               for (uint32_t m = k; m < NFC_SCAN_TILE && pos + (int32_t)m < (int32_t)end; m++, span++)
-                  first += tile[lane * (NFC_SCAN_TILE + 1) + m];
-               first = first / (float)span;
+               for (uint32_t k = 0; k < n; k++)
+                  first += row[k];
+               first = first / (float)n;
 
-               nfc_scan_begin(w, from, clockBase + (uint32_t)sp, first);
-               begun = true;
+               nfc_scan_begin(w, from, clockBase + pos, first);
             }
-
-            if (ch.index != 0 && (uint32_t)sp == walkFrom + WU / 3)
-               nfc_scan_reseed(w);
-
-            if ((uint32_t)sp == start)
-               nfc_scan_point(w, seam.start);
-
-            if ((uint32_t)sp >= start && ((uint32_t)sp % NFC_SCAN_POINT) == 0)
-               nfc_scan_point(w, A.points[job->firstPoint + (uint32_t)sp / NFC_SCAN_POINT]);
-
-            nfc_scan_sample(cc, w, x);
-
-            if (((uint32_t)sp % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || (uint32_t)sp == end - 1)
-            {
-               NfcScanTile stat;
-               nfc_scan_tile_end(w, stat);
-               if ((uint32_t)sp >= start)
-                  A.tileStats[job->firstTile + (uint32_t)sp / NFC_SCAN_TILE] = stat;
-            }
+            begun = true;
          }
+
+         if (ch.index != 0 && !repair && pos == reseedAt)
+            nfc_scan_reseed(w);
+
+         if (pos == start)
+            nfc_scan_point(w, seam.start);
+
+         if (pos >= start && (pos % NFC_SCAN_POINT) == 0)
+            nfc_scan_point(w, A.points[job->firstPoint + pos / NFC_SCAN_POINT]);
+
+         for (uint32_t k = 0; k < n; k++)
+            nfc_scan_sample(cc, w, row[k]);
+
+         NfcScanTile stat;
+         nfc_scan_tile_end(w, stat);
+
+         if (repair)
+            stat.bits |= NFC_TILE_REWALKED;
+
+         if (pos >= start)
+            A.tileStats[job->firstTile + pos / NFC_SCAN_TILE] = stat;
       }
 
       __syncthreads();
@@ -629,12 +653,25 @@ __global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restric
    {
       if (begun)
          nfc_scan_point(w, seam.end);
+      if (repair)
+         seam.start = A.seams[g].start; /* as the seam check set it */
       A.seams[g] = seam;
    }
 }
 
+__global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
+{
+   __shared__ float tile[NFC_LANES * NFC_SCAN_PITCH];
+   __shared__ uint32_t rows[NFC_LANES * 4];
+
+   if (A.stride == 2)
+      nfc_scan_body<2>(cfgPtr, A, tile, rows);
+   else
+      nfc_scan_body<1>(cfgPtr, A, tile, rows);
+}
+
 /* one thread per job: seams, then windows (the two are cheap and sequential per stream) */
-__global__ __launch_bounds__(64) void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams)
+__global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
 {
    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -643,26 +680,59 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(const NfcConfig *__rest
 
    NfcScanJob job = A.jobs[j];
 
-   NfcConfig cc;
-   nfc_fixed_runtime_config(cfgPtr, cc);
-
-   if (checkSeams)
+   if (first)
    {
       job.status = 0;
       job.passes = 0;
-      nfc_seams_check(cc, A.params, job, A.seams, A.points, A.tileStats, A.stride, A.chunkEdge, A.states[job.slot].edgeTime, A.states[job.slot].clock);
    }
+
+   nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
+
+   A.jobs[j] = job;
+}
+
+/* one thread per tile: the tile tests */
+__global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t nTilesTotal)
+{
+   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (i >= nTilesTotal)
+      return;
+
+   /* the job this tile belongs to: last job whose first tile is <= i */
+   uint32_t lo = 0, hi = A.nJobs;
+   while (hi - lo > 1)
+   {
+      const uint32_t mid = (lo + hi) / 2;
+      if (A.jobs[mid].firstTile <= i)
+         lo = mid;
+      else
+         hi = mid;
+   }
+
+   NfcConfig cc;
+   nfc_fixed_runtime_config(cfgPtr, cc);
+
+   const uint32_t first = A.jobs[lo].firstTile;
+   const uint32_t flags = nfc_tile_flags(cc, A.params, A.tileStats + first, i - first);
+
+   A.tiles[i] = flags;
+
+   if (flags & NFC_TILE_OFFGRID)
+      atomicOr(&A.jobs[lo].status, NFC_JOB_OFFGRID);
+}
+
+/* one thread per job: retire / dark marks and the windows */
+__global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
+{
+   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (j >= A.nJobs)
+      return;
+
+   NfcScanJob job = A.jobs[j];
 
    job.status &= ~NFC_JOB_OVERFLOW;
-
-   const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-   for (uint32_t i = 0; i < nTiles; i++)
-   {
-      const uint32_t flags = nfc_tile_flags(cc, A.params, A.tileStats + job.firstTile, i);
-      A.tiles[job.firstTile + i] = flags;
-      if (flags & NFC_TILE_OFFGRID)
-         job.status |= NFC_JOB_OFFGRID;
-   }
 
    /* count, reserve, fill: the speculative windows of a job are contiguous and ordered */
    const uint32_t need = nfc_windows_build(job, j, A.tiles, nullptr, 0);

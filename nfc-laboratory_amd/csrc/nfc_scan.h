@@ -113,8 +113,10 @@ struct NfcScanJob
 struct NfcScanChunk
 {
    uint32_t job;
-   uint32_t index; /* chunk number inside the job */
+   uint32_t index; /* chunk number inside the job; bit 31: walk it again from the true end state of the chunk before (no warm-up) */
 };
+
+#define NFC_CHUNK_REPAIR 0x80000000u
 
 /* state a window inherits from whatever ran before it on the stream, apart from the front end (scanned) and the
  * history / correlation rings (rebuilt by the warm-up): compared field by field by the chain kernel */

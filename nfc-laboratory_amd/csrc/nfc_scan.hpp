@@ -265,80 +265,44 @@ NFC_DEV void nfc_scan_resume(NfcScanLane &w, const NfcScanPoint &p, uint32_t edg
 }
 
 /* Seams of a job, chunks in order (one thread). A chunk whose walk did not start from the state the chunk before ends
- * with - the envelope tracker is not contractive, the other recurrences sometimes need longer than the warm-up - is
- * walked again from that state, sequentially, until the new walk meets the recorded one at a stored point (from there
- * on the record is the truth) or the chunk ends; points and tile records on the way are replaced. The result is exact
- * whatever the warm-up achieved; what the warm-up buys is that this happens rarely.
- * chunkEdge[k] = edge-tracker time that points of chunk k without a time of their own inherit. */
-NFC_DEV void nfc_seams_check(const NfcConfig &c, const NfcScanParams &sp, NfcScanJob &job, NfcScanSeam *seams, NfcScanPoint *points,
-                             NfcScanTile *tiles, uint32_t stride, uint32_t *chunkEdge, uint32_t startEdge, uint32_t startClock)
+ * with - the envelope tracker is not contractive, the other recurrences sometimes need longer than the warm-up - has to
+ * be walked again from that state: the first such chunk of the job is put on the repair list (the scan kernel walks the
+ * listed chunks again, all of them in parallel, and this check runs once more). The result is exact whatever the warm-up
+ * achieved; what the warm-up buys is that repairs are rare. Returns true when the job is waiting for a repair.
+ * chunkEdge[k] = edge-tracker time at the start of chunk k (points without a time of their own inherit it). */
+NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *seams, uint32_t *chunkEdge, uint32_t startEdge, NfcScanChunk *repairs,
+                             uint32_t *repairCount)
 {
    uint32_t edge = startEdge; /* true edge time at the start of the chunk at hand */
 
    for (uint32_t k = 0; k < job.chunks; k++)
    {
       NfcScanSeam &s = seams[job.firstChunk + k];
-      uint32_t inherit = edge;
 
       const bool sound = k == 0 || (nfc_point_same(s.start, seams[job.firstChunk + k - 1].end) &&
                                     (!(s.start.zone & NFC_ZONE_EDGE_KNOWN) || s.start.edgeTime == edge));
 
+      chunkEdge[job.firstChunk + k] = edge;
+
       if (!sound)
       {
-         const uint32_t from = k * sp.chunkSamples;
-         const uint32_t to = from + sp.chunkSamples < job.count ? from + sp.chunkSamples : job.count;
+         /* from the true state, edge time included */
+         s.start = seams[job.firstChunk + k - 1].end;
+         s.start.edgeTime = edge;
+         s.start.zone |= NFC_ZONE_EDGE_KNOWN | NFC_ZONE_EDGE_SYNCED;
 
-         NfcScanLane w;
-         nfc_scan_resume(w, seams[job.firstChunk + k - 1].end, edge, startClock + from);
-
-         bool met = false;
-
-         for (uint32_t i = from; i < to; i++)
-         {
-            if ((i % NFC_SCAN_POINT) == 0)
-            {
-               NfcScanPoint &p = points[job.firstPoint + i / NFC_SCAN_POINT];
-               NfcScanPoint mine;
-               nfc_scan_point(w, mine);
-
-               /* met: same recurrences, and the recorded walk's edge tracker is in step from here on */
-               if (i > from && nfc_point_same(p, mine) && (p.zone & NFC_ZONE_EDGE_SYNCED) &&
-                   (!(p.zone & NFC_ZONE_EDGE_KNOWN) || p.edgeTime == mine.edgeTime))
-               {
-                  met = true;
-                  inherit = mine.edgeTime;
-                  break;
-               }
-
-               p = mine;
-            }
-
-            nfc_scan_sample(c, w, NFC_SAMPLE_AT(job.data, stride, i));
-
-            if ((i % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || i == to - 1)
-            {
-               NfcScanTile stat;
-               nfc_scan_tile_end(w, stat);
-               stat.bits |= NFC_TILE_REWALKED;
-               tiles[job.firstTile + i / NFC_SCAN_TILE] = stat;
-            }
-         }
-
-         if (!met)
-         {
-            nfc_scan_point(w, s.end);
-            inherit = edge; /* every point of the chunk has been rewritten with its own time */
-         }
+         NfcScanChunk &r = repairs[NFC_ATOMIC_ADD(repairCount, 1u)];
+         r.job = jobIndex;
+         r.index = k | NFC_CHUNK_REPAIR;
+         return true;
       }
-
-      chunkEdge[job.firstChunk + k] = inherit;
 
       /* true edge time at the end of the chunk */
       if (s.end.zone & NFC_ZONE_EDGE_KNOWN)
          edge = s.end.edgeTime;
-      else
-         edge = inherit;
    }
+
+   return false;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -34,7 +34,9 @@ __global__ void nfc_demod_fixed_exact_kernel(const NfcConfig *__restrict__ cfgPt
 #include "nfc_config_fixed.inc"
 __global__ void nfc_init_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, uint32_t keepFrontEnd);
 __global__ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
-__global__ void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams);
+__global__ void nfc_seams_kernel(NfcScanArgs A, uint32_t first);
+__global__ void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t nTilesTotal);
+__global__ void nfc_windows_kernel(NfcScanArgs A);
 __global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint32_t pass);
 __global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass);
 __global__ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
@@ -129,7 +131,7 @@ struct nfcgpu_ctx
       void *ptr = nullptr;
       size_t bytes = 0;
    };
-   DevBuf wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
+   DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
@@ -603,7 +605,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
        (rc = grow(ctx, ctx->wPoints, sizeof(NfcScanPoint) * (size_t)points)) || (rc = grow(ctx, ctx->wSeams, sizeof(NfcScanSeam) * nChunks)) ||
        (rc = grow(ctx, ctx->wChunkEdge, 4 * (size_t)nChunks)) || (rc = grow(ctx, ctx->wTiles, 4 * (size_t)tiles)) ||
        (rc = grow(ctx, ctx->wTileStats, sizeof(NfcScanTile) * (size_t)tiles)) ||
-       (rc = grow(ctx, ctx->wCounters, 64)))
+       (rc = grow(ctx, ctx->wCounters, 64)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nJobs)))
       return rc;
 
    /* lanes: a first guess (one window per 8192 samples); the window kernel reports what it needs */
@@ -678,6 +680,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.runCount = counters + 2;
    A.runNext = counters + 3;
    A.runList = (uint32_t *)ctx->wRunList.ptr;
+   A.repairs = (NfcScanChunk *)ctx->wRepairs.ptr;
+   A.repairCount = counters + 7;
 
    const NfcConfig *dCfg = ctx->dConfigs + config;
 
@@ -692,9 +696,37 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    /* windows (again with more room when the guess was short) */
    uint32_t nWindows = 0;
 
+   /* seams: chunks that did not start from the true state are walked again, a round at a time */
+   for (uint32_t round = 0;; round++)
+   {
+      HIP_TRY(ctx, hipMemsetAsync(counters + 7, 0, 4, ctx->stream));
+      hipLaunchKernelGGL(nfc_seams_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, round == 0 ? 1u : 0u);
+      HIP_TRY(ctx, hipGetLastError());
+
+      uint32_t repairs = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(&repairs, counters + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+      if (!repairs)
+         break;
+
+      NfcScanArgs R = A;
+      R.chunks = A.repairs;
+      R.nChunks = repairs;
+
+      ProfiledLaunch pr {nullptr, nullptr};
+      record_span(ctx, ctx->timedScan, pr, true);
+      hipLaunchKernelGGL(nfc_scan_kernel, dim3((repairs + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
+      HIP_TRY(ctx, hipGetLastError());
+      record_span(ctx, ctx->timedScan, pr, false);
+      ctx->stats.scan_repairs += repairs;
+   }
+   hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
+   HIP_TRY(ctx, hipGetLastError());
+
    for (int attempt = 0; attempt < 2; attempt++)
    {
-      hipLaunchKernelGGL(nfc_windows_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, dCfg, A, attempt == 0 ? 1u : 0u);
+      hipLaunchKernelGGL(nfc_windows_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemcpyAsync(&nWindows, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1100,7 +1132,7 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    if (ctx->hStage)
       (void)hipHostFree(ctx->hStage);
 
-   for (nfcgpu_ctx::DevBuf *b: {&ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
+   for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
                                 &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl})
    {
       if (b->ptr)

@@ -85,6 +85,7 @@ class Stats(ctypes.Structure):
         ("window_passes", ctypes.c_uint64),
         ("windowed_streams", ctypes.c_uint64),
         ("fallback_streams", ctypes.c_uint64),
+        ("scan_repairs", ctypes.c_uint64),
     ]
 
 

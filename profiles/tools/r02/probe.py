@@ -19,9 +19,17 @@ T = K * L
 data = torch.empty((S, T, 2), dtype=torch.float32, device=dev)
 synth.fill_iq_torch(data, template_dev, first_stream=0, chunk_streams=max(1, min(1024, (1 << 26) // T)))
 if os.environ.get("PROBE_IDLE") == "1":
-    noise = (torch.arange(T, device=dev) * 2654435761 % 5).to(torch.float32) / 32768.0
-    data[:, :, 0] = 0.25 + noise[None, :]
-    data[:, :, 1] = 0.0
+    # unmodulated carrier with a few LSB of (non-periodic, per-stream) noise on the int16 grid
+    t = torch.arange(T, device=dev, dtype=torch.int64)
+    for s0 in range(0, S, 256):
+        s1 = min(S, s0 + 256)
+        sid = torch.arange(s0, s1, device=dev, dtype=torch.int64)[:, None]
+        h = (t[None, :] * 2654435761 + sid * 40503) & 0xFFFFFFFF
+        h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+        h = (h ^ (h >> 13)) * 3266489917 & 0xFFFFFFFF
+        h = h ^ (h >> 16)
+        data[s0:s1, :, 0] = 0.25 + ((h % 9) - 4).to(torch.float32) / 32768.0
+        data[s0:s1, :, 1] = 0.0
 sink_words = 64 << 20
 sink = torch.zeros(sink_words, dtype=torch.int32, device=dev)
 ctl = torch.zeros(4, dtype=torch.int32, device=dev)

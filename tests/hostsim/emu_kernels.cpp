@@ -454,13 +454,16 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 {
    const uint32_t L = A.params.chunkSamples, WU = A.params.warmSamples;
 
-   for (uint32_t g = 0; g < A.nChunks; g++)
+   for (uint32_t listed = 0; listed < A.nChunks; listed++)
    {
-      const NfcScanChunk ch = A.chunks[g];
+      NfcScanChunk ch = A.chunks[listed];
+      const bool repair = (ch.index & NFC_CHUNK_REPAIR) != 0;
+      ch.index &= ~NFC_CHUNK_REPAIR;
       const NfcScanJob *job = A.jobs + ch.job;
+      const uint32_t g = job->firstChunk + ch.index;
       const uint32_t start = ch.index * L;
       const uint32_t end = start + L < job->count ? start + L : job->count;
-      const uint32_t walkFrom = ch.index == 0 ? 0u : start - WU;
+      const uint32_t walkFrom = (ch.index == 0 || repair) ? start : start - WU;
       const NfcStreamState *st = A.states + job->slot;
 
       NfcScanLane w;
@@ -481,11 +484,14 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
                first += sample_of(job->data, A.stride, sp + k);
             first = first / (float)span;
 
-            nfc_scan_begin(w, ch.index == 0 ? st : nullptr, st->clock + sp, first);
+            if (repair)
+               nfc_scan_resume(w, A.seams[g].start, A.seams[g].start.edgeTime, st->clock + sp);
+            else
+               nfc_scan_begin(w, ch.index == 0 ? st : nullptr, st->clock + sp, first);
             begun = true;
          }
 
-         if (ch.index != 0 && sp == walkFrom + WU / 3)
+         if (ch.index != 0 && !repair && sp == walkFrom + WU / 3 / NFC_SCAN_TILE * NFC_SCAN_TILE)
             nfc_scan_reseed(w);
 
          if (sp == start)
@@ -500,6 +506,8 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
          {
             NfcScanTile stat;
             nfc_scan_tile_end(w, stat);
+            if (repair)
+               stat.bits |= NFC_TILE_REWALKED;
             if (sp >= start)
                A.tileStats[job->firstTile + sp / NFC_SCAN_TILE] = stat;
          }
@@ -507,25 +515,33 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 
       if (begun)
          nfc_scan_point(w, seam.end);
+      if (repair)
+         seam.start = A.seams[g].start;
       A.seams[g] = seam;
    }
 }
 
-void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t checkSeams)
+void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
 {
    for (uint32_t j = 0; j < A.nJobs; j++)
    {
       NfcScanJob job = A.jobs[j];
-
-      if (checkSeams)
+      if (first)
       {
          job.status = 0;
          job.passes = 0;
-         nfc_seams_check(*cfgPtr, A.params, job, A.seams, A.points, A.tileStats, A.stride, A.chunkEdge, A.states[job.slot].edgeTime, A.states[job.slot].clock);
       }
+      nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
+      A.jobs[j] = job;
+   }
+}
 
-      job.status &= ~NFC_JOB_OVERFLOW;
-
+void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t nTilesTotal)
+{
+   (void)nTilesTotal;
+   for (uint32_t j = 0; j < A.nJobs; j++)
+   {
+      NfcScanJob &job = A.jobs[j];
       const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
       uint32_t rewalked = 0;
       for (uint32_t i = 0; i < nTiles; i++)
@@ -537,7 +553,19 @@ void nfc_windows_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uin
          rewalked += (flags & NFC_TILE_REWALKED) ? 1 : 0;
       }
       if (std::getenv("NFC_EMU_DEBUG"))
-         std::fprintf(stderr, "[emu] job %u: %u of %u tiles had their envelope walked again\n", j, rewalked, nTiles);
+         std::fprintf(stderr, "[emu] job %u: %u of %u tiles had their front end walked again\n", j, rewalked, nTiles);
+   }
+}
+
+void nfc_windows_kernel(NfcScanArgs A)
+{
+   for (uint32_t j = 0; j < A.nJobs; j++)
+   {
+      NfcScanJob job = A.jobs[j];
+
+      job.status &= ~NFC_JOB_OVERFLOW;
+
+      const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
 
       const uint32_t need = nfc_windows_build(job, j, A.tiles, nullptr, 0);
       const uint32_t first = emu_add(A.windowCount, need);
