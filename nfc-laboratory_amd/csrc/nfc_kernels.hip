@@ -682,11 +682,17 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
 
    if (first)
    {
-      job.status = 0;
       job.passes = 0;
+
+      /* routing, from the tile tests on the unrepaired scan (an estimate is all it takes): where most of the signal is
+       * busy the lanes would be long and their hand-overs many; such a stream is decoded sequentially */
+      const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+      if ((uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
+         job.status |= NFC_JOB_DENSE;
    }
 
-   nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
+   if (!(job.status & NFC_JOB_INVALID))
+      nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
 
    A.jobs[j] = job;
 }
@@ -720,6 +726,9 @@ __global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restr
 
    if (flags & NFC_TILE_OFFGRID)
       atomicOr(&A.jobs[lo].status, NFC_JOB_OFFGRID);
+
+   if ((flags & NFC_TILE_BUSY) && !(flags & NFC_TILE_DARK))
+      atomicAdd(&A.jobs[lo].busyTiles, 1u);
 }
 
 /* one thread per job: retire / dark marks and the windows */
@@ -733,6 +742,13 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
    NfcScanJob job = A.jobs[j];
 
    job.status &= ~NFC_JOB_OVERFLOW;
+
+   if (job.status & NFC_JOB_INVALID)
+   {
+      job.windows = 0;
+      A.jobs[j] = job;
+      return;
+   }
 
    /* count, reserve, fill: the speculative windows of a job are contiguous and ordered */
    const uint32_t need = nfc_windows_build(job, j, A.tiles, nullptr, 0);

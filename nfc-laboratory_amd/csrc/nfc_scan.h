@@ -100,7 +100,7 @@ struct NfcScanJob
    uint32_t status;     /* NFC_JOB_* bits, written by the kernels */
    uint32_t finalLane;  /* virtual slot whose state is the stream's state after the submission (chain kernel) */
    uint32_t passes;
-   uint32_t reserved;
+   uint32_t busyTiles;  /* tiles kernel: tiles with something for the decoder to do */
 };
 
 #define NFC_JOB_OFFGRID 0x01u   /* samples off the int16 grid: sequential path */
@@ -108,7 +108,8 @@ struct NfcScanJob
 #define NFC_JOB_RERUN 0x04u     /* the chain kernel asked for another pass */
 #define NFC_JOB_GIVEUP 0x08u    /* too many passes: sequential path */
 #define NFC_JOB_OVERFLOW 0x10u  /* window table full: sequential path */
-#define NFC_JOB_INVALID (NFC_JOB_OFFGRID | NFC_JOB_SEAM | NFC_JOB_GIVEUP | NFC_JOB_OVERFLOW)
+#define NFC_JOB_DENSE 0x20u     /* so much of the signal is busy that cutting it into lanes does not pay: sequential path */
+#define NFC_JOB_INVALID (NFC_JOB_OFFGRID | NFC_JOB_SEAM | NFC_JOB_GIVEUP | NFC_JOB_OVERFLOW | NFC_JOB_DENSE)
 
 struct NfcScanChunk
 {

@@ -26,6 +26,7 @@ struct NfcScanArgs
    uint32_t nChunks;
    uint32_t stride;            /* floats per sample of every job: 1 magnitude, 2 IQ */
    NfcScanParams params;
+   uint32_t densePercent;      /* streams with more than this share of busy tiles are decoded sequentially (> 100: never) */
    const NfcStreamState *states; /* the streams' own slots (state a submission starts from) */
    NfcScanPoint *points;
    NfcScanSeam *seams;         /* [nChunks] */

@@ -132,6 +132,7 @@ struct nfcgpu_ctx
       size_t bytes = 0;
    };
    DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
+   uint32_t densePercent = 30;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
@@ -664,6 +665,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.nChunks = nChunks;
    A.stride = stride;
    A.params = sp;
+   A.densePercent = ctx->densePercent;
    A.states = ctx->dStates;
    A.points = (NfcScanPoint *)ctx->wPoints.ptr;
    A.seams = (NfcScanSeam *)ctx->wSeams.ptr;
@@ -695,6 +697,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    /* windows (again with more room when the guess was short) */
    uint32_t nWindows = 0;
+
+   /* a first run of the tile tests: how busy is each stream? (routing, nfc_seams_kernel) */
+   hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
+   HIP_TRY(ctx, hipGetLastError());
 
    /* seams: chunks that did not start from the true state are walked again, a round at a time */
    for (uint32_t round = 0;; round++)
@@ -1036,6 +1042,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
+   ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->densePercent);
    if (ctx->windowWaves == 0)
       ctx->windowWaves = 1;
 

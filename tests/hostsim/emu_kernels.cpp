@@ -528,10 +528,13 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
       NfcScanJob job = A.jobs[j];
       if (first)
       {
-         job.status = 0;
          job.passes = 0;
+         const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+         if ((uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
+            job.status |= NFC_JOB_DENSE;
       }
-      nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
+      if (!(job.status & NFC_JOB_INVALID))
+         nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
       A.jobs[j] = job;
    }
 }
@@ -550,6 +553,8 @@ void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint3
          A.tiles[job.firstTile + i] = flags;
          if (flags & NFC_TILE_OFFGRID)
             job.status |= NFC_JOB_OFFGRID;
+         if ((flags & NFC_TILE_BUSY) && !(flags & NFC_TILE_DARK))
+            job.busyTiles++;
          rewalked += (flags & NFC_TILE_REWALKED) ? 1 : 0;
       }
       if (std::getenv("NFC_EMU_DEBUG"))
@@ -564,6 +569,13 @@ void nfc_windows_kernel(NfcScanArgs A)
       NfcScanJob job = A.jobs[j];
 
       job.status &= ~NFC_JOB_OVERFLOW;
+
+      if (job.status & NFC_JOB_INVALID)
+      {
+         job.windows = 0;
+         A.jobs[j] = job;
+         continue;
+      }
 
       const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
 

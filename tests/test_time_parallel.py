@@ -1,0 +1,98 @@
+"""The time-parallel path (scan kernel -> windows -> windowed decode -> chain, nfc_scan.h) against the reference decoder:
+every fixture in one submission and split over buffers, synthetic streams through the IQ entry, input off the int16 grid
+(sequential fallback), a long quiet capture. The routing that sends busy streams the sequential way is switched off
+(NFCGPU_DENSE_PERCENT=101) so that the path itself is what is tested. Without a GPU the cases run on the emulated
+runtime of tests/hostsim (the product's host runtime and device code on a stand-in HIP); with `-m gpu` on the real
+library and kernels."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import nfc_testlib as T
+
+DRIVER = os.path.join(T.ROOT, "tests", "time_parallel_driver.py")
+EMU = os.path.join(T.ROOT, "tests", "hostsim", "libnfcgpu_emulated.so")
+
+needs_reference = pytest.mark.skipif(T.reference_lib() is None, reason="oracle/_ref not built")
+
+
+def _run(cases, emulated, extra=None):
+    env = dict(os.environ, NFCGPU_DENSE_PERCENT="101", NFCGPU_WINDOWED_MIN="4096", NFCGPU_SCAN_CHUNK="32768")
+    if emulated:
+        env["NFCGPU_LIB"] = EMU
+        env["NFCGPU_NO_TORCH"] = "1"
+    env.update(extra or {})
+    run = subprocess.run([sys.executable, DRIVER] + cases, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
+    assert run.returncode == 0, run.stderr[-3000:]
+    return json.loads(run.stdout.strip().splitlines()[-1])
+
+
+def _check(results, windowed=True):
+    assert results
+    for r in results:
+        assert r["mismatching"] == [], r
+        assert r["frames"] > 0, r
+        if windowed:
+            assert r["stats"]["windowed"] >= 1 and r["stats"]["fallback"] == 0, r
+
+
+@pytest.fixture(scope="module")
+def emulated(built):
+    if not os.path.exists(EMU):
+        subprocess.check_call(["bash", os.path.join(T.ROOT, "tests", "hostsim", "build_emulated.sh")])
+    return EMU
+
+
+@needs_reference
+def test_fixtures_through_the_time_parallel_path_emulated(emulated):
+    _check(_run(["fixtures"], True))
+
+
+@needs_reference
+def test_buffers_synthetic_and_quiet_captures_emulated(emulated):
+    res = _run(["buffers", "synthetic", "quiet"], True)
+    _check(res)
+    quiet = [r for r in res if r["name"].startswith("one exchange")][0]
+    assert quiet["stats"]["windows"] <= 16, quiet  # nearly everything skipped
+
+
+@needs_reference
+def test_small_chunks_force_repairs_emulated(emulated):
+    """chunks of 8192 samples with 1024 samples of warm-up: most seams do not verify and are walked again"""
+    res = _run(["buffers"], True, {"NFCGPU_SCAN_CHUNK": "8192", "NFCGPU_SCAN_WARM": "1024"})
+    _check(res)
+    assert sum(r["stats"]["repairs"] for r in res) > 0
+
+
+@needs_reference
+def test_input_off_the_grid_takes_the_sequential_path_emulated(emulated):
+    res = _run(["offgrid"], True)
+    _check(res, windowed=False)
+    assert res[0]["stats"]["fallback"] == 1 and res[0]["stats"]["windowed"] == 0
+
+
+@needs_reference
+def test_busy_streams_are_routed_to_the_sequential_path_emulated(emulated):
+    res = _run(["buffers"], True, {"NFCGPU_DENSE_PERCENT": "5"})
+    _check(res, windowed=False)
+    assert sum(r["stats"]["fallback"] for r in res) > 0
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_fixtures_through_the_time_parallel_path_on_the_gpu(built):
+    _check(_run(["fixtures"], False))
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_buffers_synthetic_quiet_and_offgrid_on_the_gpu(built):
+    res = _run(["buffers", "synthetic", "quiet"], False)
+    _check(res)
+    res = _run(["offgrid"], False)
+    _check(res, windowed=False)
+    res = _run(["buffers"], False, {"NFCGPU_SCAN_CHUNK": "8192", "NFCGPU_SCAN_WARM": "1024"})
+    _check(res)

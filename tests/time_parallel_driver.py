@@ -1,0 +1,89 @@
+"""Driver of tests/test_time_parallel.py (run in a subprocess so that the library under test - the real libnfcgpu.so or the
+emulated runtime of tests/hostsim - and the knobs of the time-parallel path are chosen through the environment).
+Prints one JSON object: per case the number of reference frames, whether the frames matched, and the path statistics."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "nfc-laboratory_amd"))
+
+import numpy as np
+
+import nfc_testlib as T
+import nfclab_amd
+import synth
+
+FS = 10000000
+
+
+def decode(streams, buffers=1, stride=1):
+    """streams: list of float32 magnitude arrays; returns (frames per stream, stats)"""
+    with nfclab_amd.NfcGpu(device=0, max_streams=max(64, len(streams))) as gpu:
+        first = gpu.open(count=len(streams))
+        longest = max(m.size for m in streams)
+        step = (longest + buffers - 1) // buffers
+        for pos in range(0, longest, step):
+            parts = []
+            for m in streams:
+                part = np.ascontiguousarray(m[pos:pos + step])
+                if stride == 2:
+                    part = np.ascontiguousarray(T.magnitude_to_iq(part, seed=3))
+                parts.append(part)
+            ids = [first + i for i, p in enumerate(parts) if p.size]
+            ptrs = [p.ctypes.data for p in parts if p.size]
+            cnts = [p.size // stride for p in parts if p.size]
+            gpu.submit_batch(ids, ptrs, cnts, FS, stride=stride)
+        got = [gpu.poll(first + i, capacity=16384) for i in range(len(streams))]
+        st = gpu.stats()
+    return got, {"windowed": int(st.windowed_streams), "fallback": int(st.fallback_streams), "windows": int(st.windows),
+                 "passes": int(st.window_passes), "repairs": int(st.scan_repairs)}
+
+
+def case(name, streams, **kw):
+    want = [T.reference_decode(m, keep_carrier=True, cap=16384, defined_storage=True)[0] for m in streams]
+    got, st = decode(streams, **kw)
+    bad = [i for i in range(len(streams)) if got[i] != want[i]]
+    return {"name": name, "frames": sum(len(w) for w in want), "mismatching": bad, "stats": st}
+
+
+def main():
+    which = sys.argv[1:]
+    out = []
+    template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
+
+    if not which or "fixtures" in which:
+        for name in T.fixture_names():
+            mag = np.abs(T.load_fixture(name)).astype(np.float32)
+            out.append(case(name, [mag]))
+
+    if not which or "buffers" in which:
+        for name in ("test_NFC-A_106kbps_003", "test_NFC-B_106kbps_002", "test_NFC-F_212kbps_001", "test_NFC-V_26kbps_002", "test_POLL_ABF_001"):
+            mag = np.abs(T.load_fixture(name)).astype(np.float32)
+            out.append(case(name + " in 3 buffers", [mag], buffers=3))
+
+    if not which or "synthetic" in which:
+        streams = [synth.magnitude_f32(template, s, 0, 1 << 18) for s in range(12)]
+        out.append(case("12 synthetic streams x 2^18, IQ entry, 2 buffers", streams, buffers=2, stride=2))
+
+    if not which or "offgrid" in which:
+        mag = np.abs(T.load_fixture("test_NFC-A_106kbps_001")).astype(np.float32)
+        mag = (mag * np.float32(1.0000153)).astype(np.float32)  # off the int16 grid: sequential path
+        out.append(case("off-grid magnitudes", [mag]))
+
+    if not which or "quiet" in which:
+        # long quiet carrier around one exchange: the case the path is for (nearly everything skipped)
+        rng = np.random.default_rng(5)
+        fix = np.abs(T.load_fixture("test_NFC-A_106kbps_001")).astype(np.float32)
+        level = np.float32(np.median(fix[:8000]))
+        def idle(n):
+            return (np.round((level + rng.normal(0, 0.0008, n)) * 32768.0) / 32768.0).astype(np.float32)
+        mag = np.concatenate([idle(300000), fix[9000:70000], idle(500000)])
+        out.append(case("one exchange in quiet carrier", [mag]))
+
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
