@@ -302,26 +302,21 @@ NFC_DEV void nfc_envelope_step(const NfcConfig &c, uint32_t clock, uint32_t &pul
    float env = envelope;
 
    /* reference: |x - env| / env < 0.05f. Decided without the division unless the ratio is within 0.2 % of the
-    * limit (for env > 0: dev < 0.0499*env implies fl(dev/env) < 0.05f, dev > 0.0501*env implies the opposite) */
+    * limit (for env > 0: dev < 0.0499*env implies fl(dev/env) < 0.05f, dev > 0.0501*env implies the opposite).
+    * Written with selects: the only branch left is the rare division. */
    const float dev = nfc_abs(value - env);
-   bool tracking;
+   const bool below = dev < 0.0499f * env;
+   const bool above = dev > 0.0501f * env;
+   bool tracking = below;
 
-   if (env > 0.0f && dev < 0.0499f * env)
-      tracking = true;
-   else if (env > 0.0f && dev > 0.0501f * env)
-      tracking = false;
-   else
+   if (!(env > 0.0f && (below || above)))
       tracking = (dev / env) < 0.05f;
 
-   if (tracking || pulseFilter > (uint32_t)(c.etu * 10))
-   {
-      pulseFilter = 0;
-      env = env * c.envW0 + value * c.envW1;
-   }
-   else if (clock < (uint32_t)c.etu)
-   {
-      env = value;
-   }
+   const bool update = tracking || pulseFilter > (uint32_t)(c.etu * 10);
+   const float followed = env * c.envW0 + value * c.envW1;
+
+   env = update ? followed : (clock < (uint32_t)c.etu ? value : env);
+   pulseFilter = update ? 0u : pulseFilter;
 
    envelope = env;
 }
@@ -346,20 +341,14 @@ NFC_DEV NfcNow nfc_front_end_core(const NfcConfig &c, NfcStreamState &s, float v
    now.mdev = s.mdev;
    now.depth = 0.0f;
 
-   float rectified = nfc_abs(filtered);
+   /* edge-peak tracker (selects: the three cases are mutually exclusive) */
+   const float rectified = nfc_abs(filtered);
+   const bool high = rectified > c.highThreshold;
+   const bool peak = high && rectified > s.edgePeak;
+   const bool low = !high && rectified < c.lowThreshold;
 
-   if (rectified > c.highThreshold)
-   {
-      if (rectified > s.edgePeak)
-      {
-         s.edgePeak = rectified;
-         s.edgeTime = s.clock;
-      }
-   }
-   else if (rectified < c.lowThreshold)
-   {
-      s.edgePeak = 0;
-   }
+   s.edgeTime = peak ? s.clock : s.edgeTime;
+   s.edgePeak = peak ? rectified : (low ? 0.0f : s.edgePeak);
 
    return now;
 }

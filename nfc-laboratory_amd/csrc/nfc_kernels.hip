@@ -519,16 +519,13 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
    const int32_t origin = (int32_t)start - (int32_t)WU; /* stream position of this lane's row at step 0 (may be negative) */
    const uint32_t reseedAt = walkFrom + WU / 3 / NFC_SCAN_TILE * NFC_SCAN_TILE;
 
-   /* row descriptor: where the row is at step 0, and the steps' sample range the walk covers: [fromRel, endRel) */
-   {
-      const uint64_t base = (uint64_t)(mine ? job->data : (const uint8_t *)A.tileStats) + (int64_t)origin * (int64_t)(S * 4u);
-      rows[lane * 4 + 0] = (uint32_t)base;
-      rows[lane * 4 + 1] = (uint32_t)(base >> 32);
-      rows[lane * 4 + 2] = walkFrom - (uint32_t)origin; /* origin <= walkFrom */
-      rows[lane * 4 + 3] = mine ? end - (uint32_t)origin : 0u;
-   }
-
-   __syncthreads();
+   /* row descriptor (this lane's; the other lanes read it with v_readlane): where the row is at step 0, and the steps'
+    * sample range the walk covers: [fromRel, endRel) */
+   const uint64_t rowBase = (uint64_t)(mine ? job->data : (const uint8_t *)A.tileStats) + (int64_t)origin * (int64_t)(S * 4u);
+   const uint32_t rowLo = (uint32_t)rowBase, rowHi = (uint32_t)(rowBase >> 32);
+   const uint32_t rowFrom = walkFrom - (uint32_t)origin; /* origin <= walkFrom */
+   const uint32_t rowEnd = mine ? end - (uint32_t)origin : 0u;
+   (void)rows;
 
    NfcConfig cc;
    nfc_fixed_runtime_config(cfgPtr, cc);
@@ -550,55 +547,58 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
    NfcScanSeam seam;
    __builtin_memset(&seam, 0, sizeof(seam));
 
-   const uint32_t myFrom = walkFrom - (uint32_t)origin, myEnd = mine ? end - (uint32_t)origin : 0u;
+   const uint32_t myFrom = rowFrom, myEnd = rowEnd;
+
+   /* The rows of the next step are fetched into registers while this step's tile is walked: one memory latency per step,
+    * hidden behind the walk (64 row loads in flight per wave). */
+   float re[NFC_LANES], im[NFC_LANES];
+
+   auto fetch = [&](uint32_t rel) {
+#pragma unroll
+      for (uint32_t q = 0; q < NFC_LANES; q++)
+      {
+         /* lane q's descriptor, into scalar registers */
+         const uint32_t lo = __builtin_amdgcn_readlane(rowLo, q);
+         const uint32_t hi = __builtin_amdgcn_readlane(rowHi, q);
+         const uint32_t fromRel = __builtin_amdgcn_readlane(rowFrom, q);
+         const uint32_t endRel = __builtin_amdgcn_readlane(rowEnd, q);
+
+         re[q] = 0.0f;
+         im[q] = 0.0f;
+
+         /* uniform: does the row have anything at this step? */
+         if (rel + NFC_SCAN_TILE > fromRel && rel < endRel)
+         {
+            typedef __attribute__((address_space(1))) const float GlobalFloat;
+            GlobalFloat *p = (GlobalFloat *)(((uint64_t)hi << 32) | lo);
+            uint32_t at = rel + lane;
+            at = at < fromRel ? fromRel : at;
+            at = at >= endRel ? endRel - 1u : at;
+
+            if (S == 2)
+            {
+               re[q] = p[2 * at];
+               im[q] = p[2 * at + 1];
+            }
+            else
+               re[q] = p[at];
+         }
+      }
+   };
+
+   fetch(0);
 
    for (uint32_t rel = 0; rel < WU + L; rel += NFC_SCAN_TILE)
    {
-      /* ---- stage: tile row q = the 64 samples of lane q's chunk at this step ---- */
-#pragma clang loop unroll(disable)
-      for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_SCAN_ROWS)
-      {
-         float re[NFC_SCAN_ROWS], im[NFC_SCAN_ROWS];
-
+      /* ---- park the fetched rows in LDS as magnitudes, transposed: tile row q = lane q's 64 samples of this step ---- */
 #pragma unroll
-         for (uint32_t j = 0; j < NFC_SCAN_ROWS; j++)
-         {
-            const uint32_t q = r0 + j;
-
-            /* the descriptor is the same for every lane: through the scalar unit */
-            const uint32_t lo = __builtin_amdgcn_readfirstlane(rows[q * 4 + 0]);
-            const uint32_t hi = __builtin_amdgcn_readfirstlane(rows[q * 4 + 1]);
-            const uint32_t fromRel = __builtin_amdgcn_readfirstlane(rows[q * 4 + 2]);
-            const uint32_t endRel = __builtin_amdgcn_readfirstlane(rows[q * 4 + 3]);
-
-            re[j] = 0.0f;
-            im[j] = 0.0f;
-
-            /* uniform: does the row have anything at this step? */
-            if (rel + NFC_SCAN_TILE > fromRel && rel < endRel)
-            {
-               const uint8_t *p = (const uint8_t *)(((uint64_t)hi << 32) | lo);
-               uint32_t at = rel + lane;
-               at = at < fromRel ? fromRel : at;
-               at = at >= endRel ? endRel - 1u : at;
-
-               if (S == 2)
-               {
-                  const float2 iq = reinterpret_cast<const float2 *>(p)[at];
-                  re[j] = iq.x;
-                  im[j] = iq.y;
-               }
-               else
-                  re[j] = reinterpret_cast<const float *>(p)[at];
-            }
-         }
-
-#pragma unroll
-         for (uint32_t j = 0; j < NFC_SCAN_ROWS; j++)
-            tile[(r0 + j) * NFC_SCAN_PITCH + lane] = S == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
-      }
+      for (uint32_t q = 0; q < NFC_LANES; q++)
+         tile[q * NFC_SCAN_PITCH + lane] = S == 2 ? nfc_iq_magnitude(re[q], im[q]) : re[q];
 
       __syncthreads();
+
+      if (rel + NFC_SCAN_TILE < WU + L)
+         fetch(rel + NFC_SCAN_TILE);
 
       /* ---- walk: this lane's 64 samples ---- */
       if (rel + NFC_SCAN_TILE > myFrom && rel < myEnd)

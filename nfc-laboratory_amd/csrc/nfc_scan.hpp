@@ -134,17 +134,14 @@ NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
    ++w.fe.clock;
    ++w.fe.pulseFilter;
 
-   const float peakBefore = w.fe.edgePeak;
    const uint32_t timeBefore = w.fe.edgeTime;
 
    const NfcNow now = nfc_front_end_core(c, w.fe, x);
 
-   /* edge tracker bookkeeping: a reset (peak back to zero) makes the peak the true one whatever the walk started from;
-    * a time set after that is the true time */
-   if (w.fe.edgePeak == 0.0f && !(nfc_abs(now.filt) > c.highThreshold))
-      w.edgeSynced = w.edgeSynced | (nfc_abs(now.filt) < c.lowThreshold ? 1u : 0u);
-   if (w.fe.edgeTime != timeBefore || w.fe.edgePeak != peakBefore)
-      w.edgeKnown = (w.fe.edgeTime != timeBefore && w.edgeSynced) ? 1u : w.edgeKnown;
+   /* edge tracker bookkeeping: a reset (signal below the low threshold) makes the peak the true one whatever the walk
+    * started from; a time set after that is the true time */
+   w.edgeSynced |= nfc_abs(now.filt) < c.lowThreshold ? 1u : 0u;
+   w.edgeKnown |= (w.fe.edgeTime != timeBefore) ? w.edgeSynced : 0u;
 
    w.xmin = x < w.xmin ? x : w.xmin;
    w.xmax = x > w.xmax ? x : w.xmax;
@@ -158,21 +155,13 @@ NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
       w.bits |= NFC_TILE_OFFGRID;
 
    /* NaNs make both comparisons false, exactly as in nfc_detect_carrier */
-   if (w.fe.avg > c.highThreshold)
    {
-      if (w.zone != 1u)
-      {
-         w.zone = 1u;
-         w.bits |= NFC_TILE_CARRIER;
-      }
-   }
-   else if (w.fe.avg < c.lowThreshold)
-   {
-      if (w.zone != 2u)
-      {
-         w.zone = 2u;
-         w.bits |= NFC_TILE_CARRIER;
-      }
+      const bool up = w.fe.avg > c.highThreshold;
+      const bool down = !up && w.fe.avg < c.lowThreshold;
+      const uint32_t zone = up ? 1u : (down ? 2u : w.zone);
+
+      w.bits |= zone != w.zone ? NFC_TILE_CARRIER : 0u;
+      w.zone = zone;
    }
 
    if (w.fe.clock < 1024u)

@@ -132,7 +132,7 @@ struct nfcgpu_ctx
       size_t bytes = 0;
    };
    DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
-   uint32_t densePercent = 30;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
+   uint32_t densePercent = 10;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
@@ -469,6 +469,32 @@ int launch_sequential(nfcgpu_ctx *ctx, uint32_t config, const std::vector<Window
 {
    if (items.empty())
       return NFCGPU_OK;
+
+   /* a long first buffer of fresh streams: only its first samples need the exact-modulo kernel (which is chosen per
+    * launch and is the slower one), so they get a launch of their own */
+   {
+      const uint32_t head = 2048;
+      bool split = false;
+      for (const WindowedItem &it: items)
+         split = split || (ctx->streams[it.slot].clock == 0xFFFFFFFFu && it.count > 2 * head);
+
+      if (split)
+      {
+         std::vector<WindowedItem> first, rest;
+         for (const WindowedItem &it: items)
+         {
+            const uint32_t n = it.count < head ? it.count : head;
+            first.push_back(WindowedItem {it.slot, it.data, n});
+            if (it.count > n)
+               rest.push_back(WindowedItem {it.slot, it.data + (size_t)n * stride * 4, it.count - n});
+         }
+
+         int rc = launch_sequential(ctx, config, first, stride);
+         if (rc)
+            return rc;
+         return launch_sequential(ctx, config, rest, stride);
+      }
+   }
 
    uint32_t first = 0xFFFFFFFFu, last = 0;
    uint64_t samples = 0;
