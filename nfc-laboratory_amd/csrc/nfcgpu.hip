@@ -123,7 +123,7 @@ struct nfcgpu_ctx
    /* ---- time-parallel path (nfc_scan.h): device buffers, grown on demand and kept ---- */
    bool windowed = true;           /* NFCGPU_WINDOWED=0 switches the path off */
    uint32_t windowedMinSamples = 32768; /* shortest submission (per stream) worth cutting into windows */
-   uint32_t scanChunk = 65536;     /* samples per scan chunk */
+   uint32_t scanChunk = 8192;      /* samples per scan chunk: short chunks = many lanes (the walk is latency-bound per wave) */
    uint32_t scanWarm = 6144;       /* samples walked ahead of a chunk */
    uint32_t maxPasses = 12;
    struct DevBuf
