@@ -193,6 +193,24 @@ int nfcgpu_sink_attach(nfcgpu_ctx *ctx, void *words, uint64_t capacity_words, vo
 int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold);
 int nfcgpu_sink_rewind(nfcgpu_ctx *ctx);
 
+/* ---- multi-GPU: one context (one process) per GPU, streams sharded over the ranks; the only exchange is the gather of
+ * the decoded frames, done here in C++ over RCCL so that a host that is not Python (the Qt application,
+ * nfc-rx) has it too. The unique id is made on rank 0 and carried to the other ranks by whatever the host uses to start
+ * its processes (MPI, sockets, a file, torch.distributed). librccl.so is looked up when the first of these is called. */
+#define NFCGPU_UNIQUE_ID_BYTES 128
+int nfcgpu_comm_unique_id(void *id128);
+int nfcgpu_comm_init(nfcgpu_ctx *ctx, const void *id128, int rank, int n_ranks);
+int nfcgpu_comm_destroy(nfcgpu_ctx *ctx);
+/* All-gather of every rank's packed frame records (the context's frame sink as it stands: use nfcgpu_sink_hold so that
+ * nothing has been drained): one ncclAllGather of the word counts, one padded ncclAllGather of the records. `gathered`
+ * is a device buffer of capacity_words words; rank r's records are at gathered + r * *stride_words, counts_host[r] words
+ * of them (the record format of the sink: [stream, tech, type, flags, phase, rate, start, end, length, payload words]). */
+int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacity_words, uint32_t *counts_host, uint64_t *stride_words);
+
+/* streaming-read bandwidth of this GPU over `bytes` of device memory (16-byte loads per lane, grid sized to the chip):
+ * the measured denominator of the HBM roofline, next to the vendor peak. Best of `repeats` passes, GB/s. */
+int nfcgpu_read_bandwidth(nfcgpu_ctx *ctx, const void *device_ptr, uint64_t bytes, uint32_t repeats, double *gbps);
+
 int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats);
 int nfcgpu_stats_reset(nfcgpu_ctx *ctx);
 int nfcgpu_profile(nfcgpu_ctx *ctx, int enable);

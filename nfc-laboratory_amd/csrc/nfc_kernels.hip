@@ -1430,3 +1430,23 @@ __global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch
       real.cold[to] = cold;
    }
 }
+
+/* streaming read: 16 bytes per lane per load, four loads in flight, the sums only exist so that the loads are kept */
+__global__ __launch_bounds__(256) void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restrict__ out)
+{
+   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   float acc = 0.0f;
+
+   for (; i + 3 * stride < n; i += 4 * stride)
+   {
+      const float4 a = data[i], b = data[i + stride], c = data[i + 2 * stride], d = data[i + 3 * stride];
+      acc += a.x + b.y + c.z + d.w;
+   }
+
+   for (; i < n; i += stride)
+      acc += data[i].x;
+
+   if (acc == 12345.678f)
+      out[0] = acc;
+}

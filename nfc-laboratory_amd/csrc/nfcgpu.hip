@@ -8,6 +8,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +47,7 @@ __global__ void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, Nfc
 __global__ void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
 __global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses);
 __global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
+__global__ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restrict__ out);
 
 namespace {
 
@@ -136,6 +139,11 @@ struct nfcgpu_ctx
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
+
+   /* ---- frame gather over RCCL (nfcgpu_comm_*) ---- */
+   void *comm = nullptr;
+   int commRank = 0, commRanks = 0;
+   uint32_t *dCounts = nullptr;
    std::vector<ProfiledLaunch> timed;
    std::vector<hipEvent_t> eventPool;
    nfcgpu_stats stats {};
@@ -1009,6 +1017,60 @@ void drain_sink(nfcgpu_ctx *ctx, uint64_t cursor)
 
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* RCCL, looked up at run time (a host with a single GPU does not need it)                       */
+/* ------------------------------------------------------------------------------------------ */
+/* ncclUniqueId is passed by value: 128 bytes */
+struct IdByValue
+{
+   char internal[NFCGPU_UNIQUE_ID_BYTES];
+};
+
+namespace {
+
+struct Rccl
+{
+   void *handle = nullptr;
+   int (*getUniqueId)(void *) = nullptr;
+   int (*commInitRank)(void **, int, IdByValue, int) = nullptr;
+   int (*commDestroy)(void *) = nullptr;
+   int (*allGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+   const char *(*getErrorString)(int) = nullptr;
+};
+
+Rccl *rccl()
+{
+   static Rccl r;
+   static bool tried = false;
+
+   if (!tried)
+   {
+      tried = true;
+#ifndef NFCGPU_EMULATED_TEST_BUILD
+      for (const char *name: {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      {
+         r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+         if (r.handle)
+            break;
+      }
+
+      if (r.handle)
+      {
+         r.getUniqueId = (int (*)(void *))dlsym(r.handle, "ncclGetUniqueId");
+         r.commInitRank = (int (*)(void **, int, IdByValue, int))dlsym(r.handle, "ncclCommInitRank");
+         r.commDestroy = (int (*)(void *))dlsym(r.handle, "ncclCommDestroy");
+         r.allGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.handle, "ncclAllGather");
+         r.getErrorString = (const char *(*)(int))dlsym(r.handle, "ncclGetErrorString");
+      }
+#endif
+   }
+
+   return (r.handle && r.getUniqueId && r.commInitRank && r.commDestroy && r.allGather) ? &r : nullptr;
+}
+
+}
+
 extern "C" {
 
 void nfcgpu_default_params(nfcgpu_params *p)
@@ -1164,6 +1226,8 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    (void)hipFree(ctx->dStage);
    if (ctx->hStage)
       (void)hipHostFree(ctx->hStage);
+
+   nfcgpu_comm_destroy(ctx);
 
    for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
                                 &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl})
@@ -1946,6 +2010,168 @@ int nfcgpu_sink_rewind(nfcgpu_ctx *ctx)
    HIP_TRY(ctx, hipMemsetAsync(ctx->dSinkCtl, 0, 16, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
    ctx->dirty = false;
+   return NFCGPU_OK;
+}
+
+
+int nfcgpu_comm_unique_id(void *id128)
+{
+   if (!id128)
+      return NFCGPU_EINVAL;
+   Rccl *r = rccl();
+   if (!r)
+      return NFCGPU_ENODEV;
+   return r->getUniqueId(id128) == 0 ? NFCGPU_OK : NFCGPU_EHIP;
+}
+
+int nfcgpu_comm_init(nfcgpu_ctx *ctx, const void *id128, int rank, int nRanks)
+{
+   if (!ctx || !id128 || nRanks < 1 || rank < 0 || rank >= nRanks)
+      return NFCGPU_EINVAL;
+
+   Rccl *r = rccl();
+   if (!r)
+      return fail(ctx, NFCGPU_ENODEV, "librccl.so not found");
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+   if (ctx->comm)
+      nfcgpu_comm_destroy(ctx);
+
+   IdByValue id;
+   std::memcpy(id.internal, id128, NFCGPU_UNIQUE_ID_BYTES);
+
+   const int rc = r->commInitRank(&ctx->comm, nRanks, id, rank);
+   if (rc != 0)
+   {
+      ctx->comm = nullptr;
+      return fail(ctx, NFCGPU_EHIP, r->getErrorString ? r->getErrorString(rc) : "ncclCommInitRank failed");
+   }
+
+   ctx->commRank = rank;
+   ctx->commRanks = nRanks;
+
+   if (hipMalloc((void **)&ctx->dCounts, 4 * (size_t)(nRanks + 1)) != hipSuccess)
+      return fail(ctx, NFCGPU_ENOMEM, "hipMalloc(gather counts)");
+
+   return NFCGPU_OK;
+}
+
+int nfcgpu_comm_destroy(nfcgpu_ctx *ctx)
+{
+   if (!ctx)
+      return NFCGPU_EINVAL;
+
+   Rccl *r = rccl();
+
+   if (ctx->comm && r)
+   {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)r->commDestroy(ctx->comm);
+   }
+
+   ctx->comm = nullptr;
+   ctx->commRanks = 0;
+
+   if (ctx->dCounts)
+      (void)hipFree(ctx->dCounts);
+   ctx->dCounts = nullptr;
+
+   return NFCGPU_OK;
+}
+
+int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords, uint32_t *countsHost, uint64_t *strideWords)
+{
+   if (!ctx || !gathered || !countsHost || !strideWords)
+      return NFCGPU_EINVAL;
+   if (!ctx->comm)
+      return fail(ctx, NFCGPU_EINVAL, "nfcgpu_comm_init first");
+
+   Rccl *r = rccl();
+   if (!r)
+      return fail(ctx, NFCGPU_ENODEV, "librccl.so not found");
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   /* this rank's records: what the sink holds, clamped like drain_sink does (a record is only ever written below
+    * sinkWords - NFC_FRAME_MAX_WORDS) */
+   uint32_t ctl[2] = {0, 0};
+   HIP_TRY(ctx, hipMemcpy(ctl, ctx->dSinkCtl, sizeof(ctl), hipMemcpyDeviceToHost));
+
+   uint64_t used = ctl[0];
+   const uint64_t limit = ctx->sinkWords >= NFC_FRAME_MAX_WORDS ? ctx->sinkWords - NFC_FRAME_MAX_WORDS + 1 : 0;
+   if (ctl[1] && used > limit)
+      used = limit; /* dropped frames: everything that starts below the limit is whole (nfc_emit) */
+   if (used > ctx->sinkWords)
+      used = ctx->sinkWords;
+
+   const uint32_t mine = (uint32_t)used;
+   const int n = ctx->commRanks;
+
+   /* counts */
+   HIP_TRY(ctx, hipMemcpyAsync(ctx->dCounts + n, &mine, 4, hipMemcpyHostToDevice, ctx->stream));
+   int rc = r->allGather(ctx->dCounts + n, ctx->dCounts, 1, /* ncclUint32 */ 3, ctx->comm, ctx->stream);
+   if (rc != 0)
+      return fail(ctx, NFCGPU_EHIP, r->getErrorString ? r->getErrorString(rc) : "ncclAllGather(counts) failed");
+
+   HIP_TRY(ctx, hipMemcpyAsync(countsHost, ctx->dCounts, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   uint64_t longest = 1;
+   for (int i = 0; i < n; i++)
+      longest = countsHost[i] > longest ? countsHost[i] : longest;
+
+   *strideWords = longest;
+
+   if (longest * (uint64_t)n > capacityWords)
+      return fail(ctx, NFCGPU_ENOMEM, "gather buffer too small for the longest rank's records");
+   if (longest > ctx->sinkWords)
+      return fail(ctx, NFCGPU_ENOMEM, "this rank's frame sink is smaller than the longest rank's records (padded all-gather)");
+
+   /* records, padded to the longest rank's (the words past `mine` are whatever the sink holds: ignored through counts) */
+   rc = r->allGather(ctx->dSink, gathered, (size_t)longest, /* ncclUint32 */ 3, ctx->comm, ctx->stream);
+   if (rc != 0)
+      return fail(ctx, NFCGPU_EHIP, r->getErrorString ? r->getErrorString(rc) : "ncclAllGather(records) failed");
+
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   return ctl[1] ? NFCGPU_EOVERFLOW : NFCGPU_OK;
+}
+
+int nfcgpu_read_bandwidth(nfcgpu_ctx *ctx, const void *ptr, uint64_t bytes, uint32_t repeats, double *gbps)
+{
+   if (!ctx || !ptr || bytes < 16 || !gbps || ((uintptr_t)ptr & 15))
+      return NFCGPU_EINVAL;
+
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+   float *out = nullptr;
+   HIP_TRY(ctx, hipMalloc((void **)&out, 16));
+
+   hipEvent_t a = take_event(ctx), b = take_event(ctx);
+   double best = 0.0;
+
+   for (uint32_t i = 0; i < (repeats ? repeats : 1); i++)
+   {
+      (void)hipEventRecord(a, ctx->stream);
+      hipLaunchKernelGGL(nfc_read_kernel, dim3(256 * 16), dim3(256), 0, ctx->stream, (const float4 *)ptr, bytes / 16, out);
+      (void)hipEventRecord(b, ctx->stream);
+      (void)hipStreamSynchronize(ctx->stream);
+
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0)
+      {
+         const double g = (double)(bytes / 16 * 16) / (ms * 1e-3) / 1e9;
+         best = g > best ? g : best;
+      }
+   }
+
+   ctx->eventPool.push_back(a);
+   ctx->eventPool.push_back(b);
+   (void)hipFree(out);
+
+   *gbps = best;
    return NFCGPU_OK;
 }
 

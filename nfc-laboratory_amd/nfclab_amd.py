@@ -138,6 +138,11 @@ def load_library(path=LIB_PATH):
     lib.nfcgpu_stats_get.argtypes = [vp, P(Stats)]
     lib.nfcgpu_stats_reset.argtypes = [vp]
     lib.nfcgpu_profile.argtypes = [vp, i32]
+    lib.nfcgpu_comm_unique_id.argtypes = [vp]
+    lib.nfcgpu_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.nfcgpu_comm_destroy.argtypes = [vp]
+    lib.nfcgpu_gather_frames.argtypes = [vp, vp, ctypes.c_uint64, P(ctypes.c_uint32), P(ctypes.c_uint64)]
+    lib.nfcgpu_read_bandwidth.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, P(ctypes.c_double)]
     lib.nfcgpu_hip_stream.argtypes = [vp]
     lib.nfcgpu_hip_stream.restype = vp
     lib.nfcgpu_strerror.argtypes = [i32]
@@ -284,3 +289,31 @@ class NfcGpu:
 
     def hip_stream(self):
         return self.lib.nfcgpu_hip_stream(self.ctx)
+
+    # ---- multi-GPU frame gather over RCCL, behind the C ABI ----
+    def comm_unique_id(self):
+        """128 opaque bytes made by rank 0 (ncclGetUniqueId); carry them to the other ranks"""
+        buf = ctypes.create_string_buffer(128)
+        self._check(self.lib.nfcgpu_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, n_ranks):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.nfcgpu_comm_init(self.ctx, buf, rank, n_ranks))
+        self._n_ranks = n_ranks
+
+    def comm_destroy(self):
+        self._check(self.lib.nfcgpu_comm_destroy(self.ctx))
+
+    def gather_frames(self, gathered_ptr, capacity_words):
+        """ncclAllGather of every rank's frame sink into the device buffer at gathered_ptr; returns (counts, stride)"""
+        counts = (ctypes.c_uint32 * self._n_ranks)()
+        stride = ctypes.c_uint64()
+        self._check(self.lib.nfcgpu_gather_frames(self.ctx, gathered_ptr, capacity_words, counts, ctypes.byref(stride)), allow=(-6,))
+        return list(counts), int(stride.value)
+
+    def read_bandwidth(self, device_ptr, n_bytes, repeats=5):
+        """streaming-read GB/s over a device buffer (16-byte loads): the measured HBM roofline denominator"""
+        g = ctypes.c_double()
+        self._check(self.lib.nfcgpu_read_bandwidth(self.ctx, device_ptr, n_bytes, repeats, ctypes.byref(g)))
+        return g.value

@@ -95,3 +95,91 @@ def fill_iq_torch(out, template_dev, first_stream, start=0, chunk_streams=1024):
         out[s0:s1, :, 1] = torch.where(axis == 1, m, torch.where(axis == 3, -m, zero))
         del idx, k, m, axis, zero
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sparse traffic (set S1q): what a monitoring receiver sees most of the time. A stream repeats one exchange of the
+# fixtures (a 65536-sample stretch of a capture that begins and ends in quiet carrier) every 2^19 samples (52 ms), the
+# rest is unmodulated carrier at the level the stretch begins with plus +-2 counts of deterministic noise. Everything
+# stays on the int16 grid and the IQ form is the axis-aligned one of S1.
+# ---------------------------------------------------------------------------------------------------------------------
+SPARSE_SEG = 65536
+SPARSE_PERIOD = 1 << 19
+
+
+def sparse_segments(template):
+    """(offsets, carrier levels in counts) of the stretches of the template usable as exchanges: quiet (spread < 6 %) first
+    and last 1024 samples at the same level (3 %), something modulated in between, level >= 1500 counts."""
+    a = np.abs(template.astype(np.int32))
+    offs, levels = [], []
+    for off in range(0, a.size - SPARSE_SEG, 4096):
+        h = a[off:off + 1024]
+        e = a[off + SPARSE_SEG - 1024:off + SPARSE_SEG]
+        mh, me = float(np.median(h)), float(np.median(e))
+        if mh < 1500 or (h.max() - h.min()) > 0.06 * mh or (e.max() - e.min()) > 0.06 * me or abs(mh - me) > 0.03 * mh:
+            continue
+        if a[off:off + SPARSE_SEG].min() > 0.8 * mh:
+            continue
+        offs.append(off)
+        levels.append(int(mh))
+    return np.asarray(offs, np.int64), np.asarray(levels, np.int32)
+
+
+def sparse_params(stream, nseg):
+    """(segment index, position of the exchange inside the period, starting axis) of one stream"""
+    a = splitmix64((0xD1B54A32D192ED03 * (stream + 1)) & _MASK)
+    b = splitmix64(a)
+    c = splitmix64(b)
+    return a % nseg, (b % (SPARSE_PERIOD - SPARSE_SEG)) // 64 * 64, c & 3
+
+
+def _sparse_noise_np(t, stream):
+    h = (t.astype(np.uint64) * np.uint64(2654435761) + np.uint64(stream * 40503 + 12345)) & np.uint64(0xFFFFFFFF)
+    h = ((h ^ (h >> np.uint64(15))) * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    h = ((h ^ (h >> np.uint64(13))) * np.uint64(3266489917)) & np.uint64(0xFFFFFFFF)
+    h = h ^ (h >> np.uint64(16))
+    return (h % np.uint64(5)).astype(np.int32) - 2
+
+
+def sparse_magnitude_f32(template, segs, stream, start, length):
+    offs, levels = segs
+    g, base, _ = sparse_params(stream, offs.size)
+    t = start + np.arange(length, dtype=np.int64)
+    u = t % SPARSE_PERIOD
+    inside = (u >= base) & (u < base + SPARSE_SEG)
+    idx = np.where(inside, offs[g] + u - base, 0)
+    k = np.where(inside, np.abs(template[idx].astype(np.int32)), levels[g] + _sparse_noise_np(t, stream))
+    return (k.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+def fill_sparse_iq_torch(out, template_dev, segs, first_stream, start=0, chunk_streams=256):
+    """out[S, T, 2] (float32, on the GPU) <- sparse streams first_stream .. first_stream+S-1, samples start..start+T-1"""
+    import torch
+    offs, levels = segs
+    S, T, _ = out.shape
+    dev = out.device
+    t = torch.arange(start, start + T, device=dev, dtype=torch.int64)
+    u = t % SPARSE_PERIOD
+    axis_t = t // PHASE_PERIOD
+    for s0 in range(0, S, chunk_streams):
+        s1 = min(S, s0 + chunk_streams)
+        params = [sparse_params(first_stream + s, offs.size) for s in range(s0, s1)]
+        off = torch.tensor([int(offs[p[0]]) for p in params], device=dev, dtype=torch.int64)[:, None]
+        level = torch.tensor([int(levels[p[0]]) for p in params], device=dev, dtype=torch.int64)[:, None]
+        base = torch.tensor([p[1] for p in params], device=dev, dtype=torch.int64)[:, None]
+        ph = torch.tensor([p[2] for p in params], device=dev, dtype=torch.int64)[:, None]
+        sid = torch.tensor([first_stream + s for s in range(s0, s1)], device=dev, dtype=torch.int64)[:, None]
+        inside = (u[None, :] >= base) & (u[None, :] < base + SPARSE_SEG)
+        idx = torch.where(inside, off + u[None, :] - base, torch.zeros_like(off))
+        h = (t[None, :] * 2654435761 + sid * 40503 + 12345) & 0xFFFFFFFF
+        h = ((h ^ (h >> 15)) * 2246822519) & 0xFFFFFFFF
+        h = ((h ^ (h >> 13)) * 3266489917) & 0xFFFFFFFF
+        h = h ^ (h >> 16)
+        k = torch.where(inside, template_dev[idx].to(torch.int64).abs(), level + (h % 5) - 2)
+        m = k.to(torch.float32) / 32768.0
+        axis = (axis_t[None, :] + ph) & 3
+        zero = torch.zeros_like(m)
+        out[s0:s1, :, 0] = torch.where(axis == 0, m, torch.where(axis == 2, -m, zero))
+        out[s0:s1, :, 1] = torch.where(axis == 1, m, torch.where(axis == 3, -m, zero))
+        del inside, idx, h, k, m, axis, zero
+    return out

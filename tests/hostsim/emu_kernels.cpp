@@ -833,3 +833,12 @@ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
       real.cold[job->slot] = cold;
    }
 }
+
+void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restrict__ out)
+{
+   float acc = 0.0f;
+   for (uint64_t i = 0; i < n; i++)
+      acc += data[i].x;
+   if (acc == 12345.678f)
+      out[0] = acc;
+}

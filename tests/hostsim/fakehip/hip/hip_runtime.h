@@ -38,6 +38,11 @@ struct float2
    float x, y;
 };
 
+struct float4
+{
+   float x, y, z, w;
+};
+
 namespace fakehip {
 extern dim3 launchGrid, launchBlock;
 }

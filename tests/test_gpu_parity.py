@@ -351,6 +351,40 @@ def test_frame_gather_over_rccl_single_rank(gpu):
         dist.destroy_process_group()
 
 
+def test_frame_gather_through_the_c_abi_single_rank(gpu):
+    """nfcgpu_comm_* / nfcgpu_gather_frames: the frame gather in C++ over RCCL (ncclAllGather of the counts, then of the
+    padded records), here with a one-rank communicator on the context's own sink after a real decode; and the streaming-read
+    measurement used as the second roofline denominator."""
+    import torch
+    import frames as framelib
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not available")
+    mag = np.abs(T.load_fixture("test_NFC-A_106kbps_001")).astype(np.float32)
+    want, _ = T.reference_decode(mag, keep_carrier=True)
+    sink = torch.zeros(1 << 20, dtype=torch.int32, device="cuda:0")
+    ctl = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    out = torch.zeros(1 << 20, dtype=torch.int32, device="cuda:0")
+    g = gpu
+    g.sink_attach(sink.data_ptr(), sink.numel(), ctl.data_ptr())
+    g.sink_hold(True)
+    try:
+        sid = g.open()
+        g.submit(sid, mag, FS)
+        g.sync()
+        g.comm_init(g.comm_unique_id(), 0, 1)
+        counts, stride = g.gather_frames(out.data_ptr(), out.numel())
+        torch.cuda.synchronize()
+        assert counts == [int(ctl[0].item())] and stride >= counts[0] > 0
+        got = framelib.parse_sink(out[:counts[0]].cpu().numpy(), counts[0], FS)
+        assert got[sid] == want
+        g.comm_destroy()
+        gbps = g.read_bandwidth(out.data_ptr(), out.numel() * 4, repeats=3)
+        assert gbps > 10.0
+    finally:
+        g.sink_hold(False)
+        g.sink_attach(None, 0, None)
+
+
 def test_streams_joining_a_block_at_different_times(gpu):
     """Streams of one block opened at different moments and fed ragged buffer lengths: blocks then hold streams that
     need the exact-modulo kernel (first 1024 samples) next to streams that do not, launches mix both kernels, and the

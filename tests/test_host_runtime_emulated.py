@@ -17,7 +17,7 @@ EMU = os.path.join(T.ROOT, "tests", "hostsim", "libnfcgpu_emulated.so")
 
 # need a real GPU: device tensors, RCCL, or binaries linked against the real library (those run below with the emulated
 # runtime preloaded instead)
-NEEDS_GPU = ["test_uniform_device_batch_synthetic_streams", "test_frame_gather_over_rccl_single_rank",
+NEEDS_GPU = ["test_uniform_device_batch_synthetic_streams", "test_frame_gather_over_rccl_single_rank", "test_frame_gather_through_the_c_abi_single_rank",
              "test_reference_test_sdr_harness_runs_unchanged_on_the_gpu_decoder",
              "test_reference_radio_decoder_task_runs_unchanged_on_the_gpu_decoder", "test_radio_decoder_task_fed_with_iq_buffers"]
 
