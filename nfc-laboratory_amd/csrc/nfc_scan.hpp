@@ -263,10 +263,23 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
                              uint32_t *repairCount)
 {
    uint32_t edge = startEdge; /* true edge time at the start of the chunk at hand */
+   bool waiting = false;      /* the chunk before is being walked again in this round: its end is not known yet */
+   bool pending = false;
 
    for (uint32_t k = 0; k < job.chunks; k++)
    {
       NfcScanSeam &s = seams[job.firstChunk + k];
+
+      if (waiting)
+      {
+         /* its turn comes in the next round (only if it then proves unsound); the chunks after it can still be checked
+          * against their own predecessors, whose records do not change */
+         waiting = false;
+         pending = true;
+         if (s.end.zone & NFC_ZONE_EDGE_KNOWN)
+            edge = s.end.edgeTime;
+         continue;
+      }
 
       const bool sound = k == 0 || (nfc_point_same(s.start, seams[job.firstChunk + k - 1].end) &&
                                     (!(s.start.zone & NFC_ZONE_EDGE_KNOWN) || s.start.edgeTime == edge));
@@ -283,7 +296,10 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
          NfcScanChunk &r = repairs[NFC_ATOMIC_ADD(repairCount, 1u)];
          r.job = jobIndex;
          r.index = k | NFC_CHUNK_REPAIR;
-         return true;
+
+         waiting = true;
+         pending = true;
+         continue;
       }
 
       /* true edge time at the end of the chunk */
@@ -291,7 +307,7 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
          edge = s.end.edgeTime;
    }
 
-   return false;
+   return pending;
 }
 
 /* ------------------------------------------------------------------------------------------ */

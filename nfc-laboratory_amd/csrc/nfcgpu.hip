@@ -640,7 +640,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
        (rc = grow(ctx, ctx->wPoints, sizeof(NfcScanPoint) * (size_t)points)) || (rc = grow(ctx, ctx->wSeams, sizeof(NfcScanSeam) * nChunks)) ||
        (rc = grow(ctx, ctx->wChunkEdge, 4 * (size_t)nChunks)) || (rc = grow(ctx, ctx->wTiles, 4 * (size_t)tiles)) ||
        (rc = grow(ctx, ctx->wTileStats, sizeof(NfcScanTile) * (size_t)tiles)) ||
-       (rc = grow(ctx, ctx->wCounters, 64)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nJobs)))
+       (rc = grow(ctx, ctx->wCounters, 64)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nChunks)))
       return rc;
 
    /* lanes: a first guess (one window per 8192 samples); the window kernel reports what it needs */

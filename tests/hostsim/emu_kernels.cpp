@@ -530,7 +530,7 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
       {
          job.passes = 0;
          const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-         if ((uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
+         if (A.nJobs >= NFC_LANES && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
             job.status |= NFC_JOB_DENSE;
       }
       if (!(job.status & NFC_JOB_INVALID))

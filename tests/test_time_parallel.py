@@ -76,7 +76,8 @@ def test_input_off_the_grid_takes_the_sequential_path_emulated(emulated):
 
 @needs_reference
 def test_busy_streams_are_routed_to_the_sequential_path_emulated(emulated):
-    res = _run(["buffers"], True, {"NFCGPU_DENSE_PERCENT": "5"})
+    """routing applies to submissions of at least 64 streams (a wave of sequential lanes)"""
+    res = _run(["routing"], True, {"NFCGPU_DENSE_PERCENT": "5"})
     _check(res, windowed=False)
     assert sum(r["stats"]["fallback"] for r in res) > 0
 

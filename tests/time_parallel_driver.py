@@ -67,6 +67,10 @@ def main():
         streams = [synth.magnitude_f32(template, s, 0, 1 << 18) for s in range(12)]
         out.append(case("12 synthetic streams x 2^18, IQ entry, 2 buffers", streams, buffers=2, stride=2))
 
+    if "routing" in which:
+        streams = [synth.magnitude_f32(template, s, 0, 1 << 16) for s in range(64)]
+        out.append(case("64 synthetic streams x 2^16 (dense: sequential path when routing is on)", streams))
+
     if not which or "offgrid" in which:
         mag = np.abs(T.load_fixture("test_NFC-A_106kbps_001")).astype(np.float32)
         mag = (mag * np.float32(1.0000153)).astype(np.float32)  # off the int16 grid: sequential path
