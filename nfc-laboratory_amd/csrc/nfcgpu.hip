@@ -70,14 +70,19 @@ struct StreamInfo
    std::deque<nfcgpu_frame> queue;
 };
 
-/* advance the clock mirror by one submission; true when the stream is, during it, within 1024 samples of its start
- * or of the 32-bit clock wrap (same test as nfc_exact_span in nfc_kernels.hip, which decides per stream block) */
-bool advance_clock(StreamInfo &si, uint32_t count)
+/* true when a stream whose clock mirror reads `clock` is, during a submission of `count` samples, within 1024 samples
+ * of its start or of the 32-bit clock wrap (same test as nfc_exact_span in nfc_kernels.hip, which decides per stream
+ * block). The mirror itself is only advanced once the launch has been issued (commit_clock). */
+bool exact_zone(uint32_t clock, uint32_t count)
 {
-   const uint32_t start = si.clock + 1u + 1024u;
+   const uint32_t start = clock + 1u + 1024u;
    const uint32_t untilWrap = 0u - start;
-   si.clock += count;
    return count != 0 && (start < 2048u || untilWrap < count);
+}
+
+void commit_clock(StreamInfo &si, uint32_t count)
+{
+   si.clock += count;
 }
 
 struct ProfiledLaunch
@@ -530,7 +535,7 @@ int launch_sequential(nfcgpu_ctx *ctx, uint32_t config, const std::vector<Window
       w.count = it.count;
       w.stride = stride;
       samples += it.count;
-      const bool exact = advance_clock(ctx->streams[it.slot], it.count);
+      const bool exact = exact_zone(ctx->streams[it.slot].clock, it.count);
       exactPossible = exactPossible || exact;
       exactOnly = exactOnly && (exact || it.count == 0);
    }
@@ -544,7 +549,14 @@ int launch_sequential(nfcgpu_ctx *ctx, uint32_t config, const std::vector<Window
    L.firstSlot = first;
    L.slotCount = last - first + 1;
 
-   return launch_demod(ctx, config, L, samples, exactPossible, exactOnly);
+   int rc = launch_demod(ctx, config, L, samples, exactPossible, exactOnly);
+   if (rc)
+      return rc;
+
+   for (const WindowedItem &it: items)
+      commit_clock(ctx->streams[it.slot], it.count);
+
+   return NFCGPU_OK;
 }
 
 /* may these streams take the time-parallel path for this submission? (one configuration, one sample format) */
@@ -1523,7 +1535,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
          first = id < first ? id : first;
          last = id > last ? id : last;
          groupSamples += b->n_samples[i];
-         const bool exact = advance_clock(ctx->streams[id], b->n_samples[i]);
+         const bool exact = exact_zone(ctx->streams[id].clock, b->n_samples[i]);
          exactPossible = exactPossible || exact;
          exactOnly = exactOnly && (exact || b->n_samples[i] == 0);
       }
@@ -1560,6 +1572,14 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       {
          clearWorks();
          return rc;
+      }
+
+      /* the clock mirrors follow once the launch is on its way */
+      for (uint32_t i = 0; i < b->n_streams; i++)
+      {
+         const uint32_t id = b->stream_ids[i];
+         if (ctx->streams[id].config == c)
+            commit_clock(ctx->streams[id], b->n_samples[i]);
       }
    }
 
@@ -1716,11 +1736,14 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       return NFCGPU_EINVAL;
    if ((uint64_t)first + count > ctx->maxStreams)
       return fail(ctx, NFCGPU_ESTREAM, "stream range out of bounds");
-   if (n == 0)
-      return NFCGPU_OK;
+
+   /* rows are read as float2 (IQ) or float: base and pitch have to be aligned to a sample */
+   if (((uintptr_t)base % (4u * stride)) != 0 || (count > 1 && (pitch % (4u * stride)) != 0))
+      return fail(ctx, NFCGPU_EINVAL, "base and pitch must be multiples of the sample size (4 bytes magnitude, 8 bytes IQ)");
 
    HIP_TRY(ctx, hipSetDevice(ctx->device));
 
+   /* an empty buffer still stores a new sample rate and re-initialises the stream, like nfcgpu_submit (NfcDecoder.cpp:383-388) */
    for (uint32_t i = first; i < first + count; i++)
    {
       if (!ctx->streams[i].open)
@@ -1730,6 +1753,9 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       if (rc)
          return rc;
    }
+
+   if (n == 0)
+      return NFCGPU_OK;
 
    const uint8_t *devBase = (const uint8_t *)base;
    uint64_t devPitch = pitch;
@@ -1794,7 +1820,7 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       bool exactPossible = false, exactOnly = true;
       for (uint32_t k = i; k < j; k++)
       {
-         const bool exact = advance_clock(ctx->streams[k], n);
+         const bool exact = exact_zone(ctx->streams[k].clock, n);
          exactPossible = exactPossible || exact;
          exactOnly = exactOnly && exact;
       }
@@ -1802,6 +1828,9 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i), exactPossible, exactOnly);
       if (rc)
          return rc;
+
+      for (uint32_t k = i; k < j; k++)
+         commit_clock(ctx->streams[k], n);
 
       i = j;
    }
