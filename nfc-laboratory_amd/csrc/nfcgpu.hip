@@ -133,14 +133,15 @@ struct nfcgpu_ctx
    uint32_t windowedMinSamples = 32768; /* shortest submission (per stream) worth cutting into windows */
    uint32_t scanChunk = 8192;      /* samples per scan chunk: short chunks = many lanes (the walk is latency-bound per wave) */
    uint32_t scanWarm = 6144;       /* samples walked ahead of a chunk */
-   uint32_t maxPasses = 12;
+   uint32_t maxPasses = 12;        /* decode passes before a stream of a large submission gives up (sequential path) */
+   uint32_t maxPassesFew = 48;     /* the same for submissions of fewer streams than a wave has lanes: the sequential path would crawl */
    struct DevBuf
    {
       void *ptr = nullptr;
       size_t bytes = 0;
    };
    DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
-   uint32_t densePercent = 10;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
+   uint32_t densePercent = 3;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
@@ -886,7 +887,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          return rc;
 
       HIP_TRY(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));
-      hipLaunchKernelGGL(nfc_chain_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, lanes, ctx->maxPasses);
+      hipLaunchKernelGGL(nfc_chain_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, lanes, nJobs >= NFC_LANES ? ctx->maxPasses : ctx->maxPassesFew);
       HIP_TRY(ctx, hipGetLastError());
 
       uint32_t again = 0;
@@ -1141,6 +1142,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->scanChunk = knob("NFCGPU_SCAN_CHUNK", ctx->scanChunk) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
+   ctx->maxPassesFew = knob("NFCGPU_WINDOW_PASSES", ctx->maxPassesFew);
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
    ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->densePercent);
    if (ctx->windowWaves == 0)
@@ -2254,6 +2256,29 @@ const char *nfcgpu_last_error(nfcgpu_ctx *ctx)
 {
    return ctx ? ctx->lastError.c_str() : "";
 }
+
+#ifdef NFCGPU_EMULATED_TEST_BUILD
+/* TEST HOOKS, only in the emulated build of tests/hostsim (device memory is host memory there): place a stream's sample
+ * clock (device record and host mirror) anywhere, e.g. next to the 32-bit wrap, and read it back. The reference offers no
+ * way to preset its clock, so the product has none either. */
+int nfcgpu_test_set_clock(nfcgpu_ctx *ctx, uint32_t id, uint32_t clock)
+{
+   if (!ctx || id >= ctx->maxStreams || !ctx->streams[id].open || !ctx->streams[id].initialized)
+      return NFCGPU_ESTREAM;
+   ctx->dStates[id].clock = clock;
+   ctx->streams[id].clock = clock;
+   return NFCGPU_OK;
+}
+
+int nfcgpu_test_get_clock(nfcgpu_ctx *ctx, uint32_t id, uint32_t *device, uint32_t *mirror)
+{
+   if (!ctx || id >= ctx->maxStreams || !device || !mirror)
+      return NFCGPU_ESTREAM;
+   *device = ctx->dStates[id].clock;
+   *mirror = ctx->streams[id].clock;
+   return NFCGPU_OK;
+}
+#endif
 
 const char *nfcgpu_version(void)
 {

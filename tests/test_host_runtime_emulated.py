@@ -206,3 +206,47 @@ def test_configuration_table_is_recycled(emulated, tmp_path):
     assert out["changing"] is True
     assert out["code"] == -3 and out["failed_at"] == 256, out     # NFCGPU_ENOMEM at the 257th configuration in use
     assert out["after_close"] is True
+
+
+def test_a_block_is_taken_by_one_kernel_per_launch_at_the_clock_wrap(emulated):
+    """Two stream blocks of one launch whose clocks sit one buffer apart just before the exact-modulo zone of the 32-bit
+    wrap: the common kernel runs first and advances the clocks of the blocks it takes; the exact kernel of the same launch
+    must not look at those blocks again (their clocks may have moved into its zone meanwhile). Before the launch stamp
+    (NfcStreamState::served) the second block was decoded twice and its clock ran 4096 samples ahead of the host mirror."""
+    import ctypes
+    import numpy as np
+    lib = ctypes.CDLL(emulated)
+    vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+    ctx = vp()
+    assert lib.nfcgpu_init(0, None, ctypes.byref(ctx)) == 0
+    try:
+        first = u32()
+        lib.nfcgpu_stream_open_many.argtypes = [vp, vp, u32, ctypes.POINTER(u32)]
+        assert lib.nfcgpu_stream_open_many(ctx, None, 128, ctypes.byref(first)) == 0
+        n = 4096
+        idle = (0.25 + (np.arange(n) % 3) / 32768.0).astype(np.float32)
+        ids = (u32 * 2)(first.value, first.value + 64)
+        ptrs = (vp * 2)(idle.ctypes.data, idle.ctypes.data)
+        cnts = (u32 * 2)(n, n)
+
+        class Batch(ctypes.Structure):
+            _fields_ = [("n_streams", u32), ("stride", u32), ("location", u32), ("sample_rate", u32), ("stream_ids", ctypes.POINTER(u32)),
+                        ("data", ctypes.POINTER(vp)), ("n_samples", ctypes.POINTER(u32))]
+
+        b = Batch(2, 1, 0, 10000000, ids, ptrs, cnts)
+        lib.nfcgpu_submit_batch.argtypes = [vp, ctypes.POINTER(Batch)]
+        assert lib.nfcgpu_submit_batch(ctx, ctypes.byref(b)) == 0   # initialises both streams
+        lib.nfcgpu_test_set_clock.argtypes = [vp, u32, u32]
+        lib.nfcgpu_test_get_clock.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+        zone = (1 << 32) - 1024 - 1          # clocks from here on need the exact-modulo kernel
+        c0 = zone - 2000                      # block 0: enters the zone during this buffer -> exact kernel
+        c1 = c0 - n                           # block 1: one buffer behind -> common kernel, then inside the span test
+        assert lib.nfcgpu_test_set_clock(ctx, ids[0], c0) == 0 and lib.nfcgpu_test_set_clock(ctx, ids[1], c1) == 0
+        assert lib.nfcgpu_submit_batch(ctx, ctypes.byref(b)) == 0
+        for sid, start in ((ids[0], c0), (ids[1], c1)):
+            dev, mir = u32(), u32()
+            assert lib.nfcgpu_test_get_clock(ctx, sid, ctypes.byref(dev), ctypes.byref(mir)) == 0
+            assert dev.value == (start + n) & 0xFFFFFFFF, (sid, dev.value - start)
+            assert mir.value == dev.value
+    finally:
+        lib.nfcgpu_shutdown(ctx)
