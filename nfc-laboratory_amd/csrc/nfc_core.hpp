@@ -1080,6 +1080,44 @@ NFC_DEV bool nfc_at_rest(const NfcStreamState &s)
    return busy == 0;
 }
 
+/* At rest, or with an NFC-F preamble detector that came back from another technology's lock with its windows in the
+ * past (NfcF.cpp:262-283 only clears a record on a deep pulse or after a peak): such a record sits there until the next
+ * pulse that exceeds the correlation threshold - no window end or synchronisation sample is ahead, no peak is waiting
+ * for its timeout - so through quiet tiles it is as inert as a cleared one. It is not the same as a cleared one (the
+ * next pulse finds `sync` set), which is why it travels with the lane's carry (NfcCarry::search) as it is. */
+NFC_DEV bool nfc_quiescent(const NfcStreamState &s)
+{
+   const NfcSearchRegs &r = s.u.search;
+   uint32_t busy = s.lockTech | s.unlock;
+
+   for (int i = 0; i < 3; i++)
+      busy |= r.detA[i].winStart | r.detA[i].winEnd | r.detA[i].symStart | r.detA[i].peakTime | nfc_bits(r.detA[i].peak) | nfc_bits(r.detA[i].aux);
+
+   for (int i = 0; i < 2; i++)
+      busy |= r.detB[i].winStart | r.detB[i].winEnd | r.detB[i].symStart | r.detB[i].symEnd | r.detB[i].auxTime | nfc_bits(r.detB[i].aux);
+
+   busy |= r.detV.winStart | r.detV.winEnd | r.detV.symStart | r.detV.peakTime | nfc_bits(r.detV.peak) | nfc_bits(r.detV.aux);
+
+   if (busy)
+      return false;
+
+   /* a time of the past: zero, or at least 256 samples (and less than 2^31) ago */
+   auto past = [&](uint32_t t) { return t == 0u || (uint32_t)(s.clock - t - 256u) < 0x7FFFFF00u; };
+
+   for (int i = 0; i < 2; i++)
+   {
+      const NfcDetF &f = r.detF[i];
+
+      if (f.peakTime | nfc_bits(f.peak))
+         return false;
+
+      if (!past(f.winStart) || !past(f.winEnd) || !past(f.sync))
+         return false;
+   }
+
+   return true;
+}
+
 /* run-time selection of the variant (CPU test build of this text; the kernels instantiate one variant each) */
 NFC_DEV void nfc_step(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value, bool exact)
 {

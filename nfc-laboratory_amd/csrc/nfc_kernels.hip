@@ -731,10 +731,52 @@ __global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restr
       atomicAdd(&A.jobs[lo].busyTiles, 1u);
 }
 
-/* one thread per job: retire / dark marks and the windows */
+/* One wave per job: retire / dark marks and the windows, 64 tiles per step (nfc_scan.hpp: nfc_group_*). Every lane of
+ * the wave holds the same masks and the same placer state; lane 0 writes the windows. */
+__device__ __forceinline__ uint32_t nfc_windows_place(const NfcScanJob &job, uint32_t j, const uint32_t *__restrict__ t, uint32_t nTiles, NfcWindow *out,
+                                                      uint32_t room, bool write)
+{
+   const uint32_t lane = threadIdx.x;
+   const uint32_t groups = (nTiles + 63u) / 64u;
+
+   NfcWindowPlacer placer {0u, 0u};
+   uint64_t busyBefore = ~0ull;
+
+   for (uint32_t g0 = 0; g0 < groups; g0 += 4u)
+   {
+      uint32_t f[4];
+
+      for (uint32_t k = 0; k < 4u; k++)
+      {
+         const uint32_t i = (g0 + k) * 64u + lane;
+         f[k] = i < nTiles ? t[i] : 0u;
+      }
+
+      for (uint32_t k = 0; k < 4u && g0 + k < groups; k++)
+      {
+         const uint32_t g = g0 + k;
+         const uint32_t i = g * 64u + lane;
+         const bool exists = i < nTiles;
+
+         const uint64_t busy = __ballot(exists && (f[k] & NFC_TILE_BUSY) != 0u);
+         const uint64_t cluster = __ballot(exists && nfc_tile_may_start(i, job.count) && nfc_group_cluster(busyBefore, busy, lane));
+         const uint64_t cut = __ballot(exists && !(f[k] & (NFC_TILE_RETIRE_OK | NFC_TILE_DARK)) && nfc_tile_may_cut(i, job.count));
+
+         if (cluster | cut)
+            nfc_group_place(placer, job, j, out, room, g, cluster, cut, write && lane == 0u);
+
+         busyBefore = busy;
+      }
+   }
+
+   nfc_windows_close(placer, job, j, out, room, write && lane == 0u);
+   return placer.n;
+}
+
 __global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
 {
-   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+   const uint32_t j = blockIdx.x;
+   const uint32_t lane = threadIdx.x;
 
    if (j >= A.nJobs)
       return;
@@ -746,13 +788,63 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
    if (job.status & NFC_JOB_INVALID)
    {
       job.windows = 0;
-      A.jobs[j] = job;
+      if (lane == 0u)
+         A.jobs[j] = job;
       return;
    }
 
+   const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+   const uint32_t groups = (nTiles + 63u) / 64u;
+   uint32_t *t = A.tiles + job.firstTile;
+
+   /* backwards: where a lane may retire, and how much dark signal lies ahead */
+   {
+      uint64_t blockedNext = ~0ull;
+      uint32_t carry = 0u;
+
+      for (uint32_t done = 0; done < groups; done += 4u)
+      {
+         uint32_t f[4];
+
+         for (uint32_t k = 0; k < 4u; k++)
+         {
+            const uint32_t g = groups - 1u - done - k; /* wraps for k beyond the first group: i >= nTiles then */
+            const uint32_t i = g * 64u + lane;
+            f[k] = (done + k < groups && i < nTiles) ? t[i] : 0u;
+         }
+
+         for (uint32_t k = 0; k < 4u && done + k < groups; k++)
+         {
+            const uint32_t g = groups - 1u - done - k;
+            const uint32_t i = g * 64u + lane;
+            const bool exists = i < nTiles;
+
+            const uint64_t blocked = __ballot(!exists || (f[k] & NFC_TILE_BUSY) != 0u);
+            const uint64_t dark = __ballot(exists && (f[k] & NFC_TILE_DARK) != 0u);
+            const bool full = g * 64u + 64u <= nTiles;
+
+            const uint32_t run = nfc_group_dark_run(dark, full, lane, carry);
+            const bool ok = nfc_group_retire_ok(blocked, blockedNext, lane);
+
+            if (exists)
+               t[i] = (f[k] & 0xFFFFu & ~NFC_TILE_RETIRE_OK) | (ok ? NFC_TILE_RETIRE_OK : 0u) | (run << NFC_TILE_DARK_RUN_SHIFT);
+
+            carry = nfc_group_dark_run(dark, full, 0u, carry);
+            blockedNext = blocked;
+         }
+      }
+   }
+
+   __threadfence_block();
+   __syncthreads();
+
    /* count, reserve, fill: the speculative windows of a job are contiguous and ordered */
-   const uint32_t need = nfc_windows_build(job, j, A.tiles, nullptr, 0);
-   const uint32_t first = atomicAdd(A.windowCount, need);
+   const uint32_t need = nfc_windows_place(job, j, t, nTiles, nullptr, 0u, false);
+
+   uint32_t first = 0u;
+   if (lane == 0u)
+      first = atomicAdd(A.windowCount, need);
+   first = (uint32_t)__shfl((int)first, 0, 64);
 
    job.firstWindow = A.firstWindowSlot + first;
    job.windows = need;
@@ -763,9 +855,10 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
       job.windows = 0;
    }
    else
-      nfc_windows_build(job, j, A.tiles, A.windows + job.firstWindow, need);
+      (void)nfc_windows_place(job, j, t, nTiles, A.windows + job.firstWindow, need, true);
 
-   A.jobs[j] = job;
+   if (lane == 0u)
+      A.jobs[j] = job;
 }
 
 /* Prepare lanes. Carry lanes (window index == job index, one wave per job): a copy of the stream's slot, so that the
@@ -1027,7 +1120,7 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
          nfc_lane_publish(L.windows[slot], s, *mem.cold);
 
       /* retire? (tile boundary: TILE == NFC_SCAN_TILE and every lane starts on a tile boundary of its stream) */
-      if (!stopped && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
+      if (!stopped && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_quiescent(s) &&
           s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
          stopped = true;
 
@@ -1089,7 +1182,10 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
    {
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
-      L.windows[slot].retired = handed ? 2u : (consumed < mineCount ? 1u : 0u);
+      /* out of samples in a state the closing window can take over from (nfc_lane_comparable): as good as stopped at rest,
+       * and the stream's final state is then the closing window's (768 samples to run again instead of this lane) */
+      const bool closing = L.windows[slot].activate >= L.windows[slot].start + mineCount;
+      L.windows[slot].retired = handed ? 2u : ((consumed < mineCount || (!closing && nfc_lane_comparable(s, *mem.cold))) ? 1u : 0u);
 
       atomicAdd(L.laneStats, (stepped + TILE - 1) / TILE);
       atomicMax(L.laneStats + 1, (stepped + TILE - 1) / TILE);
@@ -1225,10 +1321,14 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
             bool done = consumed >= mineCount;
             uint32_t how = done ? 0u : 1u;
 
+            /* out of samples, but not the closing window, in a state that one can take over from: see nfc_window_body */
+            if (done && L.windows[w].activate < startPos + mineCount && nfc_lane_comparable(s, *mem.cold))
+               how = 1u;
+
             if (!done && startPos + consumed == verifyPos)
                nfc_lane_publish(L.windows[w], s, *mem.cold);
 
-            if (!done && consumed >= warm && (flags[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
+            if (!done && consumed >= warm && (flags[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_quiescent(s) &&
                 s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
                done = true;
 

@@ -24,6 +24,7 @@ struct NfcScanParams
 {
    float rangeK;   /* 0.49 * smallest correlation threshold of the enabled raw-signal detectors (A, F, V); +inf when none */
    float edgeK;    /* 0.99 * NFC-B minimum modulation depth; +inf when NFC-B is disabled */
+   float deepK;    /* 0.98 * smallest maximum modulation depth of the enabled detectors */
    uint32_t chunkSamples;  /* samples per chunk (multiple of NFC_SCAN_POINT) */
    uint32_t warmSamples;   /* samples walked before a chunk to reach the true front-end state (multiple of NFC_SCAN_POINT) */
 };
@@ -200,6 +201,16 @@ NFC_DEV uint32_t nfc_tile_flags(const NfcConfig &c, const NfcScanParams &sp, con
 
       if (!((hi - lo) <= sp.rangeK * t[i].envmin))
          flags |= NFC_TILE_RANGE;
+
+      /* modulation deeper than the smallest maximum a detector accepts (NfcF.cpp:262: the one test of a search detector
+       * that is not a correlation; it clears a record that is not at rest): depth = (env - x) / env <= (envmax - xmin) / envmin */
+      {
+         float xm = t[i].xmin < t[i - 1].xmin ? t[i].xmin : t[i - 1].xmin;
+         float eh = t[i].envmax > t[i - 1].envmax ? t[i].envmax : t[i - 1].envmax;
+         float el = t[i].envmin < t[i - 1].envmin ? t[i].envmin : t[i - 1].envmin;
+         if (!((eh - xm) <= sp.deepK * el))
+            flags |= NFC_TILE_RANGE;
+      }
 
       float fm = t[i].fmin;
       for (uint32_t k = 1; k <= NFC_SCAN_EDGEBACK; k++)
@@ -396,6 +407,130 @@ NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uin
       put((job.count - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, job.count);
 
    return n;
+}
+
+/* ---- the same, 64 tiles at a time ----
+ * nfc_windows_build is the statement of the rule; one thread walking a million tiles of a long capture took longer than
+ * decoding it. The kernel (one wave per job) forms bit masks of 64 tiles with ballots and applies the rule to the masks:
+ * bit l of a mask = tile 64 * g + l. The emulated runtime runs both forms and compares them. */
+
+/* bits l .. l+63 of the 128-bit string hi:lo */
+NFC_DEV uint64_t nfc_bits_from(uint64_t lo, uint64_t hi, uint32_t l)
+{
+   return l == 0u ? lo : ((lo >> l) | (hi << (64u - l)));
+}
+
+NFC_DEV uint64_t nfc_group_valid(uint32_t nTiles, uint32_t g)
+{
+   const uint32_t first = g * 64u;
+   if (first >= nTiles)
+      return 0ull;
+   const uint32_t n = nTiles - first;
+   return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+}
+
+/* a lane may retire at tile l of the group: tiles l .. l+15 exist and are not busy (`blocked`: busy or beyond the end) */
+NFC_DEV bool nfc_group_retire_ok(uint64_t blockedHere, uint64_t blockedNext, uint32_t l)
+{
+   return (nfc_bits_from(blockedHere, blockedNext, l) & ((1ull << NFC_WINDOW_GAP) - 1ull)) == 0ull;
+}
+
+/* dark tiles in a row from tile l of the group on; `carry`: the same for the first tile of the next group (0 after the last) */
+NFC_DEV uint32_t nfc_group_dark_run(uint64_t dark, bool full, uint32_t l, uint32_t carry)
+{
+   const uint64_t inv = ~(dark >> l);
+   uint32_t run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
+   if (run > 64u - l)
+      run = 64u - l;
+   if (run == 64u - l && full)
+      run += carry;
+   return run > 0xFFFFu ? 0xFFFFu : run;
+}
+
+/* a window starts at busy tile l of the group when the 16 tiles before it exist and are quiet
+ * (`busyBefore`: the group before; all ones before the first group) */
+NFC_DEV bool nfc_group_cluster(uint64_t busyBefore, uint64_t busyHere, uint32_t l)
+{
+   if (!((busyHere >> l) & 1ull))
+      return false;
+   const uint64_t w = l >= NFC_WINDOW_GAP ? (busyHere >> (l - NFC_WINDOW_GAP)) : ((busyBefore >> (64u - NFC_WINDOW_GAP + l)) | (busyHere << (NFC_WINDOW_GAP - l)));
+   return (w & ((1ull << NFC_WINDOW_GAP) - 1ull)) == 0ull;
+}
+
+/* static conditions of a window that activates at tile i */
+NFC_DEV bool nfc_tile_may_start(uint32_t i, uint32_t count)
+{
+   return i * NFC_SCAN_TILE >= NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR + NFC_SCAN_POINT;
+}
+
+NFC_DEV bool nfc_tile_may_cut(uint32_t i, uint32_t count)
+{
+   return nfc_tile_may_start(i, count) && i * NFC_SCAN_TILE + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= count;
+}
+
+struct NfcWindowPlacer
+{
+   uint32_t lastAct; /* activation of the most recent window (the carry lane goes live at 0) */
+   uint32_t n;       /* windows so far */
+};
+
+NFC_DEV void nfc_window_put(NfcWindowPlacer &p, const NfcScanJob &job, uint32_t jobIndex, NfcWindow *out, uint32_t room, uint32_t start, uint32_t activate, bool write)
+{
+   if (write && p.n < room)
+   {
+      NfcWindow &w = out[p.n];
+      __builtin_memset(&w, 0, sizeof(w));
+      w.job = jobIndex;
+      w.start = start;
+      w.activate = activate;
+      w.verify = activate + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= job.count ? activate + NFC_WINDOW_VERIFY : 0xFFFFFFFFu;
+   }
+   p.n++;
+}
+
+/* windows of group g: `cluster` = tiles where a window starts after a gap (with nfc_tile_may_start), `cut` = tiles where a
+ * lane cannot retire (with nfc_tile_may_cut). Same order of decisions as the loop of nfc_windows_build. */
+NFC_DEV void nfc_group_place(NfcWindowPlacer &p, const NfcScanJob &job, uint32_t jobIndex, NfcWindow *out, uint32_t room, uint32_t g, uint64_t cluster,
+                             uint64_t cut, bool write)
+{
+   const uint32_t warm = NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
+   uint32_t pos = 0;
+
+   while (pos < 64u)
+   {
+      const uint64_t from = ~0ull << pos;
+      const uint64_t c = cluster & from;
+
+      /* first tile of the group a cut window may activate at */
+      const uint32_t due = (p.lastAct + NFC_WINDOW_CUT) / NFC_SCAN_TILE;
+      uint64_t e = 0ull;
+      if (due < g * 64u + 64u)
+      {
+         const uint32_t first = due > g * 64u + pos ? due - g * 64u : pos;
+         e = cut & (~0ull << first);
+      }
+
+      if (!c && !e)
+         break;
+
+      const uint32_t lc = c ? (uint32_t)__builtin_ctzll(c) : 64u;
+      const uint32_t le = e ? (uint32_t)__builtin_ctzll(e) : 64u;
+      const uint32_t l = lc <= le ? lc : le;
+      const uint32_t act = (g * 64u + l) * NFC_SCAN_TILE;
+
+      nfc_window_put(p, job, jobIndex, out, room, (act - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, act, write);
+      p.lastAct = act;
+      pos = l + 1u;
+   }
+}
+
+/* the closing window */
+NFC_DEV void nfc_windows_close(NfcWindowPlacer &p, const NfcScanJob &job, uint32_t jobIndex, NfcWindow *out, uint32_t room, bool write)
+{
+   const uint32_t warm = NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
+
+   if (job.count >= warm + NFC_SCAN_POINT && job.count > p.lastAct)
+      nfc_window_put(p, job, jobIndex, out, room, (job.count - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, job.count, write);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -855,7 +990,9 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
       x.live = 1;
       job.finalLane = lane;
 
-      if (x.retired == 0 || x.stop >= job.count)
+      /* ran to the end of the submission in a state nothing can take over from (locked, or rings not yet steady): the
+       * stream's final state is this lane's. One that got there in a comparable state hands over to the closing window */
+      if (x.retired == 0 || (x.stop >= job.count && x.retired != 1u))
          break;
 
       have = left;

@@ -13,6 +13,7 @@ struct NfcScanParams
 {
    float rangeK;
    float edgeK;
+   float deepK;
    uint32_t chunkSamples;
    uint32_t warmSamples;
 };

@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -141,7 +142,7 @@ struct nfcgpu_ctx
       size_t bytes = 0;
    };
    DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
-   uint32_t densePercent = 3;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
+   uint32_t densePercent = 8;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
@@ -615,6 +616,11 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (cfg.enabled & 8u) corr = cfg.corrThreshold[3] < corr ? cfg.corrThreshold[3] : corr;
       sp.rangeK = corr < 1.0e30f ? 0.49f * corr : 3.0e38f;
       sp.edgeK = (cfg.enabled & 2u) ? 0.99f * cfg.minDepth[1] : 3.0e38f;
+      float deep = 1.0f;
+      for (int t = 0; t < 4; t++)
+         if ((cfg.enabled >> t) & 1u)
+            deep = cfg.maxDepth[t] < deep ? cfg.maxDepth[t] : deep;
+      sp.deepK = 0.98f * deep;
       sp.chunkSamples = ctx->scanChunk;
       sp.warmSamples = ctx->scanWarm;
    }
@@ -734,6 +740,20 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    const NfcConfig *dCfg = ctx->dConfigs + config;
 
+   /* NFCGPU_WINDOW_DEBUG: where the time of a submission goes (synchronises at every mark) */
+   const bool debugStages = std::getenv("NFCGPU_WINDOW_DEBUG") != nullptr;
+   auto stageBegan = std::chrono::steady_clock::now();
+   auto mark = [&](const char *what) {
+      if (!debugStages)
+         return;
+      (void)hipStreamSynchronize(ctx->stream);
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[nfcgpu] windowed stage %-10s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - stageBegan).count());
+      stageBegan = now;
+   };
+
+   mark("tables");
+
    /* scan */
    ProfiledLaunch pl {nullptr, nullptr};
    record_span(ctx, ctx->timedScan, pl, true);
@@ -744,6 +764,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    /* windows (again with more room when the guess was short) */
    uint32_t nWindows = 0;
+
+   mark("scan");
 
    /* a first run of the tile tests: how busy is each stream? (routing, nfc_seams_kernel) */
    hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
@@ -777,9 +799,11 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
    HIP_TRY(ctx, hipGetLastError());
 
+   mark("seams");
+
    for (int attempt = 0; attempt < 2; attempt++)
    {
-      hipLaunchKernelGGL(nfc_windows_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A);
+      hipLaunchKernelGGL(nfc_windows_kernel, dim3(nJobs), dim3(64), 0, ctx->stream, A);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemcpyAsync(&nWindows, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -797,6 +821,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       A.windowRoom = room;
       HIP_TRY(ctx, hipMemsetAsync(counters, 0, 4, ctx->stream));
    }
+
+   mark("windows");
 
    NfcLaunch real = base_launch(ctx);
 
@@ -862,9 +888,12 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    record_span(ctx, ctx->timedWindow, pw, true);
 
    uint32_t pass = 0;
+   const bool debugPasses = std::getenv("NFCGPU_WINDOW_DEBUG") != nullptr;
 
    for (;;)
    {
+      const auto passBegan = std::chrono::steady_clock::now();
+
       if (nWindows)
       {
          HIP_TRY(ctx, hipMemsetAsync(counters + 2, 0, 8, ctx->stream)); /* run list: count and next */
@@ -894,14 +923,15 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       HIP_TRY(ctx, hipMemcpyAsync(&again, counters + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
-      if (std::getenv("NFCGPU_WINDOW_DEBUG"))
+      if (debugPasses)
       {
          uint32_t ls[3] = {0, 0, 0};
          HIP_TRY(ctx, hipMemcpy(ls, counters + 4, 12, hipMemcpyDeviceToHost));
          HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, 12, ctx->stream));
          HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-         std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled\n", pass, ls[2],
-                      (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again);
+         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - passBegan).count();
+         std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled, %.1f ms\n", pass, ls[2],
+                      (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again, ms);
       }
 
       ctx->stats.window_passes++;
@@ -910,6 +940,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (!again || !nWindows)
          break;
    }
+
+   mark("passes");
 
    /* the state a stream is left in: its last lane's, run once more with storage of its own */
    hipLaunchKernelGGL(nfc_final_lanes_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, dCfg, A, lanes);
@@ -925,6 +957,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    HIP_TRY(ctx, hipMemcpyAsync(jobs.data(), ctx->wJobs.ptr, sizeof(NfcScanJob) * nJobs, hipMemcpyDeviceToHost, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   mark("finish");
 
    ctx->stats.windows += nWindows + nJobs;
    ctx->stats.samples += totalSamples;

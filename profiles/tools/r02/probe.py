@@ -17,7 +17,11 @@ template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
 template_dev = torch.from_numpy(template.astype(np.int16)).to(dev)
 T = K * L
 data = torch.empty((S, T, 2), dtype=torch.float32, device=dev)
-synth.fill_iq_torch(data, template_dev, first_stream=0, chunk_streams=max(1, min(1024, (1 << 26) // T)))
+if os.environ.get("PROBE_SPARSE") == "1":
+    segs = synth.sparse_segments(template)
+    synth.fill_sparse_iq_torch(data, template_dev, segs, first_stream=0, chunk_streams=max(1, min(256, (1 << 26) // T)))
+else:
+    synth.fill_iq_torch(data, template_dev, first_stream=0, chunk_streams=max(1, min(1024, (1 << 26) // T)))
 if os.environ.get("PROBE_IDLE") == "1":
     # unmodulated carrier with a few LSB of (non-periodic, per-stream) noise on the int16 grid
     t = torch.arange(T, device=dev, dtype=torch.int64)

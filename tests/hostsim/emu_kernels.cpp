@@ -375,7 +375,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
             dump("publish");
          }
 
-         if (base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_at_rest(s) &&
+         if (base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_quiescent(s) &&
              s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
             break;
 
@@ -439,7 +439,8 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
 
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
-      L.windows[slot].retired = handed ? 2u : (consumed < mineCount ? 1u : 0u);
+      const bool closing = L.windows[slot].activate >= L.windows[slot].start + mineCount;
+      L.windows[slot].retired = handed ? 2u : ((consumed < mineCount || (!closing && nfc_lane_comparable(s, *mem.cold))) ? 1u : 0u);
 
       emu_add(L.laneStats, (stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE);
       if ((stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE > L.laneStats[1])
@@ -562,6 +563,74 @@ void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint3
    }
 }
 
+/* the kernel's form of the rule (masks of 64 tiles, nfc_group_*), tile by tile where the kernel uses a ballot */
+static uint32_t emu_windows_place(const NfcScanJob &job, uint32_t j, const uint32_t *t, uint32_t nTiles, NfcWindow *out, uint32_t room, bool write)
+{
+   const uint32_t groups = (nTiles + 63u) / 64u;
+   NfcWindowPlacer placer {0u, 0u};
+   uint64_t busyBefore = ~0ull;
+
+   for (uint32_t g = 0; g < groups; g++)
+   {
+      uint64_t busy = 0, cluster = 0, cut = 0;
+
+      for (uint32_t l = 0; l < 64u && g * 64u + l < nTiles; l++)
+         if (t[g * 64u + l] & NFC_TILE_BUSY)
+            busy |= 1ull << l;
+
+      for (uint32_t l = 0; l < 64u && g * 64u + l < nTiles; l++)
+      {
+         const uint32_t i = g * 64u + l;
+         if (nfc_tile_may_start(i, job.count) && nfc_group_cluster(busyBefore, busy, l))
+            cluster |= 1ull << l;
+         if (!(t[i] & (NFC_TILE_RETIRE_OK | NFC_TILE_DARK)) && nfc_tile_may_cut(i, job.count))
+            cut |= 1ull << l;
+      }
+
+      if (cluster | cut)
+         nfc_group_place(placer, job, j, out, room, g, cluster, cut, write);
+
+      busyBefore = busy;
+   }
+
+   nfc_windows_close(placer, job, j, out, room, write);
+   return placer.n;
+}
+
+static void emu_windows_marks(uint32_t *t, uint32_t nTiles)
+{
+   const uint32_t groups = (nTiles + 63u) / 64u;
+   uint64_t blockedNext = ~0ull;
+   uint32_t carry = 0;
+
+   for (uint32_t g = groups; g-- > 0;)
+   {
+      uint64_t blocked = 0, dark = 0;
+
+      for (uint32_t l = 0; l < 64u; l++)
+      {
+         const uint32_t i = g * 64u + l;
+         if (i >= nTiles || (t[i] & NFC_TILE_BUSY))
+            blocked |= 1ull << l;
+         if (i < nTiles && (t[i] & NFC_TILE_DARK))
+            dark |= 1ull << l;
+      }
+
+      const bool full = g * 64u + 64u <= nTiles;
+
+      for (uint32_t l = 0; l < 64u && g * 64u + l < nTiles; l++)
+      {
+         const uint32_t i = g * 64u + l;
+         const uint32_t run = nfc_group_dark_run(dark, full, l, carry);
+         const bool ok = nfc_group_retire_ok(blocked, blockedNext, l);
+         t[i] = (t[i] & 0xFFFFu & ~NFC_TILE_RETIRE_OK) | (ok ? NFC_TILE_RETIRE_OK : 0u) | (run << NFC_TILE_DARK_RUN_SHIFT);
+      }
+
+      carry = nfc_group_dark_run(dark, full, 0u, carry);
+      blockedNext = blocked;
+   }
+}
+
 void nfc_windows_kernel(NfcScanArgs A)
 {
    for (uint32_t j = 0; j < A.nJobs; j++)
@@ -579,8 +648,20 @@ void nfc_windows_kernel(NfcScanArgs A)
 
       const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
 
-      const uint32_t need = nfc_windows_build(job, j, A.tiles, nullptr, 0);
+      /* the rule as stated (nfc_windows_build), on a copy, to hold the kernel's form against */
+      std::vector<uint32_t> stated(A.tiles + job.firstTile, A.tiles + job.firstTile + nTiles);
+      const uint32_t statedNeed = nfc_windows_build(job, j, stated.data() - job.firstTile, nullptr, 0);
+
+      emu_windows_marks(A.tiles + job.firstTile, nTiles);
+
+      const uint32_t need = emu_windows_place(job, j, A.tiles + job.firstTile, nTiles, nullptr, 0, false);
       const uint32_t first = emu_add(A.windowCount, need);
+
+      if (need != statedNeed || std::memcmp(stated.data(), A.tiles + job.firstTile, 4u * nTiles) != 0)
+      {
+         std::fprintf(stderr, "[emu] window rule: the mask form differs from nfc_windows_build (job %u: %u vs %u windows)\n", j, need, statedNeed);
+         std::abort();
+      }
 
       job.firstWindow = A.firstWindowSlot + first;
       job.windows = need;
@@ -591,7 +672,17 @@ void nfc_windows_kernel(NfcScanArgs A)
          job.windows = 0;
       }
       else
-         nfc_windows_build(job, j, A.tiles, A.windows + job.firstWindow, need);
+      {
+         emu_windows_place(job, j, A.tiles + job.firstTile, nTiles, A.windows + job.firstWindow, need, true);
+
+         std::vector<NfcWindow> want(need);
+         nfc_windows_build(job, j, stated.data() - job.firstTile, want.data(), need);
+         if (need && std::memcmp(want.data(), A.windows + job.firstWindow, sizeof(NfcWindow) * need) != 0)
+         {
+            std::fprintf(stderr, "[emu] window rule: the mask form places windows differently from nfc_windows_build (job %u)\n", j);
+            std::abort();
+         }
+      }
 
       A.jobs[j] = job;
 
