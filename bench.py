@@ -78,7 +78,9 @@ def main():
     ap.add_argument("--check-streams", type=int, default=64, help="streams compared frame-by-frame with the reference")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-points", action="store_true", help="headline only")
-    ap.add_argument("--points", default="config5_dense,config5_sparse,single_dense,single_sparse")
+    ap.add_argument("--points", default="config5_sparse,config5_dense,config5_idle,share_sparse,share_dense,single_sparse,single_dense")
+    ap.add_argument("--share-streams", type=int, default=512, help="streams one GPU holds when BASELINE's 4096 are spread over 8")
+    ap.add_argument("--single-dense-samples", type=int, default=1 << 23)
     ap.add_argument("--config5-streams", type=int, default=4096)
     ap.add_argument("--config5-samples", type=int, default=1 << 20)
     ap.add_argument("--single-samples", type=int, default=1 << 26)
@@ -338,10 +340,23 @@ def main():
         segs = synth.sparse_segments(template)
         points = {}
 
-        def run_point(name, n_streams, n_samples, sparse, steps, warm, check):
+        def run_point(name, n_streams, n_samples, sparse, steps, warm, check, idle=False):
             total = (steps + warm) * n_samples
             buf = torch.empty((n_streams, total, 2), dtype=torch.float32, device=dev)
-            if sparse:
+            if idle:
+                # unmodulated carrier with a few LSB of per-stream, non-periodic noise on the int16 grid: nothing to decode
+                tix = torch.arange(total, device=dev, dtype=torch.int64)
+                for s0 in range(0, n_streams, 256):
+                    s1 = min(n_streams, s0 + 256)
+                    sid = torch.arange(s0, s1, device=dev, dtype=torch.int64)[:, None]
+                    h = (tix[None, :] * 2654435761 + sid * 40503) & 0xFFFFFFFF
+                    h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+                    h = (h ^ (h >> 13)) * 3266489917 & 0xFFFFFFFF
+                    h = h ^ (h >> 16)
+                    buf[s0:s1, :, 0] = 0.25 + ((h % 9) - 4).to(torch.float32) / 32768.0
+                    buf[s0:s1, :, 1] = 0.0
+                    del h
+            elif sparse:
                 synth.fill_sparse_iq_torch(buf, template_dev, segs, first_stream=0, chunk_streams=max(1, min(256, (1 << 27) // total)))
             else:
                 synth.fill_iq_torch(buf, template_dev, first_stream=0, chunk_streams=max(1, min(1024, (1 << 27) // total)))
@@ -370,8 +385,9 @@ def main():
             pframes = framelib.parse_sink(psink[:used].cpu().numpy(), used, FS)
             point = {
                 "workload": "%d stream(s) x %d samples per step, %s traffic (%s), IQ resident in HBM, all four decoders" % (
-                    n_streams, n_samples, "sparse" if sparse else "dense",
-                    "S1q: one exchange of the captures per 2^19 samples in quiet carrier" if sparse else "S1: the captures tiled end to end"),
+                    n_streams, n_samples, "no" if idle else ("sparse" if sparse else "dense"),
+                    "unmodulated carrier with +-4 LSB of noise" if idle else
+                    ("S1q: one exchange of the captures per 2^19 samples in quiet carrier" if sparse else "S1: the captures tiled end to end")),
                 "value": round(n_streams * n_samples * steps / (tb - ta) / 1e6, 3),
                 "unit": "Msamples/s",
                 "ms_per_step": round((tb - ta) / steps * 1e3, 3),
@@ -408,10 +424,16 @@ def main():
                     points[name], _ = run_point(name, args.config5_streams, args.config5_samples, False, 1, 1, 4)
                 elif name == "config5_sparse":
                     points[name], scan_stats = run_point(name, args.config5_streams, args.config5_samples, True, 2, 1, 4)
+                elif name == "config5_idle":
+                    points[name], _ = run_point(name, args.config5_streams, args.config5_samples, False, 2, 1, 2, idle=True)
+                elif name == "share_dense":
+                    points[name], _ = run_point(name, args.share_streams, args.config5_samples, False, 1, 1, 2)
+                elif name == "share_sparse":
+                    points[name], _ = run_point(name, args.share_streams, args.config5_samples, True, 2, 1, 2)
                 elif name == "single_dense":
-                    points[name], _ = run_point(name, 1, args.single_samples, False, 1, 0, 1)
+                    points[name], _ = run_point(name, 1, args.single_dense_samples, False, 1, 1, 1)
                 elif name == "single_sparse":
-                    points[name], _ = run_point(name, 1, args.single_samples, True, 1, 0, 1)
+                    points[name], _ = run_point(name, 1, args.single_samples, True, 2, 1, 1)
             except Exception as exc:  # a point that fails must not take the headline with it
                 points[name] = {"error": repr(exc)}
         result["config"]["points"] = points

@@ -633,8 +633,18 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          if (pos >= start && (pos % NFC_SCAN_POINT) == 0)
             nfc_scan_point(w, A.points[job->firstPoint + pos / NFC_SCAN_POINT]);
 
-         for (uint32_t k = 0; k < n; k++)
-            nfc_scan_sample(cc, w, row[k]);
+         /* (whole tiles - all but the last of a stream - with a fixed trip count) */
+         if (n == NFC_SCAN_TILE)
+         {
+#pragma unroll 8
+            for (uint32_t k = 0; k < NFC_SCAN_TILE; k++)
+               nfc_scan_sample(cc, w, row[k]);
+         }
+         else
+         {
+            for (uint32_t k = 0; k < n; k++)
+               nfc_scan_sample(cc, w, row[k]);
+         }
 
          NfcScanTile stat;
          nfc_scan_tile_end(w, stat);
@@ -955,6 +965,7 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
       w.handTo = 0;
       w.pubState = 0;
       w.pubTail = 0;
+      w.saved = 0;
       if (pass == 0)
          w.noHand = 0;
 
@@ -1345,6 +1356,31 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
                L.windows[w].retired = how;
                active = false;
 
+               /* ran to the end of the submission with nobody to take over: may be the stream's last lane. Its rings are
+                * about to be reused by the next window this lane of the wave takes: leave a copy (NfcScanArgs::saveRings) */
+               if (how == 0u && L.windows[w].activate < startPos + mineCount)
+               {
+                  const uint32_t slot = atomicAdd(A.saveNext, 1u);
+
+                  if (slot < A.saveRoom)
+                  {
+                     const uint32_t rows = L.ringBlockFloats / NFC_LANES;
+                     const float *src = mem.ring + lane;
+                     float *dst = A.saveRings + (uint64_t)slot * rows;
+
+                     for (uint32_t i = 0; i < rows; i++)
+                        dst[i] = src[(uint64_t)i * NFC_LANES];
+
+                     const uint32_t *bs = (const uint32_t *)mem.bytes;
+                     uint32_t *bd = (uint32_t *)(A.saveBytes + (uint64_t)slot * NFC_STREAM_BYTES);
+
+                     for (uint32_t i = 0; i < NFC_STREAM_BYTES / 4; i++)
+                        bd[i] = bs[i];
+
+                     L.windows[w].saved = slot + 1u;
+                  }
+               }
+
                atomicAdd(L.laneStats, (stepped + TILE - 1) / TILE);
                atomicMax(L.laneStats + 1, (stepped + TILE - 1) / TILE);
                atomicAdd(L.laneStats + 2, 1u);
@@ -1434,7 +1470,7 @@ __global__ __launch_bounds__(64) void nfc_final_lanes_kernel(const NfcConfig *__
    work.stride = A.stride;
    work.tiles = nullptr;
 
-   if (!(job->status & NFC_JOB_INVALID) && job->finalLane != j)
+   if (!(job->status & NFC_JOB_INVALID) && job->finalLane != j && A.windows[job->finalLane].saved == 0u)
    {
       NfcWindow w = A.windows[job->finalLane];
 
@@ -1507,16 +1543,34 @@ __global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch
    if (t == 0)
       nfc_finish_frames(*job, j, A.windows, lanes.cold, lanes.sink, real.sink, real.sinkCtl, real.sinkWords);
 
-   const uint32_t from = job->finalLane == j ? j : A.finalLaneSlot + j, to = job->slot;
+   /* the stream's last lane: the carry lane itself, a speculative lane that left its rings in the save area, or one that
+    * has been run again in the job's final-lane slot */
+   const uint32_t saved = job->finalLane == j ? 0u : A.windows[job->finalLane].saved;
+   const uint32_t from = job->finalLane == j ? j : (saved ? job->finalLane : A.finalLaneSlot + j), to = job->slot;
+   const uint32_t rows = real.ringBlockFloats / NFC_LANES;
 
-   const float *src = lanes.rings + (uint64_t)(from / NFC_LANES) * lanes.ringBlockFloats + (from % NFC_LANES);
    float *dst = real.rings + (uint64_t)(to / NFC_LANES) * real.ringBlockFloats + (to % NFC_LANES);
 
-   for (uint32_t i = t; i < real.ringBlockFloats / NFC_LANES; i += NFC_LANES)
-      dst[(uint64_t)i * NFC_LANES] = src[(uint64_t)i * NFC_LANES];
+   if (saved)
+   {
+      const float *src = A.saveRings + (uint64_t)(saved - 1u) * rows;
 
-   for (uint32_t i = t; i < NFC_STREAM_BYTES / 4; i += NFC_LANES)
-      ((uint32_t *)(real.bytes + (uint64_t)to * NFC_STREAM_BYTES))[i] = ((const uint32_t *)(lanes.bytes + (uint64_t)from * NFC_STREAM_BYTES))[i];
+      for (uint32_t i = t; i < rows; i += NFC_LANES)
+         dst[(uint64_t)i * NFC_LANES] = src[i];
+
+      for (uint32_t i = t; i < NFC_STREAM_BYTES / 4; i += NFC_LANES)
+         ((uint32_t *)(real.bytes + (uint64_t)to * NFC_STREAM_BYTES))[i] = ((const uint32_t *)(A.saveBytes + (uint64_t)(saved - 1u) * NFC_STREAM_BYTES))[i];
+   }
+   else
+   {
+      const float *src = lanes.rings + (uint64_t)(from / NFC_LANES) * lanes.ringBlockFloats + (from % NFC_LANES);
+
+      for (uint32_t i = t; i < rows; i += NFC_LANES)
+         dst[(uint64_t)i * NFC_LANES] = src[(uint64_t)i * NFC_LANES];
+
+      for (uint32_t i = t; i < NFC_STREAM_BYTES / 4; i += NFC_LANES)
+         ((uint32_t *)(real.bytes + (uint64_t)to * NFC_STREAM_BYTES))[i] = ((const uint32_t *)(lanes.bytes + (uint64_t)from * NFC_STREAM_BYTES))[i];
+   }
 
    if (t == 0)
    {

@@ -160,6 +160,7 @@ struct NfcWindow
    uint32_t pubTail;  /* the lane's frameTail when it published */
    uint32_t pubDigest[2];
    uint32_t stopDigest[2]; /* digest of the lane's own state where it handed over */
+   uint32_t saved;    /* out: 1 + slot of the save area holding the lane's rings as it left them (lanes that ran to the end of the submission), 0: none */
    uint32_t tracked;  /* edge-tracker time at the lane's first sample (scanned): with the carry's last carrier frame it gives the decoder's edge time */
    NfcCarry carry;    /* what the lane assumed when it last ran */
    NfcCarry want;     /* chain kernel: what it has to assume in the next pass (rerun) */

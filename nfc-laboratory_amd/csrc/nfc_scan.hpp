@@ -70,7 +70,8 @@ NFC_DEV void nfc_scan_tile_reset(NfcScanLane &w)
    w.envmin = NFC_SCAN_BIG;
    w.envmax = -NFC_SCAN_BIG;
    w.fmin = NFC_SCAN_BIG;
-   w.bits = 0;
+   /* the detectors wait for the decoder's first 1024 samples: the tile's first sample gets clock + 1 */
+   w.bits = (w.fe.clock + 1u < 1024u) ? NFC_TILE_UNARMED : 0u;
 }
 
 /* start of a walk: `exact` = from the stream's own state (first chunk of a submission), else from a guess that the
@@ -150,10 +151,10 @@ NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
    w.envmax = w.fe.env > w.envmax ? w.fe.env : w.envmax;
    w.fmin = now.filt < w.fmin ? now.filt : w.fmin;
 
-   /* on the int16 grid of the captures (k / 32768, |k| small enough for every box sum to stay exact)? */
+   /* on the int16 grid of the captures (k / 32768; |k| small enough for every box sum to stay exact: nfc_scan_tile_end)?
+    * A NaN is not equal to its floor either */
    const float scaled = x * 32768.0f;
-   if (!(scaled == __builtin_truncf(scaled)) || !(nfc_abs(x) <= 4.0f))
-      w.bits |= NFC_TILE_OFFGRID;
+   w.bits |= (scaled != __builtin_floorf(scaled)) ? NFC_TILE_OFFGRID : 0u;
 
    /* NaNs make both comparisons false, exactly as in nfc_detect_carrier */
    {
@@ -165,8 +166,6 @@ NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
       w.zone = zone;
    }
 
-   if (w.fe.clock < 1024u)
-      w.bits |= NFC_TILE_UNARMED;
 }
 
 /* end of a tile */
@@ -177,7 +176,7 @@ NFC_DEV void nfc_scan_tile_end(NfcScanLane &w, NfcScanTile &out)
    out.fmin = w.fmin;
    out.envmin = w.envmin;
    out.envmax = w.envmax;
-   out.bits = w.bits;
+   out.bits = w.bits | ((w.xmin >= -4.0f && w.xmax <= 4.0f) ? 0u : NFC_TILE_OFFGRID); /* also an empty tile, harmlessly */
    nfc_scan_tile_reset(w);
 }
 

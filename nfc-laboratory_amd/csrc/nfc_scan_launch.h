@@ -46,6 +46,13 @@ struct NfcScanArgs
    uint32_t *runList;          /* speculative lanes to run in the coming pass (indices into the lane arrays) */
    uint32_t *runCount;         /* entries of runList (device counter) */
    uint32_t *runNext;          /* next entry a persistent wave takes (device counter) */
+   /* save area: a speculative lane that runs to the end of the submission (and is not the closing window) leaves a copy
+    * of its rings and frame-assembly bytes here; should it be the stream's last lane, the stream's state is complete
+    * without running it again (the persistent waves reuse a finished lane's ring storage) */
+   float *saveRings;           /* [saveRoom][ringBlockFloats / 64] */
+   uint8_t *saveBytes;         /* [saveRoom][NFC_STREAM_BYTES] */
+   uint32_t *saveNext;         /* slots handed out (device counter) */
+   uint32_t saveRoom;
 };
 
 #endif

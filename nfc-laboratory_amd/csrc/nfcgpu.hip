@@ -98,6 +98,8 @@ struct nfcgpu_ctx
 {
    int device = 0;
    hipStream_t stream = nullptr;
+   hipStream_t side = nullptr;       /* the carry lanes of a windowed pass run beside the speculative ones */
+   hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
    uint32_t maxStreams = 0;
    uint32_t blocks = 0;
 
@@ -132,7 +134,8 @@ struct nfcgpu_ctx
    /* ---- time-parallel path (nfc_scan.h): device buffers, grown on demand and kept ---- */
    bool windowed = true;           /* NFCGPU_WINDOWED=0 switches the path off */
    uint32_t windowedMinSamples = 32768; /* shortest submission (per stream) worth cutting into windows */
-   uint32_t scanChunk = 8192;      /* samples per scan chunk: short chunks = many lanes (the walk is latency-bound per wave) */
+   uint32_t scanChunk = 8192;      /* samples per scan chunk, at least: short chunks = many lanes (the walk is latency-bound per wave) */
+   bool scanChunkFixed = false;    /* NFCGPU_SCAN_CHUNK given: no sizing by the submission */
    uint32_t scanWarm = 6144;       /* samples walked ahead of a chunk */
    uint32_t maxPasses = 12;        /* decode passes before a stream of a large submission gives up (sequential path) */
    uint32_t maxPassesFew = 48;     /* the same for submissions of fewer streams than a wave has lanes: the sequential path would crawl */
@@ -144,7 +147,7 @@ struct nfcgpu_ctx
    DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
    uint32_t densePercent = 8;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
-   DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl;
+   DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    std::vector<ProfiledLaunch> timedScan, timedWindow;
 
    /* ---- frame gather over RCCL (nfcgpu_comm_*) ---- */
@@ -623,6 +626,22 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       sp.deepK = 0.98f * deep;
       sp.chunkSamples = ctx->scanChunk;
       sp.warmSamples = ctx->scanWarm;
+
+      /* Every chunk pays the warm-up again, so chunks should be as long as the machine allows: one lane per chunk, and
+       * 131072 lanes (256 CUs x 4 SIMDs x 2 waves of the scan kernel's 204 registers x 64) are resident at a time.
+       * Measured on 4096 streams x 2^20 idle samples: 8192 -> 1347, 16384 -> 1673, 32768 -> 1906 GB/s. */
+      if (!ctx->scanChunkFixed)
+      {
+         uint64_t total = 0;
+         for (const WindowedItem &it: items)
+            total += it.count;
+
+         uint64_t chunk = total / 131072u / NFC_SCAN_POINT * NFC_SCAN_POINT;
+         if (chunk > 32768u)
+            chunk = 32768u;
+         if (chunk > sp.chunkSamples)
+            sp.chunkSamples = (uint32_t)chunk;
+      }
    }
 
    /* job and chunk tables */
@@ -738,6 +757,19 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.repairs = (NfcScanChunk *)ctx->wRepairs.ptr;
    A.repairCount = counters + 7;
 
+   /* save area for lanes that run to the end of the submission (nfc_scan_launch.h): a few per stream */
+   {
+      const uint32_t saveRoom = 2 * nJobs + 1024;
+      if ((rc = grow(ctx, ctx->vSaveRings, sizeof(float) * (size_t)(kRingBlockFloats / NFC_LANES) * saveRoom)) ||
+          (rc = grow(ctx, ctx->vSaveBytes, (size_t)NFC_STREAM_BYTES * saveRoom)))
+         return rc;
+
+      A.saveRings = (float *)ctx->vSaveRings.ptr;
+      A.saveBytes = (uint8_t *)ctx->vSaveBytes.ptr;
+      A.saveNext = counters + 8;
+      A.saveRoom = saveRoom;
+   }
+
    const NfcConfig *dCfg = ctx->dConfigs + config;
 
    /* NFCGPU_WINDOW_DEBUG: where the time of a submission goes (synchronises at every mark) */
@@ -849,7 +881,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    const uint32_t windowBlocks = (nWindows + NFC_LANES - 1) / NFC_LANES;
 
    /* one lane per slot: the carry lanes (and, at the end, the lanes that regenerate a job's final state) */
-   auto decodeSlots = [&](bool carry, uint32_t firstSlot, uint32_t slotCount) -> int {
+   auto decodeSlots = [&](bool carry, uint32_t firstSlot, uint32_t slotCount, hipStream_t on) -> int {
       if (slotCount == 0)
          return NFCGPU_OK;
 
@@ -862,7 +894,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       const uint32_t blocks = (firstSlot % NFC_LANES + slotCount + NFC_LANES - 1) / NFC_LANES;
 
-      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A);
+      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, on, dCfg, L, A);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
       return NFCGPU_OK;
@@ -899,9 +931,6 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          HIP_TRY(ctx, hipMemsetAsync(counters + 2, 0, 8, ctx->stream)); /* run list: count and next */
          hipLaunchKernelGGL(nfc_window_lanes_kernel, dim3(windowBlocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, A, lanes, pass);
          HIP_TRY(ctx, hipGetLastError());
-
-         if ((rc = decodeWindows()))
-            return rc;
       }
 
       /* the carry lanes (later passes: those the chain kernel sent on): from the stream's own state, which has not
@@ -912,8 +941,20 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          HIP_TRY(ctx, hipGetLastError());
       }
 
-      if ((rc = decodeSlots(true, 0, nJobs)))
+      /* carry lanes and speculative lanes side by side: no lane looks at what another one is doing while it runs
+       * (nfc_lane_handover), and the longest lane of either kind can be most of the submission */
+      HIP_TRY(ctx, hipEventRecord(ctx->forkEvent, ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->forkEvent, 0));
+
+      if ((rc = decodeSlots(true, 0, nJobs, ctx->side)))
          return rc;
+
+      HIP_TRY(ctx, hipEventRecord(ctx->joinEvent, ctx->side));
+
+      if (nWindows && (rc = decodeWindows()))
+         return rc;
+
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->joinEvent, 0));
 
       HIP_TRY(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));
       hipLaunchKernelGGL(nfc_chain_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, lanes, nJobs >= NFC_LANES ? ctx->maxPasses : ctx->maxPassesFew);
@@ -947,7 +988,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    hipLaunchKernelGGL(nfc_final_lanes_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, dCfg, A, lanes);
    HIP_TRY(ctx, hipGetLastError());
 
-   if ((rc = decodeSlots(false, finalLaneSlot, nJobs)))
+   if ((rc = decodeSlots(false, finalLaneSlot, nJobs, ctx->stream)))
       return rc;
 
    record_span(ctx, ctx->timedWindow, pw, false);
@@ -1173,6 +1214,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
 
    ctx->windowed = knob("NFCGPU_WINDOWED", 1) != 0;
    ctx->windowedMinSamples = knob("NFCGPU_WINDOWED_MIN", ctx->windowedMinSamples);
+   ctx->scanChunkFixed = std::getenv("NFCGPU_SCAN_CHUNK") != nullptr && std::getenv("NFCGPU_SCAN_CHUNK")[0] != 0;
    ctx->scanChunk = knob("NFCGPU_SCAN_CHUNK", ctx->scanChunk) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
@@ -1202,6 +1244,9 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->sinkWords = sinkBytes / 4;
 
    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+   ok = ok && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
+   ok = ok && hipEventCreateWithFlags(&ctx->forkEvent, hipEventDisableTiming) == hipSuccess;
+   ok = ok && hipEventCreateWithFlags(&ctx->joinEvent, hipEventDisableTiming) == hipSuccess;
 
    ok = ok && hipMalloc((void **)&ctx->dStates, sizeof(NfcStreamState) * (size_t)maxStreams) == hipSuccess;
    ok = ok && hipMalloc((void **)&ctx->dCold, sizeof(NfcStreamCold) * (size_t)maxStreams) == hipSuccess;
@@ -1278,7 +1323,7 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    nfcgpu_comm_destroy(ctx);
 
    for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
-                                &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl})
+                                &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl, &ctx->vSaveRings, &ctx->vSaveBytes})
    {
       if (b->ptr)
          (void)hipFree(b->ptr);
@@ -1293,6 +1338,12 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
       }
    }
 
+   if (ctx->forkEvent)
+      (void)hipEventDestroy(ctx->forkEvent);
+   if (ctx->joinEvent)
+      (void)hipEventDestroy(ctx->joinEvent);
+   if (ctx->side)
+      (void)hipStreamDestroy(ctx->side);
    if (ctx->stream)
       (void)hipStreamDestroy(ctx->stream);
 

@@ -304,6 +304,8 @@ void copy_lane(const NfcLaunch &from, uint32_t a, const NfcLaunch &to, uint32_t 
    std::memcpy(to.bytes + (uint64_t)b * NFC_STREAM_BYTES, from.bytes + (uint64_t)a * NFC_STREAM_BYTES, NFC_STREAM_BYTES);
 }
 
+bool emu_persistent = false; /* window_lane called for a lane of the persistent waves (ring storage not the lane's own) */
+
 /* one lane: record slot `slot` (state, cold, work, window), ring / frame-assembly storage of lane slot `storage` */
 void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, bool carry, uint32_t slot, uint32_t storage);
 
@@ -441,6 +443,22 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
       L.windows[slot].stop = L.windows[slot].start + consumed;
       const bool closing = L.windows[slot].activate >= L.windows[slot].start + mineCount;
       L.windows[slot].retired = handed ? 2u : ((consumed < mineCount || (!closing && nfc_lane_comparable(s, *mem.cold))) ? 1u : 0u);
+
+      /* nfc_window_kernel: a speculative lane that ran to the end leaves a copy of its rings in the save area */
+      if (emu_persistent && !carry && L.windows[slot].retired == 0u && !closing)
+      {
+         const uint32_t to = emu_add(A.saveNext, 1u);
+
+         if (to < A.saveRoom)
+         {
+            const uint32_t rows = L.ringBlockFloats / NFC_LANES;
+            const float *src = mem.ring + mem.lane;
+            for (uint32_t i = 0; i < rows; i++)
+               A.saveRings[(uint64_t)to * rows + i] = src[(uint64_t)i * NFC_LANES];
+            std::memcpy(A.saveBytes + (uint64_t)to * NFC_STREAM_BYTES, mem.bytes, NFC_STREAM_BYTES);
+            L.windows[slot].saved = to + 1u;
+         }
+      }
 
       emu_add(L.laneStats, (stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE);
       if ((stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE > L.laneStats[1])
@@ -776,6 +794,7 @@ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A
          w.handTo = 0;
          w.pubState = 0;
          w.pubTail = 0;
+         w.saved = 0;
          if (pass == 0)
             w.noHand = 0;
 
@@ -810,8 +829,10 @@ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcSca
     * published for long after the successor did; one after the other, that order has to be arranged */
    std::vector<uint32_t> order(A.runList, A.runList + *A.runCount);
    std::sort(order.begin(), order.end());
+   emu_persistent = true;
    for (uint32_t i = (uint32_t)order.size(); i-- > 0;)
       window_lane(cfgPtr, L, A, false, order[i], A.firstWindowSlot + (i % NFC_LANES));
+   emu_persistent = false;
    *A.runNext = *A.runCount;
 }
 
@@ -831,7 +852,7 @@ void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A,
       work.stride = A.stride;
       work.tiles = nullptr;
 
-      if (!(job->status & NFC_JOB_INVALID) && job->finalLane != j)
+      if (!(job->status & NFC_JOB_INVALID) && job->finalLane != j && A.windows[job->finalLane].saved == 0u)
       {
          NfcWindow w = A.windows[job->finalLane];
          const uint32_t chunk = job->firstChunk + w.start / A.params.chunkSamples;
@@ -912,9 +933,19 @@ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
 
       nfc_finish_frames(*job, j, A.windows, lanes.cold, lanes.sink, real.sink, real.sinkCtl, real.sinkWords);
 
-      const uint32_t from = job->finalLane == j ? j : A.finalLaneSlot + j;
+      const uint32_t saved = job->finalLane == j ? 0u : A.windows[job->finalLane].saved;
+      const uint32_t from = job->finalLane == j ? j : (saved ? job->finalLane : A.finalLaneSlot + j);
 
-      copy_lane(lanes, from, real, job->slot);
+      if (saved)
+      {
+         const uint32_t rows = real.ringBlockFloats / NFC_LANES;
+         float *dst = real.rings + (uint64_t)(job->slot / NFC_LANES) * real.ringBlockFloats + (job->slot % NFC_LANES);
+         for (uint32_t i = 0; i < rows; i++)
+            dst[(uint64_t)i * NFC_LANES] = A.saveRings[(uint64_t)(saved - 1u) * rows + i];
+         std::memcpy(real.bytes + (uint64_t)job->slot * NFC_STREAM_BYTES, A.saveBytes + (uint64_t)(saved - 1u) * NFC_STREAM_BYTES, NFC_STREAM_BYTES);
+      }
+      else
+         copy_lane(lanes, from, real, job->slot);
 
       NfcStreamState s = lanes.states[from];
       NfcStreamCold cold = lanes.cold[from];

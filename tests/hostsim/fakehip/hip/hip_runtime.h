@@ -62,8 +62,11 @@ static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::malloc(1); return hipSuccess; }
+#define hipEventDisableTiming 2u
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)std::malloc(1); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 
 /* a launch is a call: the CPU twin walks the grid itself */
