@@ -331,8 +331,31 @@ def main():
                             result["cpu_baseline"]["radio_decoder_task_value"] = round(n_task / float(done[0][3]) / 1e6, 3)
                             result["cpu_baseline"]["sample"] += "; reference RadioDecoderTask (WAV -> radio.signal.raw -> task -> radio.decoder.frame," \
                                                                " one stream, %d samples): %.1f Msamples/s" % (n_task, n_task / float(done[0][3]) / 1e6)
+                        # the same task, same WAVs, on top of the GPU decoder (host/NfcDecoder.cpp in block mode): the shim path
+                        # end to end, host buffers through the pinned staging of the C ABI
+                        task_gpu = os.path.join(ROOT, "oracle", "_ref", "task-gpu")
+                        if os.path.exists(task_gpu):
+                            segs0 = synth.sparse_segments(template)
+                            # (lengths that end on a partial buffer: the shim takes the short last buffer as the end of the stream)
+                            sparse = synth.sparse_magnitude_f32(template, segs0, 0, 0, (1 << 25) + 12345)
+                            wav_s = os.path.join(tmp, "sparse.wav")
+                            TL.write_wav(wav_s, np.clip(np.rint(sparse * 32768.0), -32768, 32767).astype(np.int16))
+                            dense_n = (1 << 23) + 12345
+                            wav_d = os.path.join(tmp, "dense.wav")
+                            TL.write_wav(wav_d, np.tile(one, max(1, dense_n // one.size + 1))[:dense_n])
+                            env = dict(os.environ, NFCGPU_SHIM_BLOCK=str(1 << 22))
+                            shim = {"block_samples": 1 << 22}
+                            for label, path, n_w in (("sparse", wav_s, sparse.size), ("dense", wav_d, dense_n)):
+                                row = {"samples": int(n_w)}
+                                for who, exe, e in (("reference_task", task, os.environ), ("gpu_task", task_gpu, env)):
+                                    o = subprocess.run([exe, path], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600, env=e).stdout
+                                    dn = [l.split() for l in o.splitlines() if l.startswith("DONE")]
+                                    row[who + "_Msamples_per_s"] = round(n_w / float(dn[0][3]) / 1e6, 3) if dn else None
+                                    row[who + "_frames"] = int(dn[0][2]) if dn and len(dn[0]) > 2 and dn[0][2].isdigit() else None
+                                shim[label] = row
+                            result["cpu_baseline"]["radio_decoder_task_gpu"] = shim
                 except Exception as exc:  # the plumbing figure is informative only
-                    result["cpu_baseline"]["radio_decoder_task_value"] = None
+                    result["cpu_baseline"].setdefault("radio_decoder_task_value", None)
                     result["cpu_baseline"]["sample"] += "; RadioDecoderTask run failed: %r" % (exc,)
 
             result["parity"] = {"streams_checked": checked, "streams_mismatching": bad,

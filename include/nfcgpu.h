@@ -148,6 +148,11 @@ int nfcgpu_stream_close(nfcgpu_ctx *ctx, uint32_t stream_id);
 /* nextFrames(valid buffer) (NfcDecoder.cpp:374-447) without the frame collection (nfcgpu_poll). A buffer whose sample rate
  * differs from the stored one stores it and re-initialises the stream first, also when it is empty (n_samples 0); a
  * buffer at the stored rate does not, whatever the stored rate was derived-from last (see nfcgpu_stream_configure). */
+/* Submissions are asynchronous: the calls return once the work is enqueued on the context's HIP stream. Host memory
+ * (NFCGPU_LOC_HOST, nfcgpu_submit) has been copied into a pinned staging buffer by then and is never retained; device
+ * memory (NFCGPU_LOC_DEVICE) is read in place and must stay as it is until the next nfcgpu_sync / nfcgpu_poll /
+ * nfcgpu_flush / nfcgpu_pending of the context. (Long grid-aligned submissions that take the time-parallel path are
+ * complete when the call returns.) */
 int nfcgpu_submit(nfcgpu_ctx *ctx, uint32_t stream_id, const float *data, uint32_t n_samples, uint32_t stride, uint32_t sample_rate);
 int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *batch);
 /* streams first..first+count-1; stream i reads n_samples*stride floats at base + i*pitch_bytes */
@@ -176,6 +181,8 @@ int nfcgpu_resample_radio(nfcgpu_ctx *ctx, const float *in, uint64_t in_pitch_by
 
 /* nextFrames(invalid buffer) (NfcDecoder.cpp:449-463): queues one carrier-state frame stamped with the stream's clock */
 int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t stream_id);
+/* waits for everything submitted, then moves the frames of the frame sink to the per-stream queues. poll / pending /
+ * flush call it; with nothing in flight and nothing to collect none of them touches the device. */
 int nfcgpu_sync(nfcgpu_ctx *ctx);
 int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t stream_id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count);
 int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t stream_id, uint32_t *count);

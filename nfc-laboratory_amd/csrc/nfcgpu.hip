@@ -116,10 +116,21 @@ struct nfcgpu_ctx
    NfcWork *dWorks = nullptr;
    NfcConfig *dConfigs = nullptr;
    bool genericOnly = false; /* NFCGPU_GENERIC_KERNELS=1: never use the sample-rate-specialised kernels (testing) */
-   uint8_t *dStage = nullptr;
-   uint8_t *hStage = nullptr; /* pinned mirror of dStage: caller memory is copied here by the CPU and never handed to the
-                                 GPU runtime (no page locking of memory whose lifetime belongs to the caller) */
-   size_t stageBytes = 0;
+   /* Staging of host-resident input: two slots, each a device buffer with a pinned mirror. Caller memory is copied into
+    * the mirror by the CPU and never handed to the GPU runtime (no page locking of memory whose lifetime belongs to the
+    * caller); the copy to the device and the launches that read it are asynchronous, and an event recorded behind them
+    * says when the slot may be written again. A submission therefore does not wait for its own kernels. */
+   struct StageSlot
+   {
+      uint8_t *d = nullptr;
+      uint8_t *h = nullptr;
+      size_t bytes = 0;
+      hipEvent_t done = nullptr;
+      bool busy = false;
+   };
+   StageSlot stage[2];
+   uint32_t stageNext = 0;
+   bool inflight = false; /* something has been enqueued since the last stream synchronisation */
 
    std::vector<NfcConfig> configs;
    std::vector<StreamInfo> streams;
@@ -1033,35 +1044,57 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    return NFCGPU_OK;
 }
 
-int ensure_stage(nfcgpu_ctx *ctx, size_t bytes)
+/* the next staging slot, idle and at least `bytes` large */
+int stage_acquire(nfcgpu_ctx *ctx, size_t bytes, nfcgpu_ctx::StageSlot **out)
 {
-   if (bytes <= ctx->stageBytes)
-      return NFCGPU_OK;
+   nfcgpu_ctx::StageSlot &slot = ctx->stage[ctx->stageNext];
+   ctx->stageNext ^= 1u;
 
-   /* the previous staging buffer may still be read by an in-flight launch */
-   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-
-   if (ctx->dStage)
-      (void)hipFree(ctx->dStage);
-   if (ctx->hStage)
-      (void)hipHostFree(ctx->hStage);
-
-   ctx->dStage = nullptr;
-   ctx->hStage = nullptr;
-   ctx->stageBytes = 0;
-
-   size_t want = bytes + bytes / 2;
-   if (hipMalloc((void **)&ctx->dStage, want) != hipSuccess)
-      return fail(ctx, NFCGPU_ENOMEM, "staging buffer allocation failed");
-   if (hipHostMalloc((void **)&ctx->hStage, want, hipHostMallocDefault) != hipSuccess)
+   if (slot.busy)
    {
-      (void)hipFree(ctx->dStage);
-      ctx->dStage = nullptr;
-      return fail(ctx, NFCGPU_ENOMEM, "pinned staging buffer allocation failed");
+      /* the launches of the submission before the last one: long done in a steady stream of submissions */
+      HIP_TRY(ctx, hipEventSynchronize(slot.done));
+      slot.busy = false;
    }
 
-   ctx->stageBytes = want;
+   if (!slot.done)
+      HIP_TRY(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+
+   if (bytes > slot.bytes)
+   {
+      if (slot.d)
+         (void)hipFree(slot.d);
+      if (slot.h)
+         (void)hipHostFree(slot.h);
+
+      slot.d = nullptr;
+      slot.h = nullptr;
+      slot.bytes = 0;
+
+      const size_t want = bytes + bytes / 2;
+      if (hipMalloc((void **)&slot.d, want) != hipSuccess)
+         return fail(ctx, NFCGPU_ENOMEM, "staging buffer allocation failed");
+      if (hipHostMalloc((void **)&slot.h, want, hipHostMallocDefault) != hipSuccess)
+      {
+         (void)hipFree(slot.d);
+         slot.d = nullptr;
+         return fail(ctx, NFCGPU_ENOMEM, "pinned staging buffer allocation failed");
+      }
+
+      slot.bytes = want;
+   }
+
+   *out = &slot;
    return NFCGPU_OK;
+}
+
+/* everything that reads the slot has been enqueued */
+void stage_release(nfcgpu_ctx *ctx, nfcgpu_ctx::StageSlot *slot)
+{
+   if (slot && hipEventRecord(slot->done, ctx->stream) == hipSuccess)
+      slot->busy = true;
+   else if (slot)
+      (void)hipStreamSynchronize(ctx->stream);
 }
 
 void drain_sink(nfcgpu_ctx *ctx, uint64_t cursor)
@@ -1316,9 +1349,15 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    (void)hipFree(ctx->ownSinkCtl ? ctx->ownSinkCtl : ctx->dSinkCtl);
    (void)hipFree(ctx->dWorks);
    (void)hipFree(ctx->dConfigs);
-   (void)hipFree(ctx->dStage);
-   if (ctx->hStage)
-      (void)hipHostFree(ctx->hStage);
+   for (nfcgpu_ctx::StageSlot &slot: ctx->stage)
+   {
+      if (slot.d)
+         (void)hipFree(slot.d);
+      if (slot.h)
+         (void)hipHostFree(slot.h);
+      if (slot.done)
+         (void)hipEventDestroy(slot.done);
+   }
 
    nfcgpu_comm_destroy(ctx);
 
@@ -1522,15 +1561,39 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       return rc;
    }
 
-   if (b->location == NFCGPU_LOC_HOST)
+   /* one launch per decoder configuration present in the batch */
+   std::vector<uint32_t> cfgs;
+   for (uint32_t i = 0; i < b->n_streams; i++)
    {
-      rc = ensure_stage(ctx, hostBytes + 256 * (size_t)b->n_streams);
-      if (rc)
-      {
-         clearWorks();
-         return rc;
-      }
+      uint32_t c = ctx->streams[b->stream_ids[i]].config;
+      bool seen = false;
+      for (uint32_t k: cfgs)
+         seen = seen || k == c;
+      if (!seen)
+         cfgs.push_back(c);
    }
+
+   /* staging slot: the samples (host batches) and one work table per configuration group, all sent from pinned memory
+    * so that nothing the copies read belongs to this call's stack or to the caller once it returns */
+   const size_t tableBytes = (sizeof(NfcWork) * (size_t)(hi - lo + 1) + 255) & ~(size_t)255;
+   nfcgpu_ctx::StageSlot *slot = nullptr;
+
+   rc = stage_acquire(ctx, (b->location == NFCGPU_LOC_HOST ? hostBytes + 256 * (size_t)b->n_streams : 0) + tableBytes * (cfgs.size() + 1) + 256, &slot);
+   if (rc)
+   {
+      clearWorks();
+      return rc;
+   }
+
+   ctx->inflight = true;
+
+   /* from here on every exit records the slot's event behind whatever has been enqueued */
+   struct Release
+   {
+      nfcgpu_ctx *ctx;
+      nfcgpu_ctx::StageSlot *slot;
+      ~Release() { stage_release(ctx, slot); }
+   } release {ctx, slot};
 
    rc = initialize_pending(ctx, lo, hi - lo + 1, true);
    if (rc)
@@ -1551,10 +1614,9 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
 
       if (b->location == NFCGPU_LOC_HOST)
       {
-         /* every submission ends with a stream synchronisation, so the pinned buffer is free here */
-         w.data = ctx->dStage + stageAt;
+         w.data = slot->d + stageAt;
          if (bytes)
-            std::memcpy(ctx->hStage + stageAt, b->data[i], bytes);
+            std::memcpy(slot->h + stageAt, b->data[i], bytes);
          stageAt += (bytes + 255) & ~(size_t)255;
       }
       else
@@ -1565,7 +1627,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
 
    if (stageAt)
    {
-      hipError_t err = hipMemcpyAsync(ctx->dStage, ctx->hStage, stageAt, hipMemcpyHostToDevice, ctx->stream);
+      hipError_t err = hipMemcpyAsync(slot->d, slot->h, stageAt, hipMemcpyHostToDevice, ctx->stream);
       if (err != hipSuccess)
       {
          clearWorks();
@@ -1573,19 +1635,7 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       }
    }
 
-   /* one launch per decoder configuration present in the batch */
-   std::vector<uint32_t> cfgs;
-   for (uint32_t i = 0; i < b->n_streams; i++)
-   {
-      uint32_t c = ctx->streams[b->stream_ids[i]].config;
-      bool seen = false;
-      for (uint32_t k: cfgs)
-         seen = seen || k == c;
-      if (!seen)
-         cfgs.push_back(c);
-   }
-
-   std::vector<NfcWork> table;
+   size_t tableAt = (stageAt + 255) & ~(size_t)255; /* the groups' work tables follow the samples in the pinned mirror */
 
    for (uint32_t c: cfgs)
    {
@@ -1628,9 +1678,14 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       }
 
       /* slots of other configurations inside [first,last] must stay idle in this launch */
-      table.assign(ctx->hWorks.begin() + first, ctx->hWorks.begin() + last + 1);
+      NfcWork *table = (NfcWork *)(slot->h + tableAt);
+      const size_t entries = (size_t)last - first + 1;
+      tableAt += tableBytes;
+
       for (uint32_t id = first; id <= last; id++)
       {
+         table[id - first] = ctx->hWorks[id];
+
          if (!ctx->streams[id].open || ctx->streams[id].config != c)
          {
             table[id - first].data = nullptr;
@@ -1639,9 +1694,8 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
          }
       }
 
-      hipError_t err = hipMemcpyAsync(ctx->dWorks + first, table.data(), sizeof(NfcWork) * table.size(), hipMemcpyHostToDevice, ctx->stream);
-      if (err == hipSuccess && cfgs.size() > 1)
-         err = hipStreamSynchronize(ctx->stream); /* `table` is reused by the next group */
+      /* (stream order: the copy lands after the launch of the group before has finished with the device table) */
+      hipError_t err = hipMemcpyAsync(ctx->dWorks + first, table, sizeof(NfcWork) * entries, hipMemcpyHostToDevice, ctx->stream);
       if (err != hipSuccess)
       {
          clearWorks();
@@ -1670,17 +1724,8 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
       }
    }
 
-   /* the staging copy and the work table must have been consumed before either is reused: wait */
-   if (cfgs.size() == 1)
-   {
-      hipError_t err = hipStreamSynchronize(ctx->stream);
-      if (err != hipSuccess)
-      {
-         clearWorks();
-         return fail(ctx, NFCGPU_EHIP, "hipStreamSynchronize", err);
-      }
-   }
-
+   /* no wait: the staging slot and its tables are protected by the slot's event (stage_release), the results are
+    * collected by whoever asks for them (nfcgpu_sync / poll / flush) */
    clearWorks();
    return NFCGPU_OK;
 }
@@ -1711,20 +1756,22 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n, float *out, u
 
    const float2 *src = (const float2 *)iq;
    float *dst = out;
+   nfcgpu_ctx::StageSlot *slot = nullptr;
+
+   ctx->inflight = true;
 
    if (location == NFCGPU_LOC_HOST)
    {
       /* staging area: IQ first, magnitudes behind it */
       const size_t inBytes = (size_t)n * 8, outBytes = (size_t)n * 4;
-      int rc = ensure_stage(ctx, inBytes + outBytes);
+      int rc = stage_acquire(ctx, inBytes + outBytes, &slot);
       if (rc)
          return rc;
 
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* staging buffers idle */
-      std::memcpy(ctx->hStage, iq, inBytes);
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->dStage, ctx->hStage, inBytes, hipMemcpyHostToDevice, ctx->stream));
-      src = (const float2 *)ctx->dStage;
-      dst = (float *)(ctx->dStage + inBytes);
+      std::memcpy(slot->h, iq, inBytes);
+      HIP_TRY(ctx, hipMemcpyAsync(slot->d, slot->h, inBytes, hipMemcpyHostToDevice, ctx->stream));
+      src = (const float2 *)slot->d;
+      dst = (float *)(slot->d + inBytes);
    }
 
    const uint32_t threads = 256;
@@ -1735,12 +1782,13 @@ int nfcgpu_magnitude(nfcgpu_ctx *ctx, const float *iq, uint64_t n, float *out, u
    HIP_TRY(ctx, hipGetLastError());
 
    if (location == NFCGPU_LOC_HOST)
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->hStage + (size_t)n * 8, dst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(slot->h + (size_t)n * 8, dst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
 
+   /* the result goes back to the caller: this entry point waits */
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
    if (location == NFCGPU_LOC_HOST)
-      std::memcpy(out, ctx->hStage + (size_t)n * 8, (size_t)n * 4);
+      std::memcpy(out, slot->h + (size_t)n * 8, (size_t)n * 4);
 
    return NFCGPU_OK;
 }
@@ -1846,22 +1894,34 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
 
    const uint8_t *devBase = (const uint8_t *)base;
    uint64_t devPitch = pitch;
+   nfcgpu_ctx::StageSlot *slot = nullptr;
+
+   ctx->inflight = true;
+
+   /* host rows go through a staging slot; its event is recorded behind whatever this call enqueues, on every exit */
+   struct Release
+   {
+      nfcgpu_ctx *ctx;
+      nfcgpu_ctx::StageSlot *slot;
+      ~Release() { if (slot) stage_release(ctx, slot); }
+   } release {ctx, nullptr};
 
    if (location == NFCGPU_LOC_HOST)
    {
       const size_t row = (size_t)n * stride * 4;
       devPitch = (row + 255) & ~(size_t)255;
 
-      int rc = ensure_stage(ctx, devPitch * count);
+      int rc = stage_acquire(ctx, devPitch * count, &slot);
       if (rc)
          return rc;
 
-      /* the previous host submission ended with a stream synchronisation: the pinned buffer is free */
       for (uint32_t r = 0; r < count; r++)
-         std::memcpy(ctx->hStage + (size_t)r * devPitch, (const uint8_t *)base + (size_t)r * pitch, row);
+         std::memcpy(slot->h + (size_t)r * devPitch, (const uint8_t *)base + (size_t)r * pitch, row);
 
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->dStage, ctx->hStage, devPitch * count, hipMemcpyHostToDevice, ctx->stream));
-      devBase = ctx->dStage;
+      release.slot = slot;
+
+      HIP_TRY(ctx, hipMemcpyAsync(slot->d, slot->h, devPitch * count, hipMemcpyHostToDevice, ctx->stream));
+      devBase = slot->d;
    }
 
    int rc = initialize_pending(ctx, first, count, false);
@@ -1922,10 +1982,7 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
       i = j;
    }
 
-   /* host buffers are never retained past the call */
-   if (location == NFCGPU_LOC_HOST)
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-
+   /* host buffers are never retained past the call: they were copied into the staging slot */
    return NFCGPU_OK;
 }
 
@@ -1934,8 +1991,13 @@ int nfcgpu_sync(nfcgpu_ctx *ctx)
    if (!ctx)
       return NFCGPU_EINVAL;
 
+   /* nothing enqueued since the last synchronisation and nothing to collect: no device call at all */
+   if (!ctx->inflight && !ctx->dirty && ctx->timed.empty() && ctx->timedScan.empty() && ctx->timedWindow.empty())
+      return NFCGPU_OK;
+
    HIP_TRY(ctx, hipSetDevice(ctx->device));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+   ctx->inflight = false;
 
    for (auto &pl: ctx->timed)
    {

@@ -104,6 +104,26 @@ struct NfcDecoder::Impl
    bool debugEnabled = false;
    bool dirty = false; /* params changed since last push to the device side */
 
+   /* Block mode (NFCGPU_SHIM_BLOCK=<samples>, off by default). One stream fills one lane of one wavefront, so a 65536-sample
+    * buffer at a time runs at a fraction of real time; the library's time-parallel path needs long submissions. In block
+    * mode the buffers of nextFrames() are collected until `blockSamples` are there, submitted in one piece (asynchronous),
+    * and the frames of a block are handed out when the next block is submitted (or at the end of the stream): the GPU
+    * decodes block k while the caller produces block k+1. Frames, their order and their sample clocks are unchanged; they
+    * are delivered up to two blocks later than the reference would deliver them. Anything that takes effect "from the
+    * next buffer on" (parameters, initialize(), a new sample rate, a buffer of another kind) submits what is pending first.
+    * The reference's interface can only hand frames out as the return value of nextFrames(), and RadioDecoderTask ends a
+    * stream with cleanup(), not with nextFrames({}) (RadioDecoderTask.cpp:381-397): what is still pending then has nowhere
+    * to go. A buffer shorter than the one before it - the last buffer of a file - is therefore taken as the end of the
+    * stream: everything is submitted and collected before the call returns. A host that ends a stream on a full buffer
+    * has to call nextFrames({}) before cleanup(). */
+   size_t blockSamples = 0;
+   std::vector<float> pending;
+   unsigned int pendingStride = 1;
+   unsigned int pendingRate = 0;
+   unsigned int lastCount = 0; /* samples of the buffer before this one */
+   std::list<RawFrame> backlog; /* frames collected at a moment that was not a nextFrames() call */
+   long submittedStreamTime = 0; /* streamTime() in force for the frames not collected yet */
+
    Impl() : ctx(shared.get())
    {
       std::lock_guard<std::recursive_mutex> use(shared.use);
@@ -114,6 +134,9 @@ struct NfcDecoder::Impl
 
       if (rc != NFCGPU_OK)
          throw std::runtime_error(std::string("nfcgpu_stream_open failed: ") + nfcgpu_strerror(rc));
+
+      if (const char *block = std::getenv("NFCGPU_SHIM_BLOCK"))
+         blockSamples = (size_t)std::strtoull(block, nullptr, 10);
    }
 
    ~Impl()
@@ -137,9 +160,23 @@ struct NfcDecoder::Impl
    {
       if (dirty)
       {
+         dispatch(); /* what has been handed over so far is decoded with the parameters it was handed over under */
          check(nfcgpu_stream_configure(ctx, stream, &params), "stream_configure");
          dirty = false;
       }
+   }
+
+   /* block mode: submit what is pending; the frames of everything submitted before go to the backlog */
+   void dispatch()
+   {
+      if (pending.empty())
+         return;
+
+      backlog.splice(backlog.end(), collect());
+
+      check(nfcgpu_submit(ctx, stream, pending.data(), (uint32_t)(pending.size() / pendingStride), pendingStride, pendingRate), "submit");
+      submittedStreamTime = (long)params.stream_time;
+      pending.clear();
    }
 
    void setTech(uint32_t bit, bool enabled)
@@ -188,7 +225,7 @@ struct NfcDecoder::Impl
             frame.setSampleRate(f.sample_rate);
             frame.setTimeStart(static_cast<double>(f.sample_start) / static_cast<double>(f.sample_rate));
             frame.setTimeEnd(static_cast<double>(f.sample_end) / static_cast<double>(f.sample_rate));
-            frame.setDateTime(params.stream_time + frame.timeStart());
+            frame.setDateTime(submittedStreamTime + frame.timeStart());
             frame.put(f.data, f.length).flip();
 
             frames.push_back(frame);
@@ -212,6 +249,7 @@ void NfcDecoder::initialize()
       return;
 
    impl->push();
+   impl->dispatch();
    impl->check(nfcgpu_stream_reset(impl->ctx, impl->stream), "stream_reset");
 }
 
@@ -239,19 +277,53 @@ std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
       {
          const unsigned int count = samples.remaining() / stride;
 
+         if (impl->blockSamples && count)
+         {
+            /* block mode: a buffer of another kind or rate closes the block before it */
+            if (!impl->pending.empty() && (impl->pendingStride != stride || impl->pendingRate != samples.sampleRate()))
+               impl->dispatch();
+
+            impl->pendingStride = stride;
+            impl->pendingRate = samples.sampleRate();
+            impl->pending.insert(impl->pending.end(), samples.ptr(), samples.ptr() + (size_t)count * stride);
+            impl->params.sample_rate = samples.sampleRate();
+
+            const bool last = count < impl->lastCount;
+            impl->lastCount = count;
+
+            if (impl->pending.size() / stride >= impl->blockSamples || last)
+               impl->dispatch();
+
+            if (last)
+               impl->backlog.splice(impl->backlog.end(), impl->collect()); /* waits for the block just submitted */
+
+            std::list<RawFrame> frames;
+            frames.swap(impl->backlog);
+            return frames;
+         }
+
+         impl->dispatch();
+
          /* an empty buffer still counts: a sample rate that differs from the stored one re-initialises the decoder
           * at this point (NfcDecoder.cpp:383-388), with the thresholds set at this point */
          impl->check(nfcgpu_submit(impl->ctx, impl->stream, samples.ptr(), count, stride, samples.sampleRate()), "submit");
+         impl->submittedStreamTime = (long)impl->params.stream_time;
 
          impl->params.sample_rate = samples.sampleRate();
       }
    }
    else
    {
+      impl->dispatch();
+      impl->backlog.splice(impl->backlog.end(), impl->collect());
+      impl->submittedStreamTime = (long)impl->params.stream_time;
       impl->check(nfcgpu_flush(impl->ctx, impl->stream), "flush");
    }
 
-   return impl->collect();
+   std::list<RawFrame> frames;
+   frames.swap(impl->backlog);
+   frames.splice(frames.end(), impl->collect());
+   return frames;
 }
 
 bool NfcDecoder::isDebugEnabled() const { return impl->debugEnabled; }

@@ -274,6 +274,20 @@ def test_reference_radio_decoder_task_runs_unchanged_on_the_gpu_decoder(built, t
         assert got[name] == T.load_golden(name), name
 
 
+def test_radio_decoder_task_with_the_shim_in_block_mode(built, tmp_path, monkeypatch):
+    """NFCGPU_SHIM_BLOCK: buffers collected into long asynchronous submissions (time-parallel path, pinned double-buffered
+    staging), frames of a block handed out when the next block goes in: the task still publishes the golden frames."""
+    exe = os.path.join(T.ROOT, "oracle", "_ref", "task-gpu")
+    if not os.path.exists(exe):
+        pytest.skip("task-gpu not built (needs the reference tree at build time)")
+    monkeypatch.setenv("NFCGPU_SHIM_BLOCK", "300000")
+    names = ["test_NFC-A_106kbps_001", "test_NFC-B_106kbps_002", "test_NFC-F_212kbps_001", "test_NFC-V_26kbps_001", "test_POLL_ABF_001"]
+    for iq in (False, True):
+        got = T.run_task_harness(exe, names, tmp_path, iq=iq)
+        for name in names:
+            assert got[name] == T.load_golden(name), (name, iq)
+
+
 def test_radio_decoder_task_fed_with_iq_buffers(built, tmp_path):
     """the task publishes interleaved IQ (SIGNAL_TYPE_RADIO_IQ) instead of host-computed
     magnitudes; the GPU decoder behind the unchanged RadioDecoderTask demodulates from IQ and yields the goldens."""
