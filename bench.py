@@ -342,7 +342,8 @@ def main():
                             TL.write_wav(wav_s, np.clip(np.rint(sparse * 32768.0), -32768, 32767).astype(np.int16))
                             dense_n = (1 << 23) + 12345
                             wav_d = os.path.join(tmp, "dense.wav")
-                            TL.write_wav(wav_d, np.tile(one, max(1, dense_n // one.size + 1))[:dense_n])
+                            dense = synth.magnitude_f32(template, 0, 0, dense_n)
+                            TL.write_wav(wav_d, np.clip(np.rint(dense * 32768.0), -32768, 32767).astype(np.int16))
                             env = dict(os.environ, NFCGPU_SHIM_BLOCK=str(1 << 22))
                             shim = {"block_samples": 1 << 22}
                             for label, path, n_w in (("sparse", wav_s, sparse.size), ("dense", wav_d, dense_n)):
