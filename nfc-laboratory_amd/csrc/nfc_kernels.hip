@@ -1041,13 +1041,140 @@ __device__ __forceinline__ void nfc_stage_lanes(const NfcLaunch &L, const uint8_
    }
 }
 
+/* nfc_fwait_first_hot for the whole wave: 64 samples per step. The samples go through an inclusive wave scan (grid units,
+ * 32-bit wrap-around arithmetic: only differences over at most p1 samples are used); `pp` (192 words of LDS) holds the
+ * prefix sums of the 128 samples before the block at hand and of the block, so that lane i finds W(k) = pp[k] - pp[k-p2]
+ * for the three windows of its sample's step. Every argument is wave-uniform; requires delay + p1 <= NFC_FWAIT_LOOKBACK
+ * and from >= NFC_FWAIT_LOOKBACK. */
+__device__ uint32_t nfc_wave_first_hot(const uint8_t *data, uint32_t stride, uint32_t count, uint32_t from, uint32_t limit, uint32_t p1, uint32_t p2,
+                                       uint32_t delay, float thr, uint32_t *pp)
+{
+   const uint32_t lane = threadIdx.x;
+   uint32_t carry = 0u;
+
+   __syncthreads();
+   pp[lane] = 0u;
+   pp[64u + lane] = 0u;
+   pp[128u + lane] = 0u;
+   __syncthreads();
+
+   for (uint32_t t0 = from - NFC_FWAIT_LOOKBACK; t0 < limit; t0 += 64u)
+   {
+      const uint32_t a = pp[64u + lane], b = pp[128u + lane];
+      __syncthreads();
+      pp[lane] = a;
+      pp[64u + lane] = b;
+
+      const uint32_t idx = t0 + lane;
+      uint32_t v = idx < count ? (uint32_t)nfc_grid_units(data, stride, idx) : 0u;
+
+      for (uint32_t off = 1u; off < 64u; off <<= 1)
+      {
+         const uint32_t other = (uint32_t)__shfl_up((int)v, (int)off, 64);
+         if (lane >= off)
+            v += other;
+      }
+
+      v += carry;
+      carry = (uint32_t)__shfl((int)v, 63, 64);
+
+      pp[128u + lane] = v;
+      __syncthreads();
+
+      if (t0 >= from)
+      {
+         const uint32_t n = t0 + lane;
+         const uint32_t cur = 128u + lane - delay; /* pp index of the decode point of sample n's step */
+         const uint32_t d = p1 - p2;
+
+         const int32_t w0 = (int32_t)(pp[cur] - pp[cur - p2]);
+         const int32_t wd = (int32_t)(pp[cur - d] - pp[cur - d - p2]);
+         const int32_t w1 = (int32_t)(pp[cur - 1u] - pp[cur - 1u - p2]);
+
+         const uint64_t hot = __ballot(n < limit && nfc_fwait_hot(w0, wd, w1, p2, thr));
+
+         if (hot)
+            return t0 + (uint32_t)__builtin_ctzll(hot);
+      }
+   }
+
+   return limit;
+}
+
+/* Lanes of the wave whose decoder is an idle waiting NFC-F decoder: one after the other the wave looks ahead for them
+ * (nfc_wave_first_hot) and the lane jumps (nfc_lane_fwait_jump). `pos`: the lane's stream position (tile boundary);
+ * lockFrontUntil / lockUpkeepUntil / nextWaitScan: the lane's own bookkeeping (stream positions). Called by all lanes. */
+__device__ __forceinline__ uint32_t nfc_wave_fwait(const NfcConfig &cc, const NfcScanArgs &A, const NfcWindow *windows, bool candidate, uint32_t w,
+                                                   uint32_t pos, uint32_t stride, NfcStreamState &s, const NfcStreamCold *cold, uint32_t &lockFrontUntil,
+                                                   uint32_t &lockUpkeepUntil, uint32_t &nextWaitScan, uint32_t *pp)
+{
+   const uint32_t lane = threadIdx.x;
+   uint32_t landed = pos;
+
+   /* what the wave needs to know about the lane */
+   uint32_t jobIndex = 0u, limit = 0u, p1 = 0u, p2 = 0u, delay = 0u;
+   float thr = 0.0f;
+
+   if (candidate)
+   {
+      const NfcRate &rt = s.u.decode.rt;
+      p1 = rt.p1;
+      p2 = rt.p2;
+      delay = rt.delay;
+      thr = s.u.decode.lock.thr;
+      jobIndex = windows[w].job;
+
+      const NfcScanJob &job = A.jobs[jobIndex];
+      uint64_t end = (uint64_t)pos + (uint32_t)(s.u.decode.waitingEnd - s.clock);
+      limit = end > job.count ? job.count : (uint32_t)end;
+
+      candidate = delay + p1 <= NFC_FWAIT_LOOKBACK && pos >= NFC_FWAIT_LOOKBACK + NFC_SCAN_TILE && p2 != 0u && p1 > p2;
+   }
+
+   uint64_t todo = __ballot(candidate);
+
+   while (todo)
+   {
+      const int who = (int)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+
+      const uint32_t j = (uint32_t)__shfl((int)jobIndex, who, 64);
+      const uint32_t from = (uint32_t)__shfl((int)pos, who, 64);
+      const uint32_t lim = (uint32_t)__shfl((int)limit, who, 64);
+      const uint32_t q1 = (uint32_t)__shfl((int)p1, who, 64);
+      const uint32_t q2 = (uint32_t)__shfl((int)p2, who, 64);
+      const uint32_t dl = (uint32_t)__shfl((int)delay, who, 64);
+      const float th = __shfl(thr, who, 64);
+
+      const NfcScanJob &job = A.jobs[j];
+
+      const uint32_t firstHot = nfc_wave_first_hot(job.data, stride, job.count, from, lim, q1, q2, dl, th, pp);
+
+      if ((int)lane == who)
+      {
+         const uint32_t land = nfc_lane_fwait_jump(cc, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, pos, firstHot, s, *cold);
+
+         if (land != pos)
+         {
+            landed = land;
+            lockFrontUntil = land + NFC_WINDOW_WARM_FRONT;
+            lockUpkeepUntil = land + NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
+         }
+         else
+            nextWaitScan = firstHot + NFC_SCAN_TILE;
+      }
+   }
+
+   return landed;
+}
+
 /* The windowed decode: nfc_demod_body with lanes that stop on their own. A lane consumes its row tile by tile: front
  * end only, then correlator upkeep (both lengths are the launch's), then the full step machine; at a tile boundary it
  * retires when the decoder is at rest, the rings hold nothing from before its last unlock and the scan found nothing
  * ahead (NFC_TILE_RETIRE_OK). CARRY lanes continue a stream from its own state (no warm-up, exact-modulo ring positions
  * where the clock asks for them). */
 template <bool CARRY>
-__device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, float *tile)
+__device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, float *tile, uint32_t *waitScan)
 {
    const uint32_t lane = threadIdx.x;
    const uint32_t block = L.firstBlock + blockIdx.x;
@@ -1116,8 +1243,10 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
          succ = succEnd; /* a final lane (regenerates a state): runs on its own */
    }
 
-   /* `base`: samples of the row this lane has consumed (lanes may jump ahead through dark signal: nfc_lane_dark_jump) */
+   /* `base`: samples of the row this lane has consumed (lanes may jump ahead through dark signal: nfc_lane_dark_jump, and
+    * through the wait of an NFC-F decoder: nfc_lane_fwait_jump) */
    uint32_t base = 0;
+   uint32_t lockFrontUntil = 0, lockUpkeepUntil = 0, nextWaitScan = 0; /* stream positions */
 
    for (;;)
    {
@@ -1148,6 +1277,17 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
                                    flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - startPos;
       }
 
+      /* a waiting NFC-F decoder: skip to where its correlator can next reach the threshold */
+      {
+         const uint32_t pos = startPos + base;
+         const bool waiting = !stopped && base >= warm && pos >= lockUpkeepUntil && pos >= nextWaitScan && nfc_fwait_idle(s) &&
+                              !nfc_exact_span(s.clock, TILE);
+
+         if (__any(waiting))
+            base = nfc_wave_fwait(cc, A, L.windows, waiting, slot, pos, L.uniformStride, s, mem.cold, lockFrontUntil, lockUpkeepUntil, nextWaitScan,
+                                  waitScan) - startPos;
+      }
+
       if (__any(!stopped) == 0)
          break;
 
@@ -1169,6 +1309,16 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
          {
             for (uint32_t k = 0; k < n; k++)
                nfc_step_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+         }
+         else if (startPos + base < lockFrontUntil)
+         {
+            for (uint32_t k = 0; k < n; k++)
+               nfc_step_lock_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+         }
+         else if (startPos + base < lockUpkeepUntil)
+         {
+            for (uint32_t k = 0; k < n; k++)
+               nfc_step_fwait_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
          }
          else if (CARRY && __any(nfc_exact_span(s.clock, n)) != 0)
          {
@@ -1209,7 +1359,8 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
 __global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
-   nfc_window_body<false>(cfgPtr, L, A, tile);
+   __shared__ uint32_t waitScan[192];
+   nfc_window_body<false>(cfgPtr, L, A, tile, waitScan);
 }
 
 /* The windowed decode of the speculative lanes: persistent waves that refill their lanes. A wave keeps 64 windows in
@@ -1222,6 +1373,7 @@ __global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *_
 __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
+   __shared__ uint32_t waitScan[192];
 
    const uint32_t lane = threadIdx.x;
    const uint32_t ringBlock = A.firstWindowSlot / NFC_LANES + blockIdx.x;
@@ -1252,6 +1404,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
    bool active = false;
    uint32_t w = 0, consumed = 0, mineCount = 0, stepped = 0;
    uint32_t startPos = 0, verifyPos = 0xFFFFFFFFu, succ = 0, succEnd = 0;
+   uint32_t lockFrontUntil = 0, lockUpkeepUntil = 0, nextWaitScan = 0; /* stream positions (nfc_lane_fwait_jump) */
    const uint8_t *data = nullptr;
    const uint32_t *flags = nullptr;
    uint32_t steps = 0; /* steps of this wave since its lanes last all started together (multiple of 512 at a join) */
@@ -1289,6 +1442,9 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
             consumed = 0;
             stepped = 0;
             active = mineCount != 0;
+            lockFrontUntil = 0;
+            lockUpkeepUntil = 0;
+            nextWaitScan = 0;
 
             mem.cold = L.cold + w;
             mem.streamId = w;
@@ -1395,6 +1551,16 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
                                           flags[consumed / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - startPos;
          }
 
+         /* a waiting NFC-F decoder: skip to where its correlator can next reach the threshold */
+         {
+            const uint32_t pos = startPos + consumed;
+            const bool waiting = active && consumed >= warm && consumed < mineCount && pos >= lockUpkeepUntil && pos >= nextWaitScan && nfc_fwait_idle(s);
+
+            if (__any(waiting))
+               consumed = nfc_wave_fwait(cc, A, L.windows, waiting, w, pos, L.uniformStride, s, mem.cold, lockFrontUntil, lockUpkeepUntil, nextWaitScan,
+                                         waitScan) - startPos;
+         }
+
          /* stage: row r = the next 64 samples of lane r's window */
          nfc_stage_lanes(L, active ? data + (uint64_t)consumed * L.uniformStride * 4u : nullptr, active ? mineCount - consumed : 0u, lane, tile);
 
@@ -1406,7 +1572,9 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
 
             const bool front = active && consumed < L.warmFront;
             const bool upkeep = active && !front && consumed < warm;
-            const bool full = active && !front && !upkeep;
+            const bool lockFront = active && !front && !upkeep && startPos + consumed < lockFrontUntil;
+            const bool lockUpkeep = active && !front && !upkeep && !lockFront && startPos + consumed < lockUpkeepUntil;
+            const bool full = active && !front && !upkeep && !lockFront && !lockUpkeep;
 
             if (__any(front))
             {
@@ -1423,6 +1591,24 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
                {
                   if (upkeep && k < n)
                      nfc_step_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+               }
+            }
+
+            if (__any(lockFront))
+            {
+               for (uint32_t k = 0; k < TILE; k++)
+               {
+                  if (lockFront && k < n)
+                     nfc_step_lock_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
+               }
+            }
+
+            if (__any(lockUpkeep))
+            {
+               for (uint32_t k = 0; k < TILE; k++)
+               {
+                  if (lockUpkeep && k < n)
+                     nfc_step_fwait_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
                }
             }
 
@@ -1449,7 +1635,8 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
 __global__ __launch_bounds__(64) void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
-   nfc_window_body<true>(cfgPtr, L, A, tile);
+   __shared__ uint32_t waitScan[192];
+   nfc_window_body<true>(cfgPtr, L, A, tile, waitScan);
 }
 
 /* once the chain is settled: jobs whose last lane is a speculative window get that window set up again in their own

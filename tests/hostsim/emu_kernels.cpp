@@ -346,6 +346,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
       uint32_t consumed = 0;
       uint32_t stepped = 0;
       uint32_t handed = 0;
+      uint32_t lockFrontUntil = 0, lockUpkeepUntil = 0, nextWaitScan = 0; /* stream positions (nfc_lane_fwait_jump) */
 
       NfcWindow &me = L.windows[slot];
       const NfcScanJob &job = L.jobs[me.job];
@@ -416,6 +417,34 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
             base = nfc_lane_dark_jump(*cfgPtr, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, me.start + base,
                                       flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - me.start;
 
+         /* a waiting NFC-F decoder: skip to where its correlator can next reach the threshold */
+         if (base >= warm && me.start + base >= lockUpkeepUntil && me.start + base >= nextWaitScan && nfc_fwait_idle(s) &&
+             !exact_span(s.clock, NFC_SCAN_TILE) && !std::getenv("NFC_EMU_NO_FWAIT"))
+         {
+            const NfcRate &rt = s.u.decode.rt;
+            const uint32_t pos = me.start + base;
+
+            if (rt.delay + rt.p1 <= NFC_FWAIT_LOOKBACK && pos >= NFC_FWAIT_LOOKBACK + NFC_SCAN_TILE)
+            {
+               /* the step that takes sample n has clock s.clock + 1 + (n - pos): the waiting time is over at the first n with clock > waitingEnd */
+               uint64_t limit = (uint64_t)pos + (uint32_t)(s.u.decode.waitingEnd - s.clock);
+               if (limit > job.count)
+                  limit = job.count;
+
+               const uint32_t firstHot = nfc_fwait_first_hot(job.data, L.uniformStride, pos, (uint32_t)limit, rt.p1, rt.p2, rt.delay, s.u.decode.lock.thr);
+               const uint32_t land = nfc_lane_fwait_jump(*cfgPtr, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, pos, firstHot, s, *mem.cold);
+
+               if (land != pos)
+               {
+                  base = land - me.start;
+                  lockFrontUntil = land + NFC_WINDOW_WARM_FRONT;
+                  lockUpkeepUntil = land + NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
+               }
+               else
+                  nextWaitScan = firstHot + NFC_SCAN_TILE;
+            }
+         }
+
          const uint32_t left = mineCount - base;
          const uint32_t n = left < NFC_SCAN_TILE ? left : NFC_SCAN_TILE;
          const bool exact = carry && exact_span(s.clock, n);
@@ -428,6 +457,10 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
                nfc_step_front<false>(*cfgPtr, s, mem, v);
             else if (base < warm)
                nfc_step_upkeep<false>(*cfgPtr, s, mem, v);
+            else if (me.start + base < lockFrontUntil)
+               nfc_step_lock_front<false>(*cfgPtr, s, mem, v);
+            else if (me.start + base < lockUpkeepUntil)
+               nfc_step_fwait_upkeep<false>(*cfgPtr, s, mem, v);
             else if (exact)
                nfc_step_as<true>(*cfgPtr, s, mem, v);
             else
