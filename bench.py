@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--samples", type=int, default=8192, help="samples per stream per step (headline)")
     ap.add_argument("--cpu-streams", type=int, default=24576, help="streams of rank 0 replayed on the host CPU")
     ap.add_argument("--check-streams", type=int, default=64, help="streams compared frame-by-frame with the reference")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --streams per GPU (the driver's contract); strong: --streams in total, rank r decodes streams [r*S/N, (r+1)*S/N) of the same dataset")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-points", action="store_true", help="headline only")
     ap.add_argument("--points", default="fixtures_single,config5_sparse,config5_dense,config5_idle,share_sparse,share_dense,single_sparse,single_dense")
@@ -132,6 +134,8 @@ def main():
     import frames as framelib
 
     S, L, K, W = args.streams, args.samples, args.steps, args.warmup
+    if args.scaling == "strong":
+        S = max(64, (args.streams // world) // 64 * 64)  # the same dataset cut over the ranks (whole stream blocks)
     T = (K + W) * L
 
     template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
@@ -230,7 +234,7 @@ def main():
         "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
