@@ -618,6 +618,7 @@ NFC_DEV void nfc_enter_lock(NfcStreamState &s, const NfcLaneMem &mem, uint32_t t
    mem.cold->parked = s.u.search;
    s.u.decode = mem.cold->init;
    s.u.decode.maxFrame = mem.cold->tim[tech - NFC_TECH_A].maxFrameSize;
+   mem.cold->usedTech |= 1u << (tech - NFC_TECH_A);
    s.lockTech = tech;
    NFC_DRAIN();
 }
@@ -801,6 +802,13 @@ NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLa
    NFC_OPAQUE(isF);
    NFC_OPAQUE(isV);
 
+   /* for the time-parallel path: did the classification read a lastCommand the lane had inherited? (NfcStreamCold::usedTech) */
+   const uint32_t techIndex = tech - NFC_TECH_A;
+   const uint32_t commandBefore = mem.cold->tim[techIndex & 3u].lastCommand;
+
+   if (type != NFC_FRAME_POLL && !((mem.cold->usedTech >> (8u + techIndex)) & 1u))
+      mem.cold->usedTech |= 1u << (4u + techIndex);
+
    if (isA == NFC_TECH_A)
       nfca_process(c, s, mem, type, data, len, flags, phase);
    if (isB == NFC_TECH_B)
@@ -809,6 +817,9 @@ NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLa
       nfcf_process(c, s, mem, type, data, len, flags, phase);
    if (isV == NFC_TECH_V)
       nfcv_process(c, s, mem, type, data, len, flags, phase);
+
+   if (mem.cold->tim[techIndex & 3u].lastCommand != commandBefore)
+      mem.cold->usedTech |= 1u << (8u + techIndex);
 
    nfc_emit(mem, s, tech, type, flags, phase, rate, start, end, data, len);
 

@@ -1764,6 +1764,9 @@ __global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch
       NfcStreamState s = lanes.states[from];
       NfcStreamCold cold = lanes.cold[from];
 
+      if (job->finalLane != j)
+         nfc_final_fixup(s, cold, A.windows[job->finalLane].want);
+
       cold.frameHead = 0;
       cold.frameTail = 0;
 

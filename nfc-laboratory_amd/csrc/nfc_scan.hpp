@@ -595,11 +595,18 @@ NFC_DEV void nfc_records_canonical(NfcSearchRegs &r)
    r.detV.acc = 0.0f;
 }
 
-NFC_DEV bool nfc_records_same(const NfcSearchRegs &a, const NfcSearchRegs &b)
+NFC_DEV bool nfc_records_same(const NfcSearchRegs &a, const NfcSearchRegs &b, uint32_t used = 0xFFFFFu)
 {
    NfcSearchRegs x = a, y = b;
    nfc_records_canonical(x);
    nfc_records_canonical(y);
+
+   /* an NFC-F record the lane never ran its tracker on before clearing it need not agree (NfcStreamCold::usedTech) */
+   for (int i = 0; i < 2; i++)
+   {
+      if (!((used >> (14 + i)) & 1u))
+         y.detF[i] = x.detF[i];
+   }
 
    /* memcmp, not words through an integer alias of the float fields (type-based alias analysis would let the loads
     * pass the stores of the canonical form) */
@@ -617,19 +624,22 @@ NFC_DEV uint32_t nfc_edge_time(const NfcCarry &x, uint32_t tracked)
 /* Two carries of lanes meeting at the same sample (`meeting`: their decoders' edge times are compared as they are), or
  * an assumption against what the stream holds at a lane's first sample (`tracked`: edge-tracker time there; the last
  * carrier frame only matters through the edge time it leaves the lane with). */
-NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked)
+/* `used`: the technologies whose protocol state the lane in question has looked at (NfcStreamCold::usedTech); the others'
+ * need not agree. */
+NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked, uint32_t used = 0xFFFFFu)
 {
-   bool same = a.chainedA == b.chainedA && (a.carrierOn != 0) == (b.carrierOn != 0) && (a.carrierOff != 0) == (b.carrierOff != 0) &&
+   bool same = ((used & 1u) == 0u || a.chainedA == b.chainedA) && (a.carrierOn != 0) == (b.carrierOn != 0) && (a.carrierOff != 0) == (b.carrierOff != 0) &&
                (meeting ? a.edgeTime == b.edgeTime : nfc_edge_time(a, tracked) == nfc_edge_time(b, tracked));
 
    for (int t = 0; t < 4; t++)
-      same = same && a.tim[t].lastCommand == b.tim[t].lastCommand && a.tim[t].maxFrameSize == b.tim[t].maxFrameSize &&
-             a.tim[t].protoGuardTime == b.tim[t].protoGuardTime && a.tim[t].protoWaitingTime == b.tim[t].protoWaitingTime;
+      same = same && (((used >> t) & 1u) == 0u ||
+                      ((((used >> (4 + t)) & 1u) == 0u || a.tim[t].lastCommand == b.tim[t].lastCommand) && a.tim[t].maxFrameSize == b.tim[t].maxFrameSize &&
+                       a.tim[t].protoGuardTime == b.tim[t].protoGuardTime && a.tim[t].protoWaitingTime == b.tim[t].protoWaitingTime));
 
    for (int i = 0; i < 2; i++)
-      same = same && a.pulsesF[i] == b.pulsesF[i] && nfc_bits(a.thrF[i]) == nfc_bits(b.thrF[i]);
+      same = same && (((used >> (12 + i)) & 1u) == 0u || (a.pulsesF[i] == b.pulsesF[i] && nfc_bits(a.thrF[i]) == nfc_bits(b.thrF[i])));
 
-   same = same && nfc_records_same(a.search, b.search);
+   same = same && nfc_records_same(a.search, b.search, used);
 
 #ifdef NFC_CARRY_DEBUG
    if (!same)
@@ -1046,7 +1056,41 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
          /* what the lane had where it took over: its assumption at its start, or what it published */
          const NfcCarry &had = handed ? x.pubCarry : x.carry;
 
-         if (!nfc_carry_same(had, have, handed, x.tracked))
+         /* protocol state of the technologies the lane never locked: it did not look at what it had assumed there and
+          * hands on what the stream holds */
+         const uint32_t used = colds[lane].usedTech;
+
+         for (int t = 0; t < 4; t++)
+         {
+            if (!((used >> t) & 1u))
+               left.tim[t] = have.tim[t];
+            else if (!((used >> (8 + t)) & 1u))
+               left.tim[t].lastCommand = have.tim[t].lastCommand; /* never changed by the lane: what the stream holds */
+         }
+
+         if (!(used & 1u))
+            left.chainedA = have.chainedA;
+
+         /* what an NFC-F detector remembers across its partial resets, when the lane neither looked at it nor started the
+          * record over: unchanged, so it is what the stream holds */
+         for (int i = 0; i < 2; i++)
+         {
+            if (!((used >> (12 + i)) & 1u) && !left.clearedF[i])
+            {
+               left.pulsesF[i] = have.pulsesF[i];
+               left.thrF[i] = have.thrF[i];
+            }
+
+            /* the record itself, when the lane neither ran the tracker on it nor reset it */
+            if (!((used >> (14 + i)) & 1u) && !((used >> (16 + i)) & 1u))
+               left.search.detF[i] = have.search.detF[i];
+         }
+
+         /* kept for the finish: should this be the stream's last lane, what it never looked at is put right in the state
+          * it leaves (nfc_final_fixup); a lane that has to run again gets its `want` below */
+         x.want = have;
+
+         if (!nfc_carry_same(had, have, handed, x.tracked, used))
          {
             /* ran on a wrong assumption. At its start it has to assume `have`, corrected by what it did itself between
              * its start and the sample it took over at */
@@ -1149,6 +1193,48 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
 /* ------------------------------------------------------------------------------------------ */
 /* finish: one thread per job, once the chain is settled                                        */
 /* ------------------------------------------------------------------------------------------ */
+
+/* The state a stream's last lane leaves, where that lane ran on assumptions the chain let pass because the lane never
+ * looked at them (NfcStreamCold::usedTech): those fields still hold the assumption; `have` is what the stream really held
+ * where the lane took over (NfcWindow::want as nfc_chain_follow left it). The counterpart of the substitutions
+ * nfc_chain_follow makes in `left` for the lanes in between. */
+NFC_DEV void nfc_final_fixup(NfcStreamState &s, NfcStreamCold &cold, const NfcCarry &have)
+{
+   const uint32_t used = cold.usedTech;
+
+   for (int t = 0; t < 4; t++)
+   {
+      if (!((used >> t) & 1u))
+         cold.tim[t] = have.tim[t];
+      else if (!((used >> (8 + t)) & 1u))
+         cold.tim[t].lastCommand = have.tim[t].lastCommand;
+   }
+
+   if (!(used & 1u))
+      s.chainedA = have.chainedA;
+
+   /* the detector records are parked while a technology is locked */
+   NfcSearchRegs &r = s.lockTech ? cold.parked : s.u.search;
+
+   for (int i = 0; i < 2; i++)
+   {
+      const float acc = r.detF[i].acc; /* the lane's own running sum goes with the lane's rings */
+
+      if (!((used >> (14 + i)) & 1u) && !((used >> (16 + i)) & 1u))
+      {
+         r.detF[i] = have.search.detF[i];
+         r.detF[i].pulses = have.pulsesF[i];
+         r.detF[i].thr = have.thrF[i];
+      }
+      else if (!((used >> (12 + i)) & 1u) && !cold.clearedF[i])
+      {
+         r.detF[i].pulses = have.pulsesF[i];
+         r.detF[i].thr = have.thrF[i];
+      }
+
+      r.detF[i].acc = acc;
+   }
+}
 
 /* A lane of a windowed launch chains its frame records in the staging sink: [next][record as nfc_emit writes it];
  * NfcStreamCold::frameHead is the word offset + 1 of the lane's first record. Copies the records of the live lanes,

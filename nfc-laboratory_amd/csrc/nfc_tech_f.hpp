@@ -104,7 +104,8 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 /* the preamble tracker shared by search (NfcF.cpp:267-405) and listen-SOF (NfcF.cpp:815-933);
  * returns true when a complete, length-checked preamble has just ended */
 template <class M>
-NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, float sd, float s0, bool above, uint32_t &polarity, uint32_t *cleared)
+NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, float sd, float s0, bool above, uint32_t &polarity, uint32_t *cleared,
+                                 uint32_t *used = nullptr, uint32_t usedBit = 0u)
 {
    if (above)
    {
@@ -130,6 +131,11 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, flo
 
    if (s.clock != m.winEnd)
       return false;
+
+   /* the pulse counter and the threshold of the last pulse are looked at from here on: if the record has not started
+    * over since the lane began, what the lane inherited matters (NfcStreamCold::usedTech) */
+   if (used && cleared && !*cleared)
+      *used |= usedBit;
 
    if (m.pulses++ < 94)
    {
@@ -227,6 +233,7 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
       /* (detectorPeak* are never set by this detector: nothing to clear) */
       m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
       m.peakTime = 0; m.peak = 0;
+      mem.cold->usedTech |= 1u << (15 + R); /* from here on the record is the lane's own (NfcStreamCold::usedTech) */
    }
 
    if (s.clock < m.winStart)
@@ -239,7 +246,11 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
 
    uint32_t polarity = 0;
 
-   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1]))
+   /* the tracker looks at the record: if the lane has not cleared it since it started, what it inherited matters */
+   if (!((mem.cold->usedTech >> (15 + R)) & 1u))
+      mem.cold->usedTech |= 1u << (13 + R);
+
+   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1], &mem.cold->usedTech, 1u << (11 + R)))
       return false;
 
    /* preamble complete: lock this bitrate, the sync bytes follow (copy the detector record before it is parked) */

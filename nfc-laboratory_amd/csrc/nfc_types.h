@@ -267,7 +267,14 @@ struct NfcStreamCold
     * (stream start, 32-bit clock wrap) compute positions from the clock and have to add it. */
    uint32_t label[7];
    uint32_t clearedF[2]; /* an NFC-F preamble detector cleared its pulse counter since the lane started (NfcCarry::pulsesF) */
-   uint32_t reserved;
+   uint32_t usedTech;    /* bit t: technology t (A B F V) has been locked since the lane started. The protocol timing of a
+                            technology is only read when it locks and while its frames are processed, so a lane that never
+                            locked it neither depends on what it assumed there nor changes it (nfc_chain_follow).
+                            bit 4+t: a listen frame of t was classified by a lastCommand the lane had not written itself
+                            (poll frames are classified by their first byte and write it: nfc*_process); bit 8+t: the
+                            lane has changed lastCommand of t; bit 12+i: NFC-F preamble detector i evaluated a pulse with the
+                            counter / threshold it had inherited (nfcf_track_preamble); bit 14+i: its tracker ran on the
+                            record the lane had inherited; bit 16+i: the lane has (partially) reset that record */
 };
 
 /* header of one frame in the frame sink, followed by (length+3)/4 payload words */

@@ -982,6 +982,8 @@ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
 
       NfcStreamState s = lanes.states[from];
       NfcStreamCold cold = lanes.cold[from];
+      if (job->finalLane != j)
+         nfc_final_fixup(s, cold, A.windows[job->finalLane].want);
       cold.frameHead = 0;
       cold.frameTail = 0;
       real.states[job->slot] = s;

@@ -53,7 +53,7 @@ def test_fixtures_through_the_time_parallel_path_emulated(emulated):
 
 @needs_reference
 def test_buffers_synthetic_and_quiet_captures_emulated(emulated):
-    res = _run(["buffers", "synthetic", "quiet"], True)
+    res = _run(["buffers", "synthetic", "quiet", "carried"], True)
     _check(res)
     quiet = [r for r in res if r["name"].startswith("one exchange")][0]
     assert quiet["stats"]["windows"] <= 16, quiet  # nearly everything skipped
@@ -91,7 +91,7 @@ def test_fixtures_through_the_time_parallel_path_on_the_gpu(built):
 @needs_reference
 @pytest.mark.gpu
 def test_buffers_synthetic_quiet_and_offgrid_on_the_gpu(built):
-    res = _run(["buffers", "synthetic", "quiet"], False)
+    res = _run(["buffers", "synthetic", "quiet", "carried"], False)
     _check(res)
     res = _run(["offgrid"], False)
     _check(res, windowed=False)

@@ -67,6 +67,15 @@ def main():
         streams = [synth.magnitude_f32(template, s, 0, 1 << 18) for s in range(12)]
         out.append(case("12 synthetic streams x 2^18, IQ entry, 2 buffers", streams, buffers=2, stride=2))
 
+    if not which or "carried" in which:
+        # what a lane leaves behind without having looked at it (protocol state of a technology it never locked, an NFC-F
+        # record it never ran) goes on to the next submission: dense streams in three submissions, sparse ones in four
+        streams = [synth.magnitude_f32(template, s, 0, 1 << 20) for s in (29, 5, 17)]
+        out.append(case("3 dense synthetic streams x 2^20 in 3 buffers", streams, buffers=3))
+        segs = synth.sparse_segments(template)
+        streams = [synth.sparse_magnitude_f32(template, segs, s, 0, 1 << 20) for s in range(24)]
+        out.append(case("24 sparse synthetic streams x 2^20 in 4 buffers", streams, buffers=4))
+
     if "routing" in which:
         streams = [synth.magnitude_f32(template, s, 0, 1 << 16) for s in range(64)]
         out.append(case("64 synthetic streams x 2^16 (dense: sequential path when routing is on)", streams))
