@@ -43,6 +43,7 @@ struct NfcScanArgs
    uint32_t *rerunCount;       /* jobs that need another decode pass (device counter) */
    NfcScanChunk *repairs;      /* chunks to walk again (nfc_seams_check), at most one per job and round */
    uint32_t *repairCount;
+   uint32_t *denseCount;       /* jobs routed to the sequential kernels (device counter) */
    uint32_t *runList;          /* speculative lanes to run in the coming pass (indices into the lane arrays) */
    uint32_t *runCount;         /* entries of runList (device counter) */
    uint32_t *runNext;          /* next entry a persistent wave takes (device counter) */

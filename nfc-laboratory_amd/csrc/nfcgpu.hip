@@ -767,6 +767,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.runList = (uint32_t *)ctx->wRunList.ptr;
    A.repairs = (NfcScanChunk *)ctx->wRepairs.ptr;
    A.repairCount = counters + 7;
+   A.denseCount = counters + 9;
 
    /* save area for lanes that run to the end of the submission (nfc_scan_launch.h): a few per stream */
    {
@@ -821,9 +822,18 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       hipLaunchKernelGGL(nfc_seams_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, round == 0 ? 1u : 0u);
       HIP_TRY(ctx, hipGetLastError());
 
-      uint32_t repairs = 0;
-      HIP_TRY(ctx, hipMemcpyAsync(&repairs, counters + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
+      uint32_t word[3] = {0, 0, 0}; /* repairs, (save area), dense jobs */
+      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 12, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      const uint32_t repairs = word[0];
+
+      /* The sequential kernels take as long for one stream as for a hundred thousand (one lane each): once half of the
+       * submission goes there anyway, cutting the other half into lanes first only adds its time on top. */
+      if (round == 0 && (uint64_t)word[2] * 2u >= nJobs)
+      {
+         ctx->stats.fallback_streams += nJobs;
+         return launch_sequential(ctx, config, items, stride);
+      }
 
       if (!repairs)
          break;
