@@ -79,6 +79,8 @@ struct NfcLaneMem
    NfcStreamCold *cold;  /* protocol timing of this stream (HBM) */
    const NfcConfig *tables; /* configuration in memory, for its dynamically indexed tables (NFC-V pulse slots) */
    bool linked;          /* frame records are chained per lane in a staging sink (time-parallel path) */
+   uint32_t *flags;      /* time-parallel lanes only (linked): what the lane has looked at of the state it inherited, bits of
+                            NfcStreamCold::usedTech; kept in fast storage during the run (the sequential kernels track nothing) */
 };
 
 /* ring regions (in slots) inside a stream block */
@@ -618,7 +620,8 @@ NFC_DEV void nfc_enter_lock(NfcStreamState &s, const NfcLaneMem &mem, uint32_t t
    mem.cold->parked = s.u.search;
    s.u.decode = mem.cold->init;
    s.u.decode.maxFrame = mem.cold->tim[tech - NFC_TECH_A].maxFrameSize;
-   mem.cold->usedTech |= 1u << (tech - NFC_TECH_A);
+   if (mem.linked)
+      *mem.flags |= 1u << (tech - NFC_TECH_A);
    s.lockTech = tech;
    NFC_DRAIN();
 }
@@ -804,10 +807,10 @@ NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLa
 
    /* for the time-parallel path: did the classification read a lastCommand the lane had inherited? (NfcStreamCold::usedTech) */
    const uint32_t techIndex = tech - NFC_TECH_A;
-   const uint32_t commandBefore = mem.cold->tim[techIndex & 3u].lastCommand;
+   const uint32_t commandBefore = mem.linked ? mem.cold->tim[techIndex & 3u].lastCommand : 0u;
 
-   if (type != NFC_FRAME_POLL && !((mem.cold->usedTech >> (8u + techIndex)) & 1u))
-      mem.cold->usedTech |= 1u << (4u + techIndex);
+   if (mem.linked && type != NFC_FRAME_POLL && !((*mem.flags >> (8u + techIndex)) & 1u))
+      *mem.flags |= 1u << (4u + techIndex);
 
    if (isA == NFC_TECH_A)
       nfca_process(c, s, mem, type, data, len, flags, phase);
@@ -818,8 +821,8 @@ NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLa
    if (isV == NFC_TECH_V)
       nfcv_process(c, s, mem, type, data, len, flags, phase);
 
-   if (mem.cold->tim[techIndex & 3u].lastCommand != commandBefore)
-      mem.cold->usedTech |= 1u << (8u + techIndex);
+   if (mem.linked && mem.cold->tim[techIndex & 3u].lastCommand != commandBefore)
+      *mem.flags |= 1u << (8u + techIndex);
 
    nfc_emit(mem, s, tech, type, flags, phase, rate, start, end, data, len);
 

@@ -203,6 +203,7 @@ __device__ __forceinline__ void nfc_demod_body(const NfcConfig *__restrict__ cfg
    mem.lane = lane;
    mem.exact = false;
    mem.linked = false;
+   mem.flags = nullptr;
    mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
    mem.sink = L.sink;
    mem.sinkCursor = L.sinkCtl;
@@ -1211,6 +1212,8 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
    mem.lane = lane;
    mem.exact = false;
    mem.linked = true;
+   mem.flags = waitScan + 192 + lane; /* (the wave's LDS words behind the look-ahead buffer) */
+   waitScan[192 + lane] = 0u;
    mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
    mem.sink = L.sink;
    mem.sinkCursor = L.sinkCtl;
@@ -1344,6 +1347,7 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
 
    if (mineCount)
    {
+      mem.cold->usedTech = *mem.flags;
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
       /* out of samples in a state the closing window can take over from (nfc_lane_comparable): as good as stopped at rest,
@@ -1362,7 +1366,7 @@ __device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cf
 __global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ uint32_t waitScan[192];
+   __shared__ uint32_t waitScan[192 + NFC_LANES];
    nfc_window_body<false>(cfgPtr, L, A, tile, waitScan);
 }
 
@@ -1376,7 +1380,7 @@ __global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *_
 __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ uint32_t waitScan[192];
+   __shared__ uint32_t waitScan[192 + NFC_LANES];
 
    const uint32_t lane = threadIdx.x;
    const uint32_t ringBlock = A.firstWindowSlot / NFC_LANES + blockIdx.x;
@@ -1386,6 +1390,8 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
    mem.lane = lane;
    mem.exact = false;
    mem.linked = true;
+   mem.flags = waitScan + 192 + lane;
+   waitScan[192 + lane] = 0u;
    mem.bytes = L.bytes + ((uint64_t)ringBlock * NFC_LANES + lane) * NFC_STREAM_BYTES;
    mem.sink = L.sink;
    mem.sinkCursor = L.sinkCtl;
@@ -1448,6 +1454,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
             lockFrontUntil = 0;
             lockUpkeepUntil = 0;
             nextWaitScan = 0;
+            *mem.flags = 0u;
 
             mem.cold = L.cold + w;
             mem.streamId = w;
@@ -1510,6 +1517,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
 
             if (done)
             {
+               mem.cold->usedTech = *mem.flags;
                L.states[w] = s;
                L.windows[w].stop = startPos + consumed;
                L.windows[w].retired = how;
@@ -1638,7 +1646,7 @@ __global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConf
 __global__ __launch_bounds__(64) void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ uint32_t waitScan[192];
+   __shared__ uint32_t waitScan[192 + NFC_LANES];
    nfc_window_body<true>(cfgPtr, L, A, tile, waitScan);
 }
 

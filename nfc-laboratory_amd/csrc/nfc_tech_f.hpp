@@ -233,7 +233,8 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
       /* (detectorPeak* are never set by this detector: nothing to clear) */
       m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
       m.peakTime = 0; m.peak = 0;
-      mem.cold->usedTech |= 1u << (15 + R); /* from here on the record is the lane's own (NfcStreamCold::usedTech) */
+      if (mem.linked)
+         *mem.flags |= 1u << (15 + R); /* from here on the record is the lane's own (NfcStreamCold::usedTech) */
    }
 
    if (s.clock < m.winStart)
@@ -247,10 +248,10 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    uint32_t polarity = 0;
 
    /* the tracker looks at the record: if the lane has not cleared it since it started, what it inherited matters */
-   if (!((mem.cold->usedTech >> (15 + R)) & 1u))
-      mem.cold->usedTech |= 1u << (13 + R);
+   if (mem.linked && !((*mem.flags >> (15 + R)) & 1u))
+      *mem.flags |= 1u << (13 + R);
 
-   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1], &mem.cold->usedTech, 1u << (11 + R)))
+   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1], mem.linked ? mem.flags : nullptr, 1u << (11 + R)))
       return false;
 
    /* preamble complete: lock this bitrate, the sync bytes follow (copy the detector record before it is parked) */

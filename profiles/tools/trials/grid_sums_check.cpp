@@ -20,7 +20,7 @@ int main(int argc,char**argv){
   FILE*f=fopen(argv[1],"rb"); std::vector<float> x; float v; while(fread(&v,4,1,f)==1) x.push_back(v); fclose(f);
   NfcHostParams p; p.sampleRate=10000000; p.enabled=0xF; NfcConfig cfg; nfc_build_config(p,cfg);
   std::vector<float> rings((4*NFC_HIST+NFC_PROD+cfg.corrTotal)*NFC_LANES,0.f); std::vector<uint8_t> bytes(NFC_STREAM_BYTES,0); std::vector<uint32_t> arena(1u<<22,0);
-  NfcLaneMem mem; mem.ring=rings.data(); mem.lane=0; mem.exact=true; mem.bytes=bytes.data(); uint32_t ctl[2]={0,0}; mem.sink=arena.data(); mem.sinkCursor=&ctl[0]; mem.sinkDropped=&ctl[1]; mem.sinkWords=arena.size(); mem.streamId=0;
+  NfcLaneMem mem; mem.linked=false; mem.flags=nullptr; mem.ring=rings.data(); mem.lane=0; mem.exact=true; mem.bytes=bytes.data(); uint32_t ctl[2]={0,0}; mem.sink=arena.data(); mem.sinkCursor=&ctl[0]; mem.sinkDropped=&ctl[1]; mem.sinkWords=arena.size(); mem.streamId=0;
   NfcStreamState s; NfcStreamCold cold; memset(&s,0,sizeof s); memset(&cold,0,sizeof cold); mem.cold=&cold; mem.tables=&cfg; nfc_state_init(cfg,s,cold,false);
   uint64_t checked=0, bad=0, gapless=1, locks=0; double off[3]; bool have[3]={false,false,false};
   std::vector<double> pre(x.size()+1,0.0); for(size_t i=0;i<x.size();i++) pre[i+1]=pre[i]+(double)x[i];

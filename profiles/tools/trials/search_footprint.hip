@@ -56,6 +56,8 @@ __device__ __forceinline__ void body(const NfcConfig *cfgPtr, NfcLaunch L, float
    if (MASK & 4) { for (int r = 0; r < 2; r++) { s.posF[r] = g.posF[r]; s.u.search.detF[r] = g.u.search.detF[r]; } }
    if (MASK & 8) { s.posV1 = g.posV1; s.posV0 = g.posV0; s.u.search.detV = g.u.search.detV; }
    NfcLaneMem mem;
+   mem.linked = false;
+   mem.flags = nullptr;
    mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats; mem.lane = lane; mem.exact = false;
    mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES; mem.sink = L.sink; mem.sinkCursor = L.sinkCtl;
    mem.sinkDropped = L.sinkCtl + 1; mem.sinkWords = L.sinkWords; mem.streamId = slot; mem.cold = L.cold + slot; mem.tables = cfgPtr;

@@ -38,6 +38,8 @@ __device__ __forceinline__ void body(const NfcConfig *cfgPtr, NfcLaunch L, Parke
    float *tileIn = lds, *tileE = lds + 64 * (T + 1); /* the other per-sample results of the front end are read back from the history rings */
 
    NfcLaneMem mem;
+   mem.linked = false;
+   mem.flags = nullptr;
    mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats; mem.lane = lane; mem.exact = false;
    mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES; mem.sink = L.sink; mem.sinkCursor = L.sinkCtl;
    mem.sinkDropped = L.sinkCtl + 1; mem.sinkWords = L.sinkWords; mem.streamId = slot; mem.cold = L.cold + slot; mem.tables = cfgPtr;

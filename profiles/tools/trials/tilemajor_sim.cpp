@@ -81,6 +81,8 @@ long tilemajor_decode(const float *samples, uint64_t count, uint32_t sampleRate,
    std::vector<uint32_t> arena(1u << 22, 0);
 
    NfcLaneMem mem;
+   mem.linked = false;
+   mem.flags = nullptr;
    mem.ring = rings.data();
    mem.lane = lane;
    mem.exact = true; /* ring positions by exact modulo throughout: always right, and independent of the order of the passes */

@@ -148,6 +148,7 @@ void demod(const NfcConfig *cfgPtr, const NfcLaunch &L, bool exactKernel)
          mem.lane = lane;
          mem.exact = false;
          mem.linked = false;
+         mem.flags = nullptr;
          mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
          mem.sink = L.sink;
          mem.sinkCursor = L.sinkCtl;
@@ -333,6 +334,8 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
       mem.lane = storage % NFC_LANES;
       mem.exact = false;
       mem.linked = true;
+      uint32_t laneFlags = 0;
+      mem.flags = &laneFlags;
       mem.bytes = L.bytes + (uint64_t)storage * NFC_STREAM_BYTES;
       mem.sink = L.sink;
       mem.sinkCursor = L.sinkCtl;
@@ -472,6 +475,7 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
          stepped += n;
       }
 
+      mem.cold->usedTech = laneFlags;
       L.states[slot] = s;
       L.windows[slot].stop = L.windows[slot].start + consumed;
       const bool closing = L.windows[slot].activate >= L.windows[slot].start + mineCount;

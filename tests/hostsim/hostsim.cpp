@@ -55,6 +55,7 @@ long hostsim_decode_after_idle(const float *idle, uint32_t idleCount, uint64_t r
    mem.lane = lane;
    mem.exact = true;
    mem.linked = false;
+   mem.flags = nullptr;
    mem.bytes = bytes.data();
    uint32_t ctl[2] = {0, 0};
    mem.sink = arena.data();
