@@ -184,6 +184,8 @@ int nfcgpu_flush(nfcgpu_ctx *ctx, uint32_t stream_id);
 /* waits for everything submitted, then moves the frames of the frame sink to the per-stream queues. poll / pending /
  * flush call it; with nothing in flight and nothing to collect none of them touches the device. */
 int nfcgpu_sync(nfcgpu_ctx *ctx);
+/* Frames wait in a queue per stream until they are polled: nfcgpu_sync moves the frames of every stream there, so a stream
+ * that is never polled keeps what it has produced (memory grows with its frames; nfcgpu_stream_close releases it). */
 int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t stream_id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count);
 int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t stream_id, uint32_t *count);
 
