@@ -709,6 +709,13 @@ NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamSt
    return t;
 }
 
+/* a lane of the time-parallel path notes that it has set lastCommand of technology k (NfcStreamCold::usedTech) */
+NFC_DEV void nfc_command_written(const NfcLaneMem &mem, uint32_t k)
+{
+   if (mem.linked)
+      *mem.flags |= 1u << (8u + k);
+}
+
 /* a frame has been assembled on this sample: remember it; classification (process*), emission and the mode change
  * that follows are done in one place per decode step */
 NFC_DEV void nfc_pend_frame(NfcStreamState &s, uint32_t type, uint32_t flags)
@@ -807,10 +814,31 @@ NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLa
 
    /* for the time-parallel path: did the classification read a lastCommand the lane had inherited? (NfcStreamCold::usedTech) */
    const uint32_t techIndex = tech - NFC_TECH_A;
-   const uint32_t commandBefore = mem.linked ? mem.cold->tim[techIndex & 3u].lastCommand : 0u;
 
-   if (mem.linked && type != NFC_FRAME_POLL && !((*mem.flags >> (8u + techIndex)) & 1u))
-      *mem.flags |= 1u << (4u + techIndex);
+   if (mem.linked)
+   {
+      const uint32_t seen = *mem.flags;
+
+      /* a listen frame is classified by lastCommand: the lane's own, or the one it inherited */
+      if (type != NFC_FRAME_POLL && !((seen >> (8u + techIndex)) & 1u))
+         *mem.flags |= 1u << (4u + techIndex);
+
+      /* The first frame of this technology the lane processes is the command that starts its protocol over - REQA / WUPA
+       * (NfcA.cpp:1480-1510), REQB / WUPB, REQC - : it sets every field of the technology's timing, the times of the
+       * frame at hand included, and (NFC-A) the chaining flags before anything reads them; what the lane had inherited
+       * there is gone without having mattered. (The frame size limit read at the lock cannot have mattered either: the
+       * smallest limit is 16 bytes, these frames are shorter.) */
+      if (type == NFC_FRAME_POLL && !((seen >> (18u + techIndex)) & 1u))
+      {
+         const uint32_t b0 = nfc_byte(data, len, 0);
+         const bool restart = (tech == NFC_TECH_A && len == 1 && (b0 == 0x26 || b0 == 0x52)) || (tech == NFC_TECH_B && len == 5 && b0 == 0x05) ||
+                              (tech == NFC_TECH_F && nfc_byte(data, len, 1) == 0x00);
+         if (restart)
+            *mem.flags |= 1u << (22u + techIndex);
+      }
+
+      *mem.flags |= 1u << (18u + techIndex);
+   }
 
    if (isA == NFC_TECH_A)
       nfca_process(c, s, mem, type, data, len, flags, phase);
@@ -821,8 +849,6 @@ NFC_DEV void nfc_finish_frame(const NfcConfig &c, NfcStreamState &s, const NfcLa
    if (isV == NFC_TECH_V)
       nfcv_process(c, s, mem, type, data, len, flags, phase);
 
-   if (mem.linked && mem.cold->tim[techIndex & 3u].lastCommand != commandBefore)
-      *mem.flags |= 1u << (8u + techIndex);
 
    nfc_emit(mem, s, tech, type, flags, phase, rate, start, end, data, len);
 

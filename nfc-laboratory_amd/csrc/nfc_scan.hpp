@@ -626,13 +626,17 @@ NFC_DEV uint32_t nfc_edge_time(const NfcCarry &x, uint32_t tracked)
  * carrier frame only matters through the edge time it leaves the lane with). */
 /* `used`: the technologies whose protocol state the lane in question has looked at (NfcStreamCold::usedTech); the others'
  * need not agree. */
-NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked, uint32_t used = 0xFFFFFu)
+NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked, uint32_t used = 0x3FFFFu)
 {
-   bool same = ((used & 1u) == 0u || a.chainedA == b.chainedA) && (a.carrierOn != 0) == (b.carrierOn != 0) && (a.carrierOff != 0) == (b.carrierOff != 0) &&
+   /* protocol state of a technology the lane never locked, or whose first frame in the lane started the protocol over:
+    * nothing the lane did depended on it */
+   const uint32_t matters = used & ~(used >> 22) & 0xFu;
+
+   bool same = ((matters & 1u) == 0u || a.chainedA == b.chainedA) && (a.carrierOn != 0) == (b.carrierOn != 0) && (a.carrierOff != 0) == (b.carrierOff != 0) &&
                (meeting ? a.edgeTime == b.edgeTime : nfc_edge_time(a, tracked) == nfc_edge_time(b, tracked));
 
    for (int t = 0; t < 4; t++)
-      same = same && (((used >> t) & 1u) == 0u ||
+      same = same && (((matters >> t) & 1u) == 0u ||
                       ((((used >> (4 + t)) & 1u) == 0u || a.tim[t].lastCommand == b.tim[t].lastCommand) && a.tim[t].maxFrameSize == b.tim[t].maxFrameSize &&
                        a.tim[t].protoGuardTime == b.tim[t].protoGuardTime && a.tim[t].protoWaitingTime == b.tim[t].protoWaitingTime));
 

@@ -88,7 +88,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       if ((b0 == 0x26 || b0 == 0x52) && len == 1)
       {
          phase = NFC_PHASE_SELECTION;
-         t.lastCommand = b0;
+         t.lastCommand = b0, nfc_command_written(mem, 0u);
          nfca_default_timing(c, t);
          t.guardTime = nfc_tu(c, 1024);     /* NFCA_FGT_DEF  */
          t.waitingTime = nfc_tu(c, 128 * 18); /* NFCA_FWT_ATQA */
@@ -108,7 +108,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       phase = NFC_PHASE_SELECTION;
       if (!crcOk)
          flags |= NFC_FLAG_CRC;
-      t.lastCommand = b0;
+      t.lastCommand = b0, nfc_command_written(mem, 0u);
       nfca_default_timing(c, t);
       s.chainedA = 0;
       nfca_reset(c, s, mem);
@@ -127,7 +127,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             phase = NFC_PHASE_SELECTION;
             if (poll)
             {
-               t.lastCommand = b0;
+               t.lastCommand = b0, nfc_command_written(mem, 0u);
                t.guardTime = nfc_tu(c, 1024);
                t.waitingTime = nfc_tu(c, 128 * 18);
             }
@@ -139,7 +139,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             {
                static const uint16_t fsd[16] = {16, 24, 32, 40, 48, 64, 96, 128, 256, 512, 1024, 2048, 4096, 0, 0, 0};
                uint32_t fsdi = (nfc_byte(data, len, 1) >> 4) & 0x0F;
-               t.lastCommand = b0;
+               t.lastCommand = b0, nfc_command_written(mem, 0u);
                t.maxFrameSize = fsd[fsdi];
                t.waitingTime = nfc_tu(c, 71680); /* NFC_FWT_ACTIVATION */
             }
@@ -180,7 +180,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          else if (poll ? ((b0 & 0xF0) == 0xD0) : (last == 0xD0))
          {
             if (poll)
-               t.lastCommand = b0 & 0xF0;
+               t.lastCommand = b0 & 0xF0, nfc_command_written(mem, 0u);
             phase = NFC_PHASE_SELECTION;
             if (!crcOk)
                flags |= NFC_FLAG_CRC;
@@ -191,7 +191,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
             phase = NFC_PHASE_APPLICATION;
             if (poll)
             {
-               t.lastCommand = b0;
+               t.lastCommand = b0, nfc_command_written(mem, 0u);
                if (!crcOk)
                   flags |= NFC_FLAG_CRC;
             }
@@ -204,7 +204,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          else if (poll ? ((b0 & 0xE2) == 0x02 && len > 4) : (last == 0x02))
          {
             if (poll)
-               t.lastCommand = b0 & 0xE2;
+               t.lastCommand = b0 & 0xE2, nfc_command_written(mem, 0u);
             phase = NFC_PHASE_APPLICATION;
             if (!crcOk)
                flags |= NFC_FLAG_CRC;
@@ -213,7 +213,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          else if (poll ? ((b0 & 0xE6) == 0xA2 && len == 3) : (last == 0xA2))
          {
             if (poll)
-               t.lastCommand = b0 & 0xE6;
+               t.lastCommand = b0 & 0xE6, nfc_command_written(mem, 0u);
             phase = NFC_PHASE_APPLICATION;
             if (!crcOk)
                flags |= NFC_FLAG_CRC;
@@ -222,7 +222,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          else if (poll ? ((b0 & 0xC7) == 0xC0 && len == 4) : (last == 0xC0))
          {
             if (poll)
-               t.lastCommand = b0 & 0xC7;
+               t.lastCommand = b0 & 0xC7, nfc_command_written(mem, 0u);
             phase = NFC_PHASE_APPLICATION;
             if (!crcOk)
                flags |= NFC_FLAG_CRC;
@@ -263,7 +263,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
 
       s.u.decode.frameType = 0;
-      t.lastCommand = 0;
+      t.lastCommand = 0, nfc_command_written(mem, 0u);
    }
 
    if (locked)

@@ -51,7 +51,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    /* REQB / WUPB and its ATQB */
    if (poll && b0 == 0x05 && len == 5)
    {
-      t.lastCommand = b0;
+      t.lastCommand = b0, nfc_command_written(mem, 1u);
       t.maxFrameSize = 256;
       t.protoGuardTime = nfc_tu(c, 1024);
       t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
@@ -78,7 +78,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    {
       static const uint16_t tr0min[4] = {0, 48 * 16, 16 * 16, 0};
 
-      t.lastCommand = b0;
+      t.lastCommand = b0, nfc_command_written(mem, 1u);
 
       uint32_t param1 = nfc_byte(data, len, 5);
       uint32_t param2 = nfc_byte(data, len, 6);
@@ -130,7 +130,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
 
       s.u.decode.frameType = 0;
-      t.lastCommand = 0;
+      t.lastCommand = 0, nfc_command_written(mem, 1u);
    }
 
    s.u.decode.frameStart = 0;

@@ -48,7 +48,7 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    /* REQC (command code 0x00 in the second byte) and its responses */
    if (poll && nfc_byte(data, len, 1) == 0x00)
    {
-      t.lastCommand = 0x00;
+      t.lastCommand = 0x00, nfc_command_written(mem, 2u);
 
       int tsn = (int)nfc_byte(data, len, 5);
 
@@ -94,7 +94,7 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + delay;
 
       s.u.decode.frameType = 0;
-      t.lastCommand = 0;
+      t.lastCommand = 0, nfc_command_written(mem, 2u);
    }
 
    s.u.decode.frameStart = 0;

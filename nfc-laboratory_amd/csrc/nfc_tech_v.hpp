@@ -66,7 +66,7 @@ NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          s.u.decode.guardEnd = s.u.decode.frameEnd + t.guardTime + c.v.delay;
 
       s.u.decode.frameType = 0;
-      t.lastCommand = 0;
+      t.lastCommand = 0, nfc_command_written(mem, 3u);
    }
 
    s.u.decode.frameStart = 0;

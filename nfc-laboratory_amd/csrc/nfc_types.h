@@ -272,7 +272,8 @@ struct NfcStreamCold
                             locked it neither depends on what it assumed there nor changes it (nfc_chain_follow).
                             bit 4+t: a listen frame of t was classified by a lastCommand the lane had not written itself
                             (poll frames are classified by their first byte and write it: nfc*_process); bit 8+t: the
-                            lane has changed lastCommand of t; bit 12+i: NFC-F preamble detector i evaluated a pulse with the
+                            lane has set lastCommand of t; bit 18+t: a frame of t has been processed; bit 22+t: the first
+                            one was the command that starts the technology's protocol over (nfc_finish_frame); bit 12+i: NFC-F preamble detector i evaluated a pulse with the
                             counter / threshold it had inherited (nfcf_track_preamble); bit 14+i: its tracker ran on the
                             record the lane had inherited; bit 16+i: the lane has (partially) reset that record */
 };
