@@ -44,12 +44,13 @@ def git_head():
 
 
 def sources_digest():
-    """sha1 over the kernel and host-runtime sources (what a stored counter figure belongs to)"""
+    """sha1 over the kernel sources - everything under csrc/ but the host runtime nfcgpu.hip - : what a stored counter
+    figure belongs to"""
     import hashlib
     src = os.path.join(ROOT, "nfc-laboratory_amd", "csrc")
     h = hashlib.sha1()
     for f in sorted(os.listdir(src)):
-        if not f.endswith((".h", ".hpp", ".hip")):
+        if not f.endswith((".h", ".hpp", ".hip")) or f == "nfcgpu.hip":
             continue
         with open(os.path.join(src, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())

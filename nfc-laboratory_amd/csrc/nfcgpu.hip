@@ -99,6 +99,7 @@ struct nfcgpu_ctx
    int device = 0;
    hipStream_t stream = nullptr;
    hipStream_t side = nullptr;       /* the carry lanes of a windowed pass run beside the speculative ones */
+   uint32_t sideMode = 2;            /* NFCGPU_SIDE_STREAM: 0 one stream, 1 two fixed events, 2 events per pass */
    hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
    uint32_t maxStreams = 0;
    uint32_t blocks = 0;
@@ -942,6 +943,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    uint32_t pass = 0;
    const bool debugPasses = std::getenv("NFCGPU_WINDOW_DEBUG") != nullptr;
+   std::vector<hipEvent_t> passEvents; /* fork / join events in flight; back to the pool once the pass has been waited for */
 
    for (;;)
    {
@@ -964,18 +966,39 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       /* carry lanes and speculative lanes side by side: no lane looks at what another one is doing while it runs
        * (nfc_lane_handover), and the longest lane of either kind can be most of the submission */
-      HIP_TRY(ctx, hipEventRecord(ctx->forkEvent, ctx->stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->forkEvent, 0));
+      if (ctx->sideMode == 0 || nWindows == 0)
+      {
+         /* nothing to run beside (or NFCGPU_SIDE_STREAM=0): one stream */
+         if ((rc = decodeSlots(true, 0, nJobs, ctx->stream)))
+            return rc;
+         if (nWindows && (rc = decodeWindows()))
+            return rc;
+      }
+      else
+      {
+         /* events of this pass only (never recorded again while a wait on them may be pending) */
+         hipEvent_t fork = ctx->sideMode == 2 ? take_event(ctx) : ctx->forkEvent;
+         hipEvent_t join = ctx->sideMode == 2 ? take_event(ctx) : ctx->joinEvent;
 
-      if ((rc = decodeSlots(true, 0, nJobs, ctx->side)))
-         return rc;
+         HIP_TRY(ctx, hipEventRecord(fork, ctx->stream));
+         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, fork, 0));
 
-      HIP_TRY(ctx, hipEventRecord(ctx->joinEvent, ctx->side));
+         if ((rc = decodeSlots(true, 0, nJobs, ctx->side)))
+            return rc;
 
-      if (nWindows && (rc = decodeWindows()))
-         return rc;
+         HIP_TRY(ctx, hipEventRecord(join, ctx->side));
 
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->joinEvent, 0));
+         if ((rc = decodeWindows()))
+            return rc;
+
+         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, join, 0));
+
+         if (ctx->sideMode == 2)
+         {
+            passEvents.push_back(fork);
+            passEvents.push_back(join);
+         }
+      }
 
       HIP_TRY(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));
       hipLaunchKernelGGL(nfc_chain_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, lanes, nJobs >= NFC_LANES ? ctx->maxPasses : ctx->maxPassesFew);
@@ -995,6 +1018,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled, %.1f ms\n", pass, ls[2],
                       (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again, ms);
       }
+
+      for (hipEvent_t e: passEvents)
+         ctx->eventPool.push_back(e); /* (the stream has been synchronised above) */
+      passEvents.clear();
 
       ctx->stats.window_passes++;
       pass++;
@@ -1264,6 +1291,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->maxPassesFew = knob("NFCGPU_WINDOW_PASSES", ctx->maxPassesFew);
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
    ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->densePercent);
+   ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);
    if (ctx->windowWaves == 0)
       ctx->windowWaves = 1;
 
