@@ -385,14 +385,16 @@ void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs 
              s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
             break;
 
-         if (std::getenv("NFC_EMU_DEBUG5") && base >= warm && base > 0 && base > 60000)
+         if (std::getenv("NFC_EMU_DEBUG5") && base >= warm && base > 0)
          {
             uint32_t k = succ;
             while (k < succEnd && L.windows[k].verify < me.start + base)
                k++;
             if (k < succEnd && L.windows[k].verify == me.start + base && !nfc_lane_comparable(s, *mem.cold))
-               std::fprintf(stderr, "[emu] lane %u (start %u) at %u (after %u steps) not comparable: lock %x unlock %x bank %d run %u env %g\n", slot, me.start,
-                            me.start + base, base, s.lockTech, s.unlock, (int)(s.bankClock == s.clock), (uint32_t)(s.clock - mem.cold->bankRun), s.env);
+               std::fprintf(stderr, "[emu] lane %u (start %u) at %u (after %u steps) not comparable: lock %x unlock %x bank %d run %u env %g type %u fstart %u towait %d\n", slot, me.start,
+                            me.start + base, base, s.lockTech, s.unlock, (int)(s.bankClock == s.clock), (uint32_t)(s.clock - mem.cold->bankRun), s.env,
+                            s.lockTech ? s.u.decode.frameType : 0u, s.lockTech ? s.u.decode.frameStart : 0u,
+                            s.lockTech ? (int)(s.u.decode.waitingEnd - s.clock) : 0);
          }
 
          if (base >= warm && base > 0 && nfc_lane_handover(L.windows, me, succ, succEnd, me.start + base, s, *mem.cold))
