@@ -164,11 +164,27 @@ def main():
 
     # the frame gather lives behind the C ABI (ncclAllGather in C++): the unique id travels over torch.distributed
     gathered = None
+    abi_gather = world > 1
     if world > 1:
-        ident = [gpu.comm_unique_id() if rank == 0 else None]
+        ok = 1
+        try:
+            ident = [gpu.comm_unique_id() if rank == 0 else None]
+        except Exception:
+            ident, ok = [None], 0
         dist.broadcast_object_list(ident, src=0)
-        gpu.comm_init(ident[0], rank, world)
-        gathered = torch.zeros(world * (8 << 20), dtype=torch.int32, device=dev)
+        try:
+            if ident[0] is None:
+                raise RuntimeError("no RCCL unique id")
+            gpu.comm_init(ident[0], rank, world)
+        except Exception as exc:
+            ok = 0
+            sys.stderr.write("rank %d: nfcgpu_comm_init failed (%r)\n" % (rank, exc))
+        # every rank takes the same way: the C ABI's gather, or (should RCCL not come up behind it on some rank) its torch twin
+        agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        abi_gather = bool(int(agreed.item()))
+        if abi_gather:
+            gathered = torch.zeros(world * (8 << 20), dtype=torch.int32, device=dev)
 
     pitch = T * 8
 
@@ -196,9 +212,13 @@ def main():
     # frame gather: every rank's packed records to every rank (RCCL over xGMI, C ABI), or to the host when N == 1
     dropped = int(ctl[1].item())
     host_used = clamp_used(int(ctl[0].item()), dropped, sink_words)
-    if world > 1:
+    if world > 1 and abi_gather:
         counts, stride = gpu.gather_frames(gathered.data_ptr(), gathered.numel())
         host_words = gathered[rank * stride:rank * stride + host_used].cpu().numpy()
+        total_words = sum(counts)
+    elif world > 1:
+        everyone, counts = framelib.gather_sinks(sink, host_used, world)
+        host_words = everyone[rank, :host_used].cpu().numpy()
         total_words = sum(counts)
     else:
         host_words = sink[:host_used].cpu().numpy()
@@ -248,7 +268,8 @@ def main():
             "samples_per_stream_per_step": L,
             "sample_rate": FS,
             "frames_decoded_rank0": None,
-            "parallelism": "stream-parallel x%d (one process per GPU, frames gathered with ncclAllGather behind the C ABI)" % world,
+            "parallelism": "stream-parallel x%d (one process per GPU, frames gathered with %s)" % (
+                world, "ncclAllGather behind the C ABI" if abi_gather or world == 1 else "torch.distributed all_gather (the C ABI's RCCL communicator did not come up)"),
             "git": git_head(),
         },
         "roofline": {
