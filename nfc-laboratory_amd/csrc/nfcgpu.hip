@@ -148,6 +148,8 @@ struct nfcgpu_ctx
    uint32_t windowedMinSamples = 32768; /* shortest submission (per stream) worth cutting into windows */
    uint32_t scanChunk = 8192;      /* samples per scan chunk, at least: short chunks = many lanes (the walk is latency-bound per wave) */
    bool scanChunkFixed = false;    /* NFCGPU_SCAN_CHUNK given: no sizing by the submission */
+   uint32_t blockSamples = 1u << 23; /* a few long busy streams are decoded this many samples at a time (NFCGPU_BLOCK_SAMPLES) */
+   bool inBlocks = false;
    uint32_t scanWarm = 6144;       /* samples walked ahead of a chunk */
    uint32_t maxPasses = 12;        /* decode passes before a stream of a large submission gives up (sequential path) */
    uint32_t maxPassesFew = 48;     /* the same for submissions of fewer streams than a wave has lanes: the sequential path would crawl */
@@ -615,6 +617,38 @@ void record_span(nfcgpu_ctx *ctx, std::vector<ProfiledLaunch> &into, ProfiledLau
    }
 }
 
+int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride);
+
+/* the same submission, `blockSamples` at a time */
+int run_in_blocks(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride)
+{
+   uint32_t longest = 0;
+   for (const WindowedItem &it: items)
+      longest = it.count > longest ? it.count : longest;
+
+   int rc = NFCGPU_OK;
+   ctx->inBlocks = true;
+
+   for (uint64_t at = 0; at < longest && rc == NFCGPU_OK; at += ctx->blockSamples)
+   {
+      std::vector<WindowedItem> block;
+
+      for (const WindowedItem &it: items)
+      {
+         if (it.count > at)
+         {
+            const uint64_t left = it.count - at;
+            block.push_back(WindowedItem {it.slot, it.data + (size_t)at * stride * 4, (uint32_t)(left < ctx->blockSamples ? left : ctx->blockSamples)});
+         }
+      }
+
+      rc = windowed_eligible(ctx, config, block) ? run_windowed(ctx, config, block, stride) : launch_sequential(ctx, config, block, stride);
+   }
+
+   ctx->inBlocks = false;
+   return rc;
+}
+
 /* One submission of `items` (all of configuration `config`, `stride` floats per sample, data resident on the device)
  * through scan -> windows -> windowed decode -> chain -> finish; streams the path cannot vouch for (samples off the
  * int16 grid, a seam that did not verify, no settled chain) are then decoded sequentially from their untouched state. */
@@ -823,10 +857,23 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       hipLaunchKernelGGL(nfc_seams_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, round == 0 ? 1u : 0u);
       HIP_TRY(ctx, hipGetLastError());
 
-      uint32_t word[3] = {0, 0, 0}; /* repairs, (save area), dense jobs */
-      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 12, hipMemcpyDeviceToHost, ctx->stream));
+      uint32_t word[4] = {0, 0, 0, 0}; /* repairs, (save area), dense jobs of a large submission, of a small one */
+      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 16, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       const uint32_t repairs = word[0];
+
+      /* A few long busy streams: the passes the chain needs grow with the length of the submission (a frame that changes
+       * the protocol timing is learnt one generation per pass), so it is decoded in blocks, each settled before the next.
+       * Nothing has been touched yet (the scan only reads). */
+      if (round == 0 && word[3] != 0 && !ctx->inBlocks)
+      {
+         uint32_t longest = 0;
+         for (const WindowedItem &it: items)
+            longest = it.count > longest ? it.count : longest;
+
+         if (longest > ctx->blockSamples)
+            return run_in_blocks(ctx, config, items, stride);
+      }
 
       /* The sequential kernels take as long for one stream as for a hundred thousand (one lane each): once half of the
        * submission goes there anyway, cutting the other half into lanes first only adds its time on top. */
@@ -1292,6 +1339,9 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
    ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->densePercent);
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);
+   ctx->blockSamples = knob("NFCGPU_BLOCK_SAMPLES", ctx->blockSamples) / NFC_SCAN_POINT * NFC_SCAN_POINT;
+   if (ctx->blockSamples < 65536u)
+      ctx->blockSamples = 65536u;
    if (ctx->windowWaves == 0)
       ctx->windowWaves = 1;
 

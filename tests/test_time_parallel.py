@@ -68,6 +68,16 @@ def test_small_chunks_force_repairs_emulated(emulated):
 
 
 @needs_reference
+def test_long_busy_submissions_of_few_streams_are_decoded_in_blocks_emulated(emulated):
+    """a few long busy streams: the runtime cuts the submission into blocks of NFCGPU_BLOCK_SAMPLES and settles one after the
+    other (the passes a submission needs grow with its length); same frames"""
+    res = _run(["carried"], True, {"NFCGPU_BLOCK_SAMPLES": "131072", "NFCGPU_DENSE_PERCENT": "8"})
+    _check(res)
+    dense = [r for r in res if r["name"].startswith("3 dense")][0]
+    assert dense["stats"]["windowed"] > 9, dense  # 3 streams x 3 submissions, each in several blocks
+
+
+@needs_reference
 def test_input_off_the_grid_takes_the_sequential_path_emulated(emulated):
     res = _run(["offgrid"], True)
     _check(res, windowed=False)
