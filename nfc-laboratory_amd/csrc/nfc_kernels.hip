@@ -698,16 +698,10 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
       /* routing, from the tile tests on the unrepaired scan (an estimate is all it takes): where most of the signal is
        * busy the lanes would be long and their hand-overs many; such a stream is decoded sequentially */
       const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-      if ((uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
+      if (A.nJobs >= NFC_LANES && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
       {
-         if (A.nJobs >= NFC_LANES)
-         {
-            job.status |= NFC_JOB_DENSE;
-            atomicAdd(A.denseCount, 1u);
-         }
-         else
-            atomicAdd(A.denseCount + 1, 1u); /* fewer streams than a wave has lanes: the sequential kernel would crawl, cut them
-                                                anyway (the host cuts a long submission of this kind into blocks first) */
+         job.status |= NFC_JOB_DENSE; /* (fewer streams than a wave has lanes: the sequential kernel would crawl, cut them anyway) */
+         atomicAdd(A.denseCount, 1u);
       }
    }
 

@@ -857,21 +857,33 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       hipLaunchKernelGGL(nfc_seams_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, round == 0 ? 1u : 0u);
       HIP_TRY(ctx, hipGetLastError());
 
-      uint32_t word[4] = {0, 0, 0, 0}; /* repairs, (save area), dense jobs of a large submission, of a small one */
-      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 16, hipMemcpyDeviceToHost, ctx->stream));
+      uint32_t word[3] = {0, 0, 0}; /* repairs, (save area), dense jobs */
+      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 12, hipMemcpyDeviceToHost, ctx->stream));
+
+      /* (a small submission: how busy are its streams? the tile tests have counted) */
+      const bool small = round == 0 && nJobs < NFC_LANES && !ctx->inBlocks;
+      if (small)
+         HIP_TRY(ctx, hipMemcpyAsync(jobs.data(), ctx->wJobs.ptr, sizeof(NfcScanJob) * nJobs, hipMemcpyDeviceToHost, ctx->stream));
+
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       const uint32_t repairs = word[0];
 
       /* A few long busy streams: the passes the chain needs grow with the length of the submission (a frame that changes
        * the protocol timing is learnt one generation per pass), so it is decoded in blocks, each settled before the next.
        * Nothing has been touched yet (the scan only reads). */
-      if (round == 0 && word[3] != 0 && !ctx->inBlocks)
+      if (small)
       {
          uint32_t longest = 0;
-         for (const WindowedItem &it: items)
-            longest = it.count > longest ? it.count : longest;
+         bool busy = false;
 
-         if (longest > ctx->blockSamples)
+         for (uint32_t j = 0; j < nJobs; j++)
+         {
+            const uint64_t nTiles = ((uint64_t)jobs[j].count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+            busy = busy || (uint64_t)jobs[j].busyTiles * 100u > nTiles * ctx->densePercent;
+            longest = jobs[j].count > longest ? jobs[j].count : longest;
+         }
+
+         if (busy && longest > ctx->blockSamples)
             return run_in_blocks(ctx, config, items, stride);
       }
 

@@ -588,16 +588,8 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
       {
          job.passes = 0;
          const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-         if ((uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
-         {
-            if (A.nJobs >= NFC_LANES)
-            {
-               job.status |= NFC_JOB_DENSE;
-               emu_add(A.denseCount, 1u);
-            }
-            else
-               emu_add(A.denseCount + 1, 1u);
-         }
+         if (A.nJobs >= NFC_LANES && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
+            { job.status |= NFC_JOB_DENSE; emu_add(A.denseCount, 1u); }
       }
       if (!(job.status & NFC_JOB_INVALID))
          nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
