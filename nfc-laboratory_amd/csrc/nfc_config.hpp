@@ -116,7 +116,7 @@ static inline bool nfc_build_config(const NfcHostParams &p, NfcConfig &c)
    /* every look-back must fit the history rings; the periods must be usable as ring moduli */
    const uint32_t deepest = c.v.delay + c.v.p2 + 1;
    const uint32_t deepestProd = c.v.p1 + 1;
-   bool ok = deepest < NFC_HIST && deepestProd < NFC_PROD && (c.a[2].delay + c.a[2].p1 + 1) < NFC_HIST;
+   bool ok = deepest < NFC_HIST_STORED && deepestProd < NFC_PROD && (c.a[2].delay + c.a[2].p1 + 1) < NFC_HIST_STORED;
    /* ring moduli must be usable: p2 + 1 < p1 keeps the three ring points of a correlator distinct */
    for (int r = 0; r < 3; r++)
       ok = ok && c.a[r].p8 > 0 && c.a[r].p2 >= 2 && c.a[r].p2 + 1 < c.a[r].p1 && c.f[r].p2 + 1 < c.f[r].p1;
@@ -125,7 +125,5 @@ static inline bool nfc_build_config(const NfcHostParams &p, NfcConfig &c)
    return ok;
 }
 
-/* NFC_CORR_MAX bounds corrTotal for every decodable sample rate (<= ~10.8 MS/s with 512-deep history) */
-#define NFC_CORR_MAX 704u
 
 #endif

@@ -64,10 +64,20 @@
 #define NFC_DRAIN() ((void)0)
 #endif
 
+/* Where the rings live and how they are laid out is the includer's choice: the stream-parallel kernels keep them in
+ * HBM as [slot][64 lanes] (one lane per stream), the wave decoder (nfc_wave.hpp: one wave per stream) keeps one stream's
+ * rings in LDS, [slot] only. */
+#ifndef NFC_RING_FLOAT
+#define NFC_RING_FLOAT float
+#endif
+#ifndef NFC_RING_STRIDE
+#define NFC_RING_STRIDE NFC_LANES
+#endif
+
 /* per-lane view of the stream-block storage; every ring pointer is already offset by the lane */
 struct NfcLaneMem
 {
-   float *ring;    /* stream-block ring storage (wave-uniform base), regions below, each [slots][64 lanes] */
+   NFC_RING_FLOAT *ring; /* stream-block ring storage (wave-uniform base), regions below, each [slots][NFC_RING_STRIDE] */
    uint32_t lane;  /* this stream's column */
    bool exact;     /* take ring positions by exact modulo (stream start / 32-bit clock wrap) instead of incrementally */
    uint8_t *bytes; /* frame assembly buffer, NFC_STREAM_BYTES contiguous */
@@ -92,7 +102,7 @@ struct NfcLaneMem
 #define NFC_R_CORR (4u * NFC_HIST + NFC_PROD) /* correlation rings [corrTotal] */
 
 /* 32-bit index from a wave-uniform base: the access becomes `global_load v, v_off, s[base]` */
-#define NFC_AT(m, region, slot) ((m).ring[((region) + (uint32_t)(slot)) * NFC_LANES + (m).lane])
+#define NFC_AT(m, region, slot) ((m).ring[((region) + (uint32_t)(slot)) * NFC_RING_STRIDE + (m).lane])
 #define NFC_HMASK (NFC_HIST - 1u)
 #define NFC_PMASK (NFC_PROD - 1u)
 
@@ -923,8 +933,17 @@ NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcL
  * All history reads of the step (the eight detectors' in search mode, the locked correlator's in decode mode) are
  * issued before the front end stores this sample: none of them can alias the slot being written (their delays are
  * > 0, or the value is patched in below), so a step pays one memory latency. */
-template <bool EXACT>
-NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
+/* what a caller that has the front end's results already (the wave decoder: computed ahead for the whole submission,
+ * nfc_scan.h) hands to the step instead of the raw sample; the history rings then hold the sample already */
+struct NfcGiven
+{
+   NfcNow now;
+   float env; /* signalEnvelope after this sample */
+   float avg; /* signalAverage after this sample */
+};
+
+template <bool EXACT, bool GIVEN>
+NFC_DEV void nfc_step_impl(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value, const NfcGiven *given)
 {
    NfcLaneMem mem = lane;
    mem.exact = EXACT;
@@ -969,7 +988,17 @@ NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    }
 
    /* the front end is the same in both modes */
-   const NfcNow now = nfc_front_end(c, s, mem, value);
+   NfcNow now;
+
+   if (GIVEN)
+   {
+      now = given->now;
+      s.env = given->env;
+      s.avg = given->avg;
+      s.mdev = now.mdev;
+   }
+   else
+      now = nfc_front_end(c, s, mem, value);
 
    if (inSearch == 0)
       nfc_search_detect(c, s, mem, now, ta, tb, tf, tv);
@@ -1015,6 +1044,12 @@ NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       nfc_finish_unlock(c, s, mem);
 }
 
+template <bool EXACT>
+NFC_DEV void nfc_step_as(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
+{
+   nfc_step_impl<EXACT, false>(c, s, lane, value, nullptr);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* lanes of the time-parallel path (nfc_scan.h): warm-up steps and the "at rest" test           */
 /* ------------------------------------------------------------------------------------------ */
@@ -1038,8 +1073,8 @@ NFC_DEV void nfc_step_front(const NfcConfig &c, NfcStreamState &s, const NfcLane
  * the warm-up. The sums start from zero instead of from the reference's value at that sample; every use of them is a
  * difference of two ring entries or of an entry and the running sum (S0, S1, nfc_corr_apply), and on the int16 grid all
  * of these are exact, so a constant offset never shows (nfc_scan.h). */
-template <bool EXACT>
-NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
+template <bool EXACT, bool GIVEN = false>
+NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value, const NfcGiven *given = nullptr)
 {
    NfcLaneMem mem = lane;
    mem.exact = EXACT;
@@ -1057,7 +1092,17 @@ NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLan
    nfcf_load_taps(c, s, mem, tf);
    nfcv_load_taps(c, s, mem, tv);
 
-   const NfcNow now = nfc_front_end(c, s, mem, value);
+   NfcNow now;
+
+   if (GIVEN)
+   {
+      now = given->now;
+      s.env = given->env;
+      s.avg = given->avg;
+      s.mdev = now.mdev;
+   }
+   else
+      now = nfc_front_end(c, s, mem, value);
 
    NfcSearchRegs &r = s.u.search;
 

@@ -491,7 +491,7 @@ __device__ __forceinline__ void nfc_fixed_runtime_config(const NfcConfig *cfgPtr
 #define NFC_SCAN_PITCH (NFC_SCAN_TILE + 1)
 
 /* S = floats per sample (2 IQ, 1 magnitude) */
-template <uint32_t S>
+template <uint32_t S, bool PLANES>
 __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgPtr, const NfcScanArgs &A, float *tile, uint32_t *rows)
 {
    const uint32_t lane = threadIdx.x;
@@ -631,20 +631,32 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          if (pos == start)
             nfc_scan_point(w, seam.start);
 
-         if (pos >= start && (pos % NFC_SCAN_POINT) == 0)
+         if (!PLANES && pos >= start && (pos % NFC_SCAN_POINT) == 0)
             nfc_scan_point(w, A.points[job->firstPoint + pos / NFC_SCAN_POINT]);
 
          /* (whole tiles - all but the last of a stream - with a fixed trip count) */
-         if (n == NFC_SCAN_TILE)
+         if (PLANES)
+         {
+            /* second walk, from the verified state: the front end's results per sample, for the wave decoder */
+            float4 *out = reinterpret_cast<float4 *>(A.planes) + ((uint64_t)job->firstTile * NFC_SCAN_TILE + pos);
+
+            for (uint32_t k = 0; k < n; k++)
+            {
+               const float filtered = nfc_scan_sample(cc, w, row[k]);
+               if (pos >= start)
+                  out[k] = make_float4(filtered, w.fe.env, w.fe.mdev, w.fe.avg);
+            }
+         }
+         else if (n == NFC_SCAN_TILE)
          {
 #pragma unroll 8
             for (uint32_t k = 0; k < NFC_SCAN_TILE; k++)
-               nfc_scan_sample(cc, w, row[k]);
+               (void)nfc_scan_sample(cc, w, row[k]);
          }
          else
          {
             for (uint32_t k = 0; k < n; k++)
-               nfc_scan_sample(cc, w, row[k]);
+               (void)nfc_scan_sample(cc, w, row[k]);
          }
 
          NfcScanTile stat;
@@ -653,14 +665,14 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          if (repair)
             stat.bits |= NFC_TILE_REWALKED;
 
-         if (pos >= start)
+         if (!PLANES && pos >= start)
             A.tileStats[job->firstTile + pos / NFC_SCAN_TILE] = stat;
       }
 
       __syncthreads();
    }
 
-   if (mine)
+   if (mine && !PLANES) /* (the second walk changes nothing the first one established) */
    {
       if (begun)
          nfc_scan_point(w, seam.end);
@@ -676,9 +688,21 @@ __global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restric
    __shared__ uint32_t rows[NFC_LANES * 4];
 
    if (A.stride == 2)
-      nfc_scan_body<2>(cfgPtr, A, tile, rows);
+      nfc_scan_body<2, false>(cfgPtr, A, tile, rows);
    else
-      nfc_scan_body<1>(cfgPtr, A, tile, rows);
+      nfc_scan_body<1, false>(cfgPtr, A, tile, rows);
+}
+
+/* the same walk over chunks listed for repair (from their verified start states), storing the front-end planes */
+__global__ __launch_bounds__(64) void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
+{
+   __shared__ float tile[NFC_LANES * NFC_SCAN_PITCH];
+   __shared__ uint32_t rows[NFC_LANES * 4];
+
+   if (A.stride == 2)
+      nfc_scan_body<2, true>(cfgPtr, A, tile, rows);
+   else
+      nfc_scan_body<1, true>(cfgPtr, A, tile, rows);
 }
 
 /* one thread per job: seams, then windows (the two are cheap and sequential per stream) */

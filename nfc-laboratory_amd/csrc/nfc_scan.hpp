@@ -130,8 +130,8 @@ NFC_DEV void nfc_scan_reseed(NfcScanLane &w)
    w.fe.pulseFilter = 0;
 }
 
-/* one sample: the decoder's own front end, then what the tile tests need */
-NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
+/* one sample: the decoder's own front end, then what the tile tests need; returns the DC-removed sample */
+NFC_DEV float nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
 {
    ++w.fe.clock;
    ++w.fe.pulseFilter;
@@ -166,6 +166,7 @@ NFC_DEV void nfc_scan_sample(const NfcConfig &c, NfcScanLane &w, float x)
       w.zone = zone;
    }
 
+   return now.filt;
 }
 
 /* end of a tile */

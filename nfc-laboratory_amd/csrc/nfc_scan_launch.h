@@ -54,6 +54,10 @@ struct NfcScanArgs
    uint8_t *saveBytes;         /* [saveRoom][NFC_STREAM_BYTES] */
    uint32_t *saveNext;         /* slots handed out (device counter) */
    uint32_t saveRoom;
+   /* front-end planes for the wave decoder (nfc_wave.hpp): per sample {filtered, envelope, deviation, average} as the
+    * decoder's front end leaves them after that sample, written by a second walk of the scan kernel from the verified
+    * chunk starts (null: not written). Sample i of a job is record 64 * job.firstTile + i. */
+   float *planes;
 };
 
 #endif

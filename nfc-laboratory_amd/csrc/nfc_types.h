@@ -20,9 +20,13 @@
 #include <stdint.h>
 
 #define NFC_LANES 64u          /* streams per stream-block == wavefront width            */
-#define NFC_HIST 512u          /* sample history depth (power of two, > 472)             */
+#define NFC_HIST_STORED 512u   /* sample history depth of a stream's rings in HBM (power of two, > 472) */
+#ifndef NFC_HIST               /* depth the including translation unit works with: the wave decoder (nfc_wave.hpp) keeps */
+#define NFC_HIST NFC_HIST_STORED /* 1024 samples in LDS so that a whole tile can be written ahead of the sample at hand */
+#endif
 #define NFC_PROD 256u          /* product ring depth for listen-mode integrators (> 189) */
 #define NFC_STREAM_BYTES 512u  /* frame assembly buffer, NfcTech.h:288                   */
+#define NFC_CORR_MAX 704u      /* bounds NfcConfig::corrTotal for every decodable sample rate (<= ~10.8 MS/s with the stored history depth) */
 
 /* tech / frame enums: values are the reference's wire values (lab-data RawFrame.h:29-84) */
 enum

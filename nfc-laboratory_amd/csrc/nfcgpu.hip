@@ -49,11 +49,13 @@ __global__ void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, Nf
 __global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses);
 __global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
 __global__ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restrict__ out);
+__global__ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
+__global__ void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode);
 
 namespace {
 
 constexpr uint32_t kMaxConfigs = 256; /* distinct decoder configurations in use at once (1.5 KB each on the device) */
-constexpr uint32_t kRingBlockFloats = (4 * NFC_HIST + NFC_PROD + NFC_CORR_MAX) * NFC_LANES;
+constexpr uint32_t kRingBlockFloats = (4 * NFC_HIST_STORED + NFC_PROD + NFC_CORR_MAX) * NFC_LANES;
 
 struct StreamInfo
 {
@@ -162,6 +164,8 @@ struct nfcgpu_ctx
    uint32_t densePercent = 8;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
+   bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
+   DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    std::vector<ProfiledLaunch> timedScan, timedWindow;
 
    /* ---- frame gather over RCCL (nfcgpu_comm_*) ---- */
@@ -914,6 +918,32 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    mark("seams");
 
+   /* The wave decoder takes the front end's results per sample instead of walking it again: a second walk of every
+    * chunk from its verified start state (the repair form of the scan: no warm-up) writes them. */
+   if (ctx->wave)
+   {
+      if ((rc = grow(ctx, ctx->wPlanes, (size_t)tiles * NFC_SCAN_TILE * 16u)) || (rc = grow(ctx, ctx->wPlaneChunks, sizeof(NfcScanChunk) * nChunks)))
+         return rc;
+
+      std::vector<NfcScanChunk> all(chunks);
+      for (NfcScanChunk &c: all)
+         c.index |= NFC_CHUNK_REPAIR;
+
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->wPlaneChunks.ptr, all.data(), sizeof(NfcScanChunk) * nChunks, hipMemcpyHostToDevice, ctx->stream));
+
+      A.planes = (float *)ctx->wPlanes.ptr;
+
+      NfcScanArgs P = A;
+      P.chunks = (const NfcScanChunk *)ctx->wPlaneChunks.ptr;
+      P.nChunks = nChunks;
+
+      hipLaunchKernelGGL(nfc_scan_planes_kernel, dim3((nChunks + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, P);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* (the chunk list is a local) */
+
+      mark("planes");
+   }
+
    for (int attempt = 0; attempt < 2; attempt++)
    {
       hipLaunchKernelGGL(nfc_windows_kernel, dim3(nJobs), dim3(64), 0, ctx->stream, A);
@@ -975,7 +1005,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       const uint32_t blocks = (firstSlot % NFC_LANES + slotCount + NFC_LANES - 1) / NFC_LANES;
 
-      hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, on, dCfg, L, A);
+      if (ctx->wave)
+         hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
+      else
+         hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, on, dCfg, L, A);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
       return NFCGPU_OK;
@@ -991,7 +1024,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (waves > ctx->windowWaves)
          waves = ctx->windowWaves;
 
-      hipLaunchKernelGGL(nfc_window_kernel, dim3(waves), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A);
+      if (ctx->wave)
+         hipLaunchKernelGGL(nfc_wave_kernel, dim3(nWindows), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
+      else
+         hipLaunchKernelGGL(nfc_window_kernel, dim3(waves), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
       return NFCGPU_OK;
@@ -1347,9 +1383,11 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->scanChunk = knob("NFCGPU_SCAN_CHUNK", ctx->scanChunk) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
-   ctx->maxPassesFew = knob("NFCGPU_WINDOW_PASSES", ctx->maxPassesFew);
+   ctx->maxPassesFew = knob("NFCGPU_WINDOW_PASSES_FEW", knob("NFCGPU_WINDOW_PASSES", ctx->maxPassesFew));
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
-   ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->densePercent);
+   ctx->wave = knob("NFCGPU_WAVE", 1) != 0;
+   /* busy streams: a wave per lane decodes them where they are; the lane-per-window kernels send them to the sequential ones */
+   ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->wave ? 101u : ctx->densePercent);
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);
    ctx->blockSamples = knob("NFCGPU_BLOCK_SAMPLES", ctx->blockSamples) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    if (ctx->blockSamples < 65536u)

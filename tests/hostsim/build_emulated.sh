@@ -13,6 +13,8 @@ make -s -C "$PKG" build/nfc_config_fixed.inc
 CXX="g++ -std=c++17 -O2 -fno-strict-aliasing -ffp-contract=off -msse3 -mno-avx -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -I$HERE/fakehip -I$PKG/build -DNFCGPU_EMULATED_TEST_BUILD"
 $CXX -x c++ -c "$PKG/csrc/nfcgpu.hip" -o "$HERE/emu_nfcgpu.o"
 $CXX -c "$HERE/emu_kernels.cpp" -o "$HERE/emu_kernels.o"
-g++ -shared -o "$HERE/libnfcgpu_emulated.so" "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o"
-rm -f "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o"
+# the wave decoder's own text, 64 fibres per wave (wavesim.hpp)
+$CXX -c "$HERE/emu_wave.cpp" -o "$HERE/emu_wave.o"
+g++ -shared -o "$HERE/libnfcgpu_emulated.so" "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o"
+rm -f "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o"
 echo "built $HERE/libnfcgpu_emulated.so"

@@ -579,6 +579,40 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
    }
 }
 
+/* the second walk of the scan (repair form, from the verified chunk starts): front-end planes only */
+void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
+{
+   const uint32_t L = A.params.chunkSamples;
+
+   for (uint32_t listed = 0; listed < A.nChunks; listed++)
+   {
+      NfcScanChunk ch = A.chunks[listed];
+      ch.index &= ~NFC_CHUNK_REPAIR;
+      const NfcScanJob *job = A.jobs + ch.job;
+      const uint32_t g = job->firstChunk + ch.index;
+      const uint32_t start = ch.index * L;
+      const uint32_t end = start + L < job->count ? start + L : job->count;
+      const NfcStreamState *st = A.states + job->slot;
+
+      if (start >= end)
+         continue;
+
+      NfcScanLane w;
+      nfc_scan_resume(w, A.seams[g].start, A.seams[g].start.edgeTime, st->clock + start);
+
+      float *out = A.planes + 4u * ((uint64_t)job->firstTile * NFC_SCAN_TILE);
+
+      for (uint32_t sp = start; sp < end; sp++)
+      {
+         const float filtered = nfc_scan_sample(*cfgPtr, w, sample_of(job->data, A.stride, sp));
+         out[4u * (uint64_t)sp + 0] = filtered;
+         out[4u * (uint64_t)sp + 1] = w.fe.env;
+         out[4u * (uint64_t)sp + 2] = w.fe.mdev;
+         out[4u * (uint64_t)sp + 3] = w.fe.avg;
+      }
+   }
+}
+
 void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
 {
    for (uint32_t j = 0; j < A.nJobs; j++)
@@ -995,6 +1029,14 @@ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
       real.states[job->slot] = s;
       real.cold[job->slot] = cold;
    }
+}
+
+/* the wave decoder: tests/hostsim/emu_wave.cpp runs the kernel's own text, 64 fibres per wave */
+void emu_wave_kernel(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, uint32_t mode, uint32_t blocks);
+
+void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode)
+{
+   emu_wave_kernel(cfgPtr, L, A, mode, fakehip::launchGrid.x);
 }
 
 void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restrict__ out)
