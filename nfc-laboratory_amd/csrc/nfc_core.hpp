@@ -949,7 +949,8 @@ NFC_DEV void nfc_step_impl(const NfcConfig &c, NfcStreamState &s, const NfcLaneM
    mem.exact = EXACT;
 
    ++s.clock;
-   ++s.pulseFilter;
+   if (!GIVEN)
+      ++s.pulseFilter; /* (the envelope tracker's counter: with the front end given it is not kept) */
 
    nfc_advance_positions(c, s, mem);
 
@@ -1080,7 +1081,8 @@ NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLan
    mem.exact = EXACT;
 
    ++s.clock;
-   ++s.pulseFilter;
+   if (!GIVEN)
+      ++s.pulseFilter;
 
    nfc_advance_positions(c, s, mem);
 

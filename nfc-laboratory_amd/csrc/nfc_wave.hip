@@ -49,6 +49,8 @@ __device__ __forceinline__ float nfc_sample_at(const uint8_t *data, uint32_t str
 #define NFC_WAVE_LANE() (threadIdx.x)
 #define NFC_WAVE_BARRIER() __syncthreads()
 #define NFC_WAVE_BALLOT(p) ((uint64_t)__ballot(p))
+#define NFC_WAVE_SHFL_UP_F(v, d) __shfl_up((v), (d), 64)
+#define NFC_WAVE_SHFL_XOR_F(v, d) __shfl_xor((v), (d), 64)
 #define NFC_WAVE_UNIFORM_BEGIN(u) {
 #define NFC_WAVE_UNIFORM_END(u) }
 #define NFC_WAVE_STAT_ADD(p, v) atomicAdd((p), (v))

@@ -55,6 +55,7 @@ struct NfcWaveLds
    float env[NFC_LANES];             /* envelope / average after each sample of the tile at hand */
    float avg[NFC_LANES];
    float scratch[NFC_LANES];
+   float sum[7][NFC_LANES];          /* running sums after each sample of the tile (nfc_wave_fast.hpp); [6]: hand-over to the uniform part */
 };
 
 /* what the lanes of the wave hold identically */
@@ -223,7 +224,108 @@ NFC_DEV void nfc_wave_advance(const NfcConfig &c, NfcStreamState &s, uint32_t n)
    s.posV0 = (s.posV0 + n) % c.v.p0;
 }
 
+/* statistics of the fibre build (tests/hostsim): samples committed in bulk (0) / stepped (1) per stage */
+#ifndef NFC_WAVE_COUNT
+#define NFC_WAVE_COUNT(key, which, count) ((void)0)
+#endif
+
 #include "nfc_wave_fast.hpp"
+
+/* One tile: the next n samples of the lane's row (stream position pos on). allowFast: take the bulk paths (the fibre
+ * build runs every tile a second time without them and compares: tests/hostsim/emu_wave.cpp). */
+NFC_DEV void nfc_wave_tile(const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, const NfcLaneMem &mem, NfcWaveUni &u,
+                           NfcWaveFast &fast, uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride, bool allowFast)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+
+   NFC_WAVE_BARRIER();
+   const NfcWaveTile tile = nfc_wave_load_tile(it, lds, u.consumed, n, u.s.clock, stride);
+   NFC_WAVE_BARRIER();
+
+   const bool exact = carry && nfc_wave_exact_span(u.s.clock, n);
+
+   /* per tile: the values of the bulk paths belong to the tile; is the tile on the grid? */
+   fast.key = NFC_FK_NONE;
+   fast.from = 0;
+   fast.clock0 = u.s.clock;
+   {
+      const float scaled = tile.x * 32768.0f;
+      const bool off = lane < n && !(scaled == __builtin_floorf(scaled) && tile.x >= -1.0f && tile.x <= 1.0f);
+      if (NFC_WAVE_BALLOT(off))
+         fast.gridSince = u.s.clock + n;
+   }
+
+   if (u.consumed < warmFront)
+   {
+      /* history only (nfc_step_front) */
+      NFC_WAVE_UNIFORM_BEGIN(u)
+      {
+         u.s.clock += n;
+         nfc_wave_advance(cc, u.s, n);
+         u.s.env = lds->env[n - 1u];
+         u.s.avg = lds->avg[n - 1u];
+         u.s.mdev = lds->ring[NFC_R_MDEV + (u.s.clock & NFC_HMASK)];
+      }
+      NFC_WAVE_UNIFORM_END(u)
+   }
+   else
+   {
+      const bool upkeep = u.consumed < warm;
+
+      u.at = 0;
+
+      while (u.at < n)
+      {
+         /* samples from u.at on that change nothing but sums and rings: committed in bulk */
+         if (!exact && allowFast)
+         {
+            const uint32_t run = nfc_wave_fast(cc, u, mem, lds, fast, tile, n, upkeep, it);
+
+            if (run)
+               continue;
+         }
+
+         /* carrier frame due on this sample (NfcDecoder.cpp:472-523)? it is stamped with the decoder's edge time */
+         const float avgAt = lds->avg[u.at];
+         const bool emits = !upkeep && u.s.lockTech == 0 &&
+                            ((avgAt > cc.highThreshold) ? !u.s.carrierOn : ((avgAt < cc.lowThreshold) && !u.s.carrierOff));
+         uint32_t edge = 0;
+
+         if (emits)
+            edge = nfc_wave_edge_time(cc, A, it, lds, pos + u.at, lds->cold.emitValid != 0, lds->cold.emitClock);
+
+         NFC_WAVE_COUNT(nfc_wave_stage(cc, u.s, upkeep), 1u, 1u);
+
+         NFC_WAVE_UNIFORM_BEGIN(u)
+         {
+            const uint32_t slot = (u.s.clock + 1u) & NFC_HMASK;
+
+            NfcGiven g;
+            g.now.x = lds->ring[NFC_R_X + slot];
+            g.now.filt = lds->ring[NFC_R_FILT + slot];
+            g.now.mdev = lds->ring[NFC_R_MDEV + slot];
+            g.now.depth = lds->ring[NFC_R_DEPTH + slot];
+            g.env = lds->env[u.at];
+            g.avg = lds->avg[u.at];
+
+            if (emits)
+               u.s.edgeTime = edge;
+
+            if (upkeep)
+               nfc_step_upkeep<false, true>(cc, u.s, mem, g.now.x, &g);
+            else if (exact)
+               nfc_step_impl<true, true>(cc, u.s, mem, g.now.x, &g);
+            else
+               nfc_step_impl<false, true>(cc, u.s, mem, g.now.x, &g);
+
+            u.at++;
+            u.stepped++;
+         }
+         NFC_WAVE_UNIFORM_END(u)
+      }
+   }
+
+}
 
 /* One lane of work. `lds`: this wave's LDS. Called by all 64 lanes. */
 NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcLaunch &L, const NfcScanArgs &A, uint32_t mode, uint32_t item,
@@ -327,6 +429,11 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    NfcWaveFast fast;
    nfc_wave_fast_begin(fast);
 
+   /* samples known to be on the capture grid (nfc_wave_fast.hpp): the job's own are (the scan has looked at every one;
+    * what it does not check, |x| <= 1, is checked per tile); what a carry lane finds in the stream's rings is not known */
+   fast.gridSince = carry ? u.s.clock : u.s.clock - 4096u;
+   fast.gridValid = 1;
+
    for (;;)
    {
       if (u.consumed >= it.count)
@@ -365,79 +472,11 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       const uint32_t left = it.count - u.consumed;
       const uint32_t n = left < NFC_LANES ? left : NFC_LANES;
 
-      NFC_WAVE_BARRIER();
-      const NfcWaveTile tile = nfc_wave_load_tile(it, lds, u.consumed, n, u.s.clock, stride);
-      NFC_WAVE_BARRIER();
-
-      const bool exact = carry && nfc_wave_exact_span(u.s.clock, n);
-
-      if (u.consumed < warmFront)
-      {
-         /* history only (nfc_step_front) */
-         NFC_WAVE_UNIFORM_BEGIN(u)
-         {
-            u.s.clock += n;
-            nfc_wave_advance(cc, u.s, n);
-            u.s.env = lds->env[n - 1u];
-            u.s.avg = lds->avg[n - 1u];
-            u.s.mdev = lds->ring[NFC_R_MDEV + (u.s.clock & NFC_HMASK)];
-         }
-         NFC_WAVE_UNIFORM_END(u)
-      }
-      else
-      {
-         const bool upkeep = u.consumed < warm;
-
-         u.at = 0;
-
-         while (u.at < n)
-         {
-            /* samples from u.at on that change nothing but sums and rings: committed in bulk */
-            if (!exact)
-            {
-               const uint32_t run = nfc_wave_fast(cc, u, mem, lds, fast, tile, n, upkeep, it);
-
-               if (run)
-                  continue;
-            }
-
-            /* carrier frame due on this sample (NfcDecoder.cpp:472-523)? it is stamped with the decoder's edge time */
-            const float avgAt = lds->avg[u.at];
-            const bool emits = !upkeep && u.s.lockTech == 0 &&
-                               ((avgAt > cc.highThreshold) ? !u.s.carrierOn : ((avgAt < cc.lowThreshold) && !u.s.carrierOff));
-            uint32_t edge = 0;
-
-            if (emits)
-               edge = nfc_wave_edge_time(cc, A, it, lds, pos + u.at, lds->cold.emitValid != 0, lds->cold.emitClock);
-
-            NFC_WAVE_UNIFORM_BEGIN(u)
-            {
-               const uint32_t slot = (u.s.clock + 1u) & NFC_HMASK;
-
-               NfcGiven g;
-               g.now.x = lds->ring[NFC_R_X + slot];
-               g.now.filt = lds->ring[NFC_R_FILT + slot];
-               g.now.mdev = lds->ring[NFC_R_MDEV + slot];
-               g.now.depth = lds->ring[NFC_R_DEPTH + slot];
-               g.env = lds->env[u.at];
-               g.avg = lds->avg[u.at];
-
-               if (emits)
-                  u.s.edgeTime = edge;
-
-               if (upkeep)
-                  nfc_step_upkeep<false, true>(cc, u.s, mem, g.now.x, &g);
-               else if (exact)
-                  nfc_step_impl<true, true>(cc, u.s, mem, g.now.x, &g);
-               else
-                  nfc_step_impl<false, true>(cc, u.s, mem, g.now.x, &g);
-
-               u.at++;
-               u.stepped++;
-            }
-            NFC_WAVE_UNIFORM_END(u)
-         }
-      }
+#ifdef NFC_WAVE_TILE_HOOK
+      NFC_WAVE_TILE_HOOK(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride);
+#else
+      nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, true);
+#endif
 
       u.consumed += n;
    }

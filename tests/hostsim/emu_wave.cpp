@@ -40,12 +40,172 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 #define NFC_WAVE_LANE() (wavesim::lane())
 #define NFC_WAVE_BARRIER() wavesim::barrier()
 #define NFC_WAVE_BALLOT(p) wavesim::ballot(p)
+#define NFC_WAVE_SHFL_XOR_F(v, d) wavesim::shfl((v), wavesim::lane() ^ (d))
+#define NFC_WAVE_SHFL_UP_F(v, d) wavesim::shfl((v), wavesim::lane() >= (d) ? wavesim::lane() - (d) : wavesim::lane())
 #define NFC_WAVE_UNIFORM_BEGIN(u) if (wavesim::lane() == 0) {
 #define NFC_WAVE_UNIFORM_END(u) } wavesim::uniform_sync(u);
 #define NFC_WAVE_STAT_ADD(p, v) (*(p) += (v))
 #define NFC_WAVE_STAT_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
 
+/* NFC_EMU_WAVE_VERIFY=1: every tile is decoded twice - with the bulk paths and sample by sample - and everything the two
+ * leave behind (decoder state, rings, protocol state, frame bytes) is compared bit for bit */
+#include "../../nfc-laboratory_amd/csrc/nfc_scan_launch.h"
+struct NfcWaveLds;
+struct NfcWaveUni;
+struct NfcWaveFast;
+struct NfcWaveItem;
+static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcLaneMem &mem, NfcWaveUni &u, NfcWaveFast &fast,
+                            uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride);
+#define NFC_WAVE_TILE_HOOK emu_verify_tile
+
+extern uint64_t emu_wave_counts[64][2];
+static bool emu_counting = true;
+#define NFC_WAVE_COUNT_DETECTORS(b) (emu_wave_counts[32 + (b)][0]++)
+#define NFC_WAVE_COUNT(key, which, count) do { if (wavesim::lane() == 0 && emu_counting) emu_wave_counts[(key) & 63u][(which)] += (count); } while (0)
+
 #include "../../nfc-laboratory_amd/csrc/nfc_wave.hpp"
+
+static int emu_verify_mode()
+{
+   static int mode = -1;
+   if (mode < 0)
+   {
+      const char *v = std::getenv("NFC_EMU_WAVE_VERIFY");
+      mode = v && v[0] ? std::atoi(v) : 0;
+   }
+   return mode;
+}
+
+uint64_t emu_wave_counts[64][2]; /* per stage key: samples committed in bulk, samples stepped */
+
+namespace {
+struct CountPrinter
+{
+   ~CountPrinter()
+   {
+      if (!std::getenv("NFC_EMU_WAVE_STATS"))
+         return;
+      static const char *names[] = {"none", "search", "upkeep", "unarmed", "A poll", "A ask start", "A ask symbol", "A bpsk start", "A bpsk symbol", "B poll",
+                                    "B start", "B symbol", "F data", "F start", "V poll", "V start", "V symbol"};
+      static const char *det[] = {"A106", "A212", "A424", "B106", "B212", "F212", "F424", "V"};
+      for (uint32_t k = 0; k < 8; k++)
+         if (emu_wave_counts[32 + k][0])
+            std::fprintf(stderr, "[emu wave] search stepped for %-5s %10llu\n", det[k], (unsigned long long)emu_wave_counts[32 + k][0]);
+      for (uint32_t k = 0; k < 17; k++)
+         if (emu_wave_counts[k][0] | emu_wave_counts[k][1])
+            std::fprintf(stderr, "[emu wave] %-14s bulk %12llu stepped %10llu\n", names[k], (unsigned long long)emu_wave_counts[k][0],
+                         (unsigned long long)emu_wave_counts[k][1]);
+   }
+} countPrinter;
+}
+
+static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcLaneMem &mem, NfcWaveUni &u, NfcWaveFast &fast,
+                            uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride)
+{
+   const int mode = emu_verify_mode();
+
+   if (mode == 2)
+   {
+      nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, false); /* no bulk paths at all */
+      return;
+   }
+
+   if (mode != 1)
+   {
+      nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, true);
+      return;
+   }
+
+   /* shared by the 64 fibres of the wave (they run one after the other) */
+   static NfcWaveLds savedLds, fastLds;
+   static uint32_t dummySink[4096], dummyCtl[2];
+
+   const NfcWaveUni savedU = u;
+   const NfcWaveFast savedFast = fast;
+
+   wavesim::barrier();
+   if (wavesim::lane() == 0)
+      savedLds = *lds;
+   wavesim::barrier();
+
+   const uint32_t keyBefore = nfc_wave_stage(cc, u.s, u.consumed < warm);
+
+   nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, true);
+
+   const NfcWaveUni fastU = u;
+   const NfcWaveFast fastF = fast;
+
+   wavesim::barrier();
+   if (wavesim::lane() == 0)
+   {
+      fastLds = *lds;
+      *lds = savedLds;
+      dummyCtl[0] = 0;
+      dummyCtl[1] = 0;
+   }
+   wavesim::barrier();
+
+   /* again, sample by sample, frames into a dummy sink */
+   u = savedU;
+   fast = savedFast;
+
+   NfcLaneMem quiet = mem;
+   quiet.sink = dummySink;
+   quiet.sinkCursor = dummyCtl;
+   quiet.sinkDropped = dummyCtl + 1;
+   quiet.sinkWords = 4096;
+
+   emu_counting = false;
+   nfc_wave_tile(cc, A, it, lds, quiet, u, fast, n, pos, carry, warmFront, warm, stride, false);
+   wavesim::barrier();
+   emu_counting = true;
+
+   wavesim::barrier();
+
+   if (wavesim::lane() == 0)
+   {
+      NfcWaveUni a = fastU, b = u;
+      a.stepped = b.stepped = 0;
+
+      /* the frame records are chained by their place in the sink */
+      NfcStreamCold ca = fastLds.cold, cb = lds->cold;
+      ca.frameHead = cb.frameHead = 0;
+      ca.frameTail = cb.frameTail = 0;
+
+      const bool same = std::memcmp(&a, &b, sizeof(a)) == 0 && std::memcmp(&ca, &cb, sizeof(ca)) == 0 &&
+                        std::memcmp(fastLds.ring, lds->ring, sizeof(float) * 4u * NFC_HIST) == 0 &&
+                        std::memcmp(fastLds.ring + NFC_R_CORR, lds->ring + NFC_R_CORR, sizeof(float) * NFC_CORR_MAX) == 0 &&
+                        std::memcmp(fastLds.bytes, lds->bytes, NFC_STREAM_BYTES) == 0 && fastLds.flags == lds->flags;
+
+      if (!same)
+      {
+         std::fprintf(stderr, "[emu wave verify] tile at stream position %u (clock %u..), lane slot %u, stage key before %u: bulk and stepped results differ\n", pos,
+                      savedU.s.clock + 1u, it.w, keyBefore);
+         const uint32_t *pa = (const uint32_t *)&a.s, *pb = (const uint32_t *)&b.s;
+         for (uint32_t i = 0; i < sizeof(NfcStreamState) / 4; i++)
+            if (pa[i] != pb[i])
+               std::fprintf(stderr, "   state word %u: bulk %08x stepped %08x\n", i, pa[i], pb[i]);
+         const uint32_t *qa = (const uint32_t *)&ca, *qb = (const uint32_t *)&cb;
+         for (uint32_t i = 0; i < sizeof(NfcStreamCold) / 4; i++)
+            if (qa[i] != qb[i])
+               std::fprintf(stderr, "   cold word %u: bulk %08x stepped %08x\n", i, qa[i], qb[i]);
+         for (uint32_t i = 0; i < NFC_CORR_MAX; i++)
+            if (std::memcmp(&fastLds.ring[NFC_R_CORR + i], &lds->ring[NFC_R_CORR + i], 4) != 0)
+               std::fprintf(stderr, "   corr ring %u: bulk %g stepped %g\n", i, fastLds.ring[NFC_R_CORR + i], lds->ring[NFC_R_CORR + i]);
+         if (fastLds.flags != lds->flags)
+            std::fprintf(stderr, "   flags: bulk %08x stepped %08x\n", fastLds.flags, lds->flags);
+         std::abort();
+      }
+
+      /* go on from the first run (its frames are the ones in the sink) */
+      *lds = fastLds;
+   }
+
+   wavesim::barrier();
+
+   u = fastU;
+   fast = fastF;
+}
 
 namespace {
 
