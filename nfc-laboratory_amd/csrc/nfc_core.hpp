@@ -130,6 +130,11 @@ NFC_DEV float nfc_abs(float v)
    return __builtin_fabsf(v);
 }
 
+NFC_DEV uint32_t nfc_bits(float v)
+{
+   return __builtin_bit_cast(uint32_t, v);
+}
+
 /* samples for a duration given in 1/fc units: static_cast<int>(sampleTimeUnit * units) */
 NFC_DEV uint32_t nfc_tu(const NfcConfig &c, int units)
 {
@@ -1135,11 +1140,6 @@ NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLan
    if (s.bankClock != s.clock - 1u)
       mem.cold->bankRun = s.clock;
    s.bankClock = s.clock;
-}
-
-NFC_DEV uint32_t nfc_bits(float v)
-{
-   return __builtin_bit_cast(uint32_t, v);
 }
 
 /* A locked NFC-F decoder that is waiting for an answer with a clear preamble tracker (nfcf_listen_start after the guard

@@ -525,7 +525,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
    const uint64_t rowBase = (uint64_t)(mine ? job->data : (const uint8_t *)A.tileStats) + (int64_t)origin * (int64_t)(S * 4u);
    const uint32_t rowLo = (uint32_t)rowBase, rowHi = (uint32_t)(rowBase >> 32);
    const uint32_t rowFrom = walkFrom - (uint32_t)origin; /* origin <= walkFrom */
-   const uint32_t rowEnd = mine ? end - (uint32_t)origin : 0u;
+   uint32_t rowEnd = mine ? end - (uint32_t)origin : 0u;  /* (a second walk that meets the first one's trajectory ends early) */
    (void)rows;
 
    NfcConfig cc;
@@ -548,7 +548,9 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
    NfcScanSeam seam;
    __builtin_memset(&seam, 0, sizeof(seam));
 
-   const uint32_t myFrom = rowFrom, myEnd = rowEnd;
+   const uint32_t myFrom = rowFrom;
+   uint32_t myEnd = rowEnd;
+   bool merged = false;
 
    /* The rows of the next step are fetched into registers while this step's tile is walked: one memory latency per step,
     * hidden behind the walk (64 row loads in flight per wave). */
@@ -591,6 +593,10 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
 
    for (uint32_t rel = 0; rel < WU + L; rel += NFC_SCAN_TILE)
    {
+      /* (second walks end where they meet the first one's trajectory) */
+      if (__ballot(rel < myEnd) == 0ull)
+         break;
+
       /* ---- park the fetched rows in LDS as magnitudes, transposed: tile row q = lane q's 64 samples of this step ---- */
 #pragma unroll
       for (uint32_t q = 0; q < NFC_LANES; q++)
@@ -632,7 +638,39 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
             nfc_scan_point(w, seam.start);
 
          if (!PLANES && pos >= start && (pos % NFC_SCAN_POINT) == 0)
-            nfc_scan_point(w, A.points[job->firstPoint + pos / NFC_SCAN_POINT]);
+         {
+            NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
+
+            /* a second walk: has it met the first one's trajectory? Then the rest of the chunk stands as recorded
+             * (nfc_scan_merged), up to the edge time the first walk may not have trusted */
+            if (repair && pos > start)
+            {
+               NfcScanPoint here;
+               nfc_scan_point(w, here);
+
+               if (nfc_scan_merged(here, stored))
+               {
+                  const uint32_t atMerge = stored.edgeTime;
+
+                  for (uint32_t q = pos + NFC_SCAN_POINT; q < end; q += NFC_SCAN_POINT)
+                     nfc_scan_adopt(A.points[job->firstPoint + q / NFC_SCAN_POINT], atMerge, w.fe.edgeTime);
+
+                  seam.end = A.seams[g].end;
+                  nfc_scan_adopt(seam.end, atMerge, w.fe.edgeTime);
+
+                  stored = here;
+                  merged = true;
+                  myEnd = rel;
+                  rowEnd = rel; /* nothing more to fetch for this row */
+               }
+            }
+
+            if (!merged)
+               nfc_scan_point(w, stored);
+         }
+
+         if (!merged)
+         {
 
          /* (whole tiles - all but the last of a stream - with a fixed trip count) */
          if (PLANES)
@@ -667,6 +705,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
 
          if (!PLANES && pos >= start)
             A.tileStats[job->firstTile + pos / NFC_SCAN_TILE] = stat;
+         }
       }
 
       __syncthreads();
@@ -674,7 +713,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
 
    if (mine && !PLANES) /* (the second walk changes nothing the first one established) */
    {
-      if (begun)
+      if (begun && !merged)
          nfc_scan_point(w, seam.end);
       if (repair)
          seam.start = A.seams[g].start; /* as the seam check set it */

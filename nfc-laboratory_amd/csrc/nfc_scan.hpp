@@ -266,40 +266,37 @@ NFC_DEV void nfc_scan_resume(NfcScanLane &w, const NfcScanPoint &p, uint32_t edg
 
 /* Seams of a job, chunks in order (one thread). A chunk whose walk did not start from the state the chunk before ends
  * with - the envelope tracker is not contractive, the other recurrences sometimes need longer than the warm-up - has to
- * be walked again from that state: the first such chunk of the job is put on the repair list (the scan kernel walks the
- * listed chunks again, all of them in parallel, and this check runs once more). The result is exact whatever the warm-up
- * achieved; what the warm-up buys is that repairs are rare. Returns true when the job is waiting for a repair.
+ * be walked again from that state. Every such chunk of the job goes on the repair list at once, each to start from the
+ * end its predecessor has on record now: a second walk follows the first one's trajectory from the sample on at which
+ * the two states agree bit for bit (nfc_scan_merged: it stops there and the chunk's end stands), so a predecessor that is
+ * itself being walked again usually keeps its end. Where it does not, this check - run again after every round of walks -
+ * finds the successor's start unequal to the new end and lists it again. At the fixed point every chunk starts from its
+ * predecessor's end and the first from the stream's own state: every record is the true one, whatever the warm-ups and
+ * the guesses achieved. Returns true when the job is waiting for repairs.
  * chunkEdge[k] = edge-tracker time at the start of chunk k (points without a time of their own inherit it). */
 NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *seams, uint32_t *chunkEdge, uint32_t startEdge, NfcScanChunk *repairs,
                              uint32_t *repairCount)
 {
-   uint32_t edge = startEdge; /* true edge time at the start of the chunk at hand */
-   bool waiting = false;      /* the chunk before is being walked again in this round: its end is not known yet */
+   uint32_t edge = startEdge; /* edge time at the start of the chunk at hand, by the records as they are */
    bool pending = false;
 
    for (uint32_t k = 0; k < job.chunks; k++)
    {
       NfcScanSeam &s = seams[job.firstChunk + k];
 
-      if (waiting)
-      {
-         /* its turn comes in the next round (only if it then proves unsound); the chunks after it can still be checked
-          * against their own predecessors, whose records do not change */
-         waiting = false;
-         pending = true;
-         if (s.end.zone & NFC_ZONE_EDGE_KNOWN)
-            edge = s.end.edgeTime;
-         continue;
-      }
-
       const bool sound = k == 0 || (nfc_point_same(s.start, seams[job.firstChunk + k - 1].end) &&
                                     (!(s.start.zone & NFC_ZONE_EDGE_KNOWN) || s.start.edgeTime == edge));
 
       chunkEdge[job.firstChunk + k] = edge;
 
+#ifdef NFC_SEAM_DEBUG
+      if (!sound)
+         NFC_SEAM_DEBUG(k, s.start, seams[job.firstChunk + k - 1].end, edge);
+#endif
+
       if (!sound)
       {
-         /* from the true state, edge time included */
+         /* from its predecessor's end, edge time included */
          s.start = seams[job.firstChunk + k - 1].end;
          s.start.edgeTime = edge;
          s.start.zone |= NFC_ZONE_EDGE_KNOWN | NFC_ZONE_EDGE_SYNCED;
@@ -308,17 +305,31 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
          r.job = jobIndex;
          r.index = k | NFC_CHUNK_REPAIR;
 
-         waiting = true;
          pending = true;
-         continue;
       }
 
-      /* true edge time at the end of the chunk */
+      /* edge time at the end of the chunk (a chunk about to be walked again may change it: the next round looks again) */
       if (s.end.zone & NFC_ZONE_EDGE_KNOWN)
          edge = s.end.edgeTime;
    }
 
    return pending;
+}
+
+/* A second walk has reached the stored point `was` of its chunk in state `now`: from here on it would repeat the first
+ * walk sample for sample (the front end depends on nothing else). */
+NFC_DEV bool nfc_scan_merged(const NfcScanPoint &now, const NfcScanPoint &was)
+{
+   return nfc_point_same(now, was);
+}
+
+/* What the first walk recorded after the merge stands, except that it may not have trusted its edge time: the tracker's
+ * time at a later point is the first walk's if that has moved since the merge (an update made in the merged state is the
+ * true one), else the time the second walk brings (`edge`). `atMerge`: the first walk's time at the merge. */
+NFC_DEV void nfc_scan_adopt(NfcScanPoint &p, uint32_t atMerge, uint32_t edge)
+{
+   p.edgeTime = p.edgeTime != atMerge ? p.edgeTime : edge;
+   p.zone |= NFC_ZONE_EDGE_KNOWN | NFC_ZONE_EDGE_SYNCED;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -300,6 +300,12 @@ NFC_DEV void nfca_load_taps(const NfcConfig &c, const NfcStreamState &s, const N
 }
 
 /* ---- search: SOF of a poll frame = one modified-Miller pause, NfcA.cpp:217-411 ---- */
+/* what the detector does with the correlation of this sample (num = S0 - S1 of its box-sum correlator, deep = modulation
+ * depth one eighth of a symbol before the delayed sample); the correlator itself has been stepped by the caller */
+template <int R>
+NFC_DEV bool nfca_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float num, float deepTap, float minimumCorrelation,
+                                float minimumDepth);
+
 template <int R>
 NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsA &taps, const NfcNow &now,
                               float minimumCorrelation, float minimumDepth)
@@ -314,7 +320,16 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    tap.c3 = nfc_previous_sum(mem, s, m, rt, c.corrOffset[R], s.posA[R]);
 
    NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[R], s.posA[R]);
-   const float num = k.s0 - k.s1;
+
+   return nfca_detect_decide<R>(c, s, mem, k.s0 - k.s1, taps.deep[R], minimumCorrelation, minimumDepth);
+}
+
+template <int R>
+NFC_DEV bool nfca_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float num, float deepTap, float minimumCorrelation,
+                                float minimumDepth)
+{
+   const NfcRate &rt = c.a[R];
+   NfcDetA &m = s.u.search.detA[R];
 
    /* nothing below changes the record or returns true unless the tracked pause timed out, or the search window is
     * open and either the correlation can exceed the threshold or the window ends now: one branch for the common
@@ -342,7 +357,7 @@ NFC_DEV bool nfca_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
       {
          if (sd < -minimumCorrelation)
          {
-            const float deep = taps.deep[R];
+            const float deep = deepTap;
 
             if (sd < m.peak)
             {

@@ -157,21 +157,33 @@ NFC_DEV void nfcb_load_taps(const NfcConfig &c, const NfcStreamState &s, const N
 /* ---- search: SOF = falling edge, 10-11 etu low, rising edge, 2-3 etu high, falling edge ----
  * returns 0 = keep searching, 1 = locked, 2 = abandon this sample for the remaining rates */
 template <int R>
+NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float edge, float deep);
+
+template <int R>
 NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsB &taps, const NfcNow &now)
 {
    const NfcRate &rt = c.b[R];
-   NfcDetB &m = s.u.search.detB[R];
 
    /* with no delay the sample of interest is the one the front end has just produced */
-   float edge = rt.delay ? taps.edge[R] : now.filt;
-   float deep = rt.delay ? taps.deep[R] : now.depth;
+   return nfcb_detect_decide<R>(c, s, mem, rt.delay ? taps.edge[R] : now.filt, rt.delay ? taps.deep[R] : now.depth);
+}
+
+/* edge / deep: DC-removed signal and modulation depth at the detector's decode point */
+template <int R>
+NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float edge, float deep)
+{
+   const NfcRate &rt = c.b[R];
+   NfcDetB &m = s.u.search.detB[R];
 
    /* one branch for the common case: no start of frame is being tracked, no reset, no falling edge beyond the threshold
     * and the (closed) window does not end now. The threshold of that state is recomputed on every sample before it is
     * used, so not storing it on the early exit changes nothing. */
    const bool reset = deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1);
 
-   if (!reset && !m.symStart && !(edge < -(s.env * c.minDepth[1])) && s.clock != m.winEnd)
+   /* (a reset of a record that is clear already - every sample of a 100 % ASK pause asks for one - changes nothing) */
+   const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.auxTime | nfc_bits(m.aux)) == 0u;
+
+   if ((!reset || clear) && !m.symStart && !(edge < -(s.env * c.minDepth[1])) && s.clock != m.winEnd)
       return 0;
 
    if (reset)

@@ -204,6 +204,9 @@ NFC_DEV void nfcf_load_taps(const NfcConfig &c, const NfcStreamState &s, const N
 }
 
 template <int R>
+NFC_DEV bool nfcf_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float s0, float num, float deep, float minimumCorrelation);
+
+template <int R>
 NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsF &taps, const NfcNow &now,
                               float minimumCorrelation)
 {
@@ -214,10 +217,19 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    NfcTap tap = taps.t[R];
    tap.in = now.x;
    tap.c3 = nfc_previous_sum(mem, s, m, rt, c.corrOffset[2 + R], s.posF[R - 1]);
-   const float deep = now.depth;
 
    NfcCorr k = nfc_corr_apply(mem, m, tap, c.corrOffset[2 + R], s.posF[R - 1]);
-   const float num = k.s0 - k.s1;
+
+   return nfcf_detect_decide<R>(c, s, mem, k.s0, k.s0 - k.s1, now.depth, minimumCorrelation);
+}
+
+/* what the detector does with this sample's correlation (s0, num = S0 - S1) and modulation depth; the correlator itself
+ * has been stepped by the caller */
+template <int R>
+NFC_DEV bool nfcf_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float s0, float num, float deep, float minimumCorrelation)
+{
+   const NfcRate &rt = c.f[R];
+   NfcDetF &m = s.u.search.detF[R - 1];
 
    /* one branch for the common case: without a reset, with the window closed or with a correlation that cannot exceed
     * the threshold away from the synchronisation point and the window end, nothing below changes the record */
@@ -225,7 +237,14 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    const bool eventful = s.clock >= m.winStart &&
                          (nfc_may_exceed(num, (float)rt.p2, minimumCorrelation) || s.clock == m.sync || s.clock == m.winEnd);
 
-   if (!reset && !eventful)
+   /* from a reset on the record is the lane's own (NfcStreamCold::usedTech) */
+   if (reset && mem.linked)
+      *mem.flags |= 1u << (15 + R);
+
+   /* (a reset of a record that is clear already - every sample of a 100 % ASK pause asks for one - changes nothing) */
+   const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.sync | m.peakTime | nfc_bits(m.peak)) == 0u;
+
+   if ((!reset || clear) && !eventful)
       return false;
 
    if (reset)
@@ -233,8 +252,6 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
       /* (detectorPeak* are never set by this detector: nothing to clear) */
       m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0; m.sync = 0;
       m.peakTime = 0; m.peak = 0;
-      if (mem.linked)
-         *mem.flags |= 1u << (15 + R); /* from here on the record is the lane's own (NfcStreamCold::usedTech) */
    }
 
    if (s.clock < m.winStart)
@@ -251,7 +268,7 @@ NFC_DEV bool nfcf_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLa
    if (mem.linked && !((*mem.flags >> (15 + R)) & 1u))
       *mem.flags |= 1u << (13 + R);
 
-   if (!nfcf_track_preamble(s, m, rt, sd, k.s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1], mem.linked ? mem.flags : nullptr, 1u << (11 + R)))
+   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1], mem.linked ? mem.flags : nullptr, 1u << (11 + R)))
       return false;
 
    /* preamble complete: lock this bitrate, the sync bytes follow (copy the detector record before it is parked) */

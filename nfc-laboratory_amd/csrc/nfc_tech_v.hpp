@@ -96,19 +96,28 @@ NFC_DEV float nfcv_pulse_apply(const NfcLaneMem &mem, M &m, const NfcTap &t, uin
    return (t.c2 - m.acc) / (float)rt.p2;
 }
 
+NFC_DEV bool nfcv_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float num, float raw);
+
 /* the caller has checked that the search bank is armed (nfc_search_detect) */
 NFC_DEV bool nfcv_detect(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcTapsV &taps, const NfcNow &now)
+{
+   NfcDetV &m = s.u.search.detV;
+
+   m.acc += taps.t.in;
+   m.acc -= taps.t.out;
+   NFC_AT(mem, NFC_R_CORR, c.corrOffset[5] + s.posV1) = m.acc;
+
+   return nfcv_detect_decide(c, s, mem, taps.t.c2 - m.acc, taps.t.in);
+}
+
+/* what the detector does with this sample's pulse correlation (num = ring entry half a symbol back - box sum) and the
+ * delayed raw sample; the correlator itself has been stepped by the caller */
+NFC_DEV bool nfcv_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float num, float raw)
 {
    const NfcRate &rt = c.v;
    NfcDetV &m = s.u.search.detV;
 
    const float minimumCorrelation = s.env * c.corrThreshold[3];
-   const float raw = taps.t.in;
-
-   m.acc += taps.t.in;
-   m.acc -= taps.t.out;
-   NFC_AT(mem, NFC_R_CORR, c.corrOffset[5] + s.posV1) = m.acc;
-   const float num = taps.t.c2 - m.acc;
 
    /* one branch for the common case (see nfca_detect_rate) */
    const bool timeout = m.peakTime && s.clock > m.peakTime + rt.p0;

@@ -46,22 +46,8 @@ __device__ __forceinline__ float nfc_sample_at(const uint8_t *data, uint32_t str
 #define NFC_FENCE() __threadfence()
 #include "nfc_scan.hpp"
 
-#define NFC_WAVE_LANE() (threadIdx.x)
-#define NFC_WAVE_BARRIER() __syncthreads()
-#define NFC_WAVE_BALLOT(p) ((uint64_t)__ballot(p))
-#define NFC_WAVE_SHFL_UP_F(v, d) __shfl_up((v), (d), 64)
-#define NFC_WAVE_SHFL_XOR_F(v, d) __shfl_xor((v), (d), 64)
-#define NFC_WAVE_UNIFORM_BEGIN(u) {
-#define NFC_WAVE_UNIFORM_END(u) }
-#define NFC_WAVE_STAT_ADD(p, v) atomicAdd((p), (v))
-#define NFC_WAVE_STAT_MAX(p, v) atomicMax((p), (v))
-
-#include "nfc_wave.hpp"
-
 #define NFC_FIXED_FN __device__ __forceinline__
 #include "nfc_config_fixed.inc"
-
-namespace {
 
 /* run-time part of the configuration on top of the compiled-in table (the path is only taken at that sample rate) */
 __device__ __forceinline__ void nfc_wave_config(const NfcConfig *cfgPtr, NfcConfig &cc)
@@ -82,9 +68,61 @@ __device__ __forceinline__ void nfc_wave_config(const NfcConfig *cfgPtr, NfcConf
    }
 }
 
-} // namespace
+/* wave-wide inclusive prefix sum and maximum on the data-parallel primitives of the SIMD: shifts inside the rows of 16
+ * lanes, then the row totals handed on (row_bcast:15, row_bcast:31) */
+#define NFC_DPP_F(old, src, ctrl, rows) \
+   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), (ctrl), (rows), 0xf, false))
 
-__global__ __launch_bounds__(64) void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode)
+__device__ __forceinline__ float nfc_wave_scan_add(float v)
+{
+   v += NFC_DPP_F(0.0f, v, 0x111, 0xf); /* row_shr:1 */
+   v += NFC_DPP_F(0.0f, v, 0x112, 0xf); /* row_shr:2 */
+   v += NFC_DPP_F(0.0f, v, 0x114, 0xf); /* row_shr:4 */
+   v += NFC_DPP_F(0.0f, v, 0x118, 0xf); /* row_shr:8 */
+   v += NFC_DPP_F(0.0f, v, 0x142, 0xa); /* row_bcast:15 into rows 1 and 3 */
+   v += NFC_DPP_F(0.0f, v, 0x143, 0xc); /* row_bcast:31 into rows 2 and 3 */
+   return v;
+}
+
+__device__ __forceinline__ float nfc_wave_max(float v)
+{
+   float t;
+   t = NFC_DPP_F(v, v, 0x111, 0xf); v = t > v ? t : v;
+   t = NFC_DPP_F(v, v, 0x112, 0xf); v = t > v ? t : v;
+   t = NFC_DPP_F(v, v, 0x114, 0xf); v = t > v ? t : v;
+   t = NFC_DPP_F(v, v, 0x118, 0xf); v = t > v ? t : v;
+   t = NFC_DPP_F(v, v, 0x142, 0xa); v = t > v ? t : v;
+   t = NFC_DPP_F(v, v, 0x143, 0xc); v = t > v ? t : v;
+   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+#define NFC_WAVE_LANE() (threadIdx.x)
+#define NFC_WAVE_BARRIER() __syncthreads()
+#define NFC_WAVE_BALLOT(p) ((uint64_t)__ballot(p))
+#define NFC_WAVE_UNIFORM_BEGIN {
+#define NFC_WAVE_UNIFORM_END }
+#define NFC_WAVE_UNIFORM_U32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define NFC_WAVE_SCAN_ADD_F(v) nfc_wave_scan_add(v)
+#define NFC_WAVE_MAX_F(v) nfc_wave_max(v)
+#define NFC_WAVE_PICK_F(reg, array, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)(reg)), (int)(j)))
+#define NFC_WAVE_CONFIG(cfgPtr, cc) nfc_wave_config((cfgPtr), (cc))
+/* experiments: -DNFC_WAVE_STEP_INLINE (the steps inlined into the tile loop), -DNFC_WAVE_WAVES=n (register budget for n waves per SIMD) */
+#ifdef NFC_WAVE_STEP_INLINE
+#define NFC_WAVE_NOINLINE __device__ __forceinline__
+#else
+#define NFC_WAVE_NOINLINE __device__ __attribute__((noinline))
+#endif
+#ifdef NFC_WAVE_WAVES
+#define NFC_WAVE_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(NFC_WAVE_WAVES, NFC_WAVE_WAVES)))
+#else
+#define NFC_WAVE_KERNEL_ATTR
+#endif
+#define NFC_WAVE_STAT_ADD(p, v) atomicAdd((p), (v))
+#define NFC_WAVE_STAT_MAX(p, v) atomicMax((p), (v))
+
+#include "nfc_wave.hpp"
+
+__global__ __launch_bounds__(64) NFC_WAVE_KERNEL_ATTR void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode)
 {
    __shared__ NfcWaveLds lds;
 

@@ -11,10 +11,10 @@
  *     sample ({filtered, envelope, deviation, average}: NfcScanArgs::planes), 64 of them are one coalesced 1 KiB load;
  *   - one stream's history and correlation rings live in LDS (NfcWaveLds, ~21 KiB), the history 1024 deep so that a
  *     tile is written ahead of the sample at hand;
- *   - the decoder's state is wave-uniform (every lane holds the same copy); a sample that can change it is handled by
- *     the very step of nfc_core.hpp (nfc_step_impl<.., GIVEN>) executed uniformly by the wave, so whatever the
- *     reference does at that sample (NfcDecoder.cpp:394-418 and the tech decoders) is done by the same statement the
- *     stream-parallel kernels run;
+ *   - the decoder's state is one record in LDS (NfcWaveUni) that every lane reads; a sample that can change it is
+ *     handled by the very step of nfc_core.hpp (nfc_step_impl<.., GIVEN>) run by the wave on a register copy of it, so
+ *     whatever the reference does at that sample (NfcDecoder.cpp:394-418 and the tech decoders) is done by the same
+ *     statement the stream-parallel kernels run;
  *   - samples that provably change nothing but the running sums and ring entries are not stepped: the wave evaluates
  *     the gate of the mode at hand for all remaining samples of the tile at once (nfc_wave_fast_*: correlations from
  *     wave prefix sums over the tile plus the ring as the tile found it, bit for bit the values the step would form),
@@ -25,9 +25,14 @@
  *   NFC_WAVE_LANE()               lane 0..63
  *   NFC_WAVE_BARRIER()            LDS written before it is visible to every lane after it
  *   NFC_WAVE_BALLOT(p)            uint64_t
- *   NFC_WAVE_UNIFORM_BEGIN(u) / NFC_WAVE_UNIFORM_END(u)
- *                                 bracket code every lane executes identically on the uniform record `u` (the device
- *                                 runs it in all lanes; the fibre build runs it in lane 0 and copies `u` to the others)
+ *   NFC_WAVE_UNIFORM_BEGIN / NFC_WAVE_UNIFORM_END
+ *                                 bracket code that works on the wave's shared records only (the device runs it in all
+ *                                 lanes, which hold the same values; the fibre build runs it in lane 0)
+ *   NFC_WAVE_UNIFORM_U32(x)       a value every lane holds, as a scalar
+ *   NFC_WAVE_SCAN_ADD_F(v)        inclusive prefix sum over the lanes; NFC_WAVE_MAX_F(v): maximum, in every lane
+ *   NFC_WAVE_PICK_F(reg, array, j)  element j (uniform) of a per-lane value that is also in the LDS array
+ *   NFC_WAVE_CONFIG(cfgPtr, cc)   fill the NfcConfig `cc`
+ *   NFC_WAVE_NOINLINE             keeps the step a function of its own
  *   NFC_WAVE_LDS                  address space qualifier of LDS objects
  */
 #ifndef NFC_AMD_WAVE_HPP
@@ -45,20 +50,7 @@
 
 #define NFC_WAVE_RING_FLOATS (4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX)
 
-/* LDS of one wave */
-struct NfcWaveLds
-{
-   float ring[NFC_WAVE_RING_FLOATS]; /* the regions of nfc_core.hpp (NFC_R_*), one stream */
-   NfcStreamCold cold;
-   uint8_t bytes[NFC_STREAM_BYTES];
-   uint32_t flags;                   /* NfcStreamCold::usedTech while the lane runs */
-   float env[NFC_LANES];             /* envelope / average after each sample of the tile at hand */
-   float avg[NFC_LANES];
-   float scratch[NFC_LANES];
-   float sum[7][NFC_LANES];          /* running sums after each sample of the tile (nfc_wave_fast.hpp); [6]: hand-over to the uniform part */
-};
-
-/* what the lanes of the wave hold identically */
+/* what the lanes of the wave share: the decoder's state and where the lane of work stands */
 struct NfcWaveUni
 {
    NfcStreamState s;
@@ -67,6 +59,39 @@ struct NfcWaveUni
    uint32_t stopped;  /* 1 retired at rest, 2 handed over */
    uint32_t succ;
    uint32_t at;       /* sample of the tile at hand */
+   /* bulk paths (nfc_wave_fast.hpp) */
+   uint32_t key;      /* stage the values in sum / s0 / s1 belong to */
+   uint32_t from;     /* first sample of the tile they are valid for */
+   uint32_t clock0;   /* clock of the sample before the tile */
+   uint32_t gridSince; /* clock from which on every sample has been on the capture grid */
+   uint32_t gatedLo, gatedHi; /* the gates as last evaluated, bit j = sample gatedFrom + j of the tile */
+   uint32_t gatedFrom;
+   float pass[16];    /* hand-over from single lanes to everybody */
+};
+
+/* LDS of one wave */
+struct NfcWaveLds
+{
+   float ring[NFC_WAVE_RING_FLOATS]; /* the regions of nfc_core.hpp (NFC_R_*), one stream */
+   NfcStreamCold cold;
+   uint8_t bytes[NFC_STREAM_BYTES];
+   uint32_t flags;                   /* NfcStreamCold::usedTech while the lane runs */
+   NfcWaveUni u;
+   float env[NFC_LANES];             /* envelope / average after each sample of the tile at hand */
+   float avg[NFC_LANES];
+   float scratch[NFC_LANES];
+   float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator */
+   float s0[6][NFC_LANES];           /* ... and the two differences the detectors look at */
+   float s1[6][NFC_LANES];
+};
+
+/* the frame sink of the launch */
+struct NfcWaveSink
+{
+   uint32_t *words;
+   uint32_t *ctl;
+   uint32_t capacity;
+   uint32_t streamId;
 };
 
 NFC_DEV bool nfc_wave_exact_span(uint32_t clock, uint32_t count)
@@ -90,10 +115,29 @@ struct NfcWaveItem
    const NfcScanJob *job;
 };
 
+NFC_DEV NfcLaneMem nfc_wave_mem(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveSink &sink, const NfcConfig *cfgPtr)
+{
+   NfcLaneMem mem;
+   mem.ring = (NFC_RING_FLOAT *)lds->ring;
+   mem.lane = 0;
+   mem.exact = false;
+   mem.linked = true;
+   mem.flags = (uint32_t *)&lds->flags;
+   mem.bytes = (uint8_t *)lds->bytes;
+   mem.sink = sink.words;
+   mem.sinkCursor = sink.ctl;
+   mem.sinkDropped = sink.ctl + 1;
+   mem.sinkWords = sink.capacity;
+   mem.streamId = sink.streamId;
+   mem.cold = (NfcStreamCold *)&lds->cold;
+   mem.tables = cfgPtr;
+   return mem;
+}
+
 /* the decoder's edge time after the sample at stream position `last`: the edge-peak tracker (NfcTech.cpp:86-104) walked
  * from the stored point at or before it over the filtered plane, then what the decoder's own copy holds (zeroed by the
  * last carrier frame unless the tracker has moved since: nfc_edge_time). Called by every lane. */
-NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t last, bool emitValid, uint32_t emitClock)
+NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t last)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const uint32_t q = last / NFC_SCAN_POINT;
@@ -122,6 +166,9 @@ NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, co
          peak = top ? rectified : (low ? 0.0f : peak);
       }
    }
+
+   const bool emitValid = lds->cold.emitValid != 0;
+   const uint32_t emitClock = lds->cold.emitClock;
 
    return (emitValid && (int32_t)(tracked - emitClock) <= 0) ? 0u : tracked;
 }
@@ -171,57 +218,65 @@ NFC_DEV void nfc_wave_rings_out(const NFC_WAVE_LDS NfcWaveLds *lds, float *dst, 
       dst[(uint64_t)(4u * NFC_HIST_STORED + k) * pitch] = lds->ring[4u * NFC_HIST + k];
 }
 
-/* the tile at hand: this lane's sample and the front end's results for it, parked where the step reads them */
-struct NfcWaveTile
-{
-   float x, filt, env, mdev, avg, depth;
-};
-
-NFC_DEV NfcWaveTile nfc_wave_load_tile(const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t consumed, uint32_t n, uint32_t clock, uint32_t stride)
+/* The tile at hand: this lane's sample and the front end's results for it, parked where the step reads them. Returns
+ * true when the sample is on the capture grid (nfc_wave_fast.hpp). */
+NFC_DEV bool nfc_wave_load_tile(const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t consumed, uint32_t n, uint32_t clock, uint32_t stride)
 {
    const uint32_t lane = NFC_WAVE_LANE();
-   NfcWaveTile t;
-   t.x = t.filt = t.mdev = t.avg = t.depth = 0.0f;
-   t.env = 1.0f;
+   bool onGrid = true;
 
    if (lane < n)
    {
       const uint32_t i = consumed + lane;
       const float *p = it.planes + 4u * (uint64_t)(it.startPos + i);
 
-      t.x = NFC_SAMPLE_AT(it.data, stride, i);
-      t.filt = p[0];
-      t.env = p[1];
-      t.mdev = p[2];
-      t.avg = p[3];
+      const float x = NFC_SAMPLE_AT(it.data, stride, i);
+      const float env = p[1];
 
       /* modulation depth as the front end forms it (NfcTech.cpp:79-83) */
-      const float clamped = (t.x < 0.0f) ? 0.0f : ((t.env < t.x) ? t.env : t.x);
-      t.depth = (t.env - clamped) / t.env;
+      const float clamped = (x < 0.0f) ? 0.0f : ((env < x) ? env : x);
 
       const uint32_t slot = (clock + 1u + lane) & NFC_HMASK;
 
-      lds->ring[NFC_R_X + slot] = t.x;
-      lds->ring[NFC_R_FILT + slot] = t.filt;
-      lds->ring[NFC_R_MDEV + slot] = t.mdev;
-      lds->ring[NFC_R_DEPTH + slot] = t.depth;
-      lds->env[lane] = t.env;
-      lds->avg[lane] = t.avg;
+      lds->ring[NFC_R_X + slot] = x;
+      lds->ring[NFC_R_FILT + slot] = p[0];
+      lds->ring[NFC_R_MDEV + slot] = p[2];
+      lds->ring[NFC_R_DEPTH + slot] = (env - clamped) / env;
+      lds->env[lane] = env;
+      lds->avg[lane] = p[3];
+
+      const float scaled = x * 32768.0f;
+      onGrid = scaled == __builtin_floorf(scaled) && x >= -1.0f && x <= 1.0f;
    }
 
-   return t;
+   return onGrid;
 }
 
-/* ring positions after `n` more samples (the incremental form: nfc_bump n times) */
-NFC_DEV void nfc_wave_advance(const NfcConfig &c, NfcStreamState &s, uint32_t n)
+/* v - k*p for the k that brings it below p, for v < p + 64 and p >= 22 (ring periods at the sample rate of the table) */
+NFC_DEV uint32_t nfc_wave_wrap3(uint32_t v, uint32_t p)
 {
-   s.posA[0] = (s.posA[0] + n) % c.a[0].p1;
-   s.posA[1] = (s.posA[1] + n) % c.a[1].p1;
-   s.posA[2] = (s.posA[2] + n) % c.a[2].p1;
-   s.posF[0] = (s.posF[0] + n) % c.f[1].p1;
-   s.posF[1] = (s.posF[1] + n) % c.f[2].p1;
-   s.posV1 = (s.posV1 + n) % c.v.p1;
-   s.posV0 = (s.posV0 + n) % c.v.p0;
+   v -= v >= p ? p : 0u;
+   v -= v >= p ? p : 0u;
+   v -= v >= p ? p : 0u;
+   return v;
+}
+
+NFC_DEV uint32_t nfc_wave_wrap1(uint32_t v, uint32_t p)
+{
+   return v - (v >= p ? p : 0u);
+}
+
+/* ring positions after `n` (<= 64) more samples (the incremental form: nfc_bump n times) */
+template <class S>
+NFC_DEV void nfc_wave_advance(const NfcConfig &c, S &s, uint32_t n)
+{
+   s.posA[0] = nfc_wave_wrap3(s.posA[0] + n, c.a[0].p1);
+   s.posA[1] = nfc_wave_wrap3(s.posA[1] + n, c.a[1].p1);
+   s.posA[2] = nfc_wave_wrap3(s.posA[2] + n, c.a[2].p1);
+   s.posF[0] = nfc_wave_wrap3(s.posF[0] + n, c.f[1].p1);
+   s.posF[1] = nfc_wave_wrap3(s.posF[1] + n, c.f[2].p1);
+   s.posV1 = nfc_wave_wrap3(s.posV1 + n, c.v.p1);
+   s.posV0 = nfc_wave_wrap3(s.posV0 + n, c.v.p0);
 }
 
 /* statistics of the fibre build (tests/hostsim): samples committed in bulk (0) / stepped (1) per stage */
@@ -231,100 +286,262 @@ NFC_DEV void nfc_wave_advance(const NfcConfig &c, NfcStreamState &s, uint32_t n)
 
 #include "nfc_wave_fast.hpp"
 
+/* One sample, by the step machine of nfc_core.hpp: the shared state is taken into registers, stepped, put back.
+ * kind: 0 the common step, 1 ring positions by exact modulo (stream start), 2 correlator upkeep only (a window's warm-up).
+ * A function of its own: its registers are not the bulk paths' registers. */
+NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWaveLds *lds, NfcWaveSink sink, uint32_t kind, uint32_t emits, uint32_t edge)
+{
+   NfcConfig cc;
+   NFC_WAVE_CONFIG(cfgPtr, cc);
+
+   const NfcLaneMem mem = nfc_wave_mem(lds, sink, cfgPtr);
+
+   NFC_WAVE_UNIFORM_BEGIN
+   {
+      NfcStreamState s = *(NfcStreamState *)&lds->u.s;
+      const uint32_t at = lds->u.at;
+      const uint32_t slot = (s.clock + 1u) & NFC_HMASK;
+
+      NfcGiven g;
+      g.now.x = lds->ring[NFC_R_X + slot];
+      g.now.filt = lds->ring[NFC_R_FILT + slot];
+      g.now.mdev = lds->ring[NFC_R_MDEV + slot];
+      g.now.depth = lds->ring[NFC_R_DEPTH + slot];
+      g.env = lds->env[at];
+      g.avg = lds->avg[at];
+
+      if (emits)
+         s.edgeTime = edge; /* a carrier frame is stamped with it (NfcDecoder.cpp:472-523) */
+
+      if (kind == 2u)
+         nfc_step_upkeep<false, true>(cc, s, mem, g.now.x, &g);
+      else if (kind == 1u)
+         nfc_step_impl<true, true>(cc, s, mem, g.now.x, &g);
+      else
+         nfc_step_impl<false, true>(cc, s, mem, g.now.x, &g);
+
+      *(NfcStreamState *)&lds->u.s = s;
+      lds->u.at = at + 1u;
+      lds->u.stepped++;
+   }
+   NFC_WAVE_UNIFORM_END
+}
+
+/* One sample of the search bank, from the values the bulk path has formed for the tile (sums and correlations of the
+ * six box-sum correlators at this sample): nfc_step_impl / nfc_search_detect (NfcDecoder.cpp:394-418) without walking the
+ * correlators again - the decisions are the detectors' own (nfc*_detect_decide). Requires NfcWaveUni::key ==
+ * NFC_FK_SEARCH with values valid at this sample; leaves the key at NFC_FK_NONE when they are not valid for the next. */
+NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWaveLds *lds, NfcWaveSink sink, uint32_t emits, uint32_t edge)
+{
+   NfcConfig c;
+   NFC_WAVE_CONFIG(cfgPtr, c);
+
+   const NfcLaneMem mem = nfc_wave_mem(lds, sink, cfgPtr);
+
+   NFC_WAVE_UNIFORM_BEGIN
+   {
+      NfcStreamState &s = *(NfcStreamState *)&lds->u.s;
+      const uint32_t at = lds->u.at;
+
+      ++s.clock;
+
+      s.posA[0] = nfc_wave_wrap1(s.posA[0] + 1u, c.a[0].p1);
+      s.posA[1] = nfc_wave_wrap1(s.posA[1] + 1u, c.a[1].p1);
+      s.posA[2] = nfc_wave_wrap1(s.posA[2] + 1u, c.a[2].p1);
+      s.posF[0] = nfc_wave_wrap1(s.posF[0] + 1u, c.f[1].p1);
+      s.posF[1] = nfc_wave_wrap1(s.posF[1] + 1u, c.f[2].p1);
+      s.posV1 = nfc_wave_wrap1(s.posV1 + 1u, c.v.p1);
+      s.posV0 = nfc_wave_wrap1(s.posV0 + 1u, c.v.p0);
+
+      const uint32_t slot = s.clock & NFC_HMASK;
+
+      s.env = lds->env[at];
+      s.avg = lds->avg[at];
+      s.mdev = lds->ring[NFC_R_MDEV + slot];
+
+      if (emits)
+         s.edgeTime = edge;
+
+      nfc_detect_carrier(c, s, mem);
+
+      const bool armed = s.clock >= 1024u && !(s.env < c.powerThreshold);
+      uint32_t locked = 0;
+
+      if (armed)
+      {
+         NfcSearchRegs &r = s.u.search;
+
+         /* first detector that recognises its start of frame wins, later ones skip this sample (their correlators too) */
+         if (c.enabled & 1u)
+         {
+            const float limit = s.env * c.corrThreshold[0];
+
+#define NFC_WAVE_A_RATE(R)                                                                                                                       \
+            if (!locked)                                                                                                                         \
+            {                                                                                                                                    \
+               r.detA[R].acc = lds->sum[R][at];                                                                                                  \
+               lds->ring[NFC_R_CORR + c.corrOffset[R] + s.posA[R]] = r.detA[R].acc;                                                              \
+               if (nfca_detect_decide<R>(c, s, mem, lds->s0[R][at] - lds->s1[R][at],                                                             \
+                                         lds->ring[NFC_R_DEPTH + ((s.clock - c.a[R].delay - c.a[R].p8) & NFC_HMASK)], limit, c.minDepth[0]))     \
+                  locked = NFC_TECH_A;                                                                                                           \
+            }
+            NFC_WAVE_A_RATE(0)
+            NFC_WAVE_A_RATE(1)
+            NFC_WAVE_A_RATE(2)
+#undef NFC_WAVE_A_RATE
+         }
+
+         if (!locked && (c.enabled & 2u))
+         {
+            const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_HMASK, slot1 = (s.clock - c.b[1].delay) & NFC_HMASK;
+            const int r0 = nfcb_detect_decide<0>(c, s, mem, lds->ring[NFC_R_FILT + slot0], lds->ring[NFC_R_DEPTH + slot0]);
+
+            if (r0 == 1)
+               locked = NFC_TECH_B;
+            else if (r0 == 0 && nfcb_detect_decide<1>(c, s, mem, lds->ring[NFC_R_FILT + slot1], lds->ring[NFC_R_DEPTH + slot1]) == 1)
+               locked = NFC_TECH_B;
+         }
+
+         if (!locked && (c.enabled & 4u))
+         {
+            const float limit = s.env * c.corrThreshold[2];
+            const float deep = lds->ring[NFC_R_DEPTH + slot];
+
+            r.detF[0].acc = lds->sum[3][at];
+            lds->ring[NFC_R_CORR + c.corrOffset[3] + s.posF[0]] = r.detF[0].acc;
+
+            if (nfcf_detect_decide<1>(c, s, mem, lds->s0[3][at], lds->s0[3][at] - lds->s1[3][at], deep, limit))
+               locked = NFC_TECH_F;
+            else
+            {
+               r.detF[1].acc = lds->sum[4][at];
+               lds->ring[NFC_R_CORR + c.corrOffset[4] + s.posF[1]] = r.detF[1].acc;
+
+               if (nfcf_detect_decide<2>(c, s, mem, lds->s0[4][at], lds->s0[4][at] - lds->s1[4][at], deep, limit))
+                  locked = NFC_TECH_F;
+            }
+         }
+
+         if (!locked && (c.enabled & 8u))
+         {
+            r.detV.acc = lds->sum[5][at];
+            lds->ring[NFC_R_CORR + c.corrOffset[5] + s.posV1] = r.detV.acc;
+
+            if (nfcv_detect_decide(c, s, mem, lds->s0[5][at], lds->ring[NFC_R_X + ((s.clock - c.v.delay) & NFC_HMASK)]))
+               locked = NFC_TECH_V;
+         }
+
+         if (!locked)
+         {
+            if (s.bankClock != s.clock - 1u)
+               mem.cold->bankRun = s.clock;
+            s.bankClock = s.clock;
+         }
+      }
+
+      if (locked)
+         nfc_enter_lock(s, mem, locked);
+
+      /* the values stay good for the next sample unless a detector locked (some correlators then skipped this sample)
+       * or the bank did not step at all */
+      if (locked || !armed)
+         lds->u.key = NFC_FK_NONE;
+
+      lds->u.at = at + 1u;
+      lds->u.stepped++;
+   }
+   NFC_WAVE_UNIFORM_END
+}
+
 /* One tile: the next n samples of the lane's row (stream position pos on). allowFast: take the bulk paths (the fibre
  * build runs every tile a second time without them and compares: tests/hostsim/emu_wave.cpp). */
-NFC_DEV void nfc_wave_tile(const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, const NfcLaneMem &mem, NfcWaveUni &u,
-                           NfcWaveFast &fast, uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride, bool allowFast)
+NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds,
+                           const NfcWaveSink &sink, uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride, bool allowFast)
 {
-   const uint32_t lane = NFC_WAVE_LANE();
+   const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
+   const uint32_t clock = NFC_WAVE_UNIFORM_U32(lds->u.s.clock);
 
    NFC_WAVE_BARRIER();
-   const NfcWaveTile tile = nfc_wave_load_tile(it, lds, u.consumed, n, u.s.clock, stride);
+   const bool onGrid = nfc_wave_load_tile(it, lds, consumed, n, clock, stride);
+   const bool allOnGrid = NFC_WAVE_BALLOT(!onGrid) == 0ull;
    NFC_WAVE_BARRIER();
 
-   const bool exact = carry && nfc_wave_exact_span(u.s.clock, n);
+   const bool exact = carry && nfc_wave_exact_span(clock, n);
+
+   NFC_WAVE_COUNT(43u, 0u, 1u); /* tiles */
 
    /* per tile: the values of the bulk paths belong to the tile; is the tile on the grid? */
-   fast.key = NFC_FK_NONE;
-   fast.from = 0;
-   fast.clock0 = u.s.clock;
+   NFC_WAVE_UNIFORM_BEGIN
    {
-      const float scaled = tile.x * 32768.0f;
-      const bool off = lane < n && !(scaled == __builtin_floorf(scaled) && tile.x >= -1.0f && tile.x <= 1.0f);
-      if (NFC_WAVE_BALLOT(off))
-         fast.gridSince = u.s.clock + n;
+      lds->u.key = NFC_FK_NONE;
+      lds->u.from = 0;
+      lds->u.clock0 = clock;
+      lds->u.at = 0;
+      lds->u.gatedLo = 0;
+      lds->u.gatedHi = 0;
+      lds->u.gatedFrom = 0;
+      if (!allOnGrid)
+         lds->u.gridSince = clock + n;
    }
+   NFC_WAVE_UNIFORM_END
 
-   if (u.consumed < warmFront)
+   if (consumed < warmFront)
    {
       /* history only (nfc_step_front) */
-      NFC_WAVE_UNIFORM_BEGIN(u)
+      NFC_WAVE_UNIFORM_BEGIN
       {
-         u.s.clock += n;
-         nfc_wave_advance(cc, u.s, n);
-         u.s.env = lds->env[n - 1u];
-         u.s.avg = lds->avg[n - 1u];
-         u.s.mdev = lds->ring[NFC_R_MDEV + (u.s.clock & NFC_HMASK)];
+         lds->u.s.clock = clock + n;
+         nfc_wave_advance(cc, lds->u.s, n);
+         lds->u.s.env = lds->env[n - 1u];
+         lds->u.s.avg = lds->avg[n - 1u];
+         lds->u.s.mdev = lds->ring[NFC_R_MDEV + ((clock + n) & NFC_HMASK)];
       }
-      NFC_WAVE_UNIFORM_END(u)
+      NFC_WAVE_UNIFORM_END
+      return;
    }
-   else
+
+   const bool upkeep = consumed < warm;
+   bool again = false; /* the sample at hand was gated when the gates were last evaluated */
+
+   for (;;)
    {
-      const bool upkeep = u.consumed < warm;
+      const uint32_t at = NFC_WAVE_UNIFORM_U32(lds->u.at);
 
-      u.at = 0;
+      if (at >= n)
+         break;
 
-      while (u.at < n)
+      /* Samples from `at` on that change nothing but sums and rings: committed in bulk. Gated samples tend to come in
+       * runs (a detector following a pulse): one that was gated at the last evaluation is stepped without asking
+       * again - a step is right on any sample, gated or not. */
+      if (!exact && allowFast && !again && nfc_wave_fast(cc, lds, n, upkeep))
+         continue;
+
+      /* carrier frame due on this sample (NfcDecoder.cpp:472-523)? it is stamped with the decoder's edge time */
+      const float avgAt = lds->avg[at];
+      const bool emits = !upkeep && lds->u.s.lockTech == 0 &&
+                         ((avgAt > cc.highThreshold) ? !lds->u.s.carrierOn : ((avgAt < cc.lowThreshold) && !lds->u.s.carrierOff));
+      uint32_t edge = 0;
+
+      if (emits)
+         edge = nfc_wave_edge_time(cc, A, it, lds, pos + at);
+
+      NFC_WAVE_COUNT(nfc_wave_stage(lds->u.s, upkeep), 1u, 1u);
+
+      /* the search bank from the values the bulk path holds for this sample, or the step machine itself */
+      const bool fromValues = allowFast && !exact && !upkeep && lds->u.s.lockTech == 0 && lds->u.s.unlock == 0 &&
+                              NFC_WAVE_UNIFORM_U32(lds->u.key) == NFC_FK_SEARCH && NFC_WAVE_UNIFORM_U32(lds->u.from) <= at;
+
+      if (fromValues)
+         nfc_wave_search_step(cfgPtr, lds, sink, emits ? 1u : 0u, edge);
+      else
+         nfc_wave_step(cfgPtr, lds, sink, upkeep ? 2u : (exact ? 1u : 0u), emits ? 1u : 0u, edge);
+
       {
-         /* samples from u.at on that change nothing but sums and rings: committed in bulk */
-         if (!exact && allowFast)
-         {
-            const uint32_t run = nfc_wave_fast(cc, u, mem, lds, fast, tile, n, upkeep, it);
-
-            if (run)
-               continue;
-         }
-
-         /* carrier frame due on this sample (NfcDecoder.cpp:472-523)? it is stamped with the decoder's edge time */
-         const float avgAt = lds->avg[u.at];
-         const bool emits = !upkeep && u.s.lockTech == 0 &&
-                            ((avgAt > cc.highThreshold) ? !u.s.carrierOn : ((avgAt < cc.lowThreshold) && !u.s.carrierOff));
-         uint32_t edge = 0;
-
-         if (emits)
-            edge = nfc_wave_edge_time(cc, A, it, lds, pos + u.at, lds->cold.emitValid != 0, lds->cold.emitClock);
-
-         NFC_WAVE_COUNT(nfc_wave_stage(cc, u.s, upkeep), 1u, 1u);
-
-         NFC_WAVE_UNIFORM_BEGIN(u)
-         {
-            const uint32_t slot = (u.s.clock + 1u) & NFC_HMASK;
-
-            NfcGiven g;
-            g.now.x = lds->ring[NFC_R_X + slot];
-            g.now.filt = lds->ring[NFC_R_FILT + slot];
-            g.now.mdev = lds->ring[NFC_R_MDEV + slot];
-            g.now.depth = lds->ring[NFC_R_DEPTH + slot];
-            g.env = lds->env[u.at];
-            g.avg = lds->avg[u.at];
-
-            if (emits)
-               u.s.edgeTime = edge;
-
-            if (upkeep)
-               nfc_step_upkeep<false, true>(cc, u.s, mem, g.now.x, &g);
-            else if (exact)
-               nfc_step_impl<true, true>(cc, u.s, mem, g.now.x, &g);
-            else
-               nfc_step_impl<false, true>(cc, u.s, mem, g.now.x, &g);
-
-            u.at++;
-            u.stepped++;
-         }
-         NFC_WAVE_UNIFORM_END(u)
+         const uint64_t gated = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.gatedHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.gatedLo);
+         const uint32_t next = at + 1u - NFC_WAVE_UNIFORM_U32(lds->u.gatedFrom);
+         again = allowFast && !exact && next < 64u && ((gated >> next) & 1ull) != 0ull;
       }
    }
-
 }
 
 /* One lane of work. `lds`: this wave's LDS. Called by all 64 lanes. */
@@ -372,28 +589,24 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    const uint32_t warmFront = carry ? 0u : NFC_WINDOW_WARM_FRONT;
    const uint32_t warm = carry ? 0u : NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
 
-   NfcWaveUni u;
-   u.s = L.states[it.w];
-   u.consumed = 0;
-   u.stepped = 0;
-   u.stopped = 0;
-   u.at = 0;
-   u.succ = carry ? it.job->firstWindow : it.w + 1u;
-   if (mode == NFC_WAVE_FINAL || (mode == NFC_WAVE_WINDOWS && (it.w < it.job->firstWindow || it.w >= succEnd)))
-      u.succ = succEnd; /* runs on its own */
+   NfcWaveSink sink;
+   sink.words = L.sink;
+   sink.ctl = L.sinkCtl;
+   sink.capacity = L.sinkWords;
+   sink.streamId = it.w;
 
-   /* the front-end recurrences are not walked here (planes): what of them a lane's records are compared by is kept in
-    * one form by every lane (nfc_lane_digest); a lane that reaches the end of the submission leaves the scanned state */
-   u.s.n1 = 0.0f;
-   u.s.edgePeak = 0.0f;
-   u.s.pulseFilter = 0u;
+   const uint32_t startClock = L.states[it.w].clock;
 
-   /* LDS: the stream's rings (carry lanes: from the lane's copy of the stream's storage), protocol state, frame bytes */
+   /* LDS: the decoder's state, the stream's rings (carry lanes: from the lane's copy of the stream's storage), protocol
+    * state, frame bytes */
+   for (uint32_t i = lane; i < sizeof(NfcStreamState) / 4u; i += NFC_LANES)
+      ((NFC_WAVE_LDS uint32_t *)&lds->u.s)[i] = ((const uint32_t *)(L.states + it.w))[i];
+
    const uint64_t pitch = NFC_LANES;
    float *laneRings = L.rings + (uint64_t)(it.w / NFC_LANES) * L.ringBlockFloats + (it.w % NFC_LANES);
 
    if (carry)
-      nfc_wave_rings_in(lds, laneRings, pitch, u.s.clock, cc.corrTotal);
+      nfc_wave_rings_in(lds, laneRings, pitch, startClock, cc.corrTotal);
    else
    {
       for (uint32_t i = lane; i < NFC_WAVE_RING_FLOATS; i += NFC_LANES)
@@ -406,92 +619,112 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    for (uint32_t i = lane; i < NFC_STREAM_BYTES / 4u; i += NFC_LANES)
       ((NFC_WAVE_LDS uint32_t *)lds->bytes)[i] = carry ? ((const uint32_t *)(L.bytes + (uint64_t)it.w * NFC_STREAM_BYTES))[i] : 0u;
 
-   if (lane == 0)
-      lds->flags = 0u;
-
    NFC_WAVE_BARRIER();
 
-   NfcLaneMem mem;
-   mem.ring = (NFC_RING_FLOAT *)lds->ring;
-   mem.lane = 0;
-   mem.exact = false;
-   mem.linked = true;
-   mem.flags = (uint32_t *)&lds->flags;
-   mem.bytes = (uint8_t *)lds->bytes;
-   mem.sink = L.sink;
-   mem.sinkCursor = L.sinkCtl;
-   mem.sinkDropped = L.sinkCtl + 1;
-   mem.sinkWords = L.sinkWords;
-   mem.streamId = it.w;
-   mem.cold = (NfcStreamCold *)&lds->cold;
-   mem.tables = cfgPtr;
+   NFC_WAVE_UNIFORM_BEGIN
+   {
+      lds->flags = 0u;
+      lds->u.consumed = 0;
+      lds->u.stepped = 0;
+      lds->u.stopped = 0;
+      lds->u.at = 0;
+      lds->u.succ = carry ? it.job->firstWindow : it.w + 1u;
+      if (mode == NFC_WAVE_FINAL || (mode == NFC_WAVE_WINDOWS && (it.w < it.job->firstWindow || it.w >= succEnd)))
+         lds->u.succ = succEnd; /* runs on its own */
 
-   NfcWaveFast fast;
-   nfc_wave_fast_begin(fast);
+      /* the front-end recurrences are not walked here (planes): what of them a lane's records are compared by is kept in
+       * one form by every lane (nfc_lane_digest); a lane that reaches the end of the submission leaves the scanned state */
+      lds->u.s.n1 = 0.0f;
+      lds->u.s.edgePeak = 0.0f;
+      lds->u.s.pulseFilter = 0u;
 
-   /* samples known to be on the capture grid (nfc_wave_fast.hpp): the job's own are (the scan has looked at every one;
-    * what it does not check, |x| <= 1, is checked per tile); what a carry lane finds in the stream's rings is not known */
-   fast.gridSince = carry ? u.s.clock : u.s.clock - 4096u;
-   fast.gridValid = 1;
+      /* samples known to be on the capture grid (nfc_wave_fast.hpp): the job's own are (the scan has looked at every one;
+       * what it does not check, |x| <= 1, is checked per tile); what a carry lane finds in the stream's rings is not known */
+      lds->u.key = NFC_FK_NONE;
+      lds->u.from = 0;
+      lds->u.clock0 = startClock;
+      lds->u.gridSince = carry ? startClock : startClock - 4096u;
+   }
+   NFC_WAVE_UNIFORM_END
+
+   const NfcLaneMem mem = nfc_wave_mem(lds, sink, cfgPtr);
 
    for (;;)
    {
-      if (u.consumed >= it.count)
+      const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
+
+      if (consumed >= it.count)
          break;
 
-      const uint32_t pos = it.startPos + u.consumed;
+      const uint32_t pos = it.startPos + consumed;
 
       /* ---- tile boundary: publish, retire, hand over (nfc_window_body) ---- */
-      const bool wantEdge = pos == verifyPos && pos > 0; /* a published state carries the decoder's edge time */
+      const bool past = consumed >= warm && consumed > 0;
+      const bool mayRetire = past && (it.tiles[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) != 0u;
+      const bool publishes = pos == verifyPos;
       uint32_t edgeNow = 0;
 
-      if (wantEdge)
-         edgeNow = nfc_wave_edge_time(cc, A, it, lds, pos - 1u, lds->cold.emitValid != 0, lds->cold.emitClock);
+      if (publishes && pos > 0)
+         edgeNow = nfc_wave_edge_time(cc, A, it, lds, pos - 1u); /* a published state carries the decoder's edge time */
 
-      NFC_WAVE_UNIFORM_BEGIN(u)
+      NFC_WAVE_UNIFORM_BEGIN
       {
-         if (wantEdge)
-            u.s.edgeTime = edgeNow;
+         NfcStreamState &s = *(NfcStreamState *)&lds->u.s;
 
-         if (pos == verifyPos)
-            nfc_lane_publish(*me, u.s, *mem.cold);
+         if (publishes && pos > 0)
+            s.edgeTime = edgeNow;
 
-         if (u.consumed >= warm && u.consumed > 0 && (it.tiles[u.consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_quiescent(u.s) &&
-             u.s.bankClock == u.s.clock && (uint32_t)(u.s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
-            u.stopped = 1;
+         if (publishes)
+            nfc_lane_publish(*me, s, *mem.cold);
 
-         if (!u.stopped && u.consumed >= warm && u.consumed > 0 && nfc_lane_handover(L.windows, *me, u.succ, succEnd, pos, u.s, *mem.cold))
-            u.stopped = 2;
+         if (mayRetire && nfc_quiescent(s) && s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
+            lds->u.stopped = 1;
+
+         if (!lds->u.stopped && past)
+         {
+            uint32_t succ = lds->u.succ;
+            if (nfc_lane_handover(L.windows, *me, succ, succEnd, pos, s, *mem.cold))
+               lds->u.stopped = 2;
+            lds->u.succ = succ;
+         }
       }
-      NFC_WAVE_UNIFORM_END(u)
+      NFC_WAVE_UNIFORM_END
 
-      if (u.stopped)
+      if (NFC_WAVE_UNIFORM_U32(lds->u.stopped))
          break;
 
       /* ---- the tile ---- */
-      const uint32_t left = it.count - u.consumed;
+      const uint32_t left = it.count - consumed;
       const uint32_t n = left < NFC_LANES ? left : NFC_LANES;
 
 #ifdef NFC_WAVE_TILE_HOOK
-      NFC_WAVE_TILE_HOOK(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride);
+      NFC_WAVE_TILE_HOOK(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride);
 #else
-      nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, true);
+      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, true);
 #endif
 
-      u.consumed += n;
+      NFC_WAVE_UNIFORM_BEGIN
+      {
+         lds->u.consumed = consumed + n;
+      }
+      NFC_WAVE_UNIFORM_END
    }
 
    /* ---- the lane's result ---- */
-   const bool ranOut = u.consumed >= it.count;
-   const bool atEnd = it.startPos + u.consumed >= it.job->count;
+   const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
+   const uint32_t stopped = NFC_WAVE_UNIFORM_U32(lds->u.stopped);
+   const bool ranOut = consumed >= it.count;
+   const bool atEnd = it.startPos + consumed >= it.job->count;
    const bool closing = activate >= it.startPos + it.count;
 
    uint32_t edgeEnd = 0;
-   if (!atEnd && it.startPos + u.consumed > 0)
-      edgeEnd = nfc_wave_edge_time(cc, A, it, lds, it.startPos + u.consumed - 1u, lds->cold.emitValid != 0, lds->cold.emitClock);
+   if (!atEnd && it.startPos + consumed > 0)
+      edgeEnd = nfc_wave_edge_time(cc, A, it, lds, it.startPos + consumed - 1u);
 
-   NFC_WAVE_UNIFORM_BEGIN(u)
+   NFC_WAVE_UNIFORM_BEGIN
    {
+      NfcStreamState &s = *(NfcStreamState *)&lds->u.s;
+
       if (atEnd)
       {
          /* the front end where the submission ends, as the scan left it */
@@ -499,32 +732,33 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
          const NfcScanPoint &p = A.seams[lastChunk].end;
          const uint32_t tracked = (p.zone & NFC_ZONE_EDGE_KNOWN) ? p.edgeTime : A.chunkEdge[lastChunk];
 
-         u.s.env = p.env;
-         u.s.n1 = p.n1;
-         u.s.mdev = p.mdev;
-         u.s.avg = p.avg;
-         u.s.edgePeak = p.edgePeak;
-         u.s.pulseFilter = p.pulseFilter;
-         u.s.edgeTime = (mem.cold->emitValid && (int32_t)(tracked - mem.cold->emitClock) <= 0) ? 0u : tracked;
+         s.env = p.env;
+         s.n1 = p.n1;
+         s.mdev = p.mdev;
+         s.avg = p.avg;
+         s.edgePeak = p.edgePeak;
+         s.pulseFilter = p.pulseFilter;
+         s.edgeTime = (mem.cold->emitValid && (int32_t)(tracked - mem.cold->emitClock) <= 0) ? 0u : tracked;
       }
-      else if (it.startPos + u.consumed > 0)
-         u.s.edgeTime = edgeEnd;
+      else if (it.startPos + consumed > 0)
+         s.edgeTime = edgeEnd;
+
+      lds->cold.usedTech = lds->flags;
    }
-   NFC_WAVE_UNIFORM_END(u)
+   NFC_WAVE_UNIFORM_END
+
+   NFC_WAVE_BARRIER();
 
    /* 2 handed over, 1 stopped at rest - or out of samples in a state the closing window can take over from -, 0 ran to
     * the end of the submission (nfc_window_body) */
-   const uint32_t how = u.stopped == 2 ? 2u : ((!ranOut || (!closing && nfc_lane_comparable(u.s, *mem.cold))) ? 1u : 0u);
-
-   NFC_WAVE_BARRIER();
-
-   if (lane == 0)
-      lds->cold.usedTech = lds->flags;
-
-   NFC_WAVE_BARRIER();
+   const uint32_t how = stopped == 2 ? 2u : ((!ranOut || (!closing && nfc_lane_comparable(*(const NfcStreamState *)&lds->u.s, *mem.cold))) ? 1u : 0u);
+   const uint32_t endClock = lds->u.s.clock;
 
    for (uint32_t i = lane; i < sizeof(NfcStreamCold) / 4u; i += NFC_LANES)
       ((uint32_t *)(L.cold + it.w))[i] = ((const NFC_WAVE_LDS uint32_t *)&lds->cold)[i];
+
+   for (uint32_t i = lane; i < sizeof(NfcStreamState) / 4u; i += NFC_LANES)
+      ((uint32_t *)(L.states + it.w))[i] = ((const NFC_WAVE_LDS uint32_t *)&lds->u.s)[i];
 
    /* rings and frame bytes: a carry or final lane owns storage; a window that ran to the end of the submission with
     * nobody to take over may be the stream's last lane and leaves a copy in the save area (NfcScanArgs::saveRings) */
@@ -532,28 +766,27 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
    if (mode != NFC_WAVE_WINDOWS)
    {
-      nfc_wave_rings_out(lds, laneRings, pitch, u.s.clock, cc.corrTotal);
+      nfc_wave_rings_out(lds, laneRings, pitch, endClock, cc.corrTotal);
 
       for (uint32_t i = lane; i < NFC_STREAM_BYTES / 4u; i += NFC_LANES)
          ((uint32_t *)(L.bytes + (uint64_t)it.w * NFC_STREAM_BYTES))[i] = ((const NFC_WAVE_LDS uint32_t *)lds->bytes)[i];
    }
    else if (how == 0u && !closing)
    {
-      uint32_t slot = 0;
-
-      NFC_WAVE_UNIFORM_BEGIN(u)
+      NFC_WAVE_BARRIER();
+      NFC_WAVE_UNIFORM_BEGIN
       {
-         u.at = NFC_ATOMIC_ADD(A.saveNext, 1u);
+         lds->u.at = NFC_ATOMIC_ADD(A.saveNext, 1u);
       }
-      NFC_WAVE_UNIFORM_END(u)
+      NFC_WAVE_UNIFORM_END
 
-      slot = u.at;
+      const uint32_t slot = NFC_WAVE_UNIFORM_U32(lds->u.at);
 
       if (slot < A.saveRoom)
       {
          const uint32_t rows = L.ringBlockFloats / NFC_LANES;
 
-         nfc_wave_rings_out(lds, A.saveRings + (uint64_t)slot * rows, 1u, u.s.clock, cc.corrTotal);
+         nfc_wave_rings_out(lds, A.saveRings + (uint64_t)slot * rows, 1u, endClock, cc.corrTotal);
 
          for (uint32_t i = lane; i < NFC_STREAM_BYTES / 4u; i += NFC_LANES)
             ((uint32_t *)(A.saveBytes + (uint64_t)slot * NFC_STREAM_BYTES))[i] = ((const NFC_WAVE_LDS uint32_t *)lds->bytes)[i];
@@ -564,13 +797,12 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
    if (lane == 0)
    {
-      L.states[it.w] = u.s;
-      me->stop = it.startPos + u.consumed;
+      me->stop = it.startPos + consumed;
       me->retired = how;
       if (mode == NFC_WAVE_WINDOWS)
          me->saved = saved;
 
-      const uint32_t tilesStepped = (u.stepped + NFC_LANES - 1u) / NFC_LANES;
+      const uint32_t tilesStepped = (lds->u.stepped + NFC_LANES - 1u) / NFC_LANES;
       NFC_WAVE_STAT_ADD(L.laneStats, tilesStepped);
       NFC_WAVE_STAT_MAX(L.laneStats + 1, tilesStepped);
       NFC_WAVE_STAT_ADD(L.laneStats + 2, 1u);

@@ -17,8 +17,11 @@
  *          back (BPSK listen frames): not on a grid, so the running sum is walked sample by sample in the step's own order
  *          (one dependent add and subtract per sample, every lane the same walk), everything around it is per lane.
  *   Ring taps: the entry a sample's step reads was written either by an earlier sample of this tile (then it is that
- *   sample's sum, taken from LDS scratch) or before the tile (then the ring still holds it: no write of the tile can
- *   have touched that position yet).
+ *   sample's sum, taken from LDS) or before the tile (then the ring still holds it: no write of the tile can have
+ *   touched that position yet).
+ * The per-lane values live in LDS (NfcWaveLds::sum / s0 / s1: element [k][lane] belongs to the tile sample lane `lane`
+ * holds), valid from sample NfcWaveUni::from on while the stage stays NfcWaveUni::key: stepping a gated sample does not
+ * change them (the step forms the same sums), a change of stage does.
  */
 #ifndef NFC_AMD_WAVE_FAST_HPP
 #define NFC_AMD_WAVE_FAST_HPP
@@ -48,64 +51,13 @@ enum
    NFC_FK_V_SYMBOL
 };
 
-/* per-lane values of the tile's sample this lane holds, valid from lane `from` on while the stage stays `key` */
-struct NfcWaveFast
-{
-   uint32_t key;
-   uint32_t from;    /* first lane the values are valid for */
-   uint32_t clock0;  /* clock of the sample before the tile */
-   uint32_t gridSince; /* clock from which on every sample has been on the grid */
-   uint32_t gridValid;
-   float c[6];       /* running sum after this lane's sample: search correlators A106 A212 A424 F212 F424 V; locked: c[0] */
-   float s0[6], s1[6];
-   float edge[2], deep[2]; /* NFC-B detectors: DC-removed signal and depth at their decode points */
-};
-
-NFC_DEV void nfc_wave_fast_begin(NfcWaveFast &f)
-{
-   f.key = NFC_FK_NONE;
-   f.from = 0;
-   f.clock0 = 0;
-   f.gridSince = 0;
-   f.gridValid = 0;
-}
-
-/* inclusive prefix sum over the lanes of the wave (exact: see the header) */
-NFC_DEV float nfc_wave_scan_add(float v)
-{
-   const uint32_t lane = NFC_WAVE_LANE();
-
-   for (uint32_t d = 1; d < NFC_LANES; d <<= 1)
-   {
-      const float t = NFC_WAVE_SHFL_UP_F(v, d);
-      if (lane >= d)
-         v += t;
-   }
-
-   return v;
-}
-
-/* maximum over the lanes of the wave, in every lane */
-NFC_DEV float nfc_wave_max(float v)
-{
-   for (uint32_t d = 1; d < NFC_LANES; d <<= 1)
-   {
-      const float t = NFC_WAVE_SHFL_XOR_F(v, d);
-      v = t > v ? t : v;
-   }
-
-   return v;
-}
+/* the shared decoder state, read in place */
+#define NFC_WAVE_STATE(lds) (*(const NfcStreamState *)&(lds)->u.s)
 
 /* clock of the tile sample this lane holds */
-NFC_DEV uint32_t nfc_wave_clock_of(const NfcWaveFast &f)
+NFC_DEV uint32_t nfc_wave_clock_of(uint32_t clock0)
 {
-   return f.clock0 + 1u + NFC_WAVE_LANE();
-}
-
-NFC_DEV uint32_t nfc_wave_mod(uint32_t v, uint32_t p)
-{
-   return v % p;
+   return clock0 + 1u + NFC_WAVE_LANE();
 }
 
 /* One raw box-sum correlator over the tile's samples from lane `from` on.
@@ -113,58 +65,51 @@ NFC_DEV uint32_t nfc_wave_mod(uint32_t v, uint32_t p)
  *   pos      ring position of that sample
  *   prevKnown  the ring entry one sample back is the running sum (bank stepped on the previous sample)
  *   writeFrom  first clock whose step writes the ring (NFC-F listen frames: one symbol before the guard ends)
- * Leaves the running sums in lds->sum[slot] (for the commit) and returns this lane's values. */
-struct NfcWaveRaw
-{
-   float c, c2, c3;
-};
-
-NFC_DEV NfcWaveRaw nfc_wave_raw(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, const NfcWaveFast &f, uint32_t from, float acc, uint32_t delay, uint32_t w,
-                                uint32_t p1, uint32_t shift, uint32_t base, uint32_t pos, bool prevKnown, uint32_t writeFrom)
+ * Leaves the running sums in lds->sum[slot] and the two taps in c2 / c3. */
+NFC_DEV float nfc_wave_raw(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t clock0, uint32_t from, float acc, uint32_t delay, uint32_t w, uint32_t p1,
+                           uint32_t shift, uint32_t base, uint32_t pos, bool prevKnown, uint32_t writeFrom, float &c2, float &c3)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const bool active = lane >= from;
-   const uint32_t t = nfc_wave_clock_of(f);
+   const uint32_t t = nfc_wave_clock_of(clock0);
    const uint32_t k = lane - from; /* samples after the first of the run */
 
    const float in = lds->ring[NFC_R_X + ((t - delay) & NFC_HMASK)];
    const float out = lds->ring[NFC_R_X + ((t - delay - w) & NFC_HMASK)];
 
-   NfcWaveRaw r;
-   r.c = acc + nfc_wave_scan_add(active ? in - out : 0.0f);
+   const float c = acc + NFC_WAVE_SCAN_ADD_F(active ? in - out : 0.0f);
 
    NFC_WAVE_BARRIER();
-   lds->sum[slot][lane] = r.c;
+   lds->sum[slot][lane] = c;
    NFC_WAVE_BARRIER();
 
-   const uint32_t posj = nfc_wave_mod(pos + 1u + k, p1);
+   const uint32_t posj = nfc_wave_wrap3(pos + 1u + (active ? k : 0u), p1);
 
    /* the entry `shift` samples back: written by the tile if that sample belongs to the run and wrote the ring */
    const bool c2Here = active && k >= shift && (int32_t)(t - shift - writeFrom) >= 0;
-   const float c2Ring = lds->ring[NFC_R_CORR + base + nfc_wave_mod(posj + p1 - shift, p1)];
-   r.c2 = c2Here ? lds->sum[slot][active ? lane - (k >= shift ? shift : 0u) : lane] : c2Ring;
+   const float c2Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - shift, p1)];
+   c2 = c2Here ? lds->sum[slot][c2Here ? lane - shift : lane] : c2Ring;
 
    const bool c3Here = active && k >= 1u && (int32_t)(t - 1u - writeFrom) >= 0;
-   const float c3Ring = lds->ring[NFC_R_CORR + base + nfc_wave_mod(posj + p1 - 1u, p1)];
-   r.c3 = c3Here ? lds->sum[slot][active && k >= 1u ? lane - 1u : lane] : ((k == 0u && prevKnown) ? acc : c3Ring);
+   const float c3Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - 1u, p1)];
+   c3 = c3Here ? lds->sum[slot][c3Here ? lane - 1u : lane] : ((active && k == 0u && prevKnown) ? acc : c3Ring);
 
-   return r;
+   return c;
 }
 
-/* commit of a raw correlator: ring entries of the samples [from, from + run) (the last p1 of them), positions are the
- * caller's */
-NFC_DEV void nfc_wave_raw_commit(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveFast &f, uint32_t from, uint32_t run, float c, uint32_t p1, uint32_t base,
-                                 uint32_t pos, uint32_t writeFrom)
+/* commit of a correlator ring: entries of the samples [from, from + run) (the last `period` of them) */
+NFC_DEV void nfc_wave_ring_commit(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t clock0, uint32_t from, uint32_t run, uint32_t period, uint32_t base,
+                                  uint32_t pos, uint32_t writeFrom)
 {
    const uint32_t lane = NFC_WAVE_LANE();
 
-   if (lane >= from && lane < from + run && lane + p1 >= from + run && (int32_t)(nfc_wave_clock_of(f) - writeFrom) >= 0)
-      lds->ring[NFC_R_CORR + base + nfc_wave_mod(pos + 1u + (lane - from), p1)] = c;
+   if (lane >= from && lane < from + run && lane + period >= from + run && (int32_t)(nfc_wave_clock_of(clock0) - writeFrom) >= 0)
+      lds->ring[NFC_R_CORR + base + nfc_wave_wrap3(pos + 1u + (lane - from), period)] = lds->sum[slot][lane];
 }
 
-/* running sum of a listen-mode integrator, walked in the step's order: sum += in[j]; sum -= out[j] for the samples from
- * `from` on whose clock has reached `integrateFrom`. Every lane walks (and leaves the same values in lds->sum[0]). */
-NFC_DEV float nfc_wave_walk(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveFast &f, uint32_t from, uint32_t n, float acc, float in, float out, uint32_t integrateFrom)
+/* Running sum of a listen-mode integrator, walked in the step's order: sum += in[j]; sum -= out[j] for the samples from
+ * `from` on whose clock has reached `integrateFrom`. Every lane walks the same walk; the sums go to lds->sum[0]. */
+NFC_DEV void nfc_wave_walk(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, uint32_t n, float acc, float in, float out, uint32_t integrateFrom)
 {
    const uint32_t lane = NFC_WAVE_LANE();
 
@@ -173,22 +118,25 @@ NFC_DEV float nfc_wave_walk(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveFast &f, 
    lds->sum[2][lane] = out;
    NFC_WAVE_BARRIER();
 
+   float mine = acc;
+
    for (uint32_t j = from; j < n; j++)
    {
-      if ((int32_t)(f.clock0 + 1u + j - integrateFrom) >= 0)
+      if ((int32_t)(clock0 + 1u + j - integrateFrom) >= 0)
       {
-         acc += lds->sum[1][j];
-         acc -= lds->sum[2][j];
+         acc += NFC_WAVE_PICK_F(in, lds->sum[1], j);
+         acc -= NFC_WAVE_PICK_F(out, lds->sum[2], j);
       }
-      lds->sum[0][j] = acc;
+      mine = lane == j ? acc : mine;
    }
 
    NFC_WAVE_BARRIER();
-   return lds->sum[0][lane];
+   lds->sum[0][lane] = mine;
+   NFC_WAVE_BARRIER();
 }
 
-/* which stage, and can the bulk path be taken at all? */
-NFC_DEV uint32_t nfc_wave_stage(const NfcConfig &c, const NfcStreamState &s, bool upkeep)
+/* which stage? */
+NFC_DEV uint32_t nfc_wave_stage(const NfcStreamState &s, bool upkeep)
 {
    if (upkeep)
       return NFC_FK_UPKEEP;
@@ -243,23 +191,38 @@ NFC_DEV uint32_t nfc_wave_stage(const NfcConfig &c, const NfcStreamState &s, boo
 
 /* ---- search bank ---- */
 
-/* gates of the eight detectors at this lane's sample (the early exits of nfc*_detect_rate) */
-NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, const NfcStreamState &s, const NfcWaveFast &f, const NfcWaveTile &tile)
+/* gates of the eight detectors at this lane's sample (the early exits of nfc*_detect_rate); bit per detector:
+ * A106 A212 A424 B106 B212 F212 F424 V */
+NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0)
 {
-   const uint32_t t = nfc_wave_clock_of(f);
-   const NfcSearchRegs &r = s.u.search;
-   uint32_t gate = 0; /* bit per detector: A106 A212 A424 B106 B212 F212 F424 V */
+   const uint32_t lane = NFC_WAVE_LANE();
+   const uint32_t t = nfc_wave_clock_of(clock0);
+   const NfcSearchRegs &r = NFC_WAVE_STATE(lds).u.search;
+   const float env = lds->env[lane];
+   uint32_t gate = 0;
 
    if (c.enabled & 1u)
    {
-      const float limit = tile.env * c.corrThreshold[0];
+      const float limit = env * c.corrThreshold[0];
 
       for (int i = 0; i < 3; i++)
       {
+         /* nfca_detect_rate past its first exit: a correlation beyond the threshold only changes the record when it is a
+          * new extreme of the pause being tracked (or, on the way down, a new deepest modulation) */
          const NfcDetA &m = r.detA[i];
-         const float num = f.s0[i] - f.s1[i];
-         const bool timeout = m.peakTime && t > m.peakTime + c.a[i].p1;
-         const bool eventful = t >= m.winStart && (nfc_may_exceed(num, (float)c.a[i].p2, limit) || t == m.winEnd);
+         const NfcRate &rt = c.a[i];
+         const float num = lds->s0[i][lane] - lds->s1[i][lane];
+         const bool timeout = m.peakTime && t > m.peakTime + rt.p1;
+         bool moves = false;
+
+         if (nfc_may_exceed(num, (float)rt.p2, limit))
+         {
+            const float sd = num / (float)rt.p2;
+            const float deep = lds->ring[NFC_R_DEPTH + ((t - rt.delay - rt.p8) & NFC_HMASK)];
+            moves = !m.symStart ? (sd < -limit && (sd < m.peak || deep > m.aux)) : (sd > limit && sd > m.peak);
+         }
+
+         const bool eventful = t >= m.winStart && (moves || t == m.winEnd);
          gate |= (timeout || eventful) ? 1u << i : 0u;
       }
    }
@@ -269,12 +232,14 @@ NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, const NfcStreamState &
       for (int i = 0; i < 2; i++)
       {
          const NfcDetB &m = r.detB[i];
-         const float edge = f.edge[i], deep = f.deep[i];
-         const bool reset = deep > c.maxDepth[1] || (m.auxTime && t > m.auxTime + c.b[i].p1);
+         const uint32_t slot = (t - c.b[i].delay) & NFC_HMASK;
+         const float edge = lds->ring[NFC_R_FILT + slot], deep = lds->ring[NFC_R_DEPTH + slot];
+         const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.auxTime | nfc_bits(m.aux)) == 0u;
+         const bool reset = (deep > c.maxDepth[1] || (m.auxTime && t > m.auxTime + c.b[i].p1)) && !clear;
          bool hit;
 
          if (!m.symStart)
-            hit = edge < -(tile.env * c.minDepth[1]) || t == m.winEnd;
+            hit = edge < -(env * c.minDepth[1]) || t == m.winEnd;
          else if (!m.symEnd)
             hit = t < m.winStart ? edge > m.thr : ((edge > m.thr && edge > m.aux) || t == m.winEnd);
          else
@@ -286,15 +251,31 @@ NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, const NfcStreamState &
 
    if (c.enabled & 4u)
    {
-      const float limit = tile.env * c.corrThreshold[2];
+      const float limit = env * c.corrThreshold[2];
+      const float deep = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)];
 
       for (int i = 0; i < 2; i++)
       {
          const NfcDetF &m = r.detF[i];
          const NfcRate &rt = c.f[i + 1];
-         const float num = f.s0[3 + i] - f.s1[3 + i];
-         const bool reset = tile.depth > c.maxDepth[2] || (m.peakTime && t > m.peakTime + rt.p1);
-         const bool eventful = t >= m.winStart && (nfc_may_exceed(num, (float)rt.p2, limit) || t == m.sync || t == m.winEnd);
+         /* nfcf_detect_rate / nfcf_track_preamble: a correlation above the threshold only changes the record when it is
+          * the largest of the pulse so far */
+         const float num = lds->s0[3 + i][lane] - lds->s1[3 + i][lane];
+         const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.sync | m.peakTime | nfc_bits(m.peak)) == 0u;
+         const bool asked = deep > c.maxDepth[2] || (m.peakTime && t > m.peakTime + rt.p1);
+         const bool reset = asked && !clear;
+         bool moves = false;
+
+         /* (a reset that finds the record clear only leaves its mark: bit 8 + i, folded into the commit) */
+         gate |= asked ? 256u << i : 0u;
+
+         if (nfc_may_exceed(num, (float)rt.p2, limit))
+         {
+            const float sd = nfc_abs(num) / (float)rt.p2;
+            moves = sd > limit && sd > m.peak;
+         }
+
+         const bool eventful = t >= m.winStart && (moves || t == m.sync || t == m.winEnd);
          gate |= (reset || eventful) ? 32u << i : 0u;
       }
    }
@@ -302,10 +283,21 @@ NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, const NfcStreamState &
    if (c.enabled & 8u)
    {
       const NfcDetV &m = r.detV;
-      const float limit = tile.env * c.corrThreshold[3];
-      const float num = f.s0[5]; /* c2 - sum */
+      const float limit = env * c.corrThreshold[3];
+      /* nfcv_detect: a pulse correlation above the threshold only changes the record when it is the largest so far or
+       * comes with a deeper modulation */
+      const float num = lds->s0[5][lane]; /* c2 - sum */
       const bool timeout = m.peakTime && t > m.peakTime + c.v.p0;
-      const bool eventful = t >= m.winStart && (nfc_may_exceed(num, (float)c.v.p2, limit) || t == m.winEnd);
+      bool moves = false;
+
+      if (nfc_may_exceed(num, (float)c.v.p2, limit))
+      {
+         const float q = num / (float)c.v.p2;
+         const float deep = lds->ring[NFC_R_DEPTH + ((t - c.v.delay - c.v.p8) & NFC_HMASK)];
+         moves = q > limit && (q > m.peak || deep > m.aux);
+      }
+
+      const bool eventful = t >= m.winStart && (moves || t == m.winEnd);
       gate |= (timeout || eventful) ? 128u : 0u;
    }
 
@@ -313,54 +305,47 @@ NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, const NfcStreamState &
 }
 
 /* values of the search bank for the tile's samples from `from` on */
-NFC_DEV void nfc_wave_search_values(const NfcConfig &c, const NfcStreamState &s, NFC_WAVE_LDS NfcWaveLds *lds, NfcWaveFast &f, uint32_t from)
+NFC_DEV void nfc_wave_search_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from)
 {
-   const uint32_t t = nfc_wave_clock_of(f);
+   const uint32_t lane = NFC_WAVE_LANE();
+   const NfcStreamState &s = NFC_WAVE_STATE(lds);
    const bool prevKnown = s.bankClock == s.clock;
+   const uint32_t never = s.clock - 0x40000000u;
    const NfcSearchRegs &r = s.u.search;
+   const uint32_t posA0 = s.posA[0], posA1 = s.posA[1], posA2 = s.posA[2], posF0 = s.posF[0], posF1 = s.posF[1], posV1 = s.posV1;
+   const float accA0 = r.detA[0].acc, accA1 = r.detA[1].acc, accA2 = r.detA[2].acc, accF0 = r.detF[0].acc, accF1 = r.detF[1].acc, accV = r.detV.acc;
+   float c2, c3, sum;
 
-   for (int i = 0; i < 3; i++)
-   {
-      const NfcRate &rt = c.a[i];
-      const NfcWaveRaw v = nfc_wave_raw(lds, (uint32_t)i, f, from, r.detA[i].acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, c.corrOffset[i], s.posA[i], prevKnown, s.clock - 0x40000000u);
-      f.c[i] = v.c;
-      f.s0[i] = v.c - v.c2;
-      f.s1[i] = v.c2 - v.c3;
-   }
+#define NFC_WAVE_SEARCH_ONE(k, rt, acc, base, pos)                                                                                        \
+   sum = nfc_wave_raw(lds, (k), clock0, from, (acc), (rt).delay, (rt).p2, (rt).p1, (rt).p1 - (rt).p2, (base), (pos), prevKnown, never, c2, c3); \
+   lds->s0[k][lane] = sum - c2;                                                                                                             \
+   lds->s1[k][lane] = c2 - c3;
 
-   for (int i = 0; i < 2; i++)
-   {
-      const NfcRate &rt = c.f[i + 1];
-      const NfcWaveRaw v = nfc_wave_raw(lds, 3u + (uint32_t)i, f, from, r.detF[i].acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, c.corrOffset[3 + i], s.posF[i], prevKnown, s.clock - 0x40000000u);
-      f.c[3 + i] = v.c;
-      f.s0[3 + i] = v.c - v.c2;
-      f.s1[3 + i] = v.c2 - v.c3;
-   }
+   NFC_WAVE_SEARCH_ONE(0, c.a[0], accA0, c.corrOffset[0], posA0)
+   NFC_WAVE_SEARCH_ONE(1, c.a[1], accA1, c.corrOffset[1], posA1)
+   NFC_WAVE_SEARCH_ONE(2, c.a[2], accA2, c.corrOffset[2], posA2)
+   NFC_WAVE_SEARCH_ONE(3, c.f[1], accF0, c.corrOffset[3], posF0)
+   NFC_WAVE_SEARCH_ONE(4, c.f[2], accF1, c.corrOffset[4], posF1)
+#undef NFC_WAVE_SEARCH_ONE
 
-   {
-      const NfcRate &rt = c.v;
-      const NfcWaveRaw v = nfc_wave_raw(lds, 5u, f, from, r.detV.acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, c.corrOffset[5], s.posV1, prevKnown, s.clock - 0x40000000u);
-      f.c[5] = v.c;
-      f.s0[5] = v.c2 - v.c; /* nfcv_detect: num = c2 - sum */
-      f.s1[5] = 0.0f;
-   }
-
-   for (int i = 0; i < 2; i++)
-   {
-      const uint32_t slot = (t - c.b[i].delay) & NFC_HMASK;
-      f.edge[i] = lds->ring[NFC_R_FILT + slot];
-      f.deep[i] = lds->ring[NFC_R_DEPTH + slot];
-   }
+   sum = nfc_wave_raw(lds, 5u, clock0, from, accV, c.v.delay, c.v.p2, c.v.p1, c.v.p1 - c.v.p2, c.corrOffset[5], posV1, prevKnown, never, c2, c3);
+   lds->s0[5][lane] = c2 - sum; /* nfcv_detect: num = c2 - sum */
+   lds->s1[5][lane] = 0.0f;
 }
 
 /* ---- locked stages ---- */
 
-NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, const NfcStreamState &s, const NfcWaveFast &f, const NfcWaveTile &tile, uint32_t key)
+NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t key)
 {
-   const uint32_t t = nfc_wave_clock_of(f);
-   const NfcDecodeRegs &d = s.u.decode;
+   const uint32_t lane = NFC_WAVE_LANE();
+   const uint32_t t = nfc_wave_clock_of(clock0);
+   const NfcDecodeRegs &d = NFC_WAVE_STATE(lds).u.decode;
    const NfcMod &m = d.lock;
    const NfcRate &rt = d.rt;
+   const float depth = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)]; /* of this lane's own sample */
+   const float s0 = lds->s0[0][lane];
+   const float s1 = lds->s1[0][lane];
+   const float sum = lds->sum[0][lane];
 
    switch (key)
    {
@@ -375,44 +360,43 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, const NfcStreamState &s, c
 
       case NFC_FK_A_ASK_START:
       {
-         const float s0 = f.s0[0];
          if (t < d.guardEnd)
             return false;
          const bool track = !m.symStart ? (s0 > m.thr && s0 > m.peak) : (s0 < -m.thr && s0 < m.peak);
-         return t == d.guardEnd || t > d.waitingEnd || tile.depth > c.minDepth[0] || track || t == m.winEnd;
+         return t == d.guardEnd || t > d.waitingEnd || depth > c.minDepth[0] || track || t == m.winEnd;
       }
 
       case NFC_FK_A_BPSK_START:
       {
-         const float phase = f.c[0];
+         const float phase = sum;
          if (t < d.guardEnd)
             return false;
          /* a negative phase with nothing tracked finds nothing to reset (the "preamble" it measures is the clock itself,
           * far outside 3..4 etu once the stream is a few thousand samples old) */
          const bool drop = !m.symEnd && phase < 0.0f && ((m.symStart | m.winEnd) != 0u || t <= 4096u);
-         return t == d.guardEnd || t > d.waitingEnd || tile.depth > c.minDepth[0] || phase > m.thr || drop || t == m.winEnd;
+         return t == d.guardEnd || t > d.waitingEnd || depth > c.minDepth[0] || phase > m.thr || drop || t == m.winEnd;
       }
 
       case NFC_FK_A_BPSK_SYMBOL:
       case NFC_FK_B_SYMBOL:
       {
-         const float phase = f.c[0];
+         const float phase = sum;
          const bool cross = !m.auxTime && ((phase > 0.0f && m.lastPhase < 0.0f) || (phase < 0.0f && m.lastPhase > 0.0f));
          return cross || t == m.sync;
       }
 
       case NFC_FK_B_POLL:
       {
-         const float edge = nfc_abs(f.edge[0]);
+         const float edge = nfc_abs(lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_HMASK)]);
          return (t > m.winStart && t < m.winEnd && edge > m.thr && m.aux < edge) || t == m.sync;
       }
 
       case NFC_FK_B_START:
       {
-         const float phase = f.c[0];
+         const float phase = sum;
          if (t < d.guardEnd)
             return false;
-         if (t == d.guardEnd || t > d.waitingEnd || tile.depth > c.maxDepth[1])
+         if (t == d.guardEnd || t > d.waitingEnd || depth > c.maxDepth[1])
             return true;
          if (t < m.winStart)
             return false;
@@ -424,7 +408,7 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, const NfcStreamState &s, c
 
       case NFC_FK_F_START:
       {
-         const float sd = nfc_abs(f.s0[0] - f.s1[0]) / (float)rt.p2;
+         const float sd = nfc_abs(s0 - s1) / (float)rt.p2;
          if (t < d.guardEnd)
             return false;
          if (t == d.guardEnd || t > d.waitingEnd)
@@ -434,16 +418,15 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, const NfcStreamState &s, c
 
       case NFC_FK_V_POLL:
       {
-         const float s0 = f.s0[0] / (float)rt.p2; /* (c2 - sum) / p2 */
-         return t >= m.winStart && ((s0 > m.thr && s0 > m.peak) || t == m.winEnd);
+         const float q = s0 / (float)rt.p2; /* (c2 - sum) / p2 */
+         return t >= m.winStart && ((q > m.thr && q > m.peak) || t == m.winEnd);
       }
 
       case NFC_FK_V_START:
       {
-         const float s0 = f.s0[0]; /* c2 - sum */
          if (t < d.guardEnd)
             return false;
-         if (t == d.guardEnd || t > d.waitingEnd || tile.depth > c.maxDepth[3])
+         if (t == d.guardEnd || t > d.waitingEnd || depth > c.maxDepth[3])
             return true;
          return t >= m.winStart && ((s0 < -m.thr && s0 < m.peak) || (s0 > m.thr && s0 > m.peak) || t == m.winEnd);
       }
@@ -454,10 +437,10 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, const NfcStreamState &s, c
 }
 
 /* the product ring entry of this lane's sample is written ahead (a function of the samples alone, read only at
- * older clocks than it is written at: nfc_wave.hpp), then the entry leaving the window is read */
-NFC_DEV float nfc_wave_product(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveFast &f, uint32_t from, float value, uint32_t delay, uint32_t window)
+ * older clocks than it is written at), then the entry leaving the window is read */
+NFC_DEV float nfc_wave_product(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, float value, uint32_t delay, uint32_t window)
 {
-   const uint32_t cur = nfc_wave_clock_of(f) - delay;
+   const uint32_t cur = nfc_wave_clock_of(clock0) - delay;
 
    NFC_WAVE_BARRIER();
    if (NFC_WAVE_LANE() >= from)
@@ -467,14 +450,17 @@ NFC_DEV float nfc_wave_product(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveFast &
    return lds->ring[NFC_R_PROD + ((cur - window) & NFC_PMASK)];
 }
 
-NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, const NfcStreamState &s, NFC_WAVE_LDS NfcWaveLds *lds, NfcWaveFast &f, uint32_t from, uint32_t n, uint32_t key)
+NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, uint32_t n, uint32_t key)
 {
    const uint32_t lane = NFC_WAVE_LANE();
-   const uint32_t t = nfc_wave_clock_of(f);
+   const uint32_t t = nfc_wave_clock_of(clock0);
+   const NfcStreamState &s = NFC_WAVE_STATE(lds);
    const NfcDecodeRegs &d = s.u.decode;
-   const NfcMod &m = d.lock;
-   const NfcRate &rt = d.rt;
+   const NfcRate rt = d.rt;
    const uint32_t never = s.clock - 0x40000000u;
+   const uint32_t lockBase = d.lockBase, lockPos = d.lockPos, guardEnd = d.guardEnd;
+   const float acc = d.lock.acc, phaseAcc = d.lock.phaseAcc;
+   const uint32_t posV0 = s.posV0, posV1 = s.posV1;
 
    switch (key)
    {
@@ -484,20 +470,20 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, const NfcStreamState &s,
       {
          /* NFC-F listen frames: the box sum runs from the end of the poll frame, the ring only from one symbol before the
           * guard ends (nfcf_listen_start) */
-         const uint32_t writeFrom = key == NFC_FK_F_START ? d.guardEnd - rt.p1 : never;
-         const NfcWaveRaw v = nfc_wave_raw(lds, 0u, f, from, m.acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, d.lockBase, d.lockPos, false, writeFrom);
-         f.c[0] = v.c;
-         f.s0[0] = v.c - v.c2;
-         f.s1[0] = v.c2 - v.c3;
+         const uint32_t writeFrom = key == NFC_FK_F_START ? guardEnd - rt.p1 : never;
+         float c2, c3;
+         const float sum = nfc_wave_raw(lds, 0u, clock0, from, acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, lockBase, lockPos, false, writeFrom, c2, c3);
+         lds->s0[0][lane] = sum - c2;
+         lds->s1[0][lane] = c2 - c3;
          break;
       }
 
       case NFC_FK_V_POLL:
       {
-         const NfcWaveRaw v = nfc_wave_raw(lds, 0u, f, from, m.acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, d.lockBase, s.posV1, false, never);
-         f.c[0] = v.c;
-         f.s0[0] = v.c2 - v.c;
-         f.s1[0] = 0.0f;
+         float c2, c3;
+         const float sum = nfc_wave_raw(lds, 0u, clock0, from, acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, lockBase, posV1, false, never, c2, c3);
+         lds->s0[0][lane] = c2 - sum;
+         lds->s1[0][lane] = 0.0f;
          break;
       }
 
@@ -509,33 +495,35 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, const NfcStreamState &s,
          const bool v15693 = key == NFC_FK_V_START || key == NFC_FK_V_SYMBOL;
          const uint32_t window = v15693 ? rt.p1 : rt.p2;
          const uint32_t period = v15693 ? rt.p0 : rt.p1;
-         const uint32_t pos = v15693 ? s.posV0 : d.lockPos;
+         const uint32_t pos = v15693 ? posV0 : lockPos;
          const uint32_t shift = period - window; /* NFC-V: the entry one symbol half back in the two-symbol ring */
 
          const float v = lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_HMASK)];
          const float sq = v * v * 10.0f;
-         const float old = nfc_wave_product(lds, f, from, sq, rt.delay, window);
-         const float sum = nfc_wave_walk(lds, f, from, n, m.acc, sq, old, never);
+         const float old = nfc_wave_product(lds, clock0, from, sq, rt.delay, window);
 
-         const uint32_t k = lane - from;
+         nfc_wave_walk(lds, clock0, from, n, acc, sq, old, never);
+
+         const float sum = lds->sum[0][lane];
          const bool active = lane >= from;
-         const uint32_t posj = nfc_wave_mod(pos + 1u + k, period);
-         const float c2Ring = lds->ring[NFC_R_CORR + d.lockBase + nfc_wave_mod(posj + period - shift, period)];
-         const float c2 = (active && k >= shift) ? lds->sum[0][active && k >= shift ? lane - shift : lane] : c2Ring;
-         const float c3Ring = lds->ring[NFC_R_CORR + d.lockBase + nfc_wave_mod(posj + period - 1u, period)];
-         const float c3 = (active && k >= 1u) ? lds->sum[0][active && k >= 1u ? lane - 1u : lane] : c3Ring;
-
-         f.c[0] = sum;
+         const uint32_t k = lane - from;
+         const uint32_t posj = nfc_wave_wrap3(pos + 1u + (active ? k : 0u), period);
+         const bool c2Here = active && k >= shift;
+         const float c2Ring = lds->ring[NFC_R_CORR + lockBase + nfc_wave_wrap1(posj + period - shift, period)];
+         const float c2 = c2Here ? lds->sum[0][c2Here ? lane - shift : lane] : c2Ring;
+         const bool c3Here = active && k >= 1u;
+         const float c3Ring = lds->ring[NFC_R_CORR + lockBase + nfc_wave_wrap1(posj + period - 1u, period)];
+         const float c3 = c3Here ? lds->sum[0][c3Here ? lane - 1u : lane] : c3Ring;
 
          if (v15693)
          {
-            f.s0[0] = c2 - sum;
-            f.s1[0] = 0.0f;
+            lds->s0[0][lane] = c2 - sum;
+            lds->s1[0][lane] = 0.0f;
          }
          else
          {
-            f.s0[0] = sum - c2;
-            f.s1[0] = c2 - c3;
+            lds->s0[0][lane] = sum - c2;
+            lds->s1[0][lane] = c2 - c3;
          }
          break;
       }
@@ -548,17 +536,9 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, const NfcStreamState &s,
          const float a = lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_HMASK)];
          const float b = lds->ring[NFC_R_FILT + ((t - rt.delay - rt.p1) & NFC_HMASK)];
          const float in = a * b * 10.0f;
-         const float out = nfc_wave_product(lds, f, from, in, rt.delay, rt.p4);
+         const float out = nfc_wave_product(lds, clock0, from, in, rt.delay, rt.p4);
          /* NFC-A integrates from the end of the guard time on (nfca_listen_bpsk_start returns before it until then) */
-         f.c[0] = nfc_wave_walk(lds, f, from, n, m.phaseAcc, in, out, key == NFC_FK_A_BPSK_START ? d.guardEnd : never);
-         break;
-      }
-
-      case NFC_FK_B_POLL:
-      {
-         const uint32_t slot = (t - rt.delay) & NFC_HMASK;
-         f.edge[0] = lds->ring[NFC_R_FILT + slot];
-         f.deep[0] = lds->ring[NFC_R_DEPTH + slot];
+         nfc_wave_walk(lds, clock0, from, n, phaseAcc, in, out, key == NFC_FK_A_BPSK_START ? guardEnd : never);
          break;
       }
 
@@ -572,93 +552,89 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, const NfcStreamState &s,
  * `clock != winEnd` exits. Per sample: a correlation above the running maximum (and the stage's threshold) becomes the
  * maximum and marks its time; the synchronisation sample's values are kept. Over a run: the maximum is the largest
  * candidate if that beats the maximum before the run, its time the first sample that reaches it (later equal values do
- * not replace it: the comparison is strict). Results in lds->sum[6][8..15] for the uniform part:
+ * not replace it: the comparison is strict). Results in lds->u.pass[8..15] for the uniform part:
  *   [8] 1 when the maximum moved, [9] the maximum, [10] its clock, [11] s0 there;
  *   [12] 1 when the synchronisation sample was in the run, [13] correlation, [14] s0, [15] s1 there. */
-NFC_DEV void nfc_wave_fold(NFC_WAVE_LDS NfcWaveLds *lds, const NfcStreamState &s, const NfcWaveFast &f, uint32_t key, uint32_t from, uint32_t run)
+NFC_DEV void nfc_wave_fold(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t key, uint32_t from, uint32_t run)
 {
    const uint32_t lane = NFC_WAVE_LANE();
-   const uint32_t t = nfc_wave_clock_of(f);
-   const NfcMod &m = s.u.decode.lock;
-   const NfcRate &rt = s.u.decode.rt;
+   const uint32_t t = nfc_wave_clock_of(clock0);
+   const NfcDecodeRegs &d = NFC_WAVE_STATE(lds).u.decode;
+   const float thr = d.lock.thr, peak = d.lock.peak;
+   const uint32_t winStart = d.lock.winStart, sync = d.lock.sync;
+   const float p2 = (float)d.rt.p2;
+   const float s0 = lds->s0[0][lane], s1 = lds->s1[0][lane];
 
-   const bool in = lane >= from && lane < from + run && t >= m.winStart;
+   const bool in = lane >= from && lane < from + run && t >= winStart;
 
    float sd;
    bool cand;
 
-   if (key == NFC_FK_A_POLL)
+   if (key == NFC_FK_A_POLL || key == NFC_FK_F_DATA)
    {
-      sd = nfc_abs(f.s0[0] - f.s1[0]) / (float)rt.p2;
-      cand = in && sd > m.thr;
+      sd = nfc_abs(s0 - s1) / p2;
+      cand = in && sd > thr;
    }
    else if (key == NFC_FK_A_ASK_SYMBOL)
    {
-      sd = nfc_abs(f.s0[0] - f.s1[0]);
-      cand = in && sd > m.peak; /* (no threshold; NaN: never a candidate) */
-   }
-   else if (key == NFC_FK_F_DATA)
-   {
-      sd = nfc_abs(f.s0[0] - f.s1[0]) / (float)rt.p2;
-      cand = in && sd > m.thr;
+      sd = nfc_abs(s0 - s1);
+      cand = in && sd > peak; /* (no threshold; NaN: never a candidate) */
    }
    else
    {
-      sd = nfc_abs(f.s0[0]);
-      cand = in && sd > m.thr;
+      sd = nfc_abs(s0);
+      cand = in && sd > thr;
    }
 
-   const float top = nfc_wave_max(cand ? sd : -3.0e38f);
-   const bool moved = top > m.peak;
+   const float top = NFC_WAVE_MAX_F(cand ? sd : -3.0e38f);
+   const bool moved = top > peak;
    const uint64_t at = NFC_WAVE_BALLOT(cand && sd == top);
-   const uint64_t atSync = NFC_WAVE_BALLOT(in && t == m.sync);
+   const uint64_t atSync = NFC_WAVE_BALLOT(in && t == sync);
 
    NFC_WAVE_BARRIER();
 
    if (lane == 0)
    {
-      lds->sum[6][8] = (moved && at) ? 1.0f : 0.0f;
-      lds->sum[6][12] = atSync ? 1.0f : 0.0f;
+      lds->u.pass[8] = (moved && at) ? 1.0f : 0.0f;
+      lds->u.pass[12] = atSync ? 1.0f : 0.0f;
    }
 
    if (moved && at && lane == (uint32_t)__builtin_ctzll(at))
    {
-      lds->sum[6][9] = sd;
-      lds->sum[6][10] = __builtin_bit_cast(float, t);
-      lds->sum[6][11] = f.s0[0];
+      lds->u.pass[9] = sd;
+      lds->u.pass[10] = __builtin_bit_cast(float, t);
+      lds->u.pass[11] = s0;
    }
 
    if (atSync && lane == (uint32_t)__builtin_ctzll(atSync))
    {
-      lds->sum[6][13] = sd;
-      lds->sum[6][14] = f.s0[0];
-      lds->sum[6][15] = f.s1[0];
+      lds->u.pass[13] = sd;
+      lds->u.pass[14] = s0;
+      lds->u.pass[15] = s1;
    }
 
    NFC_WAVE_BARRIER();
 }
 
-/* Samples from u.at on (at most up to n) that are committed in bulk; u.at is advanced past them. 0: the sample at u.at
- * has to be stepped. Called by every lane. */
-NFC_DEV uint32_t nfc_wave_fast(const NfcConfig &c, NfcWaveUni &u, const NfcLaneMem &mem, NFC_WAVE_LDS NfcWaveLds *lds, NfcWaveFast &f, const NfcWaveTile &tile,
-                               uint32_t n, bool upkeep, const NfcWaveItem &it)
+/* Commits the samples from lds->u.at on that change nothing but sums and rings (at most up to n) and advances
+ * lds->u.at past them; false: the sample at lds->u.at has to be stepped. Called by every lane. */
+NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t n, bool upkeep)
 {
    const uint32_t lane = NFC_WAVE_LANE();
-   const uint32_t from = u.at;
-   const NfcStreamState &s = u.s;
+   const NfcStreamState &s = NFC_WAVE_STATE(lds);
+   const uint32_t from = NFC_WAVE_UNIFORM_U32(lds->u.at);
+   const uint32_t clock0 = NFC_WAVE_UNIFORM_U32(lds->u.clock0);
 
-   uint32_t key = nfc_wave_stage(c, s, upkeep);
+   uint32_t key = NFC_WAVE_UNIFORM_U32(nfc_wave_stage(s, upkeep));
 
-   if (key == NFC_FK_NONE)
-   {
-      f.key = NFC_FK_NONE;
-      return 0u;
-   }
+   NFC_WAVE_COUNT(40u, 0u, 1u); /* calls */
 
-   const uint32_t t = nfc_wave_clock_of(f);
+   const uint32_t t = nfc_wave_clock_of(clock0);
+   const float env = lds->env[lane];
+   const float avg = lds->avg[lane];
 
    /* search: the bank is only stepped on armed samples (nfc_search_detect); a run is all armed or all unarmed */
-   const bool armed = t >= 1024u && !(tile.env < c.powerThreshold);
+   const bool armed = t >= 1024u && !(env < c.powerThreshold);
 
    if (key == NFC_FK_SEARCH)
    {
@@ -667,70 +643,89 @@ NFC_DEV uint32_t nfc_wave_fast(const NfcConfig &c, NfcWaveUni &u, const NfcLaneM
          key = NFC_FK_UNARMED;
    }
 
-   /* the raw box sums are only order-independent on the grid */
+   /* the raw box sums are only order-independent on the grid, and while they stay far inside the range in which
+    * multiples of 2^-15 are exact */
    const bool raw = key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP || key == NFC_FK_A_POLL || key == NFC_FK_F_DATA || key == NFC_FK_F_START || key == NFC_FK_V_POLL;
-
-   if (raw && (!f.gridValid || (uint32_t)(f.clock0 + 1u - f.gridSince) < NFC_FAST_GRID_BACK))
-   {
-      f.key = NFC_FK_NONE; /* (stepping goes on without the values being kept up) */
-      return 0u;
-   }
+   bool take = key != NFC_FK_NONE;
 
    if (raw)
    {
-      /* the running sums stay far inside the range in which multiples of 2^-15 are exact */
-      bool small;
-
-      if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
+      if ((uint32_t)(clock0 + 1u - lds->u.gridSince) < NFC_FAST_GRID_BACK)
+         take = false;
+      else if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
       {
          const NfcSearchRegs &r = s.u.search;
-         small = nfc_abs(r.detA[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[2].acc) <= NFC_FAST_SUM_LIMIT &&
-                 nfc_abs(r.detF[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detF[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detV.acc) <= NFC_FAST_SUM_LIMIT;
+         take = nfc_abs(r.detA[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[2].acc) <= NFC_FAST_SUM_LIMIT &&
+                nfc_abs(r.detF[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detF[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detV.acc) <= NFC_FAST_SUM_LIMIT;
       }
       else
-         small = nfc_abs(s.u.decode.lock.acc) <= NFC_FAST_SUM_LIMIT;
+         take = nfc_abs(s.u.decode.lock.acc) <= NFC_FAST_SUM_LIMIT;
+   }
 
-      if (!small)
+   if (!take)
+   {
+      /* stepping goes on without the values being kept up */
+      NFC_WAVE_UNIFORM_BEGIN
       {
-         f.key = NFC_FK_NONE;
-         return 0u;
+         lds->u.key = NFC_FK_NONE;
       }
+      NFC_WAVE_UNIFORM_END
+      return false;
    }
 
    /* ---- values (kept while the stage lasts) ---- */
-   if (f.key != key || from < f.from)
+   if (NFC_WAVE_UNIFORM_U32(lds->u.key) != key || from < NFC_WAVE_UNIFORM_U32(lds->u.from))
    {
       if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
-         nfc_wave_search_values(c, s, lds, f, from);
-      else if (key != NFC_FK_UNARMED)
-         nfc_wave_locked_values(c, s, lds, f, from, n, key);
+      {
+         NFC_WAVE_COUNT(41u, 0u, 1u); /* search values formed */
+         nfc_wave_search_values(c, lds, clock0, from);
+      }
+      else if (key != NFC_FK_UNARMED && key != NFC_FK_B_POLL)
+      {
+         NFC_WAVE_COUNT(42u, 0u, 1u); /* locked values formed */
+         nfc_wave_locked_values(c, lds, clock0, from, n, key);
+      }
 
-      f.key = key;
-      f.from = from;
+      NFC_WAVE_BARRIER();
+      NFC_WAVE_UNIFORM_BEGIN
+      {
+         lds->u.key = key;
+         lds->u.from = from;
+      }
+      NFC_WAVE_UNIFORM_END
    }
 
    /* ---- gate ---- */
    bool gate;
+   uint32_t which = 0;
 
    /* a carrier frame is due (NfcDecoder.cpp:472-523: search mode only) */
-   const bool carrier = (tile.avg > c.highThreshold) ? !s.carrierOn : ((tile.avg < c.lowThreshold) && !s.carrierOff);
-
-   uint32_t which = 0;
+   const bool carrier = (avg > c.highThreshold) ? !s.carrierOn : ((avg < c.lowThreshold) && !s.carrierOff);
 
    if (key == NFC_FK_SEARCH)
    {
-      which = nfc_wave_search_gate(c, s, f, tile);
-      gate = !armed || carrier || which != 0u;
+      which = nfc_wave_search_gate(c, lds, clock0);
+      gate = !armed || carrier || (which & 0xFFu) != 0u;
    }
    else if (key == NFC_FK_UNARMED)
       gate = armed || carrier;
    else if (key == NFC_FK_UPKEEP)
       gate = false;
    else
-      gate = nfc_wave_locked_gate(c, s, f, tile, key);
+      gate = nfc_wave_locked_gate(c, lds, clock0, key);
 
    const uint64_t gated = NFC_WAVE_BALLOT(gate && lane >= from && lane < n) >> from;
    const uint32_t run = gated ? (uint32_t)__builtin_ctzll(gated) : n - from;
+
+   /* kept for the caller: the sample after a stepped one is stepped too when it was gated here */
+   NFC_WAVE_UNIFORM_BEGIN
+   {
+      lds->u.gatedLo = (uint32_t)gated;
+      lds->u.gatedHi = (uint32_t)(gated >> 32);
+      lds->u.gatedFrom = from;
+   }
+   NFC_WAVE_UNIFORM_END
 
    if (run == 0u)
    {
@@ -740,12 +735,13 @@ NFC_DEV uint32_t nfc_wave_fast(const NfcConfig &c, NfcWaveUni &u, const NfcLaneM
             if ((which >> b) & 1u)
                NFC_WAVE_COUNT_DETECTORS(b);
 #endif
-      return 0u;
+      (void)which;
+      return false;
    }
 
    NFC_WAVE_COUNT(key, 0u, run);
 
-   /* ---- commit: ring entries by the lanes of the run, the state by everybody ---- */
+   /* ---- commit: ring entries by the lanes of the run, then the state ---- */
    const uint32_t last = from + run - 1u;
    const uint32_t never = s.clock - 0x40000000u;
 
@@ -756,104 +752,108 @@ NFC_DEV uint32_t nfc_wave_fast(const NfcConfig &c, NfcWaveUni &u, const NfcLaneM
       const bool all = key == NFC_FK_UPKEEP; /* the warm-up keeps every correlator up (nfc_step_upkeep) */
 
       if (all || (c.enabled & 1u))
-         for (int i = 0; i < 3; i++)
-            nfc_wave_raw_commit(lds, f, from, run, f.c[i], c.a[i].p1, c.corrOffset[i], s.posA[i], never);
+      {
+         nfc_wave_ring_commit(lds, 0u, clock0, from, run, c.a[0].p1, c.corrOffset[0], s.posA[0], never);
+         nfc_wave_ring_commit(lds, 1u, clock0, from, run, c.a[1].p1, c.corrOffset[1], s.posA[1], never);
+         nfc_wave_ring_commit(lds, 2u, clock0, from, run, c.a[2].p1, c.corrOffset[2], s.posA[2], never);
+      }
 
       if (all || (c.enabled & 4u))
-         for (int i = 0; i < 2; i++)
-            nfc_wave_raw_commit(lds, f, from, run, f.c[3 + i], c.f[i + 1].p1, c.corrOffset[3 + i], s.posF[i], never);
+      {
+         nfc_wave_ring_commit(lds, 3u, clock0, from, run, c.f[1].p1, c.corrOffset[3], s.posF[0], never);
+         nfc_wave_ring_commit(lds, 4u, clock0, from, run, c.f[2].p1, c.corrOffset[4], s.posF[1], never);
+      }
 
       if (all || (c.enabled & 8u))
-         nfc_wave_raw_commit(lds, f, from, run, f.c[5], c.v.p1, c.corrOffset[5], s.posV1, never);
+         nfc_wave_ring_commit(lds, 5u, clock0, from, run, c.v.p1, c.corrOffset[5], s.posV1, never);
    }
-   else if (key == NFC_FK_A_POLL || key == NFC_FK_F_DATA || key == NFC_FK_F_START)
-      nfc_wave_raw_commit(lds, f, from, run, f.c[0], s.u.decode.rt.p1, s.u.decode.lockBase, s.u.decode.lockPos, key == NFC_FK_F_START ? s.u.decode.guardEnd - s.u.decode.rt.p1 : never);
+   else if (key == NFC_FK_A_POLL || key == NFC_FK_F_DATA || key == NFC_FK_F_START || key == NFC_FK_A_ASK_START || key == NFC_FK_A_ASK_SYMBOL)
+      nfc_wave_ring_commit(lds, 0u, clock0, from, run, s.u.decode.rt.p1, s.u.decode.lockBase, s.u.decode.lockPos,
+                           key == NFC_FK_F_START ? s.u.decode.guardEnd - s.u.decode.rt.p1 : never);
    else if (key == NFC_FK_V_POLL)
-      nfc_wave_raw_commit(lds, f, from, run, f.c[0], s.u.decode.rt.p1, s.u.decode.lockBase, s.posV1, never);
-   else if (key == NFC_FK_A_ASK_START || key == NFC_FK_A_ASK_SYMBOL)
-      nfc_wave_raw_commit(lds, f, from, run, f.c[0], s.u.decode.rt.p1, s.u.decode.lockBase, s.u.decode.lockPos, never);
+      nfc_wave_ring_commit(lds, 0u, clock0, from, run, s.u.decode.rt.p1, s.u.decode.lockBase, s.posV1, never);
    else if (key == NFC_FK_V_START || key == NFC_FK_V_SYMBOL)
-      nfc_wave_raw_commit(lds, f, from, run, f.c[0], s.u.decode.rt.p0, s.u.decode.lockBase, s.posV0, never);
+      nfc_wave_ring_commit(lds, 0u, clock0, from, run, s.u.decode.rt.p0, s.u.decode.lockBase, s.posV0, never);
 
    const bool gathers = key == NFC_FK_A_POLL || key == NFC_FK_A_ASK_SYMBOL || key == NFC_FK_F_DATA || key == NFC_FK_V_SYMBOL;
 
-   if (gathers)
-      nfc_wave_fold(lds, s, f, key, from, run);
-
-   /* the sums after the last sample of the run, for everybody */
-   NFC_WAVE_BARRIER();
-   if (lane == last)
+   /* NFC-F detectors asked to reset (a clear record) somewhere in the run: the mark nfcf_detect_rate leaves */
+   uint32_t marks = 0;
+   if (key == NFC_FK_SEARCH)
    {
-      for (int i = 0; i < 6; i++)
-         lds->sum[6][i] = f.c[i];
+      const bool mine = lane >= from && lane <= last;
+      marks = (NFC_WAVE_BALLOT(mine && (which & 256u)) ? 1u << 16 : 0u) | (NFC_WAVE_BALLOT(mine && (which & 512u)) ? 1u << 17 : 0u);
    }
+
+   if (gathers)
+      nfc_wave_fold(lds, clock0, key, from, run);
+
    NFC_WAVE_BARRIER();
 
-   NFC_WAVE_UNIFORM_BEGIN(u)
+   NFC_WAVE_UNIFORM_BEGIN
    {
-      NfcStreamState &w = u.s;
+      NFC_WAVE_LDS NfcStreamState &w = lds->u.s;
       const uint32_t firstClock = w.clock + 1u;
+
+      lds->flags |= marks;
 
       if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
       {
          const bool all = key == NFC_FK_UPKEEP;
-         NfcSearchRegs &r = w.u.search;
 
          if (all || (c.enabled & 1u))
          {
-            r.detA[0].acc = lds->sum[6][0];
-            r.detA[1].acc = lds->sum[6][1];
-            r.detA[2].acc = lds->sum[6][2];
+            w.u.search.detA[0].acc = lds->sum[0][last];
+            w.u.search.detA[1].acc = lds->sum[1][last];
+            w.u.search.detA[2].acc = lds->sum[2][last];
          }
          if (all || (c.enabled & 4u))
          {
-            r.detF[0].acc = lds->sum[6][3];
-            r.detF[1].acc = lds->sum[6][4];
+            w.u.search.detF[0].acc = lds->sum[3][last];
+            w.u.search.detF[1].acc = lds->sum[4][last];
          }
          if (all || (c.enabled & 8u))
-            r.detV.acc = lds->sum[6][5];
+            w.u.search.detV.acc = lds->sum[5][last];
 
          /* the bank has stepped on every sample of the run (nfc_search_detect / nfc_step_upkeep) */
          if (w.bankClock != firstClock - 1u)
-            mem.cold->bankRun = firstClock;
+            lds->cold.bankRun = firstClock;
          w.bankClock = w.clock + run;
       }
       else if (key == NFC_FK_A_BPSK_START || key == NFC_FK_A_BPSK_SYMBOL || key == NFC_FK_B_START || key == NFC_FK_B_SYMBOL)
-         w.u.decode.lock.phaseAcc = lds->sum[6][0];
+         w.u.decode.lock.phaseAcc = lds->sum[0][last];
       else if (key != NFC_FK_UNARMED && key != NFC_FK_B_POLL)
-         w.u.decode.lock.acc = lds->sum[6][0];
+         w.u.decode.lock.acc = lds->sum[0][last];
 
       if (gathers)
       {
-         NfcMod &m = w.u.decode.lock;
-
-         if (lds->sum[6][8] != 0.0f)
+         if (lds->u.pass[8] != 0.0f)
          {
-            const uint32_t when = __builtin_bit_cast(uint32_t, lds->sum[6][10]);
-            m.peak = lds->sum[6][9];
+            const uint32_t when = __builtin_bit_cast(uint32_t, (float)lds->u.pass[10]);
+            w.u.decode.lock.peak = lds->u.pass[9];
 
             if (key == NFC_FK_V_SYMBOL)
             {
                /* nfcv_listen_symbol keeps the correlation's sign and the sample */
-               m.c0 = lds->sum[6][11];
-               m.c1 = -lds->sum[6][11];
-               m.symEnd = when;
+               w.u.decode.lock.c0 = lds->u.pass[11];
+               w.u.decode.lock.c1 = -lds->u.pass[11];
+               w.u.decode.lock.symEnd = when;
             }
             else
-               m.peakTime = when;
+               w.u.decode.lock.peakTime = when;
          }
 
-         if (lds->sum[6][12] != 0.0f && key != NFC_FK_V_SYMBOL)
+         if (lds->u.pass[12] != 0.0f && key != NFC_FK_V_SYMBOL)
          {
             if (key != NFC_FK_F_DATA)
-               m.cD = lds->sum[6][13];
-            m.c0 = lds->sum[6][14];
-            m.c1 = lds->sum[6][15];
+               w.u.decode.lock.cD = lds->u.pass[13];
+            w.u.decode.lock.c0 = lds->u.pass[14];
+            w.u.decode.lock.c1 = lds->u.pass[15];
          }
       }
 
       if (w.lockTech)
-         w.u.decode.lockPos = (w.u.decode.lockPos + run) % w.u.decode.rt.p1;
+         w.u.decode.lockPos = nfc_wave_wrap3(w.u.decode.lockPos + run, w.u.decode.rt.p1);
 
       nfc_wave_advance(c, w, run);
       w.clock += run;
@@ -861,11 +861,11 @@ NFC_DEV uint32_t nfc_wave_fast(const NfcConfig &c, NfcWaveUni &u, const NfcLaneM
       w.avg = lds->avg[last];
       w.mdev = lds->ring[NFC_R_MDEV + (w.clock & NFC_HMASK)];
 
-      u.at += run;
+      lds->u.at = from + run;
    }
-   NFC_WAVE_UNIFORM_END(u)
+   NFC_WAVE_UNIFORM_END
 
-   return run;
+   return true;
 }
 
 #endif

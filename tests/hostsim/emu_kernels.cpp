@@ -53,6 +53,16 @@ static void emu_chain_trace(uint32_t lane, const NfcCarry &assumed, const NfcCar
    std::fprintf(stderr, "\n");
 }
 #define NFC_CHAIN_TRACE(lane, a, b, c) emu_chain_trace((lane), (a), (b), (c))
+static void emu_seam_debug(uint32_t k, const NfcScanPoint &start, const NfcScanPoint &end, uint32_t edge)
+{
+   if (!std::getenv("NFC_EMU_SEAM_DEBUG"))
+      return;
+   std::fprintf(stderr, "[emu seam] chunk %u:%s%s%s%s%s%s%s%s | env %.7g vs %.7g  pf %u vs %u\n", k, start.env != end.env ? " env" : "", start.n1 != end.n1 ? " n1" : "",
+                start.mdev != end.mdev ? " mdev" : "", start.avg != end.avg ? " avg" : "", start.edgePeak != end.edgePeak ? " edgePeak" : "",
+                start.pulseFilter != end.pulseFilter ? " pulseFilter" : "", ((start.zone ^ end.zone) & 0xFFu) ? " zone" : "",
+                ((start.zone & 0x100u) && start.edgeTime != edge) ? " edgeTime" : "", start.env, end.env, start.pulseFilter, end.pulseFilter);
+}
+#define NFC_SEAM_DEBUG(k, a, b, e) emu_seam_debug((k), (a), (b), (e))
 static void emu_carry_debug(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked);
 #define NFC_CARRY_DEBUG(a, b, m, t) emu_carry_debug((a), (b), (m), (t))
 #include "../../nfc-laboratory_amd/csrc/nfc_scan.hpp"
@@ -528,8 +538,9 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
       NfcScanSeam seam;
       std::memset(&seam, 0, sizeof(seam));
       bool begun = false;
+      bool merged = false;
 
-      for (uint32_t sp = walkFrom; sp < end; sp++)
+      for (uint32_t sp = walkFrom; sp < end && !merged; sp++)
       {
          const float x = sample_of(job->data, A.stride, sp);
 
@@ -556,7 +567,30 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
             nfc_scan_point(w, seam.start);
 
          if (sp >= start && (sp % NFC_SCAN_POINT) == 0)
-            nfc_scan_point(w, A.points[job->firstPoint + sp / NFC_SCAN_POINT]);
+         {
+            NfcScanPoint &stored = A.points[job->firstPoint + sp / NFC_SCAN_POINT];
+
+            /* a second walk that has met the first one's trajectory ends here (nfc_scan_kernel does the same) */
+            if (repair && sp > start)
+            {
+               NfcScanPoint here;
+               nfc_scan_point(w, here);
+
+               if (nfc_scan_merged(here, stored))
+               {
+                  const uint32_t atMerge = stored.edgeTime;
+                  for (uint32_t q = sp + NFC_SCAN_POINT; q < end; q += NFC_SCAN_POINT)
+                     nfc_scan_adopt(A.points[job->firstPoint + q / NFC_SCAN_POINT], atMerge, w.fe.edgeTime);
+                  seam.end = A.seams[g].end;
+                  nfc_scan_adopt(seam.end, atMerge, w.fe.edgeTime);
+                  stored = here;
+                  merged = true;
+                  break;
+               }
+            }
+
+            nfc_scan_point(w, stored);
+         }
 
          nfc_scan_sample(*cfgPtr, w, x);
 
@@ -571,7 +605,7 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
          }
       }
 
-      if (begun)
+      if (begun && !merged)
          nfc_scan_point(w, seam.end);
       if (repair)
          seam.start = A.seams[g].start;

@@ -40,27 +40,54 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 #define NFC_WAVE_LANE() (wavesim::lane())
 #define NFC_WAVE_BARRIER() wavesim::barrier()
 #define NFC_WAVE_BALLOT(p) wavesim::ballot(p)
-#define NFC_WAVE_SHFL_XOR_F(v, d) wavesim::shfl((v), wavesim::lane() ^ (d))
-#define NFC_WAVE_SHFL_UP_F(v, d) wavesim::shfl((v), wavesim::lane() >= (d) ? wavesim::lane() - (d) : wavesim::lane())
-#define NFC_WAVE_UNIFORM_BEGIN(u) if (wavesim::lane() == 0) {
-#define NFC_WAVE_UNIFORM_END(u) } wavesim::uniform_sync(u);
+#define NFC_WAVE_UNIFORM_BEGIN if (wavesim::lane() == 0) {
+#define NFC_WAVE_UNIFORM_END } wavesim::barrier();
+#define NFC_WAVE_UNIFORM_U32(x) ((uint32_t)(x))
+#define NFC_WAVE_PICK_F(reg, array, j) ((array)[(j)])
+#define NFC_WAVE_CONFIG(cfgPtr, cc) ((cc) = *(cfgPtr))
+#define NFC_WAVE_NOINLINE static __attribute__((noinline))
 #define NFC_WAVE_STAT_ADD(p, v) (*(p) += (v))
 #define NFC_WAVE_STAT_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
+
+static inline float emu_scan_add(float v)
+{
+   const uint32_t lane = wavesim::lane();
+   for (uint32_t d = 1; d < 64; d <<= 1)
+   {
+      const float t = wavesim::shfl(v, lane >= d ? lane - d : lane);
+      if (lane >= d)
+         v += t;
+   }
+   return v;
+}
+
+static inline float emu_max(float v)
+{
+   for (uint32_t d = 1; d < 64; d <<= 1)
+   {
+      const float t = wavesim::shfl(v, wavesim::lane() ^ d);
+      v = t > v ? t : v;
+   }
+   return v;
+}
+
+#define NFC_WAVE_SCAN_ADD_F(v) emu_scan_add(v)
+#define NFC_WAVE_MAX_F(v) emu_max(v)
 
 /* NFC_EMU_WAVE_VERIFY=1: every tile is decoded twice - with the bulk paths and sample by sample - and everything the two
  * leave behind (decoder state, rings, protocol state, frame bytes) is compared bit for bit */
 #include "../../nfc-laboratory_amd/csrc/nfc_scan_launch.h"
 struct NfcWaveLds;
-struct NfcWaveUni;
-struct NfcWaveFast;
 struct NfcWaveItem;
-static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcLaneMem &mem, NfcWaveUni &u, NfcWaveFast &fast,
+struct NfcWaveSink;
+static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcWaveSink &sink,
                             uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride);
 #define NFC_WAVE_TILE_HOOK emu_verify_tile
 
 extern uint64_t emu_wave_counts[64][2];
 static bool emu_counting = true;
-#define NFC_WAVE_COUNT_DETECTORS(b) (emu_wave_counts[32 + (b)][0]++)
+static uint32_t emu_trace_clock;
+#define NFC_WAVE_COUNT_DETECTORS(b) do { emu_wave_counts[32 + (b)][0]++; if (std::getenv("NFC_EMU_TRACE_SEARCH")) std::fprintf(stderr, "[trace] %u %u\n", clock0 + 1u + from, (unsigned)(b)); } while (0)
 #define NFC_WAVE_COUNT(key, which, count) do { if (wavesim::lane() == 0 && emu_counting) emu_wave_counts[(key) & 63u][(which)] += (count); } while (0)
 
 #include "../../nfc-laboratory_amd/csrc/nfc_wave.hpp"
@@ -91,6 +118,8 @@ struct CountPrinter
       for (uint32_t k = 0; k < 8; k++)
          if (emu_wave_counts[32 + k][0])
             std::fprintf(stderr, "[emu wave] search stepped for %-5s %10llu\n", det[k], (unsigned long long)emu_wave_counts[32 + k][0]);
+      std::fprintf(stderr, "[emu wave] bulk-path calls %llu, search values formed %llu, locked values formed %llu, tiles %llu\n", (unsigned long long)emu_wave_counts[40][0],
+                   (unsigned long long)emu_wave_counts[41][0], (unsigned long long)emu_wave_counts[42][0], (unsigned long long)emu_wave_counts[43][0]);
       for (uint32_t k = 0; k < 17; k++)
          if (emu_wave_counts[k][0] | emu_wave_counts[k][1])
             std::fprintf(stderr, "[emu wave] %-14s bulk %12llu stepped %10llu\n", names[k], (unsigned long long)emu_wave_counts[k][0],
@@ -99,41 +128,37 @@ struct CountPrinter
 } countPrinter;
 }
 
-static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcLaneMem &mem, NfcWaveUni &u, NfcWaveFast &fast,
+static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcWaveSink &sink,
                             uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride)
 {
    const int mode = emu_verify_mode();
 
    if (mode == 2)
    {
-      nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, false); /* no bulk paths at all */
+      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, false); /* no bulk paths at all */
       return;
    }
 
    if (mode != 1)
    {
-      nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, true);
+      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, true);
       return;
    }
 
    /* shared by the 64 fibres of the wave (they run one after the other) */
    static NfcWaveLds savedLds, fastLds;
    static uint32_t dummySink[4096], dummyCtl[2];
-
-   const NfcWaveUni savedU = u;
-   const NfcWaveFast savedFast = fast;
+   static uint32_t keyBefore;
 
    wavesim::barrier();
    if (wavesim::lane() == 0)
+   {
       savedLds = *lds;
+      keyBefore = nfc_wave_stage(lds->u.s, lds->u.consumed < warm);
+   }
    wavesim::barrier();
 
-   const uint32_t keyBefore = nfc_wave_stage(cc, u.s, u.consumed < warm);
-
-   nfc_wave_tile(cc, A, it, lds, mem, u, fast, n, pos, carry, warmFront, warm, stride, true);
-
-   const NfcWaveUni fastU = u;
-   const NfcWaveFast fastF = fast;
+   nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, true);
 
    wavesim::barrier();
    if (wavesim::lane() == 0)
@@ -146,17 +171,13 @@ static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const Nfc
    wavesim::barrier();
 
    /* again, sample by sample, frames into a dummy sink */
-   u = savedU;
-   fast = savedFast;
-
-   NfcLaneMem quiet = mem;
-   quiet.sink = dummySink;
-   quiet.sinkCursor = dummyCtl;
-   quiet.sinkDropped = dummyCtl + 1;
-   quiet.sinkWords = 4096;
+   NfcWaveSink quiet = sink;
+   quiet.words = dummySink;
+   quiet.ctl = dummyCtl;
+   quiet.capacity = 4096;
 
    emu_counting = false;
-   nfc_wave_tile(cc, A, it, lds, quiet, u, fast, n, pos, carry, warmFront, warm, stride, false);
+   nfc_wave_tile(cfgPtr, cc, A, it, lds, quiet, n, pos, carry, warmFront, warm, stride, false);
    wavesim::barrier();
    emu_counting = true;
 
@@ -164,15 +185,14 @@ static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const Nfc
 
    if (wavesim::lane() == 0)
    {
-      NfcWaveUni a = fastU, b = u;
-      a.stepped = b.stepped = 0;
-
       /* the frame records are chained by their place in the sink */
       NfcStreamCold ca = fastLds.cold, cb = lds->cold;
       ca.frameHead = cb.frameHead = 0;
       ca.frameTail = cb.frameTail = 0;
 
-      const bool same = std::memcmp(&a, &b, sizeof(a)) == 0 && std::memcmp(&ca, &cb, sizeof(ca)) == 0 &&
+      const NfcStreamState &a = fastLds.u.s, &b = lds->u.s;
+
+      const bool same = std::memcmp(&a, &b, sizeof(a)) == 0 && fastLds.u.at == lds->u.at && std::memcmp(&ca, &cb, sizeof(ca)) == 0 &&
                         std::memcmp(fastLds.ring, lds->ring, sizeof(float) * 4u * NFC_HIST) == 0 &&
                         std::memcmp(fastLds.ring + NFC_R_CORR, lds->ring + NFC_R_CORR, sizeof(float) * NFC_CORR_MAX) == 0 &&
                         std::memcmp(fastLds.bytes, lds->bytes, NFC_STREAM_BYTES) == 0 && fastLds.flags == lds->flags;
@@ -180,8 +200,8 @@ static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const Nfc
       if (!same)
       {
          std::fprintf(stderr, "[emu wave verify] tile at stream position %u (clock %u..), lane slot %u, stage key before %u: bulk and stepped results differ\n", pos,
-                      savedU.s.clock + 1u, it.w, keyBefore);
-         const uint32_t *pa = (const uint32_t *)&a.s, *pb = (const uint32_t *)&b.s;
+                      savedLds.u.s.clock + 1u, it.w, keyBefore);
+         const uint32_t *pa = (const uint32_t *)&a, *pb = (const uint32_t *)&b;
          for (uint32_t i = 0; i < sizeof(NfcStreamState) / 4; i++)
             if (pa[i] != pb[i])
                std::fprintf(stderr, "   state word %u: bulk %08x stepped %08x\n", i, pa[i], pb[i]);
@@ -198,13 +218,12 @@ static void emu_verify_tile(const NfcConfig &cc, const NfcScanArgs &A, const Nfc
       }
 
       /* go on from the first run (its frames are the ones in the sink) */
+      const uint32_t stepped = fastLds.u.stepped;
       *lds = fastLds;
+      lds->u.stepped = stepped;
    }
 
    wavesim::barrier();
-
-   u = fastU;
-   fast = fastF;
 }
 
 namespace {
