@@ -1,22 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — IQ Msamples/s demodulated on MI355X (BASELINE.json metric), one process per GPU.
 
-Headline (the timed K steps, unchanged since round 1 so that rounds compare): a "step" is one pass of the demodulation
-hot path over one 8192-sample buffer of every stream of this rank (131072 streams of the fixture-derived set S1 per GPU,
-IQ resident in HBM, BASELINE config 5 shape at the stream count that saturates the per-stream sequential kernel). Streams
-are independent: sharded by rank, weak scaling, no data-path collective; the decoded frames are gathered at the end of the
-timed region (through the C ABI: ncclAllGather over RCCL when N > 1, D2H when N == 1).
+Headline = BASELINE config 5 as SURVEY 8(d) writes it: 4096 independent 10 MS/s streams of the fixture-derived set S1
+(dense traffic: the bundled captures tiled end to end, float2 IQ resident in HBM), all four decoders enabled, 2^20 samples
+per stream and step. A "step" is one submission of all streams of this rank through the C ABI (nfcgpu_submit_uniform):
+scan kernel -> front-end planes -> windows -> wave decoder passes -> chain -> finish, frames into the
+device sink. Streams are independent: with --gpus N the same 4096-stream dataset is cut over the ranks (strong scaling,
+rank r decodes streams [r*4096/N, (r+1)*4096/N), no data-path collective); the decoded frames are gathered at the end of
+the timed region through the C ABI (ncclAllGather over RCCL when N > 1, D2H when N == 1).
 
-At N == 1 the same line also carries BASELINE's own configurations as `points` (outside the timed region, each with its
-own clock): config 5 on one GPU (4096 streams x 2^20 samples) with dense S1 traffic and with sparse traffic (S1q: the
-exchanges of the captures 52 ms apart in quiet carrier, what a monitoring receiver sees most of the time), and one
-10 MS/s stream of 2^26 samples (configs 2-4) with both. Long submissions go through the time-parallel path (scan kernel
--> windows -> windowed decode -> chain) unless the scan finds the stream busy.
+At N == 1 the same line also carries, as `points` (outside the timed region, each with its own context and clock):
+BASELINE configs 2-4 (every bundled capture as one stream), config 5 with sparse and with no traffic, one long stream, the
+share of config 5 one of eight GPUs holds, set S2 (off the capture grid: rotated IQ + noise), the same share fed from host
+memory (H2D included), and the round-1/2 headline (131072 streams x 8192-sample buffers: the sequential kernel's
+saturating point).
 
 Extra objects on the JSON line:
-  roofline         HBM roofline of the dominant kernel of the headline (the sequential demodulation kernel)
+  roofline         HBM roofline of the dominant kernel of the headline (nfc_wave_kernel, all its launches of a step)
   roofline_search  the same for the scan kernel (the per-sample search kernel of the time-parallel path), measured on the
-                   sparse config-5 point
+                   config-5 point without traffic; `on_sparse_traffic`: on the sparse point
   cpu_baseline     the reference's own lab::NfcDecoder (oracle/_ref/libnfcref.so) on this box's host cores on a bounded
                    sample of the headline streams; the same leg checks GPU frames against the reference bit for bit
 """
@@ -73,6 +75,31 @@ def stored_traffic(kernel, streams, samples):
         return None, None
 
 
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of this box, from /proc/cpuinfo"""
+    model, physical, logical = None, set(), 0
+    try:
+        pkg = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model is None:
+                    model = v
+                elif k == "processor":
+                    logical += 1
+                elif k == "physical id":
+                    pkg = v
+                elif k == "core id":
+                    core = v
+                elif not k and pkg is not None and core is not None:
+                    physical.add((pkg, core))
+                    pkg = core = None
+    except Exception:
+        pass
+    return model, (len(physical) or None), (logical or None)
+
+
 def clamp_used(cursor, dropped, capacity):
     """valid words of a held sink: the cursor keeps counting past the capacity on overflow (nfc_emit)"""
     limit = capacity - (9 + 128) + 1
@@ -82,17 +109,21 @@ def clamp_used(cursor, dropped, capacity):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("NFC_BENCH_STREAMS", "131072")), help="streams per GPU (headline)")
-    ap.add_argument("--samples", type=int, default=8192, help="samples per stream per step (headline)")
-    ap.add_argument("--cpu-streams", type=int, default=24576, help="streams of rank 0 replayed on the host CPU")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("NFC_BENCH_STREAMS", "4096")),
+                    help="streams of the headline dataset (BASELINE config 5: 4096); with --scaling strong cut over the ranks, with weak per GPU")
+    ap.add_argument("--samples", type=int, default=1 << 20, help="samples per stream per step (headline)")
+    ap.add_argument("--cpu-streams", type=int, default=256, help="streams of rank 0 replayed on the host CPU")
     ap.add_argument("--check-streams", type=int, default=64, help="streams compared frame-by-frame with the reference")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --streams per GPU (the driver's contract); strong: --streams in total, rank r decodes streams [r*S/N, (r+1)*S/N) of the same dataset")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (BASELINE config 5: one 4096-stream dataset, rank r decodes streams [r*S/N, (r+1)*S/N)); weak: --streams per GPU")
+    ap.add_argument("--allow-torch-gather", action="store_true",
+                    help="N > 1: fall back to torch.distributed's all_gather when the C ABI's RCCL communicator does not come up (an error otherwise)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-points", action="store_true", help="headline only")
-    ap.add_argument("--points", default="fixtures_single,config5_sparse,config5_dense,config5_idle,share_sparse,share_dense,single_sparse,single_dense")
+    ap.add_argument("--points", default="fixtures_single,config5_sparse,config5_idle,share_sparse,share_dense,share_dense_h2d,single_sparse,single_dense,s2_share,saturating")
+    ap.add_argument("--saturating-streams", type=int, default=131072, help="streams of the `saturating` point (8192-sample buffers, sequential kernel)")
     ap.add_argument("--share-streams", type=int, default=512, help="streams one GPU holds when BASELINE's 4096 are spread over 8")
     ap.add_argument("--single-dense-samples", type=int, default=1 << 23)
     ap.add_argument("--config5-streams", type=int, default=4096)
@@ -136,14 +167,14 @@ def main():
 
     S, L, K, W = args.streams, args.samples, args.steps, args.warmup
     if args.scaling == "strong":
-        S = max(64, (args.streams // world) // 64 * 64)  # the same dataset cut over the ranks (whole stream blocks)
+        S = max(1, args.streams // world)  # the same dataset cut over the ranks
     T = (K + W) * L
 
     template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
     template_dev = torch.from_numpy(template.astype(np.int16)).to(dev)
 
     data = torch.empty((S, T, 2), dtype=torch.float32, device=dev)
-    synth.fill_iq_torch(data, template_dev, first_stream=rank * S)
+    synth.fill_iq_torch(data, template_dev, first_stream=rank * S, chunk_streams=max(1, min(1024, (1 << 27) // T)))
     if os.environ.get("NFC_BENCH_IDLE") == "1":
         # diagnostic only (not a benchmark configuration): unmodulated carrier with 2-LSB noise, every lane stays in search mode
         noise = (torch.arange(T, device=dev) * 2654435761 % 5).to(torch.float32) / 32768.0
@@ -183,8 +214,11 @@ def main():
         agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         abi_gather = bool(int(agreed.item()))
+        if not abi_gather and not args.allow_torch_gather:
+            raise SystemExit("bench.py: the frame gather behind the C ABI (nfcgpu_comm_init over RCCL) did not come up on every rank; "
+                             "--allow-torch-gather measures with torch.distributed's all_gather instead")
         if abi_gather:
-            gathered = torch.zeros(world * (8 << 20), dtype=torch.int32, device=dev)
+            gathered = torch.zeros(sink_words, dtype=torch.int32, device=dev)  # room for every rank's records, packed
 
     pitch = T * 8
 
@@ -214,7 +248,8 @@ def main():
     host_used = clamp_used(int(ctl[0].item()), dropped, sink_words)
     if world > 1 and abi_gather:
         counts, stride = gpu.gather_frames(gathered.data_ptr(), gathered.numel())
-        host_words = gathered[rank * stride:rank * stride + host_used].cpu().numpy()
+        mine_at = rank * stride if stride else sum(counts[:rank])  # (packed at exact sizes: stride 0)
+        host_words = gathered[mine_at:mine_at + host_used].cpu().numpy()
         total_words = sum(counts)
     elif world > 1:
         everyone, counts = framelib.gather_sinks(sink, host_used, world)
@@ -237,14 +272,21 @@ def main():
     samples_per_step = S * L * world
     value = samples_per_step * K / elapsed / 1e6
 
-    kernel_ms = st.kernel_ms / max(st.launches, 1)
+    # The dominant kernel of the headline: the wave decoder. A step launches it several times (carry lanes, the windows
+    # of every decode pass, final lanes); `kernel_ms` is the HIP-event time of all its launches of one step, on the
+    # streams they were launched on (nfcgpu_stats::wave_ms; rocprofv3's per-kernel total of the same command agrees:
+    # profiles/r03). Submissions the time-parallel path does not take run the sequential kernel instead.
+    wave_ms = st.wave_ms / K
+    seq_ms = st.kernel_ms / K
+    dominant = "nfc_wave_kernel" if wave_ms >= seq_ms else "nfc_demod_fixed_kernel"
+    kernel_ms = max(wave_ms, seq_ms)
     bytes_per_launch = 8.0 * S * L
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
     # the measured denominator: streaming read of this very buffer with 16-byte loads
     read_peak = gpu.read_bandwidth(data.data_ptr(), min(data.numel() * 4, 32 << 30), repeats=5)
 
-    traffic, traffic_source = stored_traffic("nfc_demod_fixed_kernel", S, L)
+    traffic, traffic_source = stored_traffic(dominant, S, L)
 
     result = {
         "metric": "IQ Msamples/s demodulated",
@@ -260,16 +302,22 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE config 5 shape, saturating point: %d independent 10 MS/s IQ streams per GPU (set S1: fixture-derived "
-                        "synthetic float2 IQ resident in HBM, dense traffic), all four tech decoders (NFC-A/B/F/V) enabled, %d-sample "
-                        "buffers per step (sequential kernel: buffers this short do not take the time-parallel path); BASELINE's own "
-                        "stream counts (config 5 on one GPU: 4096 streams x 2^20; configs 2-4: one stream x 2^26) are in `points`" % (S, L),
+            "workload": "BASELINE config 5: %d independent 10 MS/s IQ streams (set S1: fixture-derived synthetic float2 IQ resident in HBM, "
+                        "dense traffic - the bundled captures tiled end to end), %d per GPU, all four tech decoders (NFC-A/B/F/V) enabled, "
+                        "%d samples per stream and step, one submission per step through the C ABI (time-parallel path: scan -> planes -> "
+                        "windows -> wave decoder passes -> chain -> finish)" % (S * world if args.scaling == "strong" else S, S, L),
+            "streams_total": S * world,
             "streams_per_gpu": S,
             "samples_per_stream_per_step": L,
             "sample_rate": FS,
             "frames_decoded_rank0": None,
-            "parallelism": "stream-parallel x%d (one process per GPU, frames gathered with %s)" % (
-                world, "ncclAllGather behind the C ABI" if abi_gather or world == 1 else "torch.distributed all_gather (the C ABI's RCCL communicator did not come up)"),
+            "parallelism": "stream-parallel x%d (one process per GPU, %s scaling, frames gathered with %s)" % (
+                world, args.scaling, "ncclAllGather behind the C ABI" if abi_gather or world == 1 else "torch.distributed all_gather (the C ABI's RCCL communicator did not come up)"),
+            "time_parallel": {"streams": int(st.windowed_streams), "streams_sequential": int(st.fallback_streams), "lanes": int(st.windows),
+                              "decode_passes": int(st.window_passes), "chunks_rescanned": int(st.scan_repairs), "scan_kernel_ms_per_step": round(st.scan_ms / K, 3),
+                              "planes_kernel_ms_per_step": round(st.planes_ms / K, 3), "windowed_decode_ms_per_step": round(st.window_ms / K, 3),
+                              "wave_kernel_ms_per_step": round(wave_ms, 3), "wave_kernel_launches_per_step": round(st.wave_launches / K, 1),
+                              "sequential_kernel_ms_per_step": round(seq_ms, 3)},
             "git": git_head(),
         },
         "roofline": {
@@ -280,8 +328,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "kernel": "nfc_demod_fixed_kernel",
+            "kernel": dominant,
             "kernel_ms_avg": round(kernel_ms, 4),
+            "kernel_ms_is": "all launches of the kernel in one step (HIP events on the launching streams)",
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "peak_measured_streaming_read": round(read_peak, 1),
             "frac_of_measured_peak": round(achieved / read_peak, 6) if read_peak > 0 else None,
@@ -331,10 +380,14 @@ def main():
                 if frames.get(first + s, []) != fr:
                     bad += 1
 
+            cpu_model, cpu_physical, cpu_logical = host_cpu()
             result["cpu_baseline"] = {
                 "value": round(multi, 3),
                 "unit": "Msamples/s",
                 "cores": cores,
+                "cpu_model": cpu_model,
+                "physical_cores": cpu_physical,
+                "logical_cpus": cpu_logical,
                 "kind": "reference",
                 "sample": "reference lab::NfcDecoder (oracle/_ref, built from /root/reference) on the magnitudes of the first %d "
                           "streams x %d samples (%.1f s), %d-sample buffers, one decoder per stream, %d threads; single thread on %d "
@@ -401,7 +454,7 @@ def main():
         segs = synth.sparse_segments(template)
         points = {}
 
-        def run_point(name, n_streams, n_samples, sparse, steps, warm, check, idle=False):
+        def run_point(name, n_streams, n_samples, sparse, steps, warm, check, idle=False, offgrid=False, from_host=False):
             total = (steps + warm) * n_samples
             buf = torch.empty((n_streams, total, 2), dtype=torch.float32, device=dev)
             if idle:
@@ -421,6 +474,19 @@ def main():
                 synth.fill_sparse_iq_torch(buf, template_dev, segs, first_stream=0, chunk_streams=max(1, min(256, (1 << 27) // total)))
             else:
                 synth.fill_iq_torch(buf, template_dev, first_stream=0, chunk_streams=max(1, min(1024, (1 << 27) // total)))
+            if offgrid:
+                # set S2: the S1 magnitudes on a random per-stream phase plus white noise of sigma 0.002 on both
+                # components, fp32 IQ - what a radio delivers; off the capture grid (running sums no longer order-independent)
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(20260926)
+                for s0 in range(0, n_streams, 64):
+                    s1 = min(n_streams, s0 + 64)
+                    m = torch.sqrt(buf[s0:s1, :, 0] ** 2 + buf[s0:s1, :, 1] ** 2)
+                    phi = torch.rand((s1 - s0, 1), device=dev, generator=gen) * 6.283185307179586
+                    buf[s0:s1, :, 0] = m * torch.cos(phi) + torch.randn(m.shape, device=dev, generator=gen) * 0.002
+                    buf[s0:s1, :, 1] = m * torch.sin(phi) + torch.randn(m.shape, device=dev, generator=gen) * 0.002
+                    del m
+            host = buf.cpu().numpy() if from_host else None  # (the shim's way in: host buffers through the pinned staging of the C ABI)
             psink = torch.zeros(sink_words, dtype=torch.int32, device=dev)
             pctl = torch.zeros(4, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
@@ -429,14 +495,23 @@ def main():
             g.sink_hold(True)
             g.profile(True)
             f0 = g.open(nfclab_amd.default_params(), count=n_streams)
+
+            def submit(k):
+                if from_host:
+                    ids = list(range(f0, f0 + n_streams))
+                    ptrs = [host.ctypes.data + (s * total + k * n_samples) * 8 for s in range(n_streams)]
+                    g.submit_batch(ids, ptrs, [n_samples] * n_streams, FS, stride=2)
+                else:
+                    g.submit_uniform(f0, n_streams, buf.data_ptr() + k * n_samples * 8, total * 8, n_samples, FS, stride=2)
+
             for k in range(warm):
-                g.submit_uniform(f0, n_streams, buf.data_ptr() + k * n_samples * 8, total * 8, n_samples, FS, stride=2)
+                submit(k)
             g.sync()
             torch.cuda.synchronize()
             g.stats_reset()
             ta = time.perf_counter()
             for k in range(warm, warm + steps):
-                g.submit_uniform(f0, n_streams, buf.data_ptr() + k * n_samples * 8, total * 8, n_samples, FS, stride=2)
+                submit(k)
             g.sync()
             torch.cuda.synchronize()
             tb = time.perf_counter()
@@ -445,10 +520,13 @@ def main():
             used = clamp_used(int(pctl[0].item()), pdrop, sink_words)
             pframes = framelib.parse_sink(psink[:used].cpu().numpy(), used, FS)
             point = {
-                "workload": "%d stream(s) x %d samples per step, %s traffic (%s), IQ resident in HBM, all four decoders" % (
+                "workload": "%d stream(s) x %d samples per step, %s traffic (%s), %s, all four decoders" % (
                     n_streams, n_samples, "no" if idle else ("sparse" if sparse else "dense"),
                     "unmodulated carrier with +-4 LSB of noise" if idle else
-                    ("S1q: one exchange of the captures per 2^19 samples in quiet carrier" if sparse else "S1: the captures tiled end to end")),
+                    ("S1q: one exchange of the captures per 2^19 samples in quiet carrier" if sparse else
+                     ("S2: the S1 magnitudes on a random phase per stream + white noise sigma 0.002, fp32 IQ off the capture grid" if offgrid else
+                      "S1: the captures tiled end to end")),
+                    "IQ in host memory, staged and copied by the library inside the timed region (H2D included)" if from_host else "IQ resident in HBM"),
                 "value": round(n_streams * n_samples * steps / (tb - ta) / 1e6, 3),
                 "unit": "Msamples/s",
                 "ms_per_step": round((tb - ta) / steps * 1e3, 3),
@@ -459,11 +537,18 @@ def main():
                 "frames_dropped": pdrop,
                 "time_parallel": {"streams": int(ps.windowed_streams), "streams_sequential": int(ps.fallback_streams), "lanes": int(ps.windows),
                                   "decode_passes": int(ps.window_passes), "chunks_rescanned": int(ps.scan_repairs),
-                                  "scan_kernel_ms": round(ps.scan_ms, 3), "windowed_decode_ms": round(ps.window_ms, 3),
+                                  "scan_kernel_ms": round(ps.scan_ms, 3), "planes_kernel_ms": round(ps.planes_ms, 3), "windowed_decode_ms": round(ps.window_ms, 3),
+                                  "wave_kernel_ms": round(ps.wave_ms, 3), "wave_kernel_launches": int(ps.wave_launches),
                                   "sequential_kernel_ms": round(ps.kernel_ms, 3)},
             }
             if ps.scan_ms > 0:
                 point["scan_kernel_GBps"] = round(8.0 * ps.scan_samples / (ps.scan_ms * 1e-3) / 1e9, 1)
+            # HBM roofline of the point's dominant kernel: algorithmic bytes of a step over all the kernel's launches of a step
+            kern = max((("nfc_wave_kernel", ps.wave_ms), ("nfc_scan_kernel", ps.scan_ms), ("nfc_demod_fixed_kernel", ps.kernel_ms)), key=lambda kv: kv[1])
+            if kern[1] > 0:
+                ach = 8.0 * n_streams * n_samples * steps / (kern[1] * 1e-3) / 1e9
+                point["roofline"] = {"bound": "hbm", "kernel": kern[0], "kernel_ms_per_step": round(kern[1] / steps, 3), "achieved": round(ach, 3),
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6)}
             if lib is not None and check:
                 badp, ref_frames = 0, 0
                 for s in sorted(set([0, n_streams // 2, n_streams - 1] + list(range(min(n_streams, check)))))[:max(check, 1)]:
@@ -473,7 +558,7 @@ def main():
                     badp += 0 if pframes.get(f0 + s, []) == fr else 1
                 point["parity"] = {"streams_checked": min(n_streams, max(check, 1)), "streams_mismatching": badp, "reference_frames": ref_frames}
             g.close()
-            del buf, psink
+            del buf, psink, host
             torch.cuda.empty_cache()
             return point, ps
 
@@ -522,15 +607,21 @@ def main():
                 if name == "fixtures_single":
                     points[name] = run_fixtures()
                 elif name == "config5_dense":
-                    points[name], _ = run_point(name, args.config5_streams, args.config5_samples, False, 1, 1, 4)
+                    points[name], _ = run_point(name, args.config5_streams, args.config5_samples, False, 1, 1, 64)
                 elif name == "config5_sparse":
-                    points[name], scan_stats = run_point(name, args.config5_streams, args.config5_samples, True, 2, 1, 4)
+                    points[name], scan_stats = run_point(name, args.config5_streams, args.config5_samples, True, 2, 1, 64)
                 elif name == "config5_idle":
-                    points[name], idle_stats = run_point(name, args.config5_streams, args.config5_samples, False, 2, 1, 2, idle=True)
+                    points[name], idle_stats = run_point(name, args.config5_streams, args.config5_samples, False, 2, 1, 64, idle=True)
                 elif name == "share_dense":
-                    points[name], _ = run_point(name, args.share_streams, args.config5_samples, False, 1, 1, 2)
+                    points[name], _ = run_point(name, args.share_streams, args.config5_samples, False, 1, 1, 64)
                 elif name == "share_sparse":
-                    points[name], _ = run_point(name, args.share_streams, args.config5_samples, True, 2, 1, 2)
+                    points[name], _ = run_point(name, args.share_streams, args.config5_samples, True, 2, 1, 64)
+                elif name == "share_dense_h2d":
+                    points[name], _ = run_point(name, 128, args.config5_samples, False, 1, 1, 8, from_host=True)
+                elif name == "s2_share":
+                    points[name], _ = run_point(name, args.share_streams, args.config5_samples, False, 1, 1, 64, offgrid=True)
+                elif name == "saturating":
+                    points[name], _ = run_point(name, args.saturating_streams, 8192, False, 6, 2, 64)
                 elif name == "single_dense":
                     points[name], _ = run_point(name, 1, args.single_dense_samples, False, 1, 1, 1)
                 elif name == "single_sparse":

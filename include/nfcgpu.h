@@ -125,7 +125,15 @@ typedef struct nfcgpu_stats
    uint64_t windowed_streams;
    uint64_t fallback_streams;
    uint64_t scan_repairs; /* scan chunks walked a second time because their warm-up had not reached the true state */
+   /* round 3 (read through nfcgpu_stats_get_sized by callers built against this header; nfcgpu_stats_get fills the
+    * fields above only): the wave decoder's kernel - HIP-event time of all its launches and their number - and the walk
+    * that writes the front-end planes for it */
+   double wave_ms;
+   uint64_t wave_launches;
+   double planes_ms;
 } nfcgpu_stats;
+
+#define NFCGPU_STATS_SIZE_V2 104u /* bytes of nfcgpu_stats up to and including scan_repairs: what nfcgpu_stats_get writes */
 
 void nfcgpu_default_params(nfcgpu_params *params);
 
@@ -210,17 +218,22 @@ int nfcgpu_sink_rewind(nfcgpu_ctx *ctx);
 int nfcgpu_comm_unique_id(void *id128);
 int nfcgpu_comm_init(nfcgpu_ctx *ctx, const void *id128, int rank, int n_ranks);
 int nfcgpu_comm_destroy(nfcgpu_ctx *ctx);
-/* All-gather of every rank's packed frame records (the context's frame sink as it stands: use nfcgpu_sink_hold so that
- * nothing has been drained): one ncclAllGather of the word counts, one padded ncclAllGather of the records. `gathered`
- * is a device buffer of capacity_words words; rank r's records are at gathered + r * *stride_words, counts_host[r] words
- * of them (the record format of the sink: [stream, tech, type, flags, phase, rate, start, end, length, payload words]). */
+/* All-gather of every rank's packed frame records (the context's frame sink as it stands: nfcgpu_sink_hold must be on,
+ * so that nothing has been drained - NFCGPU_EINVAL otherwise): one ncclAllGather of (word count, receive capacity) per
+ * rank, on which every rank takes the same go / no-go decision (NFCGPU_ENOMEM everywhere when some rank's buffer is too
+ * small for the total), then the records at their exact sizes (one ncclBroadcast per rank, grouped). `gathered` is a
+ * device buffer of capacity_words words; the records are packed: rank r's start at the sum of counts_host[0 .. r-1],
+ * counts_host[r] words of them, and *stride_words is set to 0 (round 2 padded every rank to a common stride instead).
+ * Record format of the sink: [stream, tech, type, flags, phase, rate, start, end, length, payload words]. */
 int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacity_words, uint32_t *counts_host, uint64_t *stride_words);
 
 /* streaming-read bandwidth of this GPU over `bytes` of device memory (16-byte loads per lane, grid sized to the chip):
  * the measured denominator of the HBM roofline, next to the vendor peak. Best of `repeats` passes, GB/s. */
 int nfcgpu_read_bandwidth(nfcgpu_ctx *ctx, const void *device_ptr, uint64_t bytes, uint32_t repeats, double *gbps);
 
-int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats);
+int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats); /* writes NFCGPU_STATS_SIZE_V2 bytes (the struct of rounds 1-2) */
+/* writes min(size, sizeof(nfcgpu_stats)) bytes: pass sizeof(nfcgpu_stats) of the header the caller was built with */
+int nfcgpu_stats_get_sized(nfcgpu_ctx *ctx, void *stats, uint32_t size);
 int nfcgpu_stats_reset(nfcgpu_ctx *ctx);
 int nfcgpu_profile(nfcgpu_ctx *ctx, int enable);
 

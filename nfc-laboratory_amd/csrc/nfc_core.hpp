@@ -104,6 +104,12 @@ struct NfcLaneMem
 /* 32-bit index from a wave-uniform base: the access becomes `global_load v, v_off, s[base]` */
 #define NFC_AT(m, region, slot) ((m).ring[((region) + (uint32_t)(slot)) * NFC_RING_STRIDE + (m).lane])
 #define NFC_HMASK (NFC_HIST - 1u)
+
+/* the raw sample of clock `sampleClock`, for the deepest look-back of the path (NFC-V: 472 samples): the wave decoder,
+ * which writes a whole tile ahead into a history exactly NFC_HIST_STORED deep, keeps the samples that tile displaced */
+#ifndef NFC_X_OLD_INDEX
+#define NFC_X_OLD_INDEX(mem, sampleClock) (NFC_R_X + ((sampleClock) & NFC_HMASK)) /* slot index from the start of the ring storage */
+#endif
 #define NFC_PMASK (NFC_PROD - 1u)
 
 /* symbol patterns (private numbering; 0 = nothing yet, 1 = give up / timeout) */
@@ -522,7 +528,7 @@ NFC_DEV NfcTap nfc_tap_raw(const NfcLaneMem &mem, uint32_t clock, const NfcRate 
    NfcTap t;
    const uint32_t cur = clock - rt.delay;
    t.in = NFC_AT(mem, NFC_R_X, cur & NFC_HMASK);
-   t.out = NFC_AT(mem, NFC_R_X, (cur - rt.p2) & NFC_HMASK);
+   t.out = NFC_AT(mem, 0u, NFC_X_OLD_INDEX(mem, cur - rt.p2));
    t.c2 = NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p2, rt.p1, base));
    t.c3 = needC3 ? NFC_AT(mem, NFC_R_CORR, base + nfc_point(mem, clock, rt.delay, pos, rt.p1 - 1u, rt.p1, base)) : 0.0f;
    return t;
@@ -708,7 +714,7 @@ NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamSt
    if (NFC_ANY(raw && stored))
       t.x0 = NFC_AT(mem, 0u, raw && stored ? NFC_R_X + (cur & NFC_HMASK) : common);
    if (NFC_ANY(raw))
-      t.x2 = NFC_AT(mem, 0u, raw ? NFC_R_X + ((cur - rt.p2) & NFC_HMASK) : common);
+      t.x2 = NFC_AT(mem, 0u, raw ? NFC_X_OLD_INDEX(mem, cur - rt.p2) : common);
    if (NFC_ANY(filt && stored))
       t.f0 = NFC_AT(mem, 0u, filt && stored ? NFC_R_FILT + (cur & NFC_HMASK) : common);
    if (NFC_ANY(filt))

@@ -6,7 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define NFC_HIST 1024u
+/* the history is as deep as the stored one; the samples a tile written ahead displaces are kept beside it (nfc_wave.hpp) */
+#define NFC_X_OLD_INDEX(mem, sampleClock) nfc_wave_x_old_index((mem).ring, (sampleClock))
 #define NFC_RING_STRIDE 1u
 #define NFC_WAVE_LDS __attribute__((address_space(3)))
 #define NFC_RING_FLOAT NFC_WAVE_LDS float
@@ -24,6 +25,18 @@ __device__ __forceinline__ uint32_t nfc_wave_atomic_add(uint32_t *p, uint32_t v)
 
 #define NFC_ATOMIC_ADD(ptr, value) nfc_wave_atomic_add((ptr), (value))
 #define NFC_ANY(predicate) (predicate)
+
+#include "nfc_types.h"
+
+/* index, from the start of the wave's ring storage, of the raw sample of clock `clk`: in the history, or among the samples
+ * the tile written ahead has displaced (layout: nfc_wave.hpp, NFC_WAVE_XOLD) */
+__device__ __forceinline__ uint32_t nfc_wave_x_old_index(const NFC_RING_FLOAT *ring, uint32_t clk)
+{
+   const uint32_t displaced = 4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX;
+   const uint32_t clock0 = __builtin_bit_cast(uint32_t, (float)ring[displaced + NFC_LANES]);
+   const uint32_t k = clk - (clock0 - (NFC_HIST - 1u)); /* sample clock0 - 511 + j was displaced by tile sample j */
+   return k < NFC_LANES ? displaced + k : (clk & (NFC_HIST - 1u));
+}
 
 #include "nfc_core.hpp"
 

@@ -40,15 +40,20 @@
 
 #include "nfc_scan_launch.h"
 
-#if NFC_HIST != 1024u || NFC_RING_STRIDE != 1u
-#error "nfc_wave.hpp needs nfc_core.hpp compiled with NFC_HIST 1024 and NFC_RING_STRIDE 1"
+#if NFC_HIST != NFC_HIST_STORED || NFC_RING_STRIDE != 1u
+#error "nfc_wave.hpp needs nfc_core.hpp compiled with NFC_RING_STRIDE 1 and NFC_X_OLD_INDEX = nfc_wave_x_old_index"
 #endif
 
 #define NFC_WAVE_CARRY 0u   /* work items = jobs: the lane that continues a stream from its own state */
 #define NFC_WAVE_WINDOWS 1u /* work items = entries of the run list: speculative windows */
 #define NFC_WAVE_FINAL 2u   /* work items = jobs: the lane that regenerates the state of a stream's last window */
 
-#define NFC_WAVE_RING_FLOATS (4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX)
+/* behind the regions of nfc_core.hpp: the raw samples the tile at hand displaced in the history (one tile is written ahead
+ * into a history NFC_HIST deep; the deepest look-back of the path, NFC-V's 472 samples, reaches them), and the clock of
+ * the sample before the tile */
+#define NFC_WAVE_XOLD (4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX)
+#define NFC_WAVE_XOLD_CLOCK (NFC_WAVE_XOLD + NFC_LANES)
+#define NFC_WAVE_RING_FLOATS (NFC_WAVE_XOLD_CLOCK + 1u)
 
 /* what the lanes of the wave share: the decoder's state and where the lane of work stands */
 struct NfcWaveUni
@@ -83,6 +88,11 @@ struct NfcWaveLds
    float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator */
    float s0[6][NFC_LANES];           /* ... and the two differences the detectors look at */
    float s1[6][NFC_LANES];
+#ifdef NFC_WAVE_PROFILE
+   uint64_t prof[8];
+   uint64_t profLast;
+   uint32_t profPhase;
+#endif
 };
 
 /* the frame sink of the launch */
@@ -238,6 +248,7 @@ NFC_DEV bool nfc_wave_load_tile(const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *
 
       const uint32_t slot = (clock + 1u + lane) & NFC_HMASK;
 
+      lds->ring[NFC_WAVE_XOLD + lane] = lds->ring[NFC_R_X + slot]; /* the sample NFC_HIST back */
       lds->ring[NFC_R_X + slot] = x;
       lds->ring[NFC_R_FILT + slot] = p[0];
       lds->ring[NFC_R_MDEV + slot] = p[2];
@@ -248,6 +259,11 @@ NFC_DEV bool nfc_wave_load_tile(const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *
       const float scaled = x * 32768.0f;
       onGrid = scaled == __builtin_floorf(scaled) && x >= -1.0f && x <= 1.0f;
    }
+   else
+      lds->ring[NFC_WAVE_XOLD + lane] = lds->ring[NFC_R_X + ((clock + 1u + lane) & NFC_HMASK)]; /* (not displaced: the same value either way) */
+
+   if (lane == 0)
+      lds->ring[NFC_WAVE_XOLD_CLOCK] = __builtin_bit_cast(float, clock);
 
    return onGrid;
 }
@@ -278,6 +294,25 @@ NFC_DEV void nfc_wave_advance(const NfcConfig &c, S &s, uint32_t n)
    s.posV1 = nfc_wave_wrap3(s.posV1 + n, c.v.p1);
    s.posV0 = nfc_wave_wrap3(s.posV0 + n, c.v.p0);
 }
+
+/* -DNFC_WAVE_PROFILE: shader cycles per phase of the lane loop, summed over all waves into L.laneStats[12 + phase]
+ * (units of 1024 cycles): 0 tile boundary, 1 tile load, 2 bulk values, 3 bulk gates, 4 bulk commit, 5 the step,
+ * 6 the search step from values, 7 lane set-up and result */
+#ifdef NFC_WAVE_PROFILE
+#define NFC_WAVE_TICK(lds, phase)                                  \
+   do                                                              \
+   {                                                               \
+      const uint64_t nowTick = __builtin_readcyclecounter();       \
+      if (NFC_WAVE_LANE() == 0)                                    \
+      {                                                            \
+         (lds)->prof[(lds)->profPhase] += nowTick - (lds)->profLast; \
+         (lds)->profLast = nowTick;                                \
+         (lds)->profPhase = (phase);                               \
+      }                                                            \
+   } while (0)
+#else
+#define NFC_WAVE_TICK(lds, phase) ((void)0)
+#endif
 
 /* statistics of the fibre build (tests/hostsim): samples committed in bulk (0) / stepped (1) per stage */
 #ifndef NFC_WAVE_COUNT
@@ -340,7 +375,9 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
 
    NFC_WAVE_UNIFORM_BEGIN
    {
-      NfcStreamState &s = *(NfcStreamState *)&lds->u.s;
+      /* (in registers for the step: the detectors touch most of the record, and every access in place is an LDS round
+       * trip the next one waits for) */
+      NfcStreamState s = *(NfcStreamState *)&lds->u.s;
       const uint32_t at = lds->u.at;
 
       ++s.clock;
@@ -447,6 +484,7 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
       if (locked || !armed)
          lds->u.key = NFC_FK_NONE;
 
+      *(NfcStreamState *)&lds->u.s = s;
       lds->u.at = at + 1u;
       lds->u.stepped++;
    }
@@ -461,6 +499,7 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
    const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
    const uint32_t clock = NFC_WAVE_UNIFORM_U32(lds->u.s.clock);
 
+   NFC_WAVE_TICK(lds, 1u);
    NFC_WAVE_BARRIER();
    const bool onGrid = nfc_wave_load_tile(it, lds, consumed, n, clock, stride);
    const bool allOnGrid = NFC_WAVE_BALLOT(!onGrid) == 0ull;
@@ -531,10 +570,14 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
       const bool fromValues = allowFast && !exact && !upkeep && lds->u.s.lockTech == 0 && lds->u.s.unlock == 0 &&
                               NFC_WAVE_UNIFORM_U32(lds->u.key) == NFC_FK_SEARCH && NFC_WAVE_UNIFORM_U32(lds->u.from) <= at;
 
+      NFC_WAVE_TICK(lds, fromValues ? 6u : 5u);
+
       if (fromValues)
          nfc_wave_search_step(cfgPtr, lds, sink, emits ? 1u : 0u, edge);
       else
          nfc_wave_step(cfgPtr, lds, sink, upkeep ? 2u : (exact ? 1u : 0u), emits ? 1u : 0u, edge);
+
+      NFC_WAVE_TICK(lds, 3u);
 
       {
          const uint64_t gated = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.gatedHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.gatedLo);
@@ -619,6 +662,16 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    for (uint32_t i = lane; i < NFC_STREAM_BYTES / 4u; i += NFC_LANES)
       ((NFC_WAVE_LDS uint32_t *)lds->bytes)[i] = carry ? ((const uint32_t *)(L.bytes + (uint64_t)it.w * NFC_STREAM_BYTES))[i] : 0u;
 
+#ifdef NFC_WAVE_PROFILE
+   if (lane == 0)
+   {
+      for (int i = 0; i < 8; i++)
+         lds->prof[i] = 0;
+      lds->profLast = __builtin_readcyclecounter();
+      lds->profPhase = 7u;
+   }
+#endif
+
    NFC_WAVE_BARRIER();
 
    NFC_WAVE_UNIFORM_BEGIN
@@ -659,6 +712,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       const uint32_t pos = it.startPos + consumed;
 
       /* ---- tile boundary: publish, retire, hand over (nfc_window_body) ---- */
+      NFC_WAVE_TICK(lds, 0u);
       const bool past = consumed >= warm && consumed > 0;
       const bool mayRetire = past && (it.tiles[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) != 0u;
       const bool publishes = pos == verifyPos;
@@ -711,6 +765,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    }
 
    /* ---- the lane's result ---- */
+   NFC_WAVE_TICK(lds, 7u);
    const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
    const uint32_t stopped = NFC_WAVE_UNIFORM_U32(lds->u.stopped);
    const bool ranOut = consumed >= it.count;
@@ -806,6 +861,12 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       NFC_WAVE_STAT_ADD(L.laneStats, tilesStepped);
       NFC_WAVE_STAT_MAX(L.laneStats + 1, tilesStepped);
       NFC_WAVE_STAT_ADD(L.laneStats + 2, 1u);
+
+#ifdef NFC_WAVE_PROFILE
+      NFC_WAVE_TICK(lds, 7u);
+      for (int i = 0; i < 8; i++)
+         NFC_WAVE_STAT_ADD(L.laneStats + 12 + i, (uint32_t)(lds->prof[i] >> 10));
+#endif
    }
 }
 

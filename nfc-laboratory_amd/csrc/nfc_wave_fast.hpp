@@ -75,7 +75,7 @@ NFC_DEV float nfc_wave_raw(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t
    const uint32_t k = lane - from; /* samples after the first of the run */
 
    const float in = lds->ring[NFC_R_X + ((t - delay) & NFC_HMASK)];
-   const float out = lds->ring[NFC_R_X + ((t - delay - w) & NFC_HMASK)];
+   const float out = lds->ring[nfc_wave_x_old_index(lds->ring, t - delay - w)];
 
    const float c = acc + NFC_WAVE_SCAN_ADD_F(active ? in - out : 0.0f);
 
@@ -674,6 +674,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    }
 
    /* ---- values (kept while the stage lasts) ---- */
+   NFC_WAVE_TICK(lds, 2u);
    if (NFC_WAVE_UNIFORM_U32(lds->u.key) != key || from < NFC_WAVE_UNIFORM_U32(lds->u.from))
    {
       if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
@@ -697,6 +698,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    }
 
    /* ---- gate ---- */
+   NFC_WAVE_TICK(lds, 3u);
    bool gate;
    uint32_t which = 0;
 
@@ -742,6 +744,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    NFC_WAVE_COUNT(key, 0u, run);
 
    /* ---- commit: ring entries by the lanes of the run, then the state ---- */
+   NFC_WAVE_TICK(lds, 4u);
    const uint32_t last = from + run - 1u;
    const uint32_t never = s.clock - 0x40000000u;
 
@@ -865,6 +868,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    }
    NFC_WAVE_UNIFORM_END
 
+   NFC_WAVE_TICK(lds, 3u);
    return true;
 }
 

@@ -166,7 +166,7 @@ struct nfcgpu_ctx
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
-   std::vector<ProfiledLaunch> timedScan, timedWindow;
+   std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
 
    /* ---- frame gather over RCCL (nfcgpu_comm_*) ---- */
    void *comm = nullptr;
@@ -603,20 +603,23 @@ bool windowed_eligible(nfcgpu_ctx *ctx, uint32_t config, const std::vector<Windo
    return true;
 }
 
-void record_span(nfcgpu_ctx *ctx, std::vector<ProfiledLaunch> &into, ProfiledLaunch &pl, bool begin)
+void record_span(nfcgpu_ctx *ctx, std::vector<ProfiledLaunch> &into, ProfiledLaunch &pl, bool begin, hipStream_t on = nullptr)
 {
    if (!ctx->profile)
       return;
+
+   if (!on)
+      on = ctx->stream;
 
    if (begin)
    {
       pl.start = take_event(ctx);
       pl.stop = take_event(ctx);
-      (void)hipEventRecord(pl.start, ctx->stream);
+      (void)hipEventRecord(pl.start, on);
    }
    else
    {
-      (void)hipEventRecord(pl.stop, ctx->stream);
+      (void)hipEventRecord(pl.stop, on);
       into.push_back(pl);
    }
 }
@@ -728,7 +731,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
        (rc = grow(ctx, ctx->wPoints, sizeof(NfcScanPoint) * (size_t)points)) || (rc = grow(ctx, ctx->wSeams, sizeof(NfcScanSeam) * nChunks)) ||
        (rc = grow(ctx, ctx->wChunkEdge, 4 * (size_t)nChunks)) || (rc = grow(ctx, ctx->wTiles, 4 * (size_t)tiles)) ||
        (rc = grow(ctx, ctx->wTileStats, sizeof(NfcScanTile) * (size_t)tiles)) ||
-       (rc = grow(ctx, ctx->wCounters, 64)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nChunks)))
+       (rc = grow(ctx, ctx->wCounters, 256)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nChunks)))
       return rc;
 
    /* lanes: a first guess (one window per 8192 samples); the window kernel reports what it needs */
@@ -776,7 +779,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    HIP_TRY(ctx, hipMemcpyAsync(ctx->wJobs.ptr, jobs.data(), sizeof(NfcScanJob) * nJobs, hipMemcpyHostToDevice, ctx->stream));
    HIP_TRY(ctx, hipMemcpyAsync(ctx->wChunks.ptr, chunks.data(), sizeof(NfcScanChunk) * nChunks, hipMemcpyHostToDevice, ctx->stream));
-   HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, ctx->stream));
+   HIP_TRY(ctx, hipMemsetAsync(counters, 0, 256, ctx->stream));
    HIP_TRY(ctx, hipMemsetAsync(ctx->vSinkCtl.ptr, 0, 16, ctx->stream));
 
    NfcScanArgs A;
@@ -937,8 +940,11 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       P.chunks = (const NfcScanChunk *)ctx->wPlaneChunks.ptr;
       P.nChunks = nChunks;
 
+      ProfiledLaunch pp {nullptr, nullptr};
+      record_span(ctx, ctx->timedPlanes, pp, true);
       hipLaunchKernelGGL(nfc_scan_planes_kernel, dim3((nChunks + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, P);
       HIP_TRY(ctx, hipGetLastError());
+      record_span(ctx, ctx->timedPlanes, pp, false);
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* (the chunk list is a local) */
 
       mark("planes");
@@ -1006,7 +1012,12 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       const uint32_t blocks = (firstSlot % NFC_LANES + slotCount + NFC_LANES - 1) / NFC_LANES;
 
       if (ctx->wave)
+      {
+         ProfiledLaunch wl {nullptr, nullptr};
+         record_span(ctx, ctx->timedWave, wl, true, on);
          hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
+         record_span(ctx, ctx->timedWave, wl, false, on);
+      }
       else
          hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, on, dCfg, L, A);
       HIP_TRY(ctx, hipGetLastError());
@@ -1025,7 +1036,12 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          waves = ctx->windowWaves;
 
       if (ctx->wave)
+      {
+         ProfiledLaunch wl {nullptr, nullptr};
+         record_span(ctx, ctx->timedWave, wl, true);
          hipLaunchKernelGGL(nfc_wave_kernel, dim3(nWindows), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
+         record_span(ctx, ctx->timedWave, wl, false);
+      }
       else
          hipLaunchKernelGGL(nfc_window_kernel, dim3(waves), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A);
       HIP_TRY(ctx, hipGetLastError());
@@ -1110,6 +1126,19 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, 12, ctx->stream));
          HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
          const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - passBegan).count();
+         {
+            /* (a library built with -DNFC_WAVE_PROFILE: shader cycles per phase of the wave decoder, nfc_wave.hpp) */
+            uint32_t prof[8] = {0};
+            HIP_TRY(ctx, hipMemcpy(prof, counters + 16, 32, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemsetAsync(counters + 16, 0, 32, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            uint64_t all = 0;
+            for (uint32_t v: prof)
+               all += v;
+            if (all)
+               std::fprintf(stderr, "[nfcgpu]    wave cycles x 2^10: boundary %u, tile load %u, values %u, gates %u, commit %u, step %u, search step %u, set-up %u\n", prof[0], prof[1],
+                            prof[2], prof[3], prof[4], prof[5], prof[6], prof[7]);
+         }
          std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled, %.1f ms\n", pass, ls[2],
                       (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again, ms);
       }
@@ -1289,6 +1318,9 @@ struct Rccl
    int (*commInitRank)(void **, int, IdByValue, int) = nullptr;
    int (*commDestroy)(void *) = nullptr;
    int (*allGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+   int (*broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+   int (*groupStart)() = nullptr;
+   int (*groupEnd)() = nullptr;
    const char *(*getErrorString)(int) = nullptr;
 };
 
@@ -1314,12 +1346,15 @@ Rccl *rccl()
          r.commInitRank = (int (*)(void **, int, IdByValue, int))dlsym(r.handle, "ncclCommInitRank");
          r.commDestroy = (int (*)(void *))dlsym(r.handle, "ncclCommDestroy");
          r.allGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.handle, "ncclAllGather");
+         r.broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(r.handle, "ncclBroadcast");
+         r.groupStart = (int (*)())dlsym(r.handle, "ncclGroupStart");
+         r.groupEnd = (int (*)())dlsym(r.handle, "ncclGroupEnd");
          r.getErrorString = (const char *(*)(int))dlsym(r.handle, "ncclGetErrorString");
       }
 #endif
    }
 
-   return (r.handle && r.getUniqueId && r.commInitRank && r.commDestroy && r.allGather) ? &r : nullptr;
+   return (r.handle && r.getUniqueId && r.commInitRank && r.commDestroy && r.allGather && r.broadcast && r.groupStart && r.groupEnd) ? &r : nullptr;
 }
 
 }
@@ -2130,7 +2165,7 @@ int nfcgpu_sync(nfcgpu_ctx *ctx)
       return NFCGPU_EINVAL;
 
    /* nothing enqueued since the last synchronisation and nothing to collect: no device call at all */
-   if (!ctx->inflight && !ctx->dirty && ctx->timed.empty() && ctx->timedScan.empty() && ctx->timedWindow.empty())
+   if (!ctx->inflight && !ctx->dirty && ctx->timed.empty() && ctx->timedScan.empty() && ctx->timedWindow.empty() && ctx->timedWave.empty() && ctx->timedPlanes.empty())
       return NFCGPU_OK;
 
    HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2166,6 +2201,32 @@ int nfcgpu_sync(nfcgpu_ctx *ctx)
       ctx->eventPool.push_back(pl.stop);
    }
    ctx->timedWindow.clear();
+
+   if (!ctx->timedWave.empty() || !ctx->timedPlanes.empty())
+      (void)hipStreamSynchronize(ctx->side); /* (carry lanes run beside the windows) */
+
+   for (auto &pl: ctx->timedWave)
+   {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
+      {
+         ctx->stats.wave_ms += ms;
+         ctx->stats.wave_launches++;
+      }
+      ctx->eventPool.push_back(pl.start);
+      ctx->eventPool.push_back(pl.stop);
+   }
+   ctx->timedWave.clear();
+
+   for (auto &pl: ctx->timedPlanes)
+   {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
+         ctx->stats.planes_ms += ms;
+      ctx->eventPool.push_back(pl.start);
+      ctx->eventPool.push_back(pl.stop);
+   }
+   ctx->timedPlanes.clear();
 
    if (!ctx->dirty || ctx->hold)
       return NFCGPU_OK;
@@ -2367,7 +2428,7 @@ int nfcgpu_comm_init(nfcgpu_ctx *ctx, const void *id128, int rank, int nRanks)
    ctx->commRank = rank;
    ctx->commRanks = nRanks;
 
-   if (hipMalloc((void **)&ctx->dCounts, 4 * (size_t)(nRanks + 1)) != hipSuccess)
+   if (hipMalloc((void **)&ctx->dCounts, 8 * (size_t)(nRanks + 1)) != hipSuccess)
       return fail(ctx, NFCGPU_ENOMEM, "hipMalloc(gather counts)");
 
    return NFCGPU_OK;
@@ -2402,6 +2463,8 @@ int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords
       return NFCGPU_EINVAL;
    if (!ctx->comm)
       return fail(ctx, NFCGPU_EINVAL, "nfcgpu_comm_init first");
+   if (!ctx->hold)
+      return fail(ctx, NFCGPU_EINVAL, "nfcgpu_sink_hold first: a sink that nfcgpu_sync drains has nothing left to gather");
 
    Rccl *r = rccl();
    if (!r)
@@ -2422,33 +2485,49 @@ int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords
    if (used > ctx->sinkWords)
       used = ctx->sinkWords;
 
-   const uint32_t mine = (uint32_t)used;
    const int n = ctx->commRanks;
 
-   /* counts */
-   HIP_TRY(ctx, hipMemcpyAsync(ctx->dCounts + n, &mine, 4, hipMemcpyHostToDevice, ctx->stream));
-   int rc = r->allGather(ctx->dCounts + n, ctx->dCounts, 1, /* ncclUint32 */ 3, ctx->comm, ctx->stream);
+   /* Every rank learns every rank's word count AND what every rank's receive buffer holds: the decision to go on is
+    * then the same on all of them (a rank that returned between the two collectives would leave the others waiting). */
+   const uint32_t mine[2] = {(uint32_t)used, (uint32_t)(capacityWords > 0xFFFFFFFFull ? 0xFFFFFFFFull : capacityWords)};
+
+   HIP_TRY(ctx, hipMemcpyAsync(ctx->dCounts + 2 * n, mine, 8, hipMemcpyHostToDevice, ctx->stream));
+   int rc = r->allGather(ctx->dCounts + 2 * n, ctx->dCounts, 2, /* ncclUint32 */ 3, ctx->comm, ctx->stream);
    if (rc != 0)
       return fail(ctx, NFCGPU_EHIP, r->getErrorString ? r->getErrorString(rc) : "ncclAllGather(counts) failed");
 
-   HIP_TRY(ctx, hipMemcpyAsync(countsHost, ctx->dCounts, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+   std::vector<uint32_t> pairs(2 * (size_t)n);
+   HIP_TRY(ctx, hipMemcpyAsync(pairs.data(), ctx->dCounts, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
-   uint64_t longest = 1;
+   uint64_t total = 0, smallest = ~0ull;
    for (int i = 0; i < n; i++)
-      longest = countsHost[i] > longest ? countsHost[i] : longest;
+   {
+      countsHost[i] = pairs[2 * i];
+      total += pairs[2 * i];
+      smallest = pairs[2 * i + 1] < smallest ? pairs[2 * i + 1] : smallest;
+   }
 
-   *strideWords = longest;
+   /* packed: rank i's records start at the sum of the counts before it */
+   *strideWords = 0;
 
-   if (longest * (uint64_t)n > capacityWords)
-      return fail(ctx, NFCGPU_ENOMEM, "gather buffer too small for the longest rank's records");
-   if (longest > ctx->sinkWords)
-      return fail(ctx, NFCGPU_ENOMEM, "this rank's frame sink is smaller than the longest rank's records (padded all-gather)");
+   if (total > smallest)
+      return fail(ctx, NFCGPU_ENOMEM, "a rank's gather buffer is too small for all ranks' records (the same verdict on every rank)");
 
-   /* records, padded to the longest rank's (the words past `mine` are whatever the sink holds: ignored through counts) */
-   rc = r->allGather(ctx->dSink, gathered, (size_t)longest, /* ncclUint32 */ 3, ctx->comm, ctx->stream);
+   /* records, exact sizes: one broadcast per rank into its place, all in one group */
+   rc = r->groupStart();
+   uint64_t at = 0;
+   for (int i = 0; i < n && rc == 0; i++)
+   {
+      if (countsHost[i])
+         rc = r->broadcast(ctx->dSink, (uint32_t *)gathered + at, countsHost[i], /* ncclUint32 */ 3, i, ctx->comm, ctx->stream);
+      at += countsHost[i];
+   }
+   const int rcEnd = r->groupEnd();
+   if (rc == 0)
+      rc = rcEnd;
    if (rc != 0)
-      return fail(ctx, NFCGPU_EHIP, r->getErrorString ? r->getErrorString(rc) : "ncclAllGather(records) failed");
+      return fail(ctx, NFCGPU_EHIP, r->getErrorString ? r->getErrorString(rc) : "ncclBroadcast(records) failed");
 
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -2495,7 +2574,15 @@ int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats)
 {
    if (!ctx || !stats)
       return NFCGPU_EINVAL;
-   *stats = ctx->stats;
+   std::memcpy(stats, &ctx->stats, NFCGPU_STATS_SIZE_V2); /* a caller built against the older header holds no more */
+   return NFCGPU_OK;
+}
+
+int nfcgpu_stats_get_sized(nfcgpu_ctx *ctx, void *stats, uint32_t size)
+{
+   if (!ctx || !stats)
+      return NFCGPU_EINVAL;
+   std::memcpy(stats, &ctx->stats, size < sizeof(nfcgpu_stats) ? size : sizeof(nfcgpu_stats));
    return NFCGPU_OK;
 }
 

@@ -16,6 +16,7 @@
  * This file replaces src/nfc-lib/lib-lab/lab-radio/src/main/cpp/NfcDecoder.cpp (+ NfcTech.cpp, tech/*.cpp)
  * in the reference's lab-radio library; see INTEGRATION.md.
  */
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -121,6 +122,8 @@ struct NfcDecoder::Impl
    unsigned int pendingStride = 1;
    unsigned int pendingRate = 0;
    unsigned int lastCount = 0; /* samples of the buffer before this one */
+   std::chrono::steady_clock::time_point pendingSince {}; /* when the first samples of the pending block arrived */
+   double blockMillis = 250.0; /* NFCGPU_SHIM_BLOCK_MS */
    std::list<RawFrame> backlog; /* frames collected at a moment that was not a nextFrames() call */
    long submittedStreamTime = 0; /* streamTime() in force for the frames not collected yet */
 
@@ -137,6 +140,8 @@ struct NfcDecoder::Impl
 
       if (const char *block = std::getenv("NFCGPU_SHIM_BLOCK"))
          blockSamples = (size_t)std::strtoull(block, nullptr, 10);
+      if (const char *ms = std::getenv("NFCGPU_SHIM_BLOCK_MS"))
+         blockMillis = std::strtod(ms, nullptr);
    }
 
    ~Impl()
@@ -251,10 +256,25 @@ void NfcDecoder::initialize()
    impl->push();
    impl->dispatch();
    impl->check(nfcgpu_stream_reset(impl->ctx, impl->stream), "stream_reset");
+   impl->lastCount = 0; /* (block mode: the next buffer is not a "shorter one" than whatever came before the reset) */
 }
 
+/* The reference's cleanup() has nothing to do. In block mode samples may still be waiting for their block to fill when
+ * the host stops the decoder (RadioDecoderTask calls cleanup() on the invalid buffer that ends a stream, never
+ * nextFrames({}): RadioDecoderTask.cpp:390-399): they are decoded now, and their frames are kept for the next
+ * nextFrames() call - the interface has no other way out for them (a host that wants them at once calls
+ * nextFrames({}) before cleanup()). */
 void NfcDecoder::cleanup()
 {
+   std::lock_guard<std::recursive_mutex> use(shared.use);
+
+   if (!shared.alive() || !impl->blockSamples)
+      return;
+
+   impl->push();
+   impl->dispatch();
+   impl->backlog.splice(impl->backlog.end(), impl->collect());
+   impl->lastCount = 0;
 }
 
 std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
@@ -291,7 +311,14 @@ std::list<RawFrame> NfcDecoder::nextFrames(hw::SignalBuffer samples)
             const bool last = count < impl->lastCount;
             impl->lastCount = count;
 
-            if (impl->pending.size() / stride >= impl->blockSamples || last)
+            /* a block is also closed when its first samples have waited long enough (a slow or bursty receiver must not
+             * hold frames back without bound: NFCGPU_SHIM_BLOCK_MS, default 250 ms of wall clock) */
+            const auto now = std::chrono::steady_clock::now();
+            if (impl->pending.size() == (size_t)count * stride)
+               impl->pendingSince = now;
+            const bool stale = std::chrono::duration<double, std::milli>(now - impl->pendingSince).count() > impl->blockMillis;
+
+            if (impl->pending.size() / stride >= impl->blockSamples || last || stale)
                impl->dispatch();
 
             if (last)

@@ -86,6 +86,9 @@ class Stats(ctypes.Structure):
         ("windowed_streams", ctypes.c_uint64),
         ("fallback_streams", ctypes.c_uint64),
         ("scan_repairs", ctypes.c_uint64),
+        ("wave_ms", ctypes.c_double),
+        ("wave_launches", ctypes.c_uint64),
+        ("planes_ms", ctypes.c_double),
     ]
 
 
@@ -136,6 +139,7 @@ def load_library(path=LIB_PATH):
     lib.nfcgpu_sink_hold.argtypes = [vp, i32]
     lib.nfcgpu_sink_rewind.argtypes = [vp]
     lib.nfcgpu_stats_get.argtypes = [vp, P(Stats)]
+    lib.nfcgpu_stats_get_sized.argtypes = [vp, P(Stats), ctypes.c_uint32]
     lib.nfcgpu_stats_reset.argtypes = [vp]
     lib.nfcgpu_profile.argtypes = [vp, i32]
     lib.nfcgpu_comm_unique_id.argtypes = [vp]
@@ -281,7 +285,7 @@ class NfcGpu:
 
     def stats(self):
         s = Stats()
-        self._check(self.lib.nfcgpu_stats_get(self.ctx, ctypes.byref(s)))
+        self._check(self.lib.nfcgpu_stats_get_sized(self.ctx, ctypes.byref(s), ctypes.sizeof(Stats)))
         return s
 
     def stats_reset(self):

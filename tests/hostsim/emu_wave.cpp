@@ -11,7 +11,8 @@
 
 #include "wavesim.hpp"
 
-#define NFC_HIST 1024u
+/* the history is as deep as the stored one; the samples a tile written ahead displaces are kept beside it (nfc_wave.hpp) */
+#define NFC_X_OLD_INDEX(mem, sampleClock) nfc_wave_x_old_index((mem).ring, (sampleClock))
 #define NFC_RING_STRIDE 1u
 #define NFC_WAVE_LDS
 #define NFC_RING_FLOAT float
@@ -20,6 +21,18 @@
 static inline uint32_t emu_add(uint32_t *p, uint32_t v) { uint32_t old = *p; *p += v; return old; }
 #define NFC_ATOMIC_ADD(ptr, value) emu_add((ptr), (value))
 #define NFC_ANY(predicate) (predicate)
+#include "../../nfc-laboratory_amd/csrc/nfc_types.h"
+
+/* index, from the start of the wave's ring storage, of the raw sample of clock `clk`: in the history, or among the samples
+ * the tile written ahead has displaced (layout: nfc_wave.hpp, NFC_WAVE_XOLD) */
+static inline uint32_t nfc_wave_x_old_index(const NFC_RING_FLOAT *ring, uint32_t clk)
+{
+   const uint32_t displaced = 4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX;
+   const uint32_t clock0 = __builtin_bit_cast(uint32_t, (float)ring[displaced + NFC_LANES]);
+   const uint32_t k = clk - (clock0 - (NFC_HIST - 1u)); /* sample clock0 - 511 + j was displaced by tile sample j */
+   return k < NFC_LANES ? displaced + k : (clk & (NFC_HIST - 1u));
+}
+
 #include "../../nfc-laboratory_amd/csrc/nfc_core.hpp"
 
 static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t i)

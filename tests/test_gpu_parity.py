@@ -366,8 +366,8 @@ def test_frame_gather_over_rccl_single_rank(gpu):
 
 
 def test_frame_gather_through_the_c_abi_single_rank(gpu):
-    """nfcgpu_comm_* / nfcgpu_gather_frames: the frame gather in C++ over RCCL (ncclAllGather of the counts, then of the
-    padded records), here with a one-rank communicator on the context's own sink after a real decode; and the streaming-read
+    """nfcgpu_comm_* / nfcgpu_gather_frames: the frame gather in C++ over RCCL (ncclAllGather of the counts, then the
+    records at their exact sizes), here with a one-rank communicator on the context's own sink after a real decode; and the streaming-read
     measurement used as the second roofline denominator."""
     import torch
     import frames as framelib
@@ -388,7 +388,7 @@ def test_frame_gather_through_the_c_abi_single_rank(gpu):
         g.comm_init(g.comm_unique_id(), 0, 1)
         counts, stride = g.gather_frames(out.data_ptr(), out.numel())
         torch.cuda.synchronize()
-        assert counts == [int(ctl[0].item())] and stride >= counts[0] > 0
+        assert counts == [int(ctl[0].item())] and counts[0] > 0 and stride == 0  # records packed at their exact sizes
         got = framelib.parse_sink(out[:counts[0]].cpu().numpy(), counts[0], FS)
         assert got[sid] == want
         g.comm_destroy()

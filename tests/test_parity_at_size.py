@@ -1,0 +1,52 @@
+"""Parity at BASELINE's sizes with the library's DEFAULT routing and thresholds (no NFCGPU_* knob set): config 5's 4096
+streams x 2^20 samples of sparse traffic, and dense traffic (the captures tiled end to end) in two submissions so that
+state is carried from one to the next - every stream compared frame by frame with the reference decoder
+(tests/parity_sweep_driver.py). On the GPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import nfc_testlib as T
+
+DRIVER = os.path.join(T.ROOT, "tests", "parity_sweep_driver.py")
+
+
+def _sweep(kind, streams, samples, submissions):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("NFCGPU_")}
+    run = subprocess.run([sys.executable, DRIVER, kind, str(streams), str(samples), str(submissions)], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-3000:]
+    return json.loads(run.stdout.strip().splitlines()[-1])
+
+
+def _check(res):
+    assert res["streams_mismatching"] == [], res
+    assert res["frames_dropped"] == 0 and res["reference_frames"] > res["streams"], res
+    assert res["streams_compared"] == res["streams"]
+    return res
+
+
+needs_reference = pytest.mark.skipif(T.reference_lib() is None, reason="oracle/_ref not built")
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_config5_sparse_every_stream_matches_the_reference(built):
+    res = _check(_sweep("sparse", 4096, 1 << 20, 1))
+    assert res["time_parallel_streams"] == 4096 and res["sequential_streams"] == 0, res
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_dense_streams_in_two_submissions_match_the_reference(built):
+    res = _check(_sweep("dense", 512, 1 << 20, 2))
+    assert res["time_parallel_streams"] == 1024 and res["sequential_streams"] == 0, res  # dense traffic is decoded where it is
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_many_dense_streams_of_short_submissions_match_the_reference(built):
+    _check(_sweep("dense", 2048, 1 << 18, 2))

@@ -53,6 +53,11 @@ def main():
     out = []
     template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
 
+    # "fixture:<name>": one capture
+    for name in [w.split(":", 1)[1] for w in which if w.startswith("fixture:")]:
+        mag = np.abs(T.load_fixture(name)).astype(np.float32)
+        out.append(case(name, [mag]))
+
     if not which or "fixtures" in which:
         for name in T.fixture_names():
             mag = np.abs(T.load_fixture(name)).astype(np.float32)
