@@ -916,7 +916,9 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
    __syncthreads();
 
    /* count, reserve, fill: the speculative windows of a job are contiguous and ordered */
-   const uint32_t need = nfc_windows_place(job, j, t, nTiles, nullptr, 0u, false);
+   /* a short stream is decoded by its carry lane alone (NfcScanParams::soloSamples): one pass, nothing to speculate on */
+   const bool solo = job.count <= A.params.soloSamples;
+   const uint32_t need = solo ? 0u : nfc_windows_place(job, j, t, nTiles, nullptr, 0u, false);
 
    uint32_t first = 0u;
    if (lane == 0u)
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
       job.status |= NFC_JOB_OVERFLOW;
       job.windows = 0;
    }
-   else
+   else if (need)
       (void)nfc_windows_place(job, j, t, nTiles, A.windows + job.firstWindow, need, true);
 
    if (lane == 0u)

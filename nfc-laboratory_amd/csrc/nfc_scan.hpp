@@ -27,6 +27,7 @@ struct NfcScanParams
    float deepK;    /* 0.98 * smallest maximum modulation depth of the enabled detectors */
    uint32_t chunkSamples;  /* samples per chunk (multiple of NFC_SCAN_POINT) */
    uint32_t warmSamples;   /* samples walked before a chunk to reach the true front-end state (multiple of NFC_SCAN_POINT) */
+   uint32_t soloSamples;   /* streams of at most this many samples get no speculative windows: their carry lane decodes them alone, in one pass */
 };
 
 /* bit-for-bit equality of two records (word by word through memcpy: no library call on the device, and no loads through

@@ -16,6 +16,7 @@ struct NfcScanParams
    float deepK;
    uint32_t chunkSamples;
    uint32_t warmSamples;
+   uint32_t soloSamples;
 };
 #endif
 

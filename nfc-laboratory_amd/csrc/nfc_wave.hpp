@@ -71,6 +71,8 @@ struct NfcWaveUni
    uint32_t gridSince; /* clock from which on every sample has been on the capture grid */
    uint32_t gatedLo, gatedHi; /* the gates as last evaluated, bit j = sample gatedFrom + j of the tile */
    uint32_t gatedFrom;
+   uint32_t which;    /* search bank: detectors whose gates were up at sample whichAt (bit per detector, nfc_wave_search_gate) */
+   uint32_t whichAt;
    float pass[16];    /* hand-over from single lanes to everybody */
 };
 
@@ -399,6 +401,10 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
       if (emits)
          s.edgeTime = edge;
 
+      /* the detectors whose gates were up when the bulk path looked at this very sample (all of them when it has not:
+       * a sample stepped in the wake of another): the others would take their early exits */
+      const uint32_t ask = lds->u.whichAt == at ? lds->u.which : 0xFFFFFFFFu;
+
       nfc_detect_carrier(c, s, mem);
 
       const bool armed = s.clock >= 1024u && !(s.env < c.powerThreshold);
@@ -418,7 +424,7 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
             {                                                                                                                                    \
                r.detA[R].acc = lds->sum[R][at];                                                                                                  \
                lds->ring[NFC_R_CORR + c.corrOffset[R] + s.posA[R]] = r.detA[R].acc;                                                              \
-               if (nfca_detect_decide<R>(c, s, mem, lds->s0[R][at] - lds->s1[R][at],                                                             \
+               if (((ask >> R) & 1u) && nfca_detect_decide<R>(c, s, mem, lds->s0[R][at] - lds->s1[R][at],                                        \
                                          lds->ring[NFC_R_DEPTH + ((s.clock - c.a[R].delay - c.a[R].p8) & NFC_HMASK)], limit, c.minDepth[0]))     \
                   locked = NFC_TECH_A;                                                                                                           \
             }
@@ -431,11 +437,11 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
          if (!locked && (c.enabled & 2u))
          {
             const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_HMASK, slot1 = (s.clock - c.b[1].delay) & NFC_HMASK;
-            const int r0 = nfcb_detect_decide<0>(c, s, mem, lds->ring[NFC_R_FILT + slot0], lds->ring[NFC_R_DEPTH + slot0]);
+            const int r0 = ((ask >> 3) & 1u) ? nfcb_detect_decide<0>(c, s, mem, lds->ring[NFC_R_FILT + slot0], lds->ring[NFC_R_DEPTH + slot0]) : 0;
 
             if (r0 == 1)
                locked = NFC_TECH_B;
-            else if (r0 == 0 && nfcb_detect_decide<1>(c, s, mem, lds->ring[NFC_R_FILT + slot1], lds->ring[NFC_R_DEPTH + slot1]) == 1)
+            else if (r0 == 0 && ((ask >> 4) & 1u) && nfcb_detect_decide<1>(c, s, mem, lds->ring[NFC_R_FILT + slot1], lds->ring[NFC_R_DEPTH + slot1]) == 1)
                locked = NFC_TECH_B;
          }
 
@@ -444,17 +450,21 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
             const float limit = s.env * c.corrThreshold[2];
             const float deep = lds->ring[NFC_R_DEPTH + slot];
 
+            /* (a detector that is not asked may still have been told to reset a record that is clear: the mark it leaves) */
+            if (ask != 0xFFFFFFFFu)
+               lds->flags |= ((ask >> 8) & 1u) << 16 | ((ask >> 9) & 1u) << 17;
+
             r.detF[0].acc = lds->sum[3][at];
             lds->ring[NFC_R_CORR + c.corrOffset[3] + s.posF[0]] = r.detF[0].acc;
 
-            if (nfcf_detect_decide<1>(c, s, mem, lds->s0[3][at], lds->s0[3][at] - lds->s1[3][at], deep, limit))
+            if (((ask >> 5) & 1u) && nfcf_detect_decide<1>(c, s, mem, lds->s0[3][at], lds->s0[3][at] - lds->s1[3][at], deep, limit))
                locked = NFC_TECH_F;
             else
             {
                r.detF[1].acc = lds->sum[4][at];
                lds->ring[NFC_R_CORR + c.corrOffset[4] + s.posF[1]] = r.detF[1].acc;
 
-               if (nfcf_detect_decide<2>(c, s, mem, lds->s0[4][at], lds->s0[4][at] - lds->s1[4][at], deep, limit))
+               if (((ask >> 6) & 1u) && nfcf_detect_decide<2>(c, s, mem, lds->s0[4][at], lds->s0[4][at] - lds->s1[4][at], deep, limit))
                   locked = NFC_TECH_F;
             }
          }
@@ -464,7 +474,7 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
             r.detV.acc = lds->sum[5][at];
             lds->ring[NFC_R_CORR + c.corrOffset[5] + s.posV1] = r.detV.acc;
 
-            if (nfcv_detect_decide(c, s, mem, lds->s0[5][at], lds->ring[NFC_R_X + ((s.clock - c.v.delay) & NFC_HMASK)]))
+            if (((ask >> 7) & 1u) && nfcv_detect_decide(c, s, mem, lds->s0[5][at], lds->ring[NFC_R_X + ((s.clock - c.v.delay) & NFC_HMASK)]))
                locked = NFC_TECH_V;
          }
 
@@ -519,6 +529,8 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
       lds->u.gatedLo = 0;
       lds->u.gatedHi = 0;
       lds->u.gatedFrom = 0;
+      lds->u.which = 0xFFFFFFFFu;
+      lds->u.whichAt = 0xFFFFFFFFu;
       if (!allOnGrid)
          lds->u.gridSince = clock + n;
    }
@@ -714,7 +726,8 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       /* ---- tile boundary: publish, retire, hand over (nfc_window_body) ---- */
       NFC_WAVE_TICK(lds, 0u);
       const bool past = consumed >= warm && consumed > 0;
-      const bool mayRetire = past && (it.tiles[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) != 0u;
+      /* (a stream without windows - NfcScanParams::soloSamples - has nobody to take over from a lane that retires) */
+      const bool mayRetire = past && it.job->windows != 0u && (it.tiles[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) != 0u;
       const bool publishes = pos == verifyPos;
       uint32_t edgeNow = 0;
 

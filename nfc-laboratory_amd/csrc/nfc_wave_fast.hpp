@@ -304,32 +304,78 @@ NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLd
    return gate;
 }
 
-/* values of the search bank for the tile's samples from `from` on */
+/* running sum of one raw box-sum correlator after each of the tile's samples from lane `from` on (nfc_wave_raw, first half) */
+NFC_DEV float nfc_wave_raw_sum(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, float acc, uint32_t delay, uint32_t w)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+   const uint32_t t = nfc_wave_clock_of(clock0);
+
+   const float in = lds->ring[NFC_R_X + ((t - delay) & NFC_HMASK)];
+   const float out = lds->ring[nfc_wave_x_old_index(lds->ring, t - delay - w)];
+
+   return acc + NFC_WAVE_SCAN_ADD_F(lane >= from ? in - out : 0.0f);
+}
+
+/* ... and its two ring taps, once the sums of the whole wave are in lds->sum[slot] (second half; every clock writes) */
+NFC_DEV void nfc_wave_raw_taps(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t from, float acc, uint32_t p1, uint32_t shift, uint32_t base, uint32_t pos,
+                               bool prevKnown, float &c2, float &c3)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+   const bool active = lane >= from;
+   const uint32_t k = lane - from;
+   const uint32_t posj = nfc_wave_wrap3(pos + 1u + (active ? k : 0u), p1);
+
+   const bool c2Here = active && k >= shift;
+   const float c2Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - shift, p1)];
+   c2 = c2Here ? lds->sum[slot][c2Here ? lane - shift : lane] : c2Ring;
+
+   const bool c3Here = active && k >= 1u;
+   const float c3Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - 1u, p1)];
+   c3 = c3Here ? lds->sum[slot][c3Here ? lane - 1u : lane] : ((active && k == 0u && prevKnown) ? acc : c3Ring);
+}
+
+/* values of the search bank for the tile's samples from `from` on: the six sums, then (one barrier) their taps */
 NFC_DEV void nfc_wave_search_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const NfcStreamState &s = NFC_WAVE_STATE(lds);
    const bool prevKnown = s.bankClock == s.clock;
-   const uint32_t never = s.clock - 0x40000000u;
    const NfcSearchRegs &r = s.u.search;
    const uint32_t posA0 = s.posA[0], posA1 = s.posA[1], posA2 = s.posA[2], posF0 = s.posF[0], posF1 = s.posF[1], posV1 = s.posV1;
    const float accA0 = r.detA[0].acc, accA1 = r.detA[1].acc, accA2 = r.detA[2].acc, accF0 = r.detF[0].acc, accF1 = r.detF[1].acc, accV = r.detV.acc;
-   float c2, c3, sum;
 
-#define NFC_WAVE_SEARCH_ONE(k, rt, acc, base, pos)                                                                                        \
-   sum = nfc_wave_raw(lds, (k), clock0, from, (acc), (rt).delay, (rt).p2, (rt).p1, (rt).p1 - (rt).p2, (base), (pos), prevKnown, never, c2, c3); \
-   lds->s0[k][lane] = sum - c2;                                                                                                             \
+   const float sumA0 = nfc_wave_raw_sum(lds, clock0, from, accA0, c.a[0].delay, c.a[0].p2);
+   const float sumA1 = nfc_wave_raw_sum(lds, clock0, from, accA1, c.a[1].delay, c.a[1].p2);
+   const float sumA2 = nfc_wave_raw_sum(lds, clock0, from, accA2, c.a[2].delay, c.a[2].p2);
+   const float sumF0 = nfc_wave_raw_sum(lds, clock0, from, accF0, c.f[1].delay, c.f[1].p2);
+   const float sumF1 = nfc_wave_raw_sum(lds, clock0, from, accF1, c.f[2].delay, c.f[2].p2);
+   const float sumV = nfc_wave_raw_sum(lds, clock0, from, accV, c.v.delay, c.v.p2);
+
+   NFC_WAVE_BARRIER();
+   lds->sum[0][lane] = sumA0;
+   lds->sum[1][lane] = sumA1;
+   lds->sum[2][lane] = sumA2;
+   lds->sum[3][lane] = sumF0;
+   lds->sum[4][lane] = sumF1;
+   lds->sum[5][lane] = sumV;
+   NFC_WAVE_BARRIER();
+
+   float c2, c3;
+
+#define NFC_WAVE_SEARCH_ONE(k, rt, sum, acc, base, pos)                                                        \
+   nfc_wave_raw_taps(lds, (k), from, (acc), (rt).p1, (rt).p1 - (rt).p2, (base), (pos), prevKnown, c2, c3);     \
+   lds->s0[k][lane] = (sum) - c2;                                                                               \
    lds->s1[k][lane] = c2 - c3;
 
-   NFC_WAVE_SEARCH_ONE(0, c.a[0], accA0, c.corrOffset[0], posA0)
-   NFC_WAVE_SEARCH_ONE(1, c.a[1], accA1, c.corrOffset[1], posA1)
-   NFC_WAVE_SEARCH_ONE(2, c.a[2], accA2, c.corrOffset[2], posA2)
-   NFC_WAVE_SEARCH_ONE(3, c.f[1], accF0, c.corrOffset[3], posF0)
-   NFC_WAVE_SEARCH_ONE(4, c.f[2], accF1, c.corrOffset[4], posF1)
+   NFC_WAVE_SEARCH_ONE(0, c.a[0], sumA0, accA0, c.corrOffset[0], posA0)
+   NFC_WAVE_SEARCH_ONE(1, c.a[1], sumA1, accA1, c.corrOffset[1], posA1)
+   NFC_WAVE_SEARCH_ONE(2, c.a[2], sumA2, accA2, c.corrOffset[2], posA2)
+   NFC_WAVE_SEARCH_ONE(3, c.f[1], sumF0, accF0, c.corrOffset[3], posF0)
+   NFC_WAVE_SEARCH_ONE(4, c.f[2], sumF1, accF1, c.corrOffset[4], posF1)
 #undef NFC_WAVE_SEARCH_ONE
 
-   sum = nfc_wave_raw(lds, 5u, clock0, from, accV, c.v.delay, c.v.p2, c.v.p1, c.v.p1 - c.v.p2, c.corrOffset[5], posV1, prevKnown, never, c2, c3);
-   lds->s0[5][lane] = c2 - sum; /* nfcv_detect: num = c2 - sum */
+   nfc_wave_raw_taps(lds, 5u, from, accV, c.v.p1, c.v.p1 - c.v.p2, c.corrOffset[5], posV1, prevKnown, c2, c3);
+   lds->s0[5][lane] = c2 - sumV; /* nfcv_detect: num = c2 - sum */
    lds->s1[5][lane] = 0.0f;
 }
 
@@ -731,6 +777,12 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
    if (run == 0u)
    {
+      /* the search step only has to ask the detectors whose gates are up (the others take their early exits) */
+      if (lane == from)
+      {
+         lds->u.which = key == NFC_FK_SEARCH ? (which & 0x3FFu) : 0xFFFFFFFFu; /* (bits 8, 9: an NFC-F reset that only leaves its mark) */
+         lds->u.whichAt = from;
+      }
 #ifdef NFC_WAVE_COUNT_DETECTORS
       if (lane == from)
          for (uint32_t b = 0; b < 8u; b++)

@@ -165,6 +165,7 @@ struct nfcgpu_ctx
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
+   uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
 
@@ -679,6 +680,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       sp.deepK = 0.98f * deep;
       sp.chunkSamples = ctx->scanChunk;
       sp.warmSamples = ctx->scanWarm;
+      sp.soloSamples = ctx->wave ? ctx->soloSamples : 0u; /* (the lane-per-window kernels let carry lanes retire) */
 
       /* Every chunk pays the warm-up again, so chunks should be as long as the machine allows: one lane per chunk, and
        * 131072 lanes (256 CUs x 4 SIMDs x 2 waves of the scan kernel's 204 registers x 64) are resident at a time.
@@ -694,6 +696,17 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
             chunk = 32768u;
          if (chunk > sp.chunkSamples)
             sp.chunkSamples = (uint32_t)chunk;
+
+         /* A small submission is one a caller waits for (a capture, a receiver's block): what counts is the time of the
+          * longest walk, chunk + warm-up at ~0.4 us per sample and lane. Shorter chunks and a warm-up that just covers the
+          * slowest recurrence (the average: 0.995^k) cut it; seams that do not verify cost a short second walk now. */
+         if (total <= (4u << 20))
+         {
+            if (sp.chunkSamples > 4096u)
+               sp.chunkSamples = 4096u;
+            if (sp.warmSamples > 3072u)
+               sp.warmSamples = 3072u;
+         }
       }
    }
 
@@ -1421,6 +1434,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->maxPassesFew = knob("NFCGPU_WINDOW_PASSES_FEW", knob("NFCGPU_WINDOW_PASSES", ctx->maxPassesFew));
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
    ctx->wave = knob("NFCGPU_WAVE", 1) != 0;
+   ctx->soloSamples = knob("NFCGPU_SOLO_SAMPLES", ctx->soloSamples);
    /* busy streams: a wave per lane decodes them where they are; the lane-per-window kernels send them to the sequential ones */
    ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->wave ? 101u : ctx->densePercent);
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);
@@ -2439,7 +2453,9 @@ int nfcgpu_comm_destroy(nfcgpu_ctx *ctx)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   Rccl *r = rccl();
+   /* (librccl.so is only looked up for a context that has a communicator: a plain shutdown - possibly from an atexit
+    * handler of the host - must not load a library) */
+   Rccl *r = ctx->comm ? rccl() : nullptr;
 
    if (ctx->comm && r)
    {

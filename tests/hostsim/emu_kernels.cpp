@@ -779,10 +779,12 @@ void nfc_windows_kernel(NfcScanArgs A)
 
       emu_windows_marks(A.tiles + job.firstTile, nTiles);
 
-      const uint32_t need = emu_windows_place(job, j, A.tiles + job.firstTile, nTiles, nullptr, 0, false);
+      const bool solo = job.count <= A.params.soloSamples; /* (a short stream: its carry lane alone, nfc_windows_kernel) */
+      const uint32_t placed = emu_windows_place(job, j, A.tiles + job.firstTile, nTiles, nullptr, 0, false);
+      const uint32_t need = solo ? 0u : placed;
       const uint32_t first = emu_add(A.windowCount, need);
 
-      if (need != statedNeed || std::memcmp(stated.data(), A.tiles + job.firstTile, 4u * nTiles) != 0)
+      if (placed != statedNeed || std::memcmp(stated.data(), A.tiles + job.firstTile, 4u * nTiles) != 0)
       {
          std::fprintf(stderr, "[emu] window rule: the mask form differs from nfc_windows_build (job %u: %u vs %u windows)\n", j, need, statedNeed);
          std::abort();
@@ -796,7 +798,7 @@ void nfc_windows_kernel(NfcScanArgs A)
          job.status |= NFC_JOB_OVERFLOW;
          job.windows = 0;
       }
-      else
+      else if (need)
       {
          emu_windows_place(job, j, A.tiles + job.firstTile, nTiles, A.windows + job.firstWindow, need, true);
 

@@ -28,7 +28,8 @@ def emulated(built):
 
 
 def _run(cases, extra=None):
-    env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096", NFCGPU_SCAN_CHUNK="32768")
+    # (NFCGPU_SOLO_SAMPLES=0: speculative windows also on the short captures)
+    env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096", NFCGPU_SCAN_CHUNK="32768", NFCGPU_SOLO_SAMPLES="0")
     env.update(extra or {})
     run = subprocess.run([sys.executable, DRIVER] + cases, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
     assert run.returncode == 0, run.stderr[-3000:]
@@ -66,3 +67,15 @@ def test_stepping_alone_decodes_the_same_frames(emulated):
 def test_lane_per_window_kernels_still_decode(emulated):
     """NFCGPU_WAVE=0: the round-2 kernels (one lane per window, rings in HBM) stay available behind the knob"""
     _run(["fixture:test_NFC-A_106kbps_002", "quiet"], {"NFCGPU_WAVE": "0", "NFCGPU_DENSE_PERCENT": "101"})
+
+
+@needs_reference
+def test_short_streams_are_decoded_by_their_carry_lane_alone(emulated):
+    """the default: a stream of up to 2^18 samples gets no speculative windows - one lane, one pass"""
+    env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096")
+    run = subprocess.run([sys.executable, DRIVER, "fixture:test_NFC-A_106kbps_002", "fixture:test_NFC-B_106kbps_001"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    for r in json.loads(run.stdout.strip().splitlines()[-1]):
+        assert r["mismatching"] == [] and r["frames"] > 0, r
+        assert r["stats"]["windowed"] == 1 and r["stats"]["passes"] == 1 and r["stats"]["windows"] == 1, r
