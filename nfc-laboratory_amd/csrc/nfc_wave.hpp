@@ -594,7 +594,9 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
       {
          const uint64_t gated = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.gatedHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.gatedLo);
          const uint32_t next = at + 1u - NFC_WAVE_UNIFORM_U32(lds->u.gatedFrom);
-         again = allowFast && !exact && next < 64u && ((gated >> next) & 1ull) != 0ull;
+         /* (only while the decoder stays in the stage the gates were evaluated for) */
+         again = allowFast && !exact && next < 64u && ((gated >> next) & 1ull) != 0ull &&
+                 NFC_WAVE_UNIFORM_U32(lds->u.key) == NFC_WAVE_UNIFORM_U32(nfc_wave_stage(NFC_WAVE_STATE(lds), upkeep));
       }
    }
 }

@@ -43,7 +43,9 @@ def test_config5_sparse_every_stream_matches_the_reference(built):
 @pytest.mark.gpu
 def test_dense_streams_in_two_submissions_match_the_reference(built):
     res = _check(_sweep("dense", 512, 1 << 20, 2))
-    assert res["time_parallel_streams"] == 1024 and res["sequential_streams"] == 0, res  # dense traffic is decoded where it is
+    # dense traffic is decoded where it is; a stream whose lanes do not settle within the pass limit is decoded sequentially
+    # from its untouched state (exact either way: every stream has been compared above)
+    assert res["time_parallel_streams"] + res["sequential_streams"] == 1024 and res["sequential_streams"] <= 8, res
 
 
 @needs_reference
