@@ -490,7 +490,16 @@ def main():
             psink = torch.zeros(sink_words, dtype=torch.int32, device=dev)
             pctl = torch.zeros(4, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
+            torch.cuda.empty_cache()  # what the generators above left in torch's cache is memory the library cannot allocate
             g = nfclab_amd.NfcGpu(device=local, max_streams=max(64, n_streams), frame_sink_bytes=1 << 20)
+            try:
+                return run_point_on(g, name, n_streams, n_samples, sparse, steps, warm, check, idle, offgrid, from_host, buf, host, psink, pctl, total)
+            finally:
+                g.close()
+                del buf, psink, host
+                torch.cuda.empty_cache()
+
+        def run_point_on(g, name, n_streams, n_samples, sparse, steps, warm, check, idle, offgrid, from_host, buf, host, psink, pctl, total):
             g.sink_attach(psink.data_ptr(), sink_words, pctl.data_ptr())
             g.sink_hold(True)
             g.profile(True)
@@ -557,9 +566,6 @@ def main():
                     ref_frames += len(fr)
                     badp += 0 if pframes.get(f0 + s, []) == fr else 1
                 point["parity"] = {"streams_checked": min(n_streams, max(check, 1)), "streams_mismatching": badp, "reference_frames": ref_frames}
-            g.close()
-            del buf, psink, host
-            torch.cuda.empty_cache()
             return point, ps
 
         def run_fixtures():
@@ -567,6 +573,7 @@ def main():
             submission (magnitudes resident in HBM), frames against the golden vectors the reference's own test holds"""
             per = {}
             total_n, total_t, bad = 0, 0.0, 0
+            torch.cuda.empty_cache()
             g = nfclab_amd.NfcGpu(device=local, max_streams=64, frame_sink_bytes=8 << 20)
             for name in TL.fixture_names():
                 mag = torch.from_numpy(TL.load_fixture(name)).to(dev)

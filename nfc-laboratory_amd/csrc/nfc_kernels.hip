@@ -506,7 +506,8 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
 
    /* a chunk on the repair list is walked from the true end state of the chunk before, without warm-up */
    const bool repair = (ch.index & NFC_CHUNK_REPAIR) != 0;
-   ch.index &= ~NFC_CHUNK_REPAIR;
+   const bool envelopeOnly = repair && !PLANES && (ch.index & NFC_CHUNK_ENVELOPE) != 0; /* only the envelope tracker is walked again */
+   ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
 
    const NfcScanJob *job = A.jobs + ch.job;
    const uint32_t g = job->firstChunk + ch.index; /* seam / chunk record */
@@ -614,6 +615,62 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          const uint32_t n = myEnd - rel < NFC_SCAN_TILE ? myEnd - rel : NFC_SCAN_TILE;
          const float *row = tile + lane * NFC_SCAN_PITCH;
 
+         if (envelopeOnly)
+         {
+            /* The second walk of a chunk whose envelope tracker alone had started wrong (nfc_seams_check): envelope and
+             * pulse counter from the true start; what depends on them is put right - the stored points' two fields, the
+             * tiles' envelope extremes - until the walk meets the first one's trajectory. */
+            if (!begun)
+            {
+               seam = A.seams[g];
+               w.fe.clock = clockBase + pos;
+               w.fe.env = seam.start.env;
+               w.fe.pulseFilter = seam.start.pulseFilter;
+               begun = true;
+            }
+
+            if (pos > start && (pos % NFC_SCAN_POINT) == 0)
+            {
+               NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
+
+               if (nfc_bits(stored.env) == nfc_bits(w.fe.env) && stored.pulseFilter == w.fe.pulseFilter)
+               {
+                  seam.end = A.seams[g].end; /* the first walk's end stands */
+                  merged = true;
+                  myEnd = rel;
+                  rowEnd = rel;
+               }
+               else
+               {
+                  stored.env = w.fe.env;
+                  stored.pulseFilter = w.fe.pulseFilter;
+               }
+            }
+
+            if (!merged)
+            {
+               float lo = NFC_SCAN_BIG, hi = -NFC_SCAN_BIG;
+
+               for (uint32_t k = 0; k < n; k++)
+               {
+                  ++w.fe.clock;
+                  ++w.fe.pulseFilter;
+                  nfc_envelope_step(cc, w.fe.clock, w.fe.pulseFilter, w.fe.env, row[k]);
+                  lo = w.fe.env < lo ? w.fe.env : lo;
+                  hi = w.fe.env > hi ? w.fe.env : hi;
+               }
+
+               NfcScanTile &stat = A.tileStats[job->firstTile + pos / NFC_SCAN_TILE];
+               stat.envmin = lo;
+               stat.envmax = hi;
+               stat.bits |= NFC_TILE_REWALKED;
+
+               seam.end.env = w.fe.env;
+               seam.end.pulseFilter = w.fe.pulseFilter;
+            }
+         }
+         else
+         {
          if (!begun)
          {
             if (repair)
@@ -706,6 +763,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          if (!PLANES && pos >= start)
             A.tileStats[job->firstTile + pos / NFC_SCAN_TILE] = stat;
          }
+         }
       }
 
       __syncthreads();
@@ -713,11 +771,19 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
 
    if (mine && !PLANES) /* (the second walk changes nothing the first one established) */
    {
-      if (begun && !merged)
-         nfc_scan_point(w, seam.end);
-      if (repair)
-         seam.start = A.seams[g].start; /* as the seam check set it */
-      A.seams[g] = seam;
+      if (envelopeOnly)
+      {
+         if (begun)
+            A.seams[g] = seam; /* (the first walk's record with the tracker's end put right, or untouched after a merge) */
+      }
+      else
+      {
+         if (begun && !merged)
+            nfc_scan_point(w, seam.end);
+         if (repair)
+            seam.start = A.seams[g].start; /* as the seam check set it */
+         A.seams[g] = seam;
+      }
    }
 }
 

@@ -118,6 +118,8 @@ struct NfcScanChunk
 };
 
 #define NFC_CHUNK_REPAIR 0x80000000u
+#define NFC_CHUNK_ENVELOPE 0x40000000u /* with NFC_CHUNK_REPAIR: only the envelope tracker (envelope, pulse counter) started wrong; the other
+                                          recurrences do not depend on it and stand as walked: the second walk is the tracker's alone */
 
 /* state a window inherits from whatever ran before it on the stream, apart from the front end (scanned) and the
  * history / correlation rings (rebuilt by the warm-up): compared field by field by the chain kernel */

@@ -297,14 +297,32 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
 
       if (!sound)
       {
-         /* from its predecessor's end, edge time included */
-         s.start = seams[job.firstChunk + k - 1].end;
-         s.start.edgeTime = edge;
-         s.start.zone |= NFC_ZONE_EDGE_KNOWN | NFC_ZONE_EDGE_SYNCED;
+         const NfcScanPoint &before = seams[job.firstChunk + k - 1].end;
+
+         /* Usually it is the envelope tracker alone that started wrong (it is the one recurrence that is not contractive:
+          * after a level step it sits between the levels for tens of thousands of samples, a walk seeded from the signal
+          * does not). Nothing else in the front end reads the envelope: the rest of the chunk's records stand, and the
+          * second walk is the tracker's alone (a tenth of the instructions). */
+         const bool envelopeOnly = nfc_bits(s.start.n1) == nfc_bits(before.n1) && nfc_bits(s.start.mdev) == nfc_bits(before.mdev) &&
+                                   nfc_bits(s.start.avg) == nfc_bits(before.avg) && nfc_bits(s.start.edgePeak) == nfc_bits(before.edgePeak) &&
+                                   ((s.start.zone ^ before.zone) & NFC_ZONE_MASK) == 0 && (!(s.start.zone & NFC_ZONE_EDGE_KNOWN) || s.start.edgeTime == edge);
+
+         if (envelopeOnly)
+         {
+            s.start.env = before.env;
+            s.start.pulseFilter = before.pulseFilter;
+         }
+         else
+         {
+            /* from its predecessor's end, edge time included */
+            s.start = before;
+            s.start.edgeTime = edge;
+            s.start.zone |= NFC_ZONE_EDGE_KNOWN | NFC_ZONE_EDGE_SYNCED;
+         }
 
          NfcScanChunk &r = repairs[NFC_ATOMIC_ADD(repairCount, 1u)];
          r.job = jobIndex;
-         r.index = k | NFC_CHUNK_REPAIR;
+         r.index = k | NFC_CHUNK_REPAIR | (envelopeOnly ? NFC_CHUNK_ENVELOPE : 0u);
 
          pending = true;
       }

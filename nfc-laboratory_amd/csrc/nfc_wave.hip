@@ -81,6 +81,22 @@ __device__ __forceinline__ void nfc_wave_config(const NfcConfig *cfgPtr, NfcConf
    }
 }
 
+/* the same inside the step functions: the run-time part from where nfc_wave_run parked it in LDS (NfcWaveLds::cfg) */
+__device__ __forceinline__ void nfc_wave_config_parked(const NFC_WAVE_LDS uint32_t *parked, NfcConfig &cc)
+{
+   nfc_fixed_config(cc);
+   cc.enabled = parked[0];
+   cc.powerThreshold = __builtin_bit_cast(float, parked[1]);
+   cc.lowThreshold = __builtin_bit_cast(float, parked[2]);
+   cc.highThreshold = __builtin_bit_cast(float, parked[3]);
+   for (int t = 0; t < 4; t++)
+   {
+      cc.corrThreshold[t] = __builtin_bit_cast(float, parked[4 + t]);
+      cc.minDepth[t] = __builtin_bit_cast(float, parked[8 + t]);
+      cc.maxDepth[t] = __builtin_bit_cast(float, parked[12 + t]);
+   }
+}
+
 /* wave-wide inclusive prefix sum and maximum on the data-parallel primitives of the SIMD: shifts inside the rows of 16
  * lanes, then the row totals handed on (row_bcast:15, row_bcast:31) */
 #define NFC_DPP_F(old, src, ctrl, rows) \
@@ -118,7 +134,7 @@ __device__ __forceinline__ float nfc_wave_max(float v)
 #define NFC_WAVE_SCAN_ADD_F(v) nfc_wave_scan_add(v)
 #define NFC_WAVE_MAX_F(v) nfc_wave_max(v)
 #define NFC_WAVE_PICK_F(reg, array, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)(reg)), (int)(j)))
-#define NFC_WAVE_CONFIG(cfgPtr, cc) nfc_wave_config((cfgPtr), (cc))
+#define NFC_WAVE_CONFIG(cfgPtr, lds, cc) nfc_wave_config_parked((lds)->cfg, (cc))
 /* experiments: -DNFC_WAVE_STEP_INLINE (the steps inlined into the tile loop), -DNFC_WAVE_WAVES=n (register budget for n waves per SIMD) */
 #ifdef NFC_WAVE_STEP_INLINE
 #define NFC_WAVE_NOINLINE __device__ __forceinline__

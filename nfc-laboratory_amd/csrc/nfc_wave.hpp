@@ -31,7 +31,7 @@
  *   NFC_WAVE_UNIFORM_U32(x)       a value every lane holds, as a scalar
  *   NFC_WAVE_SCAN_ADD_F(v)        inclusive prefix sum over the lanes; NFC_WAVE_MAX_F(v): maximum, in every lane
  *   NFC_WAVE_PICK_F(reg, array, j)  element j (uniform) of a per-lane value that is also in the LDS array
- *   NFC_WAVE_CONFIG(cfgPtr, cc)   fill the NfcConfig `cc`
+ *   NFC_WAVE_CONFIG(cfgPtr, lds, cc)  fill the NfcConfig `cc` inside a step function (NfcWaveLds::cfg holds its run-time part)
  *   NFC_WAVE_NOINLINE             keeps the step a function of its own
  *   NFC_WAVE_LDS                  address space qualifier of LDS objects
  */
@@ -90,6 +90,9 @@ struct NfcWaveLds
    float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator */
    float s0[6][NFC_LANES];           /* ... and the two differences the detectors look at */
    float s1[6][NFC_LANES];
+   /* the run-time part of the configuration (enable mask, thresholds), parked where the step functions find it without a
+    * trip to memory: [0] enabled, [1] power, [2] low, [3] high threshold, [4..7] correlation, [8..11] minimum, [12..15] maximum depth */
+   uint32_t cfg[16];
 #ifdef NFC_WAVE_PROFILE
    uint64_t prof[8];
    uint64_t profLast;
@@ -329,7 +332,7 @@ NFC_DEV void nfc_wave_advance(const NfcConfig &c, S &s, uint32_t n)
 NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWaveLds *lds, NfcWaveSink sink, uint32_t kind, uint32_t emits, uint32_t edge)
 {
    NfcConfig cc;
-   NFC_WAVE_CONFIG(cfgPtr, cc);
+   NFC_WAVE_CONFIG(cfgPtr, lds, cc);
 
    const NfcLaneMem mem = nfc_wave_mem(lds, sink, cfgPtr);
 
@@ -371,7 +374,7 @@ NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWa
 NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWaveLds *lds, NfcWaveSink sink, uint32_t emits, uint32_t edge)
 {
    NfcConfig c;
-   NFC_WAVE_CONFIG(cfgPtr, c);
+   NFC_WAVE_CONFIG(cfgPtr, lds, c);
 
    const NfcLaneMem mem = nfc_wave_mem(lds, sink, cfgPtr);
 
@@ -685,6 +688,20 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       lds->profPhase = 7u;
    }
 #endif
+
+   if (lane == 0)
+   {
+      lds->cfg[0] = cc.enabled;
+      lds->cfg[1] = nfc_bits(cc.powerThreshold);
+      lds->cfg[2] = nfc_bits(cc.lowThreshold);
+      lds->cfg[3] = nfc_bits(cc.highThreshold);
+      for (int t = 0; t < 4; t++)
+      {
+         lds->cfg[4 + t] = nfc_bits(cc.corrThreshold[t]);
+         lds->cfg[8 + t] = nfc_bits(cc.minDepth[t]);
+         lds->cfg[12 + t] = nfc_bits(cc.maxDepth[t]);
+      }
+   }
 
    NFC_WAVE_BARRIER();
 

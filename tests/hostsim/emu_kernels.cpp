@@ -526,13 +526,63 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
    {
       NfcScanChunk ch = A.chunks[listed];
       const bool repair = (ch.index & NFC_CHUNK_REPAIR) != 0;
-      ch.index &= ~NFC_CHUNK_REPAIR;
+      const bool envelopeOnly = repair && (ch.index & NFC_CHUNK_ENVELOPE) != 0;
+      ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
       const NfcScanJob *job = A.jobs + ch.job;
       const uint32_t g = job->firstChunk + ch.index;
       const uint32_t start = ch.index * L;
       const uint32_t end = start + L < job->count ? start + L : job->count;
       const uint32_t walkFrom = (ch.index == 0 || repair) ? start : start - WU;
       const NfcStreamState *st = A.states + job->slot;
+
+      if (envelopeOnly)
+      {
+         /* the envelope tracker alone, from the true start, until it meets the first walk's trajectory (nfc_scan_kernel) */
+         NfcScanSeam seam = A.seams[g];
+         float env = seam.start.env;
+         uint32_t pf = seam.start.pulseFilter, clock = st->clock + start;
+         float lo = NFC_SCAN_BIG, hi = -NFC_SCAN_BIG;
+         bool merged = false;
+
+         for (uint32_t sp = start; sp < end; sp++)
+         {
+            if (sp > start && (sp % NFC_SCAN_POINT) == 0)
+            {
+               NfcScanPoint &stored = A.points[job->firstPoint + sp / NFC_SCAN_POINT];
+               if (nfc_bits(stored.env) == nfc_bits(env) && stored.pulseFilter == pf)
+               {
+                  merged = true;
+                  break;
+               }
+               stored.env = env;
+               stored.pulseFilter = pf;
+            }
+
+            ++clock;
+            ++pf;
+            nfc_envelope_step(*cfgPtr, clock, pf, env, sample_of(job->data, A.stride, sp));
+            lo = env < lo ? env : lo;
+            hi = env > hi ? env : hi;
+
+            if ((sp % NFC_SCAN_TILE) == NFC_SCAN_TILE - 1 || sp == end - 1)
+            {
+               NfcScanTile &stat = A.tileStats[job->firstTile + sp / NFC_SCAN_TILE];
+               stat.envmin = lo;
+               stat.envmax = hi;
+               stat.bits |= NFC_TILE_REWALKED;
+               lo = NFC_SCAN_BIG;
+               hi = -NFC_SCAN_BIG;
+            }
+         }
+
+         if (!merged)
+         {
+            seam.end.env = env;
+            seam.end.pulseFilter = pf;
+         }
+         A.seams[g] = seam;
+         continue;
+      }
 
       NfcScanLane w;
       NfcScanSeam seam;

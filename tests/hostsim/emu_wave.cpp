@@ -57,7 +57,7 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 #define NFC_WAVE_UNIFORM_END } wavesim::barrier();
 #define NFC_WAVE_UNIFORM_U32(x) ((uint32_t)(x))
 #define NFC_WAVE_PICK_F(reg, array, j) ((array)[(j)])
-#define NFC_WAVE_CONFIG(cfgPtr, cc) ((cc) = *(cfgPtr))
+#define NFC_WAVE_CONFIG(cfgPtr, lds, cc) ((cc) = *(cfgPtr))
 #define NFC_WAVE_NOINLINE static __attribute__((noinline))
 #define NFC_WAVE_STAT_ADD(p, v) (*(p) += (v))
 #define NFC_WAVE_STAT_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
