@@ -168,24 +168,25 @@ NFC_DEV int nfcb_detect_rate(const NfcConfig &c, NfcStreamState &s, const NfcLan
    return nfcb_detect_decide<R>(c, s, mem, rt.delay ? taps.edge[R] : now.filt, rt.delay ? taps.deep[R] : now.depth);
 }
 
-/* edge / deep: DC-removed signal and modulation depth at the detector's decode point */
+/* The start-of-frame tracker of one rate on its record alone. clock / env: the decoder's at this sample; edge / deep:
+ * DC-removed signal and modulation depth at the detector's decode point. Returns 0 = keep searching, 1 = start of frame
+ * recognised (the record still holds it: the caller locks), 2 = abandon this sample for the remaining rates.
+ * Only a record past its second edge (symEnd set) can return anything but 0. */
 template <int R>
-NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float edge, float deep)
+NFC_DEV int nfcb_track(const NfcConfig &c, NfcDetB &m, uint32_t clock, float env, float edge, float deep)
 {
    const NfcRate &rt = c.b[R];
-   NfcDetB &m = s.u.search.detB[R];
 
    /* one branch for the common case: no start of frame is being tracked, no reset, no falling edge beyond the threshold
-    * and the (closed) window does not end now. The threshold of that state is recomputed on every sample before it is
-    * used, so not storing it on the early exit changes nothing. */
-   const bool reset = deep > c.maxDepth[1] || (m.auxTime && s.clock > m.auxTime + rt.p1);
+    * that is a new extreme, and the (closed) window does not end now. The threshold of that state is recomputed on every
+    * sample before it is used, so not storing it on the early exit changes nothing. */
+   const bool reset = deep > c.maxDepth[1] || (m.auxTime && clock > m.auxTime + rt.p1);
 
    /* (a reset of a record that is clear already - every sample of a 100 % ASK pause asks for one - changes nothing) */
    const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.auxTime | nfc_bits(m.aux)) == 0u;
 
-   if ((!reset || clear) && !m.symStart && !(edge < -(s.env * c.minDepth[1])) && s.clock != m.winEnd)
+   if ((!reset || clear) && !m.symStart && !(edge < -(env * c.minDepth[1]) && edge < m.aux) && clock != m.winEnd)
       return 0;
-
    if (reset)
    {
       m.symStart = 0; m.symEnd = 0; m.winStart = 0; m.winEnd = 0;
@@ -194,16 +195,16 @@ NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcL
 
    if (!m.symStart)
    {
-      m.thr = s.env * c.minDepth[1];
+      m.thr = env * c.minDepth[1];
 
       if (edge < -m.thr && edge < m.aux)
       {
          m.aux = edge;
-         m.auxTime = s.clock;
-         m.winEnd = s.clock + rt.p4;
+         m.auxTime = clock;
+         m.winEnd = clock + rt.p4;
       }
 
-      if (s.clock != m.winEnd)
+      if (clock != m.winEnd)
          return 0;
 
       m.symStart = m.auxTime - rt.p8;
@@ -217,7 +218,7 @@ NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcL
 
    if (!m.symEnd)
    {
-      if (s.clock < m.winStart)
+      if (clock < m.winStart)
       {
          if (edge > m.thr)
          {
@@ -230,11 +231,11 @@ NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcL
       if (edge > m.thr && edge > m.aux)
       {
          m.aux = edge;
-         m.auxTime = s.clock;
-         m.winEnd = s.clock + rt.p4;
+         m.auxTime = clock;
+         m.winEnd = clock + rt.p4;
       }
 
-      if (s.clock != m.winEnd)
+      if (clock != m.winEnd)
          return 0;
 
       if (!m.auxTime)
@@ -252,7 +253,7 @@ NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcL
       return 0;
    }
 
-   if (s.clock < m.winStart)
+   if (clock < m.winStart)
    {
       if (edge < -m.thr)
       {
@@ -265,11 +266,11 @@ NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcL
    if (edge < -m.thr && m.aux > edge)
    {
       m.aux = edge;
-      m.auxTime = s.clock;
-      m.winEnd = s.clock + rt.p4;
+      m.auxTime = clock;
+      m.winEnd = clock + rt.p4;
    }
 
-   if (s.clock != m.winEnd)
+   if (clock != m.winEnd)
       return 0;
 
    if (!m.auxTime)
@@ -278,6 +279,21 @@ NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcL
       m.auxTime = 0; m.aux = 0;
       return 2; /* the reference leaves the rate loop here (NfcB.cpp:396) */
    }
+
+   return 1;
+}
+
+/* edge / deep: DC-removed signal and modulation depth at the detector's decode point */
+template <int R>
+NFC_DEV int nfcb_detect_decide(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, float edge, float deep)
+{
+   const NfcRate &rt = c.b[R];
+   NfcDetB &m = s.u.search.detB[R];
+
+   const int tracked = nfcb_track<R>(c, m, s.clock, s.env, edge, deep);
+
+   if (tracked != 1)
+      return tracked;
 
    /* SOF recognised: lock; the first bit is sampled half a symbol after the last edge, no search window yet */
    const uint32_t symStart = m.symStart, symEnd = m.auxTime;

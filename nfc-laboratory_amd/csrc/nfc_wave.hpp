@@ -73,6 +73,7 @@ struct NfcWaveUni
    uint32_t gatedFrom;
    uint32_t which;    /* search bank: detectors whose gates were up at sample whichAt (bit per detector, nfc_wave_search_gate) */
    uint32_t whichAt;
+   uint32_t maskValid; /* search bank: the detectors whose gates over the tile at hand (NfcWaveLds::gate) still stand (bit per detector) */
    float pass[16];    /* hand-over from single lanes to everybody */
 };
 
@@ -87,6 +88,7 @@ struct NfcWaveLds
    float env[NFC_LANES];             /* envelope / average after each sample of the tile at hand */
    float avg[NFC_LANES];
    float scratch[NFC_LANES];
+   uint32_t gate[NFC_LANES];         /* search bank: the detectors' gates per sample of the tile (nfc_wave_search_bits) */
    float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator */
    float s0[6][NFC_LANES];           /* ... and the two differences the detectors look at */
    float s1[6][NFC_LANES];
@@ -94,7 +96,7 @@ struct NfcWaveLds
     * trip to memory: [0] enabled, [1] power, [2] low, [3] high threshold, [4..7] correlation, [8..11] minimum, [12..15] maximum depth */
    uint32_t cfg[16];
 #ifdef NFC_WAVE_PROFILE
-   uint64_t prof[8];
+   uint64_t prof[12];
    uint64_t profLast;
    uint32_t profPhase;
 #endif
@@ -235,18 +237,45 @@ NFC_DEV void nfc_wave_rings_out(const NFC_WAVE_LDS NfcWaveLds *lds, float *dst, 
 
 /* The tile at hand: this lane's sample and the front end's results for it, parked where the step reads them. Returns
  * true when the sample is on the capture grid (nfc_wave_fast.hpp). */
-NFC_DEV bool nfc_wave_load_tile(const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t consumed, uint32_t n, uint32_t clock, uint32_t stride)
+/* this lane's sample of a tile and what the front end made of it (the planes), fetched while the tile before is decoded */
+struct NfcWaveFetch
+{
+   float x, filt, env, mdev, avg;
+};
+
+NFC_DEV NfcWaveFetch nfc_wave_fetch(const NfcWaveItem &it, uint32_t consumed, uint32_t stride)
 {
    const uint32_t lane = NFC_WAVE_LANE();
-   bool onGrid = true;
+   const uint32_t left = consumed < it.count ? it.count - consumed : 0u;
+   NfcWaveFetch f = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
-   if (lane < n)
+   if (lane < left)
    {
       const uint32_t i = consumed + lane;
       const float *p = it.planes + 4u * (uint64_t)(it.startPos + i);
 
-      const float x = NFC_SAMPLE_AT(it.data, stride, i);
-      const float env = p[1];
+      f.x = NFC_SAMPLE_AT(it.data, stride, i);
+      f.filt = p[0];
+      f.env = p[1];
+      f.mdev = p[2];
+      f.avg = p[3];
+   }
+
+   return f;
+}
+
+NFC_DEV bool nfc_wave_load_tile(const NfcWaveFetch &f, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t n, uint32_t clock)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+   bool onGrid = true;
+
+#ifdef NFC_WAVE_DEBUG_FETCH
+   NFC_WAVE_DEBUG_FETCH(f, clock);
+#endif
+   if (lane < n)
+   {
+      const float x = f.x;
+      const float env = f.env;
 
       /* modulation depth as the front end forms it (NfcTech.cpp:79-83) */
       const float clamped = (x < 0.0f) ? 0.0f : ((env < x) ? env : x);
@@ -255,11 +284,11 @@ NFC_DEV bool nfc_wave_load_tile(const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *
 
       lds->ring[NFC_WAVE_XOLD + lane] = lds->ring[NFC_R_X + slot]; /* the sample NFC_HIST back */
       lds->ring[NFC_R_X + slot] = x;
-      lds->ring[NFC_R_FILT + slot] = p[0];
-      lds->ring[NFC_R_MDEV + slot] = p[2];
+      lds->ring[NFC_R_FILT + slot] = f.filt;
+      lds->ring[NFC_R_MDEV + slot] = f.mdev;
       lds->ring[NFC_R_DEPTH + slot] = (env - clamped) / env;
       lds->env[lane] = env;
-      lds->avg[lane] = p[3];
+      lds->avg[lane] = f.avg;
 
       const float scaled = x * 32768.0f;
       onGrid = scaled == __builtin_floorf(scaled) && x >= -1.0f && x <= 1.0f;
@@ -302,7 +331,8 @@ NFC_DEV void nfc_wave_advance(const NfcConfig &c, S &s, uint32_t n)
 
 /* -DNFC_WAVE_PROFILE: shader cycles per phase of the lane loop, summed over all waves into L.laneStats[12 + phase]
  * (units of 1024 cycles): 0 tile boundary, 1 tile load, 2 bulk values, 3 bulk gates, 4 bulk commit, 5 the step,
- * 6 the search step from values, 7 lane set-up and result */
+ * 6 the search step from values, 7 lane set-up and result, 8 bulk prologue, 9 gates of a locked stage, 10 NFC-B detectors
+ * stepped on their own, 11 between a step and the next call */
 #ifdef NFC_WAVE_PROFILE
 #define NFC_WAVE_TICK(lds, phase)                                  \
    do                                                              \
@@ -317,6 +347,12 @@ NFC_DEV void nfc_wave_advance(const NfcConfig &c, S &s, uint32_t n)
    } while (0)
 #else
 #define NFC_WAVE_TICK(lds, phase) ((void)0)
+#endif
+
+/* (the fibre build runs the lanes of a wave one after the other between barriers: every lane has to have read a shared
+ * word before one of them goes on to change it; on the GPU the lanes of a wave read together) */
+#ifndef NFC_WAVE_READ_FENCE
+#define NFC_WAVE_READ_FENCE() ((void)0)
 #endif
 
 /* statistics of the fibre build (tests/hostsim): samples committed in bulk (0) / stepped (1) per stage */
@@ -361,6 +397,7 @@ NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWa
          nfc_step_impl<false, true>(cc, s, mem, g.now.x, &g);
 
       *(NfcStreamState *)&lds->u.s = s;
+      lds->u.maskValid = 0u;
       lds->u.at = at + 1u;
       lds->u.stepped++;
    }
@@ -455,7 +492,13 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
 
             /* (a detector that is not asked may still have been told to reset a record that is clear: the mark it leaves) */
             if (ask != 0xFFFFFFFFu)
+            {
                lds->flags |= ((ask >> 8) & 1u) << 16 | ((ask >> 9) & 1u) << 17;
+
+               /* ... or have looked at a record the lane inherited (nfc_wave_gate_f) */
+               const uint32_t seen = lds->flags;
+               lds->flags = seen | (((ask >> 10) & 1u & ~(seen >> 16)) << 14) | (((ask >> 11) & 1u & ~(seen >> 17)) << 15);
+            }
 
             r.detF[0].acc = lds->sum[3][at];
             lds->ring[NFC_R_CORR + c.corrOffset[3] + s.posF[0]] = r.detF[0].acc;
@@ -497,6 +540,9 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
       if (locked || !armed)
          lds->u.key = NFC_FK_NONE;
 
+      /* the gates of the detectors that were asked no longer stand (NFC-F: the marks with them) */
+      lds->u.maskValid &= ~(ask & 0xFFu);
+
       *(NfcStreamState *)&lds->u.s = s;
       lds->u.at = at + 1u;
       lds->u.stepped++;
@@ -507,18 +553,22 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
 /* One tile: the next n samples of the lane's row (stream position pos on). allowFast: take the bulk paths (the fibre
  * build runs every tile a second time without them and compares: tests/hostsim/emu_wave.cpp). */
 NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds,
-                           const NfcWaveSink &sink, uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride, bool allowFast)
+                           const NfcWaveSink &sink, uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, const NfcWaveFetch &fetched, bool allowFast)
 {
    const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
    const uint32_t clock = NFC_WAVE_UNIFORM_U32(lds->u.s.clock);
 
    NFC_WAVE_TICK(lds, 1u);
    NFC_WAVE_BARRIER();
-   const bool onGrid = nfc_wave_load_tile(it, lds, consumed, n, clock, stride);
+   const bool onGrid = nfc_wave_load_tile(fetched, lds, n, clock);
    const bool allOnGrid = NFC_WAVE_BALLOT(!onGrid) == 0ull;
    NFC_WAVE_BARRIER();
 
-   const bool exact = carry && nfc_wave_exact_span(clock, n);
+   /* Ring positions by exact modulo (nfc_core.hpp, nfc_exact_zone): around the wrap of the 32-bit clock on every sample;
+    * at the start of a stream only to put the positions of a fresh state right - the first step of the tile does that,
+    * from there on counting along gives the same positions. */
+   const bool exactSpan = carry && nfc_wave_exact_span(clock, n);
+   const bool streamStart = (uint32_t)(clock + 1u + 1024u) < 2048u;
 
    NFC_WAVE_COUNT(43u, 0u, 1u); /* tiles */
 
@@ -534,6 +584,7 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
       lds->u.gatedFrom = 0;
       lds->u.which = 0xFFFFFFFFu;
       lds->u.whichAt = 0xFFFFFFFFu;
+      lds->u.maskValid = 0u;
       if (!allOnGrid)
          lds->u.gridSince = clock + n;
    }
@@ -559,16 +610,25 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
 
    for (;;)
    {
-      const uint32_t at = NFC_WAVE_UNIFORM_U32(lds->u.at);
+      uint32_t at = NFC_WAVE_UNIFORM_U32(lds->u.at);
+      NFC_WAVE_READ_FENCE();
 
       if (at >= n)
          break;
 
+      const bool exact = exactSpan && (!streamStart || at == 0u || !allowFast);
+
       /* Samples from `at` on that change nothing but sums and rings: committed in bulk. Gated samples tend to come in
        * runs (a detector following a pulse): one that was gated at the last evaluation is stepped without asking
        * again - a step is right on any sample, gated or not. */
-      if (!exact && allowFast && !again && nfc_wave_fast(cc, lds, n, upkeep))
-         continue;
+      if (!exact && allowFast && !again)
+      {
+         if (nfc_wave_fast(cc, lds, n, upkeep))
+            continue;
+
+         at = NFC_WAVE_UNIFORM_U32(lds->u.at); /* (it may have committed a run before the sample to step) */
+         NFC_WAVE_READ_FENCE();
+      }
 
       /* carrier frame due on this sample (NfcDecoder.cpp:472-523)? it is stamped with the decoder's edge time */
       const float avgAt = lds->avg[at];
@@ -580,25 +640,29 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
          edge = nfc_wave_edge_time(cc, A, it, lds, pos + at);
 
       NFC_WAVE_COUNT(nfc_wave_stage(lds->u.s, upkeep), 1u, 1u);
+      if (again)
+         NFC_WAVE_COUNT(45u, 0u, 1u); /* stepped in the wake of another */
 
       /* the search bank from the values the bulk path holds for this sample, or the step machine itself */
       const bool fromValues = allowFast && !exact && !upkeep && lds->u.s.lockTech == 0 && lds->u.s.unlock == 0 &&
                               NFC_WAVE_UNIFORM_U32(lds->u.key) == NFC_FK_SEARCH && NFC_WAVE_UNIFORM_U32(lds->u.from) <= at;
 
       NFC_WAVE_TICK(lds, fromValues ? 6u : 5u);
+      NFC_WAVE_READ_FENCE(); /* (everything above has been read from the state as it stood) */
 
       if (fromValues)
          nfc_wave_search_step(cfgPtr, lds, sink, emits ? 1u : 0u, edge);
       else
          nfc_wave_step(cfgPtr, lds, sink, upkeep ? 2u : (exact ? 1u : 0u), emits ? 1u : 0u, edge);
 
-      NFC_WAVE_TICK(lds, 3u);
+      NFC_WAVE_TICK(lds, 11u);
 
       {
          const uint64_t gated = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.gatedHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.gatedLo);
          const uint32_t next = at + 1u - NFC_WAVE_UNIFORM_U32(lds->u.gatedFrom);
          /* (only while the decoder stays in the stage the gates were evaluated for) */
-         again = allowFast && !exact && next < 64u && ((gated >> next) & 1ull) != 0ull &&
+         /* (the search bank keeps its gates per detector: asking again is cheap there, and tells which detectors to ask) */
+         again = allowFast && !exact && next < 64u && ((gated >> next) & 1ull) != 0ull && NFC_WAVE_UNIFORM_U32(lds->u.key) != NFC_FK_SEARCH &&
                  NFC_WAVE_UNIFORM_U32(lds->u.key) == NFC_WAVE_UNIFORM_U32(nfc_wave_stage(NFC_WAVE_STATE(lds), upkeep));
       }
    }
@@ -682,7 +746,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 #ifdef NFC_WAVE_PROFILE
    if (lane == 0)
    {
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < 12; i++)
          lds->prof[i] = 0;
       lds->profLast = __builtin_readcyclecounter();
       lds->profPhase = 7u;
@@ -732,6 +796,8 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    NFC_WAVE_UNIFORM_END
 
    const NfcLaneMem mem = nfc_wave_mem(lds, sink, cfgPtr);
+
+   NfcWaveFetch fetched = nfc_wave_fetch(it, 0u, stride);
 
    for (;;)
    {
@@ -783,11 +849,16 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       const uint32_t left = it.count - consumed;
       const uint32_t n = left < NFC_LANES ? left : NFC_LANES;
 
+      /* (the next tile's samples are on their way while this one is decoded) */
+      const NfcWaveFetch ahead = nfc_wave_fetch(it, consumed + n, stride);
+
 #ifdef NFC_WAVE_TILE_HOOK
-      NFC_WAVE_TILE_HOOK(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride);
+      NFC_WAVE_TILE_HOOK(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, fetched);
 #else
-      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, true);
+      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, fetched, true);
 #endif
+
+      fetched = ahead;
 
       NFC_WAVE_UNIFORM_BEGIN
       {
@@ -896,7 +967,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
 #ifdef NFC_WAVE_PROFILE
       NFC_WAVE_TICK(lds, 7u);
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < 12; i++)
          NFC_WAVE_STAT_ADD(L.laneStats + 12 + i, (uint32_t)(lds->prof[i] >> 10));
 #endif
    }

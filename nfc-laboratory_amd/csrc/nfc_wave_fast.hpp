@@ -191,117 +191,165 @@ NFC_DEV uint32_t nfc_wave_stage(const NfcStreamState &s, bool upkeep)
 
 /* ---- search bank ---- */
 
-/* gates of the eight detectors at this lane's sample (the early exits of nfc*_detect_rate); bit per detector:
- * A106 A212 A424 B106 B212 F212 F424 V */
-NFC_DEV uint32_t nfc_wave_search_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0)
+/* The gates of the search bank, one detector at a time: does this lane's sample change the detector's record (given the
+ * record as it stands - the state is that of the sample before the run)? Each restates the early exits of its detector
+ * (nfca_detect_decide, nfcb_track, nfcf_detect_decide, nfcv_detect_decide). A gate that is up where nothing would have
+ * changed only costs a step; one that is down where something would have is an error. */
+template <int I>
+NFC_DEV bool nfc_wave_gate_a(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env)
+{
+   /* nfca_detect_rate past its first exit: a correlation beyond the threshold only changes the record when it is a new
+    * extreme of the pause being tracked (or, on the way down, a new deepest modulation) */
+   const uint32_t lane = NFC_WAVE_LANE();
+   const NfcDetA &m = NFC_WAVE_STATE(lds).u.search.detA[I];
+   const NfcRate &rt = c.a[I];
+   const float limit = env * c.corrThreshold[0];
+   const float num = lds->s0[I][lane] - lds->s1[I][lane];
+   const bool timeout = m.peakTime && t > m.peakTime + rt.p1;
+   bool moves = false;
+
+   if (nfc_may_exceed(num, (float)rt.p2, limit))
+   {
+      const float sd = num / (float)rt.p2;
+      const float deep = lds->ring[NFC_R_DEPTH + ((t - rt.delay - rt.p8) & NFC_HMASK)];
+      moves = !m.symStart ? (sd < -limit && (sd < m.peak || deep > m.aux)) : (sd > limit && sd > m.peak);
+   }
+
+   return timeout || (t >= m.winStart && (moves || t == m.winEnd));
+}
+
+/* (the record `m` given: the bulk path steps this detector on its own, nfc_wave_fast) */
+template <int I>
+NFC_DEV bool nfc_wave_gate_b(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, const NfcDetB &m, uint32_t t, float env)
+{
+   const uint32_t slot = (t - c.b[I].delay) & NFC_HMASK;
+   const float edge = lds->ring[NFC_R_FILT + slot], deep = lds->ring[NFC_R_DEPTH + slot];
+   const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.auxTime | nfc_bits(m.aux)) == 0u;
+   const bool reset = (deep > c.maxDepth[1] || (m.auxTime && t > m.auxTime + c.b[I].p1)) && !clear;
+   bool hit;
+
+   if (!m.symStart)
+      hit = (edge < -(env * c.minDepth[1]) && edge < m.aux) || t == m.winEnd;
+   else if (!m.symEnd)
+      hit = t < m.winStart ? edge > m.thr : ((edge > m.thr && edge > m.aux) || t == m.winEnd);
+   else
+      hit = t < m.winStart ? edge < -m.thr : ((edge < -m.thr && m.aux > edge) || t == m.winEnd);
+
+   return reset || hit;
+}
+
+/* asked: the detector is told to reset; on a clear record that only leaves its mark (folded into the commit).
+ * looked: the detector gets as far as looking at its record (a correlation that may exceed the threshold with the window
+ * open): when the record is one the lane inherited, that leaves a mark too (NfcStreamCold::usedTech, bit 14 + I) */
+template <int I>
+NFC_DEV bool nfc_wave_gate_f(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env, bool &asked, bool &looked)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+   const NfcDetF &m = NFC_WAVE_STATE(lds).u.search.detF[I];
+   const NfcRate &rt = c.f[I + 1];
+   const float limit = env * c.corrThreshold[2];
+   const float deep = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)];
+   /* nfcf_detect_rate / nfcf_track_preamble: a correlation above the threshold only changes the record when it is the
+    * largest of the pulse so far */
+   const float num = lds->s0[3 + I][lane] - lds->s1[3 + I][lane];
+   const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.sync | m.peakTime | nfc_bits(m.peak)) == 0u;
+   bool moves = false;
+
+   asked = deep > c.maxDepth[2] || (m.peakTime && t > m.peakTime + rt.p1);
+   looked = false;
+
+   if (nfc_may_exceed(num, (float)rt.p2, limit))
+   {
+      const float sd = nfc_abs(num) / (float)rt.p2;
+      moves = sd > limit && sd > m.peak;
+      looked = t >= m.winStart;
+   }
+
+   return (asked && !clear) || (t >= m.winStart && (moves || t == m.sync || t == m.winEnd));
+}
+
+NFC_DEV bool nfc_wave_gate_v(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+   const NfcDetV &m = NFC_WAVE_STATE(lds).u.search.detV;
+   const float limit = env * c.corrThreshold[3];
+   /* nfcv_detect: a pulse correlation above the threshold only changes the record when it is the largest so far or comes
+    * with a deeper modulation */
+   const float num = lds->s0[5][lane]; /* c2 - sum */
+   const bool timeout = m.peakTime && t > m.peakTime + c.v.p0;
+   bool moves = false;
+
+   if (nfc_may_exceed(num, (float)c.v.p2, limit))
+   {
+      const float q = num / (float)c.v.p2;
+      const float deep = lds->ring[NFC_R_DEPTH + ((t - c.v.delay - c.v.p8) & NFC_HMASK)];
+      moves = q > limit && (q > m.peak || deep > m.aux);
+   }
+
+   return timeout || (t >= m.winStart && (moves || t == m.winEnd));
+}
+
+/* The gates of the bank, a word per sample of the tile (this lane's: NfcWaveLds::gate), kept while the records they were
+ * evaluated for stand: bits 0..2 NFC-A, 3..4 NFC-B, 5..6 NFC-F, 7 NFC-V, 8..9 the NFC-F reset marks, 10..11 where the
+ * NFC-F detectors look at their records (nfc_wave_gate_f). `valid`: the detectors whose bits still stand (a step clears
+ * the bits of the detectors it asked). */
+#define NFC_WAVE_GATE_HARD 0xE7u /* a gate of these detectors is a sample to step */
+#define NFC_WAVE_GATE_B 0x18u    /* NFC-B detectors before their second edge are stepped on their own (nfc_wave_fast) */
+#define NFC_WAVE_GATE_OTHER 0x1000u /* bit 12: the bank is not armed at this sample, or a carrier frame is due */
+
+NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t valid, uint32_t w)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const uint32_t t = nfc_wave_clock_of(clock0);
-   const NfcSearchRegs &r = NFC_WAVE_STATE(lds).u.search;
    const float env = lds->env[lane];
-   uint32_t gate = 0;
 
    if (c.enabled & 1u)
    {
-      const float limit = env * c.corrThreshold[0];
-
-      for (int i = 0; i < 3; i++)
-      {
-         /* nfca_detect_rate past its first exit: a correlation beyond the threshold only changes the record when it is a
-          * new extreme of the pause being tracked (or, on the way down, a new deepest modulation) */
-         const NfcDetA &m = r.detA[i];
-         const NfcRate &rt = c.a[i];
-         const float num = lds->s0[i][lane] - lds->s1[i][lane];
-         const bool timeout = m.peakTime && t > m.peakTime + rt.p1;
-         bool moves = false;
-
-         if (nfc_may_exceed(num, (float)rt.p2, limit))
-         {
-            const float sd = num / (float)rt.p2;
-            const float deep = lds->ring[NFC_R_DEPTH + ((t - rt.delay - rt.p8) & NFC_HMASK)];
-            moves = !m.symStart ? (sd < -limit && (sd < m.peak || deep > m.aux)) : (sd > limit && sd > m.peak);
-         }
-
-         const bool eventful = t >= m.winStart && (moves || t == m.winEnd);
-         gate |= (timeout || eventful) ? 1u << i : 0u;
-      }
+      if (!(valid & 1u))
+         w = (w & ~1u) | (nfc_wave_gate_a<0>(c, lds, t, env) ? 1u : 0u);
+      if (!(valid & 2u))
+         w = (w & ~2u) | (nfc_wave_gate_a<1>(c, lds, t, env) ? 2u : 0u);
+      if (!(valid & 4u))
+         w = (w & ~4u) | (nfc_wave_gate_a<2>(c, lds, t, env) ? 4u : 0u);
    }
 
    if (c.enabled & 2u)
    {
-      for (int i = 0; i < 2; i++)
+      if (!(valid & 8u))
       {
-         const NfcDetB &m = r.detB[i];
-         const uint32_t slot = (t - c.b[i].delay) & NFC_HMASK;
-         const float edge = lds->ring[NFC_R_FILT + slot], deep = lds->ring[NFC_R_DEPTH + slot];
-         const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.auxTime | nfc_bits(m.aux)) == 0u;
-         const bool reset = (deep > c.maxDepth[1] || (m.auxTime && t > m.auxTime + c.b[i].p1)) && !clear;
-         bool hit;
-
-         if (!m.symStart)
-            hit = edge < -(env * c.minDepth[1]) || t == m.winEnd;
-         else if (!m.symEnd)
-            hit = t < m.winStart ? edge > m.thr : ((edge > m.thr && edge > m.aux) || t == m.winEnd);
-         else
-            hit = t < m.winStart ? edge < -m.thr : ((edge < -m.thr && m.aux > edge) || t == m.winEnd);
-
-         gate |= (reset || hit) ? 8u << i : 0u;
+         const NfcDetB m = NFC_WAVE_STATE(lds).u.search.detB[0];
+         w = (w & ~8u) | (nfc_wave_gate_b<0>(c, lds, m, t, env) ? 8u : 0u);
+      }
+      if (!(valid & 16u))
+      {
+         const NfcDetB m = NFC_WAVE_STATE(lds).u.search.detB[1];
+         w = (w & ~16u) | (nfc_wave_gate_b<1>(c, lds, m, t, env) ? 16u : 0u);
       }
    }
 
    if (c.enabled & 4u)
    {
-      const float limit = env * c.corrThreshold[2];
-      const float deep = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)];
-
-      for (int i = 0; i < 2; i++)
+      if (!(valid & 32u))
       {
-         const NfcDetF &m = r.detF[i];
-         const NfcRate &rt = c.f[i + 1];
-         /* nfcf_detect_rate / nfcf_track_preamble: a correlation above the threshold only changes the record when it is
-          * the largest of the pulse so far */
-         const float num = lds->s0[3 + i][lane] - lds->s1[3 + i][lane];
-         const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.sync | m.peakTime | nfc_bits(m.peak)) == 0u;
-         const bool asked = deep > c.maxDepth[2] || (m.peakTime && t > m.peakTime + rt.p1);
-         const bool reset = asked && !clear;
-         bool moves = false;
-
-         /* (a reset that finds the record clear only leaves its mark: bit 8 + i, folded into the commit) */
-         gate |= asked ? 256u << i : 0u;
-
-         if (nfc_may_exceed(num, (float)rt.p2, limit))
-         {
-            const float sd = nfc_abs(num) / (float)rt.p2;
-            moves = sd > limit && sd > m.peak;
-         }
-
-         const bool eventful = t >= m.winStart && (moves || t == m.sync || t == m.winEnd);
-         gate |= (reset || eventful) ? 32u << i : 0u;
+         bool asked, looked;
+         const bool gate = nfc_wave_gate_f<0>(c, lds, t, env, asked, looked);
+         w = (w & ~0x520u) | (gate ? 0x20u : 0u) | (asked ? 0x100u : 0u) | (looked ? 0x400u : 0u);
+      }
+      if (!(valid & 64u))
+      {
+         bool asked, looked;
+         const bool gate = nfc_wave_gate_f<1>(c, lds, t, env, asked, looked);
+         w = (w & ~0xA40u) | (gate ? 0x40u : 0u) | (asked ? 0x200u : 0u) | (looked ? 0x800u : 0u);
       }
    }
 
    if (c.enabled & 8u)
    {
-      const NfcDetV &m = r.detV;
-      const float limit = env * c.corrThreshold[3];
-      /* nfcv_detect: a pulse correlation above the threshold only changes the record when it is the largest so far or
-       * comes with a deeper modulation */
-      const float num = lds->s0[5][lane]; /* c2 - sum */
-      const bool timeout = m.peakTime && t > m.peakTime + c.v.p0;
-      bool moves = false;
-
-      if (nfc_may_exceed(num, (float)c.v.p2, limit))
-      {
-         const float q = num / (float)c.v.p2;
-         const float deep = lds->ring[NFC_R_DEPTH + ((t - c.v.delay - c.v.p8) & NFC_HMASK)];
-         moves = q > limit && (q > m.peak || deep > m.aux);
-      }
-
-      const bool eventful = t >= m.winStart && (moves || t == m.winEnd);
-      gate |= (timeout || eventful) ? 128u : 0u;
+      if (!(valid & 128u))
+         w = (w & ~128u) | (nfc_wave_gate_v(c, lds, t, env) ? 128u : 0u);
    }
 
-   return gate;
+   return w;
 }
 
 /* running sum of one raw box-sum correlator after each of the tile's samples from lane `from` on (nfc_wave_raw, first half) */
@@ -671,6 +719,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    const uint32_t from = NFC_WAVE_UNIFORM_U32(lds->u.at);
    const uint32_t clock0 = NFC_WAVE_UNIFORM_U32(lds->u.clock0);
 
+   NFC_WAVE_TICK(lds, 8u);
    uint32_t key = NFC_WAVE_UNIFORM_U32(nfc_wave_stage(s, upkeep));
 
    NFC_WAVE_COUNT(40u, 0u, 1u); /* calls */
@@ -710,6 +759,11 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
    if (!take)
    {
+      NFC_WAVE_COUNT(46u, 0u, 1u); /* bulk paths not taken */
+      NFC_WAVE_COUNT(key, 1u, 0u);
+#ifdef NFC_WAVE_COUNT_NOT_TAKEN
+      NFC_WAVE_COUNT_NOT_TAKEN(key, raw && (uint32_t)(clock0 + 1u - lds->u.gridSince) < NFC_FAST_GRID_BACK);
+#endif
       /* stepping goes on without the values being kept up */
       NFC_WAVE_UNIFORM_BEGIN
       {
@@ -721,7 +775,9 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
    /* ---- values (kept while the stage lasts) ---- */
    NFC_WAVE_TICK(lds, 2u);
-   if (NFC_WAVE_UNIFORM_U32(lds->u.key) != key || from < NFC_WAVE_UNIFORM_U32(lds->u.from))
+   const bool formed = NFC_WAVE_UNIFORM_U32(lds->u.key) != key || from < NFC_WAVE_UNIFORM_U32(lds->u.from);
+
+   if (formed)
    {
       if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
       {
@@ -745,26 +801,118 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
    /* ---- gate ---- */
    NFC_WAVE_TICK(lds, 3u);
-   bool gate;
    uint32_t which = 0;
+   uint32_t run;
+   uint64_t gated;   /* bit j: sample from + j is gated */
+   uint32_t bits = 0; /* search: this lane's gate word */
 
    /* a carrier frame is due (NfcDecoder.cpp:472-523: search mode only) */
    const bool carrier = (avg > c.highThreshold) ? !s.carrierOn : ((avg < c.lowThreshold) && !s.carrierOff);
+   const uint64_t range = n < 64u ? (1ull << n) - 1ull : ~0ull;
 
    if (key == NFC_FK_SEARCH)
    {
-      which = nfc_wave_search_gate(c, lds, clock0);
-      gate = !armed || carrier || (which & 0xFFu) != 0u;
-   }
-   else if (key == NFC_FK_UNARMED)
-      gate = armed || carrier;
-   else if (key == NFC_FK_UPKEEP)
-      gate = false;
-   else
-      gate = nfc_wave_locked_gate(c, lds, clock0, key);
+      /* The detectors' gates are kept per sample while their records stand. A sample only NFC-B detectors still looking
+       * for their first or second edge react to is taken in the run: it cannot lock, the records of the two rates are all
+       * it touches (nfcb_track), and in a busy signal of the other technologies every pause is a falling edge to them. */
+      bits = nfc_wave_search_bits(c, lds, clock0, formed ? 0u : NFC_WAVE_UNIFORM_U32(lds->u.maskValid), formed ? 0u : lds->gate[lane]);
+      bits = (bits & ~NFC_WAVE_GATE_OTHER) | ((!armed || carrier) ? NFC_WAVE_GATE_OTHER : 0u);
 
-   const uint64_t gated = NFC_WAVE_BALLOT(gate && lane >= from && lane < n) >> from;
-   const uint32_t run = gated ? (uint32_t)__builtin_ctzll(gated) : n - from;
+      const uint64_t hard = NFC_WAVE_BALLOT((bits & (NFC_WAVE_GATE_HARD | NFC_WAVE_GATE_OTHER)) != 0u) & range;
+      uint64_t soft = NFC_WAVE_BALLOT((bits & NFC_WAVE_GATE_B) != 0u) & range;
+      uint32_t at = from, g = n;
+
+      for (;;)
+      {
+         const uint64_t rest = at < 64u ? (hard | soft) >> at : 0ull;
+
+         g = rest ? at + (uint32_t)__builtin_ctzll(rest) : n;
+
+         if (g >= n || ((hard >> g) & 1ull))
+            break;
+
+         const uint32_t here = NFC_WAVE_PICK_U32(bits, lds->gate, g);
+         const bool on0 = (here & 8u) != 0u, on1 = (here & 16u) != 0u;
+
+         if ((on0 && s.u.search.detB[0].symEnd) || (on1 && s.u.search.detB[1].symEnd))
+            break;
+
+         NFC_WAVE_READ_FENCE(); /* (the records are about to change) */
+
+         NFC_WAVE_COUNT(44u, 0u, 1u); /* NFC-B detectors stepped on their own */
+         NFC_WAVE_TICK(lds, 10u);
+
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            const uint32_t clk = clock0 + 1u + g;
+            const float envAt = lds->env[g];
+
+            if (on0)
+            {
+               const uint32_t slot = (clk - c.b[0].delay) & NFC_HMASK;
+               NfcDetB m = *(NfcDetB *)&lds->u.s.u.search.detB[0];
+               (void)nfcb_track<0>(c, m, clk, envAt, lds->ring[NFC_R_FILT + slot], lds->ring[NFC_R_DEPTH + slot]);
+               *(NfcDetB *)&lds->u.s.u.search.detB[0] = m;
+            }
+
+            if (on1)
+            {
+               const uint32_t slot = (clk - c.b[1].delay) & NFC_HMASK;
+               NfcDetB m = *(NfcDetB *)&lds->u.s.u.search.detB[1];
+               (void)nfcb_track<1>(c, m, clk, envAt, lds->ring[NFC_R_FILT + slot], lds->ring[NFC_R_DEPTH + slot]);
+               *(NfcDetB *)&lds->u.s.u.search.detB[1] = m;
+            }
+         }
+         NFC_WAVE_UNIFORM_END
+
+         /* their gates over the rest of the tile, for the records as they now stand */
+         if (on0)
+         {
+            const NfcDetB m = s.u.search.detB[0];
+            bits = (bits & ~8u) | (nfc_wave_gate_b<0>(c, lds, m, t, env) ? 8u : 0u);
+         }
+         if (on1)
+         {
+            const NfcDetB m = s.u.search.detB[1];
+            bits = (bits & ~16u) | (nfc_wave_gate_b<1>(c, lds, m, t, env) ? 16u : 0u);
+         }
+
+         soft = NFC_WAVE_BALLOT((bits & NFC_WAVE_GATE_B) != 0u) & range;
+         at = g + 1u;
+      }
+
+      NFC_WAVE_TICK(lds, 3u);
+      run = g - from;
+      /* (for the caller's wake rule the NFC-B gates do not count: the next call takes those samples) */
+      gated = ((hard | (g < n ? 1ull << g : 0ull)) & ~((g < 64u ? 1ull << g : 0ull) - 1ull)) >> from;
+
+      if (g < n)
+         which = NFC_WAVE_PICK_U32(bits, lds->gate, g) & 0xFFFu;
+
+      lds->gate[lane] = bits;
+
+      NFC_WAVE_UNIFORM_BEGIN
+      {
+         lds->u.maskValid = 0xFFu;
+      }
+      NFC_WAVE_UNIFORM_END
+   }
+   else
+   {
+      bool gate;
+
+      NFC_WAVE_TICK(lds, 9u);
+
+      if (key == NFC_FK_UNARMED)
+         gate = armed || carrier;
+      else if (key == NFC_FK_UPKEEP)
+         gate = false;
+      else
+         gate = nfc_wave_locked_gate(c, lds, clock0, key);
+
+      gated = NFC_WAVE_BALLOT(gate && lane >= from && lane < n) >> from;
+      run = gated ? (uint32_t)__builtin_ctzll(gated) : n - from;
+   }
 
    /* kept for the caller: the sample after a stepped one is stepped too when it was gated here */
    NFC_WAVE_UNIFORM_BEGIN
@@ -775,23 +923,30 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    }
    NFC_WAVE_UNIFORM_END
 
-   if (run == 0u)
+   /* the sample after the run is one to step: the caller goes there straight from here (false) */
+   const bool more = from + run < n;
+
+   if (more)
    {
+      if (key == NFC_FK_SEARCH && (which & 0xFFu) == 0u)
+         NFC_WAVE_COUNT(47u, 0u, 1u); /* search: unarmed sample or carrier frame */
       /* the search step only has to ask the detectors whose gates are up (the others take their early exits) */
-      if (lane == from)
+      NFC_WAVE_UNIFORM_BEGIN
       {
-         lds->u.which = key == NFC_FK_SEARCH ? (which & 0x3FFu) : 0xFFFFFFFFu; /* (bits 8, 9: an NFC-F reset that only leaves its mark) */
-         lds->u.whichAt = from;
+         lds->u.which = key == NFC_FK_SEARCH ? (which & 0xFFFu) : 0xFFFFFFFFu; /* (bits 8 .. 11: what an NFC-F detector that is not asked still leaves) */
+         lds->u.whichAt = from + run;
       }
+      NFC_WAVE_UNIFORM_END
 #ifdef NFC_WAVE_COUNT_DETECTORS
       if (lane == from)
          for (uint32_t b = 0; b < 8u; b++)
             if ((which >> b) & 1u)
                NFC_WAVE_COUNT_DETECTORS(b);
 #endif
-      (void)which;
-      return false;
    }
+
+   if (run == 0u)
+      return false;
 
    NFC_WAVE_COUNT(key, 0u, run);
 
@@ -837,7 +992,17 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    if (key == NFC_FK_SEARCH)
    {
       const bool mine = lane >= from && lane <= last;
-      marks = (NFC_WAVE_BALLOT(mine && (which & 256u)) ? 1u << 16 : 0u) | (NFC_WAVE_BALLOT(mine && (which & 512u)) ? 1u << 17 : 0u);
+
+      for (uint32_t i = 0; i < 2u; i++)
+      {
+         const uint64_t asked = NFC_WAVE_BALLOT(mine && ((bits >> (8u + i)) & 1u)), looked = NFC_WAVE_BALLOT(mine && ((bits >> (10u + i)) & 1u));
+
+         /* (a detector that looks at its record before the lane has reset it: NfcStreamCold::usedTech, bit 14 + i) */
+         if (looked && !((lds->flags >> (16u + i)) & 1u) && (!asked || __builtin_ctzll(looked) < __builtin_ctzll(asked)))
+            marks |= 1u << (14u + i);
+         if (asked)
+            marks |= 1u << (16u + i);
+      }
    }
 
    if (gathers)
@@ -920,8 +1085,8 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    }
    NFC_WAVE_UNIFORM_END
 
-   NFC_WAVE_TICK(lds, 3u);
-   return true;
+   NFC_WAVE_TICK(lds, 11u);
+   return !more;
 }
 
 #endif

@@ -1141,16 +1141,30 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - passBegan).count();
          {
             /* (a library built with -DNFC_WAVE_PROFILE: shader cycles per phase of the wave decoder, nfc_wave.hpp) */
-            uint32_t prof[8] = {0};
-            HIP_TRY(ctx, hipMemcpy(prof, counters + 16, 32, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemsetAsync(counters + 16, 0, 32, ctx->stream));
+            uint32_t prof[12] = {0};
+            HIP_TRY(ctx, hipMemcpy(prof, counters + 16, 48, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemsetAsync(counters + 16, 0, 48, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             uint64_t all = 0;
             for (uint32_t v: prof)
                all += v;
             if (all)
-               std::fprintf(stderr, "[nfcgpu]    wave cycles x 2^10: boundary %u, tile load %u, values %u, gates %u, commit %u, step %u, search step %u, set-up %u\n", prof[0], prof[1],
-                            prof[2], prof[3], prof[4], prof[5], prof[6], prof[7]);
+               std::fprintf(stderr, "[nfcgpu]    wave cycles x 2^10: boundary %u, tile load %u, values %u, search gates %u, commit %u, step %u, search step %u, set-up %u, "
+                                    "prologue %u, locked gates %u, NFC-B alone %u, between %u\n", prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6], prof[7],
+                            prof[8], prof[9], prof[10], prof[11]);
+         }
+         if (std::atoi(std::getenv("NFCGPU_WINDOW_DEBUG")) >= 2 && nWindows)
+         {
+            /* the lanes of the first stream as the pass left them */
+            std::vector<NfcScanJob> jb(1);
+            HIP_TRY(ctx, hipMemcpy(jb.data(), ctx->wJobs.ptr, sizeof(NfcScanJob), hipMemcpyDeviceToHost));
+            std::vector<NfcWindow> ws(jb[0].windows);
+            if (!ws.empty())
+               HIP_TRY(ctx, hipMemcpy(ws.data(), (const NfcWindow *)ctx->wWindows.ptr + jb[0].firstWindow, sizeof(NfcWindow) * ws.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < ws.size(); i++)
+               std::fprintf(stderr, "[nfcgpu]    lane %3zu: start %8u live from %8u verify %8u stop %8u (%7u samples) retired %u to %3u, rerun %u live %u pub %u\n", i, ws[i].start,
+                            ws[i].activate, ws[i].verify, ws[i].stop, ws[i].stop - ws[i].start, ws[i].retired, ws[i].handTo - jb[0].firstWindow, ws[i].rerun, ws[i].live,
+                            ws[i].pubState);
          }
          std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled, %.1f ms\n", pass, ls[2],
                       (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again, ms);

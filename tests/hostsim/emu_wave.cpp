@@ -56,7 +56,9 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 #define NFC_WAVE_UNIFORM_BEGIN if (wavesim::lane() == 0) {
 #define NFC_WAVE_UNIFORM_END } wavesim::barrier();
 #define NFC_WAVE_UNIFORM_U32(x) ((uint32_t)(x))
+#define NFC_WAVE_READ_FENCE() wavesim::barrier()
 #define NFC_WAVE_PICK_F(reg, array, j) ((array)[(j)])
+#define NFC_WAVE_PICK_U32(reg, array, j) (wavesim::shfl((reg), (j)))
 #define NFC_WAVE_CONFIG(cfgPtr, lds, cc) ((cc) = *(cfgPtr))
 #define NFC_WAVE_NOINLINE static __attribute__((noinline))
 #define NFC_WAVE_STAT_ADD(p, v) (*(p) += (v))
@@ -93,16 +95,19 @@ static inline float emu_max(float v)
 struct NfcWaveLds;
 struct NfcWaveItem;
 struct NfcWaveSink;
+struct NfcWaveFetch;
 static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcWaveSink &sink,
-                            uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride);
+                            uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, const NfcWaveFetch &fetched);
 #define NFC_WAVE_TILE_HOOK emu_verify_tile
 
 extern uint64_t emu_wave_counts[64][2];
 static bool emu_counting = true;
 static uint32_t emu_trace_clock;
 #define NFC_WAVE_COUNT_DETECTORS(b) do { emu_wave_counts[32 + (b)][0]++; if (std::getenv("NFC_EMU_TRACE_SEARCH")) std::fprintf(stderr, "[trace] %u %u\n", clock0 + 1u + from, (unsigned)(b)); } while (0)
+#define NFC_WAVE_COUNT_NOT_TAKEN(key, grid) do { if (wavesim::lane() == 0 && std::getenv("NFC_EMU_TRACE_NOT_TAKEN")) std::fprintf(stderr, "[not taken] key %u grid %d clock %u\n", (unsigned)(key), (int)(grid), clock0 + 1u + from); } while (0)
 #define NFC_WAVE_COUNT(key, which, count) do { if (wavesim::lane() == 0 && emu_counting) emu_wave_counts[(key) & 63u][(which)] += (count); } while (0)
 
+#define NFC_WAVE_DEBUG_FETCH(f, clock) do { if (std::getenv("NFC_EMU_DEBUG_FETCH") && (wavesim::lane() < 2) && (clock) >= 131071u && (clock) < 131300u) std::fprintf(stderr, "[fetch] lane %u clock %u &f %p env %g x %g\n", wavesim::lane(), (unsigned)(clock), (const void *)&(f), (f).env, (f).x); } while (0)
 #include "../../nfc-laboratory_amd/csrc/nfc_wave.hpp"
 
 static int emu_verify_mode()
@@ -131,6 +136,9 @@ struct CountPrinter
       for (uint32_t k = 0; k < 8; k++)
          if (emu_wave_counts[32 + k][0])
             std::fprintf(stderr, "[emu wave] search stepped for %-5s %10llu\n", det[k], (unsigned long long)emu_wave_counts[32 + k][0]);
+      std::fprintf(stderr, "[emu wave] NFC-B detectors stepped on their own %llu, steps in the wake of another %llu, bulk paths not taken %llu, unarmed / carrier steps %llu\n",
+                   (unsigned long long)emu_wave_counts[44][0], (unsigned long long)emu_wave_counts[45][0], (unsigned long long)emu_wave_counts[46][0],
+                   (unsigned long long)emu_wave_counts[47][0]);
       std::fprintf(stderr, "[emu wave] bulk-path calls %llu, search values formed %llu, locked values formed %llu, tiles %llu\n", (unsigned long long)emu_wave_counts[40][0],
                    (unsigned long long)emu_wave_counts[41][0], (unsigned long long)emu_wave_counts[42][0], (unsigned long long)emu_wave_counts[43][0]);
       for (uint32_t k = 0; k < 17; k++)
@@ -142,19 +150,19 @@ struct CountPrinter
 }
 
 static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NfcWaveLds *lds, const NfcWaveSink &sink,
-                            uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, uint32_t stride)
+                            uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, const NfcWaveFetch &fetched)
 {
    const int mode = emu_verify_mode();
 
    if (mode == 2)
    {
-      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, false); /* no bulk paths at all */
+      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, fetched, false); /* no bulk paths at all */
       return;
    }
 
    if (mode != 1)
    {
-      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, true);
+      nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, fetched, true);
       return;
    }
 
@@ -171,7 +179,7 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
    }
    wavesim::barrier();
 
-   nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, stride, true);
+   nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, fetched, true);
 
    wavesim::barrier();
    if (wavesim::lane() == 0)
@@ -190,7 +198,7 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
    quiet.capacity = 4096;
 
    emu_counting = false;
-   nfc_wave_tile(cfgPtr, cc, A, it, lds, quiet, n, pos, carry, warmFront, warm, stride, false);
+   nfc_wave_tile(cfgPtr, cc, A, it, lds, quiet, n, pos, carry, warmFront, warm, fetched, false);
    wavesim::barrier();
    emu_counting = true;
 
@@ -225,6 +233,11 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
          for (uint32_t i = 0; i < NFC_CORR_MAX; i++)
             if (std::memcmp(&fastLds.ring[NFC_R_CORR + i], &lds->ring[NFC_R_CORR + i], 4) != 0)
                std::fprintf(stderr, "   corr ring %u: bulk %g stepped %g\n", i, fastLds.ring[NFC_R_CORR + i], lds->ring[NFC_R_CORR + i]);
+         std::fprintf(stderr, "   at: bulk %u stepped %u; n %u; env[0] %g %g env[n-1] %g %g; fetched.env (fibre 0) %g; stepped count %u %u\n", fastLds.u.at, lds->u.at, n, fastLds.env[0], lds->env[0],
+                      fastLds.env[n - 1], lds->env[n - 1], fetched.env, fastLds.u.stepped, lds->u.stepped);
+         for (uint32_t i = 0; i < n; i++)
+            if (fastLds.env[i] != lds->env[i])
+               std::fprintf(stderr, "   env[%u]: bulk %g stepped %g\n", i, fastLds.env[i], lds->env[i]);
          if (fastLds.flags != lds->flags)
             std::fprintf(stderr, "   flags: bulk %08x stepped %08x\n", fastLds.flags, lds->flags);
          std::abort();
