@@ -832,6 +832,11 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
          job.status |= NFC_JOB_DENSE; /* (fewer streams than a wave has lanes: the sequential kernel would crawl, cut them anyway) */
          atomicAdd(A.denseCount, 1u);
       }
+
+      /* Speculative lanes buy parallelism inside a stream with warm-ups, hand-overs that fail and further passes. A
+       * submission of hundreds of busy streams has lanes enough without: one lane per stream, start to end, one pass. */
+      if (A.params.aloneStreams && A.nJobs >= A.params.aloneStreams && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.params.alonePercent)
+         job.status |= NFC_JOB_ALONE;
    }
 
    if (!(job.status & NFC_JOB_INVALID))
@@ -983,7 +988,7 @@ __global__ __launch_bounds__(64) void nfc_windows_kernel(NfcScanArgs A)
 
    /* count, reserve, fill: the speculative windows of a job are contiguous and ordered */
    /* a short stream is decoded by its carry lane alone (NfcScanParams::soloSamples): one pass, nothing to speculate on */
-   const bool solo = job.count <= A.params.soloSamples;
+   const bool solo = job.count <= A.params.soloSamples || (job.status & NFC_JOB_ALONE) != 0u;
    const uint32_t need = solo ? 0u : nfc_windows_place(job, j, t, nTiles, nullptr, 0u, false);
 
    uint32_t first = 0u;

@@ -28,6 +28,8 @@ struct NfcScanParams
    uint32_t chunkSamples;  /* samples per chunk (multiple of NFC_SCAN_POINT) */
    uint32_t warmSamples;   /* samples walked before a chunk to reach the true front-end state (multiple of NFC_SCAN_POINT) */
    uint32_t soloSamples;   /* streams of at most this many samples get no speculative windows: their carry lane decodes them alone, in one pass */
+   uint32_t aloneStreams;  /* ... and so do the busy streams of a submission of at least this many streams (0: never): there are lanes enough */
+   uint32_t alonePercent;  /* busy: more than this share of the tiles has something for the decoder to do */
 };
 
 /* bit-for-bit equality of two records (word by word through memcpy: no library call on the device, and no loads through

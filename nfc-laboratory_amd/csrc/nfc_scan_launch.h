@@ -17,6 +17,8 @@ struct NfcScanParams
    uint32_t chunkSamples;
    uint32_t warmSamples;
    uint32_t soloSamples;
+   uint32_t aloneStreams;
+   uint32_t alonePercent;
 };
 #endif
 

@@ -96,7 +96,7 @@ struct NfcWaveLds
     * trip to memory: [0] enabled, [1] power, [2] low, [3] high threshold, [4..7] correlation, [8..11] minimum, [12..15] maximum depth */
    uint32_t cfg[16];
 #ifdef NFC_WAVE_PROFILE
-   uint64_t prof[12];
+   uint64_t prof[16];
    uint64_t profLast;
    uint32_t profPhase;
 #endif
@@ -372,6 +372,8 @@ NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWa
 
    const NfcLaneMem mem = nfc_wave_mem(lds, sink, cfgPtr);
 
+   NFC_WAVE_TICK(lds, 12u); /* (profile build: 5 call and configuration, 12 state in, 13 the step machine, 14 state out) */
+
    NFC_WAVE_UNIFORM_BEGIN
    {
       NfcStreamState s = *(NfcStreamState *)&lds->u.s;
@@ -389,12 +391,16 @@ NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWa
       if (emits)
          s.edgeTime = edge; /* a carrier frame is stamped with it (NfcDecoder.cpp:472-523) */
 
+      NFC_WAVE_TICK(lds, 13u);
+
       if (kind == 2u)
          nfc_step_upkeep<false, true>(cc, s, mem, g.now.x, &g);
       else if (kind == 1u)
          nfc_step_impl<true, true>(cc, s, mem, g.now.x, &g);
       else
          nfc_step_impl<false, true>(cc, s, mem, g.now.x, &g);
+
+      NFC_WAVE_TICK(lds, 14u);
 
       *(NfcStreamState *)&lds->u.s = s;
       lds->u.maskValid = 0u;
@@ -746,7 +752,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 #ifdef NFC_WAVE_PROFILE
    if (lane == 0)
    {
-      for (int i = 0; i < 12; i++)
+      for (int i = 0; i < 16; i++)
          lds->prof[i] = 0;
       lds->profLast = __builtin_readcyclecounter();
       lds->profPhase = 7u;
@@ -967,7 +973,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
 #ifdef NFC_WAVE_PROFILE
       NFC_WAVE_TICK(lds, 7u);
-      for (int i = 0; i < 12; i++)
+      for (int i = 0; i < 16; i++)
          NFC_WAVE_STAT_ADD(L.laneStats + 12 + i, (uint32_t)(lds->prof[i] >> 10));
 #endif
    }

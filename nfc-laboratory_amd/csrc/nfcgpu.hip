@@ -166,6 +166,8 @@ struct nfcgpu_ctx
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
    uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
+   uint32_t aloneStreams = 256;     /* ... and so are the busy streams of a submission of at least this many streams (NFCGPU_ALONE_STREAMS, 0: never) */
+   uint32_t alonePercent = 25;      /* busy: more than this share of a stream's tiles has work for the decoder (NFCGPU_ALONE_PERCENT) */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
 
@@ -681,6 +683,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       sp.chunkSamples = ctx->scanChunk;
       sp.warmSamples = ctx->scanWarm;
       sp.soloSamples = ctx->wave ? ctx->soloSamples : 0u; /* (the lane-per-window kernels let carry lanes retire) */
+      sp.aloneStreams = ctx->wave ? ctx->aloneStreams : 0u;
+      sp.alonePercent = ctx->alonePercent;
 
       /* Every chunk pays the warm-up again, so chunks should be as long as the machine allows: one lane per chunk, and
        * 131072 lanes (256 CUs x 4 SIMDs x 2 waves of the scan kernel's 204 registers x 64) are resident at a time.
@@ -1141,17 +1145,17 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - passBegan).count();
          {
             /* (a library built with -DNFC_WAVE_PROFILE: shader cycles per phase of the wave decoder, nfc_wave.hpp) */
-            uint32_t prof[12] = {0};
-            HIP_TRY(ctx, hipMemcpy(prof, counters + 16, 48, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemsetAsync(counters + 16, 0, 48, ctx->stream));
+            uint32_t prof[16] = {0};
+            HIP_TRY(ctx, hipMemcpy(prof, counters + 16, 64, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemsetAsync(counters + 16, 0, 64, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             uint64_t all = 0;
             for (uint32_t v: prof)
                all += v;
             if (all)
                std::fprintf(stderr, "[nfcgpu]    wave cycles x 2^10: boundary %u, tile load %u, values %u, search gates %u, commit %u, step %u, search step %u, set-up %u, "
-                                    "prologue %u, locked gates %u, NFC-B alone %u, between %u\n", prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6], prof[7],
-                            prof[8], prof[9], prof[10], prof[11]);
+                                    "prologue %u, locked gates %u, NFC-B alone %u, between %u, step: state in %u, machine %u, state out %u\n", prof[0], prof[1], prof[2], prof[3], prof[4], prof[5],
+                            prof[6], prof[7], prof[8], prof[9], prof[10], prof[11], prof[12], prof[13], prof[14]);
          }
          if (std::atoi(std::getenv("NFCGPU_WINDOW_DEBUG")) >= 2 && nWindows)
          {
@@ -1449,6 +1453,8 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
    ctx->wave = knob("NFCGPU_WAVE", 1) != 0;
    ctx->soloSamples = knob("NFCGPU_SOLO_SAMPLES", ctx->soloSamples);
+   ctx->aloneStreams = knob("NFCGPU_ALONE_STREAMS", ctx->aloneStreams);
+   ctx->alonePercent = knob("NFCGPU_ALONE_PERCENT", ctx->alonePercent);
    /* busy streams: a wave per lane decodes them where they are; the lane-per-window kernels send them to the sequential ones */
    ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->wave ? 101u : ctx->densePercent);
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);

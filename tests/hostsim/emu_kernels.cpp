@@ -708,6 +708,8 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
          const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
          if (A.nJobs >= NFC_LANES && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
             { job.status |= NFC_JOB_DENSE; emu_add(A.denseCount, 1u); }
+         if (A.params.aloneStreams && A.nJobs >= A.params.aloneStreams && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.params.alonePercent)
+            job.status |= NFC_JOB_ALONE;
       }
       if (!(job.status & NFC_JOB_INVALID))
          nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
@@ -829,7 +831,7 @@ void nfc_windows_kernel(NfcScanArgs A)
 
       emu_windows_marks(A.tiles + job.firstTile, nTiles);
 
-      const bool solo = job.count <= A.params.soloSamples; /* (a short stream: its carry lane alone, nfc_windows_kernel) */
+      const bool solo = job.count <= A.params.soloSamples || (job.status & NFC_JOB_ALONE) != 0u; /* (its carry lane alone, nfc_windows_kernel) */
       const uint32_t placed = emu_windows_place(job, j, A.tiles + job.firstTile, nTiles, nullptr, 0, false);
       const uint32_t need = solo ? 0u : placed;
       const uint32_t first = emu_add(A.windowCount, need);
