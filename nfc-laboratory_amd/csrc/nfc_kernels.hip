@@ -567,25 +567,31 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          const uint32_t fromRel = __builtin_amdgcn_readlane(rowFrom, q);
          const uint32_t endRel = __builtin_amdgcn_readlane(rowEnd, q);
 
-         re[q] = 0.0f;
-         im[q] = 0.0f;
+         /* Does the row have anything at this step (uniform)? The load is issued either way - from the first word of the
+          * tile records where it has not - so that the 64 of a step are in flight together: behind a branch each would
+          * wait for the one before (seen on the second walks, which run a wave or two per CU: a memory latency per row). */
+         const bool has = rel + NFC_SCAN_TILE > fromRel && rel < endRel;
 
-         /* uniform: does the row have anything at this step? */
-         if (rel + NFC_SCAN_TILE > fromRel && rel < endRel)
+         typedef __attribute__((address_space(1))) const float GlobalFloat;
+         const uint64_t row = ((uint64_t)hi << 32) | lo;
+
+         uint32_t at = rel + lane;
+         at = at < fromRel ? fromRel : at;
+         at = at >= endRel ? endRel - 1u : at;
+
+         if (S == 2)
          {
-            typedef __attribute__((address_space(1))) const float GlobalFloat;
-            GlobalFloat *p = (GlobalFloat *)(((uint64_t)hi << 32) | lo);
-            uint32_t at = rel + lane;
-            at = at < fromRel ? fromRel : at;
-            at = at >= endRel ? endRel - 1u : at;
-
-            if (S == 2)
-            {
-               re[q] = p[2 * at];
-               im[q] = p[2 * at + 1];
-            }
-            else
-               re[q] = p[at];
+            GlobalFloat *p = has ? (GlobalFloat *)row + 2u * at : (GlobalFloat *)A.tileStats;
+            const float vx = p[0], vy = p[1];
+            re[q] = has ? vx : 0.0f;
+            im[q] = has ? vy : 0.0f;
+         }
+         else
+         {
+            GlobalFloat *p = has ? (GlobalFloat *)row + at : (GlobalFloat *)A.tileStats;
+            const float v = *p;
+            re[q] = has ? v : 0.0f;
+            im[q] = 0.0f;
          }
       }
    };

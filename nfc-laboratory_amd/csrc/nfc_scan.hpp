@@ -59,6 +59,7 @@ struct NfcScanLane
    uint32_t edgeKnown;  /* ... and it has set a time since: fe.edgeTime is the true one */
    float xmin, xmax, envmin, envmax, fmin; /* of the tile being walked */
    uint32_t bits;
+   float seedMax; /* largest raw sample of the whole tiles walked so far (nfc_scan_reseed) */
 };
 
 #define NFC_SCAN_BIG 3.0e38f
@@ -123,13 +124,15 @@ NFC_DEV void nfc_scan_point(const NfcScanLane &w, NfcScanPoint &p)
    p.zone = w.zone | (w.edgeKnown ? NFC_ZONE_EDGE_KNOWN : 0u) | (w.edgeSynced ? NFC_ZONE_EDGE_SYNCED : 0u);
 }
 
-/* A third of the way into the warm-up the guessed envelope is replaced by the average, which has converged by then
- * whatever it started from (a plain EMA): on unmodulated carrier the two agree within the noise, so the envelope
- * tracker starts inside its 5 % capture range. (Started further away it only moves once per ten symbols and can take
- * a whole chunk to find the carrier level.) */
+/* A third of the way into the warm-up the guessed envelope is replaced by the largest sample seen so far. The tracker
+ * only follows the signal inside a 5 % capture range; outside it moves once per ten symbols and can take a whole chunk to
+ * find the level. In a modulated signal (pauses of a reader, a card's load modulation) the true tracker sits at the
+ * unmodulated carrier level and holds through the modulation: that level is the largest the signal reaches, up to the
+ * noise. (The average, used here before, lies between the levels of a modulated signal: started there the tracker settled
+ * on whichever level came first, and most seams of a busy capture did not verify.) */
 NFC_DEV void nfc_scan_reseed(NfcScanLane &w)
 {
-   w.fe.env = w.fe.avg;
+   w.fe.env = w.seedMax > 0.0f ? w.seedMax : w.fe.avg;
    w.fe.pulseFilter = 0;
 }
 
@@ -181,6 +184,7 @@ NFC_DEV void nfc_scan_tile_end(NfcScanLane &w, NfcScanTile &out)
    out.envmin = w.envmin;
    out.envmax = w.envmax;
    out.bits = w.bits | ((w.xmin >= -4.0f && w.xmax <= 4.0f) ? 0u : NFC_TILE_OFFGRID); /* also an empty tile, harmlessly */
+   w.seedMax = w.xmax > w.seedMax ? w.xmax : w.seedMax;
    nfc_scan_tile_reset(w);
 }
 

@@ -166,7 +166,7 @@ struct nfcgpu_ctx
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
    uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
-   uint32_t aloneStreams = 256;     /* ... and so are the busy streams of a submission of at least this many streams (NFCGPU_ALONE_STREAMS, 0: never) */
+   uint32_t aloneStreams = 0;       /* ... and so are the busy streams of a submission of at least this many streams (NFCGPU_ALONE_STREAMS; 0, the default: never - measured on MI355X a lone lane does 2.4 MS/s of busy signal, so 2^20 samples take longer than the passes they save) */
    uint32_t alonePercent = 25;      /* busy: more than this share of a stream's tiles has work for the decoder (NFCGPU_ALONE_PERCENT) */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
@@ -918,6 +918,9 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          ctx->stats.fallback_streams += nJobs;
          return launch_sequential(ctx, config, items, stride);
       }
+
+      if (debugStages)
+         std::fprintf(stderr, "[nfcgpu]    seams round %u: %u chunks to walk again\n", round, repairs);
 
       if (!repairs)
          break;

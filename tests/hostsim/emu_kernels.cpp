@@ -585,6 +585,7 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
       }
 
       NfcScanLane w;
+      std::memset(&w, 0, sizeof(w));
       NfcScanSeam seam;
       std::memset(&seam, 0, sizeof(seam));
       bool begun = false;
