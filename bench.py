@@ -331,6 +331,7 @@ def main():
             "kernel": dominant,
             "kernel_ms_avg": round(kernel_ms, 4),
             "kernel_ms_is": "all launches of the kernel in one step (HIP events on the launching streams)",
+            "kernel_launches_per_step": round((st.wave_launches if dominant == "nfc_wave_kernel" else st.launches) / K, 1),
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "peak_measured_streaming_read": round(read_peak, 1),
             "frac_of_measured_peak": round(achieved / read_peak, 6) if read_peak > 0 else None,
