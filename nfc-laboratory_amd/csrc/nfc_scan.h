@@ -101,6 +101,7 @@ struct NfcScanJob
    uint32_t finalLane;  /* virtual slot whose state is the stream's state after the submission (chain kernel) */
    uint32_t passes;
    uint32_t busyTiles;  /* tiles kernel: tiles with something for the decoder to do */
+   uint32_t cut;        /* inside busy signal a new lane starts this often (NFC_WINDOW_CUT, or more when the submission has lanes to spare) */
 };
 
 #define NFC_JOB_OFFGRID 0x01u   /* samples off the int16 grid: sequential path */

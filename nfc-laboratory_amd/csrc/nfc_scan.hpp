@@ -430,8 +430,8 @@ NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uin
       }
 
       /* where lanes cannot retire (busy signal, or not enough quiet signal ahead) a new lane starts every
-       * NFC_WINDOW_CUT samples: whoever is running there hands over to it if their states agree (nfc_lane_handover) */
-      if (!(t[i] & (NFC_TILE_RETIRE_OK | NFC_TILE_DARK)) && act >= lastAct + NFC_WINDOW_CUT && act >= warm + NFC_SCAN_POINT &&
+       * NfcScanJob::cut samples: whoever is running there hands over to it if their states agree (nfc_lane_handover) */
+      if (!(t[i] & (NFC_TILE_RETIRE_OK | NFC_TILE_DARK)) && act >= lastAct + job.cut && act >= warm + NFC_SCAN_POINT &&
           act + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= job.count)
       {
          put((act - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT, act);
@@ -538,7 +538,7 @@ NFC_DEV void nfc_group_place(NfcWindowPlacer &p, const NfcScanJob &job, uint32_t
       const uint64_t c = cluster & from;
 
       /* first tile of the group a cut window may activate at */
-      const uint32_t due = (p.lastAct + NFC_WINDOW_CUT) / NFC_SCAN_TILE;
+      const uint32_t due = (p.lastAct + job.cut) / NFC_SCAN_TILE;
       uint64_t e = 0ull;
       if (due < g * 64u + 64u)
       {

@@ -165,6 +165,8 @@ struct nfcgpu_ctx
    uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
+   uint32_t lanesWanted = 16384;    /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart) */
+   uint32_t cutMax = 1u << 17;      /* ... but never further apart than this (NFCGPU_CUT_MAX) */
    uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
    uint32_t aloneStreams = 0;       /* ... and so are the busy streams of a submission of at least this many streams (NFCGPU_ALONE_STREAMS; 0, the default: never - measured on MI355X a lone lane does 2.4 MS/s of busy signal, so 2^20 samples take longer than the passes they save) */
    uint32_t alonePercent = 25;      /* busy: more than this share of a stream's tiles has work for the decoder (NFCGPU_ALONE_PERCENT) */
@@ -494,10 +496,26 @@ int grow(nfcgpu_ctx *ctx, nfcgpu_ctx::DevBuf &b, size_t bytes)
    b.ptr = nullptr;
    b.bytes = 0;
 
-   const size_t want = bytes + bytes / 4 + 256;
+   /* some room to grow into (a quarter; little for the buffers that are gigabytes), none when that does not fit */
+   size_t want = bytes + (bytes < ((size_t)1 << 30) ? bytes / 4 : bytes / 32) + 256;
 
    if (hipMalloc(&b.ptr, want) != hipSuccess)
-      return fail(ctx, NFCGPU_ENOMEM, "device allocation for the time-parallel path failed");
+   {
+      (void)hipGetLastError();
+      want = bytes;
+
+      if (hipMalloc(&b.ptr, want) != hipSuccess)
+      {
+         size_t freeBytes = 0, totalBytes = 0;
+         (void)hipGetLastError();
+         (void)hipMemGetInfo(&freeBytes, &totalBytes);
+         b.ptr = nullptr;
+         char what[160];
+         std::snprintf(what, sizeof(what), "device allocation for the time-parallel path failed (%.2f GiB wanted, %.2f of %.2f GiB free)", (double)bytes / (double)(1 << 30),
+                       (double)freeBytes / (double)(1 << 30), (double)totalBytes / (double)(1 << 30));
+         return fail(ctx, NFCGPU_ENOMEM, what);
+      }
+   }
 
    b.bytes = want;
    return NFCGPU_OK;
@@ -737,6 +755,18 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       for (uint32_t k = 0; k < job.chunks; k++)
          chunks.push_back(NfcScanChunk {j, k});
+   }
+
+   /* Lanes inside busy signal: NFC_WINDOW_CUT samples apart when the submission is small (every lane is parallelism),
+    * further apart - fewer warm-ups, fewer hand-overs to go wrong - when that still leaves several lanes per wave slot
+    * of the machine (NFCGPU_LANES_WANTED, default 16384 = 8 per slot of 256 CUs x 8 waves) */
+   {
+      uint64_t cut = ctx->lanesWanted ? totalSamples / ctx->lanesWanted : 0u;
+      cut = cut / NFC_SCAN_POINT * NFC_SCAN_POINT;
+      cut = cut < NFC_WINDOW_CUT ? NFC_WINDOW_CUT : (cut > ctx->cutMax ? ctx->cutMax : cut);
+
+      for (NfcScanJob &job: jobs)
+         job.cut = (uint32_t)cut;
    }
 
    const uint32_t nChunks = (uint32_t)chunks.size();
@@ -1456,6 +1486,10 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
    ctx->wave = knob("NFCGPU_WAVE", 1) != 0;
    ctx->soloSamples = knob("NFCGPU_SOLO_SAMPLES", ctx->soloSamples);
+   ctx->lanesWanted = knob("NFCGPU_LANES_WANTED", ctx->lanesWanted);
+   ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
+   if (ctx->cutMax < NFC_WINDOW_CUT)
+      ctx->cutMax = NFC_WINDOW_CUT;
    ctx->aloneStreams = knob("NFCGPU_ALONE_STREAMS", ctx->aloneStreams);
    ctx->alonePercent = knob("NFCGPU_ALONE_PERCENT", ctx->alonePercent);
    /* busy streams: a wave per lane decodes them where they are; the lane-per-window kernels send them to the sequential ones */
