@@ -167,6 +167,7 @@ struct nfcgpu_ctx
    bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
    uint32_t lanesWanted = 16384;    /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart) */
    uint32_t cutMax = 1u << 17;      /* ... but never further apart than this (NFCGPU_CUT_MAX) */
+   uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
    uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
    uint32_t aloneStreams = 0;       /* ... and so are the busy streams of a submission of at least this many streams (NFCGPU_ALONE_STREAMS; 0, the default: never - measured on MI355X a lone lane does 2.4 MS/s of busy signal, so 2^20 samples take longer than the passes they save) */
    uint32_t alonePercent = 25;      /* busy: more than this share of a stream's tiles has work for the decoder (NFCGPU_ALONE_PERCENT) */
@@ -1034,6 +1035,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    lanes.sink = (uint32_t *)ctx->vSink.ptr;
    lanes.sinkCtl = (uint32_t *)ctx->vSinkCtl.ptr;
    lanes.sinkWords = (uint32_t)(ctx->vSink.bytes / 4 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ctx->vSink.bytes / 4);
+   if (ctx->stagingWords && lanes.sinkWords > ctx->stagingWords)
+      lanes.sinkWords = ctx->stagingWords; /* (NFCGPU_STAGING_WORDS: the tests make it run full) */
    lanes.ringBlockFloats = kRingBlockFloats;
    lanes.works = (const NfcWork *)ctx->wWorks.ptr;
    lanes.windows = (NfcWindow *)ctx->wWindows.ptr;
@@ -1106,6 +1109,24 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    const bool debugPasses = std::getenv("NFCGPU_WINDOW_DEBUG") != nullptr;
    std::vector<hipEvent_t> passEvents; /* fork / join events in flight; back to the pool once the pass has been waited for */
 
+   /* Whatever way this function is left while the side stream may still be running kernels of the pass (a launch that
+    * failed after the fork, an event that could not be recorded): the side stream is waited for before anyone reuses the
+    * staging slot or the lane buffers it reads, and the events of the pass go back to the pool. */
+   struct SideGuard
+   {
+      nfcgpu_ctx *ctx;
+      std::vector<hipEvent_t> *events;
+      bool running;
+      ~SideGuard()
+      {
+         if (running)
+            (void)hipStreamSynchronize(ctx->side);
+         for (hipEvent_t e: *events)
+            ctx->eventPool.push_back(e);
+         events->clear();
+      }
+   } sideGuard {ctx, &passEvents, false};
+
    for (;;)
    {
       const auto passBegan = std::chrono::steady_clock::now();
@@ -1141,8 +1162,15 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          hipEvent_t fork = ctx->sideMode == 2 ? take_event(ctx) : ctx->forkEvent;
          hipEvent_t join = ctx->sideMode == 2 ? take_event(ctx) : ctx->joinEvent;
 
+         if (ctx->sideMode == 2)
+         {
+            passEvents.push_back(fork);
+            passEvents.push_back(join);
+         }
+
          HIP_TRY(ctx, hipEventRecord(fork, ctx->stream));
          HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, fork, 0));
+         sideGuard.running = true;
 
          if ((rc = decodeSlots(true, 0, nJobs, ctx->side)))
             return rc;
@@ -1153,12 +1181,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
             return rc;
 
          HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, join, 0));
-
-         if (ctx->sideMode == 2)
-         {
-            passEvents.push_back(fork);
-            passEvents.push_back(join);
-         }
+         sideGuard.running = false; /* (the main stream now waits for it) */
       }
 
       HIP_TRY(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));
@@ -1219,6 +1242,22 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    }
 
    mark("passes");
+
+   /* The lanes chain their frame records in a staging sink that is sized from an estimate and written by every lane of
+    * every pass, live in the end or not. Should it have run full, frames of live lanes may be among the ones that did not
+    * fit: nothing of the streams has been touched yet, so the submission is decoded by the sequential kernels instead. */
+   {
+      uint32_t stagingCtl[2] = {0, 0};
+      HIP_TRY(ctx, hipMemcpyAsync(stagingCtl, ctx->vSinkCtl.ptr, 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+      if (stagingCtl[1])
+      {
+         HIP_TRY(ctx, hipMemsetAsync(ctx->vSinkCtl.ptr, 0, 16, ctx->stream));
+         ctx->stats.fallback_streams += nJobs;
+         return launch_sequential(ctx, config, items, stride);
+      }
+   }
 
    /* the state a stream is left in: its last lane's, run once more with storage of its own */
    hipLaunchKernelGGL(nfc_final_lanes_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, dCfg, A, lanes);
@@ -1486,6 +1525,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
    ctx->wave = knob("NFCGPU_WAVE", 1) != 0;
    ctx->soloSamples = knob("NFCGPU_SOLO_SAMPLES", ctx->soloSamples);
+   ctx->stagingWords = knob("NFCGPU_STAGING_WORDS", ctx->stagingWords);
    ctx->lanesWanted = knob("NFCGPU_LANES_WANTED", ctx->lanesWanted);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
    if (ctx->cutMax < NFC_WINDOW_CUT)
@@ -1576,6 +1616,8 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
 
    if (ctx->stream)
       (void)hipStreamSynchronize(ctx->stream);
+   if (ctx->side)
+      (void)hipStreamSynchronize(ctx->side); /* (nothing of its work may outlive the buffers freed below) */
 
    for (auto &pl: ctx->timed)
    {

@@ -80,6 +80,16 @@ def test_long_busy_submissions_of_few_streams_are_decoded_in_blocks_emulated(emu
 
 
 @needs_reference
+def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emulated(emulated):
+    """the lanes chain their frames in a staging sink sized from an estimate; when it runs full (NFCGPU_STAGING_WORDS: a cap for
+    this test) frames of live lanes may be missing, so the untouched streams are decoded sequentially: same frames, none lost"""
+    res = _run(["buffers"], True, {"NFCGPU_STAGING_WORDS": "96"})
+    for r in res:
+        assert r["mismatching"] == [] and r["frames"] > 0, r
+    assert sum(r["stats"]["fallback"] for r in res) > 0, res
+
+
+@needs_reference
 def test_random_multi_submission_scenarios_emulated(emulated):
     """a short run of profiles/tools/r02/emulated_fuzz.py (random mixes of sparse and dense streams cut into submissions at
     random samples: both paths, carried state, final-state fix-ups) - the long runs are in profiles/r02/emulated_fuzz.json"""
