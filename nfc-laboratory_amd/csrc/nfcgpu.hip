@@ -1648,13 +1648,14 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
    nfcgpu_comm_destroy(ctx);
 
    for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
-                                &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl, &ctx->vSaveRings, &ctx->vSaveBytes})
+                                &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl, &ctx->vSaveRings, &ctx->vSaveBytes,
+                                &ctx->wPlanes, &ctx->wPlaneChunks})
    {
       if (b->ptr)
          (void)hipFree(b->ptr);
    }
 
-   for (auto *list: {&ctx->timedScan, &ctx->timedWindow})
+   for (auto *list: {&ctx->timedScan, &ctx->timedWindow, &ctx->timedWave, &ctx->timedPlanes})
    {
       for (auto &pl: *list)
       {

@@ -238,6 +238,27 @@ def test_frame_sink_overflow_is_reported_not_silent(built):
         assert e.value.code == -6
 
 
+def test_a_closed_context_gives_its_device_memory_back(built):
+    """three contexts in a row, each taking a capture through the time-parallel path (scan records, planes, lane storage): the
+    free device memory afterwards is what it was (a context that kept its front-end planes - 16 B per sample - made the
+    third large point of a bench run fail)"""
+    import torch
+    import nfclab_amd
+    x = np.abs(T.load_fixture("test_NFC-F_212kbps_003")).astype(np.float32)
+    torch.cuda.synchronize()
+    free = []
+    for k in range(4):
+        with nfclab_amd.NfcGpu(device=0, max_streams=64) as g:
+            sid = g.open()
+            g.submit(sid, x, FS)
+            assert len(g.poll(sid)) > 0
+            st = g.stats()
+            assert st.windowed_streams == 1 and st.planes_ms >= 0
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info(0)[0])
+    assert abs(free[-1] - free[0]) < (8 << 20), free   # (the first context may leave the runtime's own pools behind)
+
+
 def test_reference_test_sdr_harness_runs_unchanged_on_the_gpu_decoder(built, tmp_path):
     """Drop-in check: the reference's own test-sdr main.cpp, linked against our lab::NfcDecoder shim
     (nfc-laboratory_amd/host/NfcDecoder.cpp -> C ABI -> HIP), must print PASS for its golden files."""
