@@ -20,7 +20,7 @@ EMU = os.path.join(T.ROOT, "tests", "hostsim", "libnfcgpu_emulated.so")
 NEEDS_GPU = ["test_uniform_device_batch_synthetic_streams", "test_frame_gather_over_rccl_single_rank", "test_frame_gather_through_the_c_abi_single_rank",
              "test_reference_test_sdr_harness_runs_unchanged_on_the_gpu_decoder",
              "test_reference_radio_decoder_task_runs_unchanged_on_the_gpu_decoder", "test_radio_decoder_task_fed_with_iq_buffers",
-             "test_radio_decoder_task_with_the_shim_in_block_mode"]
+             "test_radio_decoder_task_with_the_shim_in_block_mode", "test_a_closed_context_gives_its_device_memory_back"]
 
 
 @pytest.fixture(scope="module")
