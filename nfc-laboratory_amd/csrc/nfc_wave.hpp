@@ -351,6 +351,9 @@ NFC_DEV void nfc_wave_advance(const NfcConfig &c, S &s, uint32_t n)
 
 /* (the fibre build runs the lanes of a wave one after the other between barriers: every lane has to have read a shared
  * word before one of them goes on to change it; on the GPU the lanes of a wave read together) */
+#ifndef NFC_WAVE_DEBUG_POINT
+#define NFC_WAVE_DEBUG_POINT(lds, tag) ((void)0)
+#endif
 #ifndef NFC_WAVE_READ_FENCE
 #define NFC_WAVE_READ_FENCE() ((void)0)
 #endif
@@ -569,6 +572,7 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
    const bool onGrid = nfc_wave_load_tile(fetched, lds, n, clock);
    const bool allOnGrid = NFC_WAVE_BALLOT(!onGrid) == 0ull;
    NFC_WAVE_BARRIER();
+   NFC_WAVE_DEBUG_POINT(lds, 4u);
 
    /* Ring positions by exact modulo (nfc_core.hpp, nfc_exact_zone): around the wrap of the 32-bit clock on every sample;
     * at the start of a stream only to put the positions of a fresh state right - the first step of the tile does that,
@@ -629,7 +633,9 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
        * again - a step is right on any sample, gated or not. */
       if (!exact && allowFast && !again)
       {
-         if (nfc_wave_fast(cc, lds, n, upkeep))
+         const bool went = nfc_wave_fast(cc, lds, n, upkeep);
+         NFC_WAVE_DEBUG_POINT(lds, 1u);
+         if (went)
             continue;
 
          at = NFC_WAVE_UNIFORM_U32(lds->u.at); /* (it may have committed a run before the sample to step) */
@@ -662,6 +668,7 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
          nfc_wave_step(cfgPtr, lds, sink, upkeep ? 2u : (exact ? 1u : 0u), emits ? 1u : 0u, edge);
 
       NFC_WAVE_TICK(lds, 11u);
+      NFC_WAVE_DEBUG_POINT(lds, fromValues ? 2u : 3u);
 
       {
          const uint64_t gated = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.gatedHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.gatedLo);

@@ -22,6 +22,8 @@ while time.time()<deadline:
         streams.append(m)
     nb=int(rng.integers(1,6))
     cuts=sorted(set([0,L]+[int(x) for x in rng.integers(1,L,size=nb-1)]))
+    if os.environ.get("NFC_FUZZ_TRACE"):
+        print("SCENARIO", json.dumps({"kind":str(kind),"S":S,"L":L,"base":base,"cuts":cuts,"round":rounds}), file=sys.stderr, flush=True)
     want=[T.reference_decode(m, keep_carrier=True, cap=65536, defined_storage=True)[0] for m in streams]
     with nfclab_amd.NfcGpu(device=0, max_streams=64) as gpu:
         first=gpu.open(count=S)

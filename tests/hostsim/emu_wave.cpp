@@ -108,6 +108,15 @@ static uint32_t emu_trace_clock;
 #define NFC_WAVE_COUNT(key, which, count) do { if (wavesim::lane() == 0 && emu_counting) emu_wave_counts[(key) & 63u][(which)] += (count); } while (0)
 
 #define NFC_WAVE_DEBUG_FETCH(f, clock) do { if (std::getenv("NFC_EMU_DEBUG_FETCH") && (wavesim::lane() < 2) && (clock) >= 131071u && (clock) < 131300u) std::fprintf(stderr, "[fetch] lane %u clock %u &f %p env %g x %g\n", wavesim::lane(), (unsigned)(clock), (const void *)&(f), (f).env, (f).x); } while (0)
+/* NFC_EMU_WATCH=<index>: report the phase of the tile loop after which ring[index] first differs from what it held when the tile began */
+static int emu_watch_index = -2;
+static float emu_watch_value;
+static bool emu_watch_armed;
+#define NFC_WAVE_DEBUG_POINT(lds, tag) do { if (emu_watch_index == -2) { const char *w = std::getenv("NFC_EMU_WATCH"); emu_watch_index = w ? std::atoi(w) : -1; } \
+   if (emu_watch_index >= 0 && emu_watch_armed && std::memcmp(&(lds)->ring[emu_watch_index], &emu_watch_value, 4) != 0) { \
+      std::fprintf(stderr, "[watch] ring[%d] changed to %g (was %g) after phase %u (1 bulk call, 2 search step, 3 step, 4 load, 5 end), fibre %u at %u clock %u key %u\n", emu_watch_index, \
+                   (lds)->ring[emu_watch_index], emu_watch_value, (unsigned)(tag), wavesim::lane(), (lds)->u.at, (lds)->u.s.clock, (lds)->u.key); emu_watch_value = (lds)->ring[emu_watch_index]; } } while (0)
+#include <cstring>
 #include "../../nfc-laboratory_amd/csrc/nfc_wave.hpp"
 
 static int emu_verify_mode()
@@ -179,7 +188,16 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
    }
    wavesim::barrier();
 
+   if (wavesim::lane() == 0 && emu_watch_index >= 0 && !std::getenv("NFC_EMU_WATCH_STEPPED"))
+   {
+      emu_watch_value = lds->ring[emu_watch_index];
+      emu_watch_armed = true;
+   }
    nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, fetched, true);
+   wavesim::barrier();
+   NFC_WAVE_DEBUG_POINT(lds, 5u);
+   wavesim::barrier();
+   emu_watch_armed = false;
 
    wavesim::barrier();
    if (wavesim::lane() == 0)
@@ -188,6 +206,10 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
       *lds = savedLds;
       dummyCtl[0] = 0;
       dummyCtl[1] = 0;
+      /* (the lane's frame records are chained through the sink: a record emitted into the dummy sink must not be linked
+       * to one whose place is a place in the real sink - nfc_emit would write the link far outside the dummy) */
+      lds->cold.frameHead = 0;
+      lds->cold.frameTail = 0;
    }
    wavesim::barrier();
 
@@ -198,7 +220,13 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
    quiet.capacity = 4096;
 
    emu_counting = false;
+   if (wavesim::lane() == 0 && emu_watch_index >= 0 && std::getenv("NFC_EMU_WATCH_STEPPED"))
+   {
+      emu_watch_value = lds->ring[emu_watch_index];
+      emu_watch_armed = true;
+   }
    nfc_wave_tile(cfgPtr, cc, A, it, lds, quiet, n, pos, carry, warmFront, warm, fetched, false);
+   emu_watch_armed = false;
    wavesim::barrier();
    emu_counting = true;
 
@@ -235,6 +263,12 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
                std::fprintf(stderr, "   corr ring %u: bulk %g stepped %g\n", i, fastLds.ring[NFC_R_CORR + i], lds->ring[NFC_R_CORR + i]);
          std::fprintf(stderr, "   at: bulk %u stepped %u; n %u; env[0] %g %g env[n-1] %g %g; fetched.env (fibre 0) %g; stepped count %u %u\n", fastLds.u.at, lds->u.at, n, fastLds.env[0], lds->env[0],
                       fastLds.env[n - 1], lds->env[n - 1], fetched.env, fastLds.u.stepped, lds->u.stepped);
+         for (uint32_t i = 0; i < 4u * NFC_HIST; i++)
+            if (std::memcmp(&fastLds.ring[i], &lds->ring[i], 4) != 0)
+               std::fprintf(stderr, "   history ring %u (region %u slot %u): bulk %g stepped %g\n", i, i / NFC_HIST, i % NFC_HIST, fastLds.ring[i], lds->ring[i]);
+         for (uint32_t i = 0; i < NFC_STREAM_BYTES; i++)
+            if (fastLds.bytes[i] != lds->bytes[i])
+               std::fprintf(stderr, "   frame byte %u: bulk %02x stepped %02x\n", i, fastLds.bytes[i], lds->bytes[i]);
          for (uint32_t i = 0; i < n; i++)
             if (fastLds.env[i] != lds->env[i])
                std::fprintf(stderr, "   env[%u]: bulk %g stepped %g\n", i, fastLds.env[i], lds->env[i]);
