@@ -922,6 +922,8 @@ NFC_DEV void nfc_finish_unlock(const NfcConfig &c, NfcStreamState &s, const NfcL
       nfc_mod_clear(s.u.search.detF[1]);
       mem.cold->clearedF[0] = 1;
       mem.cold->clearedF[1] = 1;
+      mem.cold->boundF[0].flags |= NFC_FBOUND_THR_OWN;
+      mem.cold->boundF[1].flags |= NFC_FBOUND_THR_OWN;
       /* the two rings are adjacent */
       nfc_zero_ring(mem, NFC_R_CORR + c.corrOffset[3], c.f[1].p1 + c.f[2].p1);
    }

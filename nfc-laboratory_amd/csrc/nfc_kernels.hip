@@ -1918,10 +1918,11 @@ __global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch
       NfcStreamCold cold = lanes.cold[from];
 
       if (job->finalLane != j)
-         nfc_final_fixup(s, cold, A.windows[job->finalLane].want);
+         nfc_final_fixup(s, cold, A.windows[job->finalLane]);
 
       cold.frameHead = 0;
       cold.frameTail = 0;
+      __builtin_memset(cold.boundF, 0, sizeof(cold.boundF)); /* (a lane's notes: nothing of the stream's) */
 
       real.states[to] = s;
       real.cold[to] = cold;

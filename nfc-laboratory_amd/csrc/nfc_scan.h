@@ -140,6 +140,7 @@ struct NfcCarry
    uint32_t pulsesF[2];
    float thrF[2];
    uint32_t clearedF[2]; /* result only: the lane's detector started its pulse count over (not compared) */
+   uint32_t ownF[2];     /* result only: ... or set the threshold of the last pulse itself (NFC_FBOUND_THR_OWN) */
    /* The detector records (running sums apart). A lane starts with all of them at rest; one that was tracking something
     * when another technology locked comes back from the lock with its window in the past and stays like that until the
     * next strong pulse (NfcF.cpp:262-283 and the like): a state no amount of warm-up reproduces, so it travels here. */
@@ -166,6 +167,8 @@ struct NfcWindow
    uint32_t stopDigest[2]; /* digest of the lane's own state where it handed over */
    uint32_t saved;    /* out: 1 + slot of the save area holding the lane's rings as it left them (lanes that ran to the end of the submission), 0: none */
    uint32_t tracked;  /* edge-tracker time at the lane's first sample (scanned): with the carry's last carrier frame it gives the decoder's edge time */
+   int32_t pulsesFix[2]; /* chain kernel: the lane ran on an NFC-F pulse counter that was off by this much, without consequence (NfcFBound): what it leaves is put right by it */
+   uint32_t thrPass[2];  /* ... and never set the threshold of the last pulse: it leaves the one the stream held */
    NfcCarry carry;    /* what the lane assumed when it last ran */
    NfcCarry want;     /* chain kernel: what it has to assume in the next pass (rerun) */
    NfcCarry pubCarry; /* the lane's carry when it published */

@@ -591,6 +591,7 @@ NFC_DEV void nfc_carry_take(NfcCarry &x, const NfcStreamState &s, const NfcStrea
       x.pulsesF[i] = s.lockTech ? 0u : s.u.search.detF[i].pulses;
       x.thrF[i] = s.lockTech ? 0.0f : s.u.search.detF[i].thr;
       x.clearedF[i] = cold.clearedF[i];
+      x.ownF[i] = (cold.boundF[i].flags & NFC_FBOUND_THR_OWN) ? 1u : 0u;
    }
 
    if (s.lockTech)
@@ -656,6 +657,53 @@ NFC_DEV bool nfc_records_same(const NfcSearchRegs &a, const NfcSearchRegs &b, ui
 NFC_DEV uint32_t nfc_edge_time(const NfcCarry &x, uint32_t tracked)
 {
    return (x.emitValid && (int32_t)(tracked - x.emitClock) <= 0) ? 0u : tracked;
+}
+
+/* The pulse memory of an NFC-F preamble detector (counter, threshold of the last pulse) a lane ran on - `had`: what it
+ * assumed at its start, or what it held at the sample it took over at - against what the stream really held there (`have`).
+ * The memory is read at the evaluation of a pulse only (nfcf_track_preamble), and there only through two comparisons: the
+ * counter against 94 and the pulse against the threshold; the counter is counted on from whatever it was, the threshold is
+ * replaced by the first pulse that is accepted or clears the record. The lane has recorded what its evaluations found
+ * (NfcFBound, until the record started over): any other memory that puts every one of those comparisons on the same side
+ * would have made the lane decide, emit and leave exactly the same, up to the counter's offset and a threshold it never
+ * replaced - which nfc_chain_follow puts right in what the lane leaves. `startedOver` / `ownThreshold`: at a meeting
+ * sample, whether the lane's counter / threshold were no longer the assumed ones there (then they have to be the same). */
+NFC_DEV bool nfc_fbound_admits(const NfcFBound &b, uint32_t hadPulses, float hadThr, uint32_t havePulses, float haveThr, bool startedOver, bool ownThreshold)
+{
+   const bool samePulses = hadPulses == havePulses;
+   const bool sameThr = nfc_bits(hadThr) == nfc_bits(haveThr);
+
+   if (samePulses && sameThr)
+      return true;
+
+   if (b.flags & NFC_FBOUND_EXACT)
+      return false;
+
+   if (!samePulses)
+   {
+      if (startedOver)
+         return false;
+
+      /* an evaluation that found k found k + d in truth */
+      const int64_t d = (int64_t)havePulses - (int64_t)hadPulses;
+
+      if (b.lowMax && !((int64_t)(b.lowMax - 1u) + d < 94))
+         return false;
+      if (b.highMin && !((int64_t)(b.highMin - 1u) + d >= 94))
+         return false;
+   }
+
+   if (!sameThr)
+   {
+      if (ownThreshold)
+         return false;
+      if ((b.flags & NFC_FBOUND_ABOVE) && !(haveThr > b.thrAbove))
+         return false;
+      if ((b.flags & NFC_FBOUND_BELOW) && !(haveThr < b.thrBelow))
+         return false;
+   }
+
+   return true;
 }
 
 /* Two carries of lanes meeting at the same sample (`meeting`: their decoders' edge times are compared as they are), or
@@ -1071,9 +1119,13 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
       w[i].live = 0;
       w[i].liveFrom = 0;
       w[i].rerun = 0;
+      w[i].pulsesFix[0] = w[i].pulsesFix[1] = 0;
+      w[i].thrPass[0] = w[i].thrPass[1] = 0;
    }
 
    windows[jobIndex].rerun = 0;
+   windows[jobIndex].pulsesFix[0] = windows[jobIndex].pulsesFix[1] = 0;
+   windows[jobIndex].thrPass[0] = windows[jobIndex].thrPass[1] = 0;
 
    bool again = false;
    uint32_t lane = jobIndex; /* the carry lane comes first */
@@ -1131,7 +1183,39 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
           * it leaves (nfc_final_fixup); a lane that has to run again gets its `want` below */
          x.want = have;
 
-         if (!nfc_carry_same(had, have, handed, x.tracked, used))
+         /* an NFC-F pulse memory the lane did look at, but that was as good as the true one (nfc_fbound_admits): compared
+          * as if it had been the true one; what the lane leaves is put right below */
+         NfcCarry hadAdmitted = had;
+         int32_t pulsesFix[2] = {0, 0};
+         uint32_t thrPass[2] = {0u, 0u};
+
+         for (int i = 0; i < 2; i++)
+         {
+            if (((used >> (12 + i)) & 1u) &&
+                nfc_fbound_admits(colds[lane].boundF[i], had.pulsesF[i], had.thrF[i], have.pulsesF[i], have.thrF[i], handed && had.clearedF[i] != 0u,
+                                  handed && had.ownF[i] != 0u))
+            {
+               pulsesFix[i] = (int32_t)(have.pulsesF[i] - had.pulsesF[i]);
+               thrPass[i] = nfc_bits(have.thrF[i]) != nfc_bits(had.thrF[i]) ? 1u : 0u;
+               hadAdmitted.pulsesF[i] = have.pulsesF[i];
+               hadAdmitted.thrF[i] = have.thrF[i];
+            }
+         }
+
+         if (nfc_carry_same(hadAdmitted, have, handed, x.tracked, used))
+         {
+            for (int i = 0; i < 2; i++)
+            {
+               if (!left.clearedF[i])
+                  left.pulsesF[i] += (uint32_t)pulsesFix[i];
+               if (thrPass[i] && !left.ownF[i])
+                  left.thrF[i] = have.thrF[i];
+
+               x.pulsesFix[i] = left.clearedF[i] ? 0 : pulsesFix[i];
+               x.thrPass[i] = (thrPass[i] && !left.ownF[i]) ? 1u : 0u;
+            }
+         }
+         else
          {
             /* ran on a wrong assumption. At its start it has to assume `have`, corrected by what it did itself between
              * its start and the sample it took over at */
@@ -1239,8 +1323,10 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
  * looked at them (NfcStreamCold::usedTech): those fields still hold the assumption; `have` is what the stream really held
  * where the lane took over (NfcWindow::want as nfc_chain_follow left it). The counterpart of the substitutions
  * nfc_chain_follow makes in `left` for the lanes in between. */
-NFC_DEV void nfc_final_fixup(NfcStreamState &s, NfcStreamCold &cold, const NfcCarry &have)
+NFC_DEV void nfc_final_fixup(NfcStreamState &s, NfcStreamCold &cold, const NfcWindow &lane)
 {
+   const NfcCarry &have = lane.want;
+
    const uint32_t used = cold.usedTech;
 
    for (int t = 0; t < 4; t++)
@@ -1271,6 +1357,14 @@ NFC_DEV void nfc_final_fixup(NfcStreamState &s, NfcStreamCold &cold, const NfcCa
       {
          r.detF[i].pulses = have.pulsesF[i];
          r.detF[i].thr = have.thrF[i];
+      }
+      else
+      {
+         /* looked at, found as good as the true one (nfc_fbound_admits): counted on from the true one, and a threshold the
+          * lane never set is the one the stream held */
+         r.detF[i].pulses += (uint32_t)lane.pulsesFix[i];
+         if (lane.thrPass[i])
+            r.detF[i].thr = have.thrF[i];
       }
 
       r.detF[i].acc = acc;

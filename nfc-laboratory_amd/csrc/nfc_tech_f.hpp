@@ -105,7 +105,7 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
  * returns true when a complete, length-checked preamble has just ended */
 template <class M>
 NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, float sd, float s0, bool above, uint32_t &polarity, uint32_t *cleared,
-                                 uint32_t *used = nullptr, uint32_t usedBit = 0u)
+                                 uint32_t *used = nullptr, uint32_t usedBit = 0u, NfcFBound *bound = nullptr)
 {
    if (above)
    {
@@ -135,7 +135,41 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, flo
    /* the pulse counter and the threshold of the last pulse are looked at from here on: if the record has not started
     * over since the lane began, what the lane inherited matters (NfcStreamCold::usedTech) */
    if (used && cleared && !*cleared)
+   {
       *used |= usedBit;
+
+      /* ... and what this evaluation requires of them (NfcFBound): the counter on the same side of 94; the threshold,
+       * while it is still the one the lane was given, on the same side of the pulse */
+      if (bound)
+      {
+         const uint32_t counted = m.pulses;
+
+         if (counted < 94u)
+            bound->lowMax = counted + 1u > bound->lowMax ? counted + 1u : bound->lowMax;
+         else
+            bound->highMin = (bound->highMin == 0u || counted + 1u < bound->highMin) ? counted + 1u : bound->highMin;
+
+         if (!(bound->flags & NFC_FBOUND_THR_OWN))
+         {
+            if (counted < 94u && m.peakTime == 0)
+               ; /* cleared whatever the threshold */
+            else if (counted < 94u && m.syncValue < m.thr)
+            {
+               bound->thrAbove = (bound->flags & NFC_FBOUND_ABOVE) && bound->thrAbove > m.syncValue ? bound->thrAbove : m.syncValue;
+               bound->flags |= NFC_FBOUND_ABOVE;
+            }
+            else if (m.syncValue > m.thr)
+            {
+               bound->thrBelow = (bound->flags & NFC_FBOUND_BELOW) && bound->thrBelow < m.syncValue ? bound->thrBelow : m.syncValue;
+               bound->flags |= NFC_FBOUND_BELOW;
+            }
+            else
+               bound->flags |= NFC_FBOUND_EXACT; /* (equal to the threshold, or not a number: the end-of-preamble path) */
+         }
+         else if (!(m.syncValue > m.thr) && !(counted < 94u && (m.peakTime == 0 || m.syncValue < m.thr)))
+            bound->flags |= NFC_FBOUND_EXACT; /* the end-of-preamble path reads more of the record than the bounds speak of */
+      }
+   }
 
    if (m.pulses++ < 94)
    {
@@ -145,12 +179,17 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, flo
          m.pulses = 0; m.thr = 0; m.peak = 0; m.peakTime = 0;
          if (cleared)
             *cleared = 1; /* the pulse counter starts over (NfcStreamCold::clearedF) */
+         if (bound)
+            bound->flags |= NFC_FBOUND_THR_OWN;
          return false;
       }
    }
 
    if (m.syncValue > m.thr)
    {
+      if (bound)
+         bound->flags |= NFC_FBOUND_THR_OWN; /* (set from this pulse below) */
+
       if (!m.symStart)
          m.symStart = m.peakTime - rt.p2;
 
@@ -178,6 +217,8 @@ NFC_DEV bool nfcf_track_preamble(NfcStreamState &s, M &m, const NfcRate &rt, flo
       m.pulses = 0; m.thr = 0; m.peak = 0; m.peakTime = 0;
       if (cleared)
          *cleared = 1;
+      if (bound)
+         bound->flags |= NFC_FBOUND_THR_OWN;
       return false;
    }
 
@@ -268,8 +309,13 @@ NFC_DEV bool nfcf_detect_decide(const NfcConfig &c, NfcStreamState &s, const Nfc
    if (mem.linked && !((*mem.flags >> (15 + R)) & 1u))
       *mem.flags |= 1u << (13 + R);
 
-   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1], mem.linked ? mem.flags : nullptr, 1u << (11 + R)))
+   if (!nfcf_track_preamble(s, m, rt, sd, s0, sd > minimumCorrelation, polarity, &mem.cold->clearedF[R - 1], mem.linked ? mem.flags : nullptr, 1u << (11 + R),
+                            mem.linked ? &mem.cold->boundF[R - 1] : nullptr))
       return false;
+
+   /* (a preamble completed on a pulse memory the lane was given: the lock copies the counter - only the assumed values will do) */
+   if (mem.linked && !mem.cold->clearedF[R - 1])
+      mem.cold->boundF[R - 1].flags |= NFC_FBOUND_EXACT;
 
    /* preamble complete: lock this bitrate, the sync bytes follow (copy the detector record before it is parked) */
    const NfcDetF k0 = m;

@@ -249,6 +249,24 @@ struct NfcStreamState
    } u;
 };
 
+/* What a lane of the time-parallel path found out about the pulse memory of an NFC-F preamble detector (pulse counter and
+ * threshold of the last pulse: NfcCarry::pulsesF / thrF) while it ran on the values it had ASSUMED: every evaluation of a
+ * pulse (nfcf_track_preamble) before the record starts over narrows the set of values the lane could have been given
+ * without deciding anything differently. All zero = no evaluation yet, nothing required. */
+struct NfcFBound
+{
+   uint32_t lowMax;   /* 1 + the largest counter value an evaluation found below 94 (0: none): the true one must be below 94 there too */
+   uint32_t highMin;  /* 1 + the smallest counter value an evaluation found at 94 or above (0: none): ... and not below 94 there */
+   float thrAbove;    /* NFC_FBOUND_ABOVE: the true threshold must be greater than this (the pulse was below the threshold: record cleared) */
+   float thrBelow;    /* NFC_FBOUND_BELOW: ... smaller than this (the pulse was above it: accepted) */
+   uint32_t flags;
+};
+
+#define NFC_FBOUND_ABOVE 1u
+#define NFC_FBOUND_BELOW 2u
+#define NFC_FBOUND_EXACT 4u   /* an evaluation the bounds do not describe (the pulse equal to the threshold, a completed preamble): only the assumed values will do */
+#define NFC_FBOUND_THR_OWN 8u /* the threshold has been set or cleared by the lane since it started: no longer the assumed one */
+
 /* the part that stays in HBM and is only touched at frame boundaries */
 struct NfcStreamCold
 {
@@ -271,6 +289,7 @@ struct NfcStreamCold
     * (stream start, 32-bit clock wrap) compute positions from the clock and have to add it. */
    uint32_t label[7];
    uint32_t clearedF[2]; /* an NFC-F preamble detector cleared its pulse counter since the lane started (NfcCarry::pulsesF) */
+   NfcFBound boundF[2];  /* ... and what the evaluations before that require of the pulse memory the lane was given */
    uint32_t usedTech;    /* bit t: technology t (A B F V) has been locked since the lane started. The protocol timing of a
                             technology is only read when it locks and while its frames are processed, so a lane that never
                             locked it neither depends on what it assumed there nor changes it (nfc_chain_follow).

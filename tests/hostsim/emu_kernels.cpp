@@ -1112,9 +1112,10 @@ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
       NfcStreamState s = lanes.states[from];
       NfcStreamCold cold = lanes.cold[from];
       if (job->finalLane != j)
-         nfc_final_fixup(s, cold, A.windows[job->finalLane].want);
+         nfc_final_fixup(s, cold, A.windows[job->finalLane]);
       cold.frameHead = 0;
       cold.frameTail = 0;
+      std::memset(cold.boundF, 0, sizeof(cold.boundF));
       real.states[job->slot] = s;
       real.cold[job->slot] = cold;
    }
