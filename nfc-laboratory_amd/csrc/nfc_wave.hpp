@@ -63,6 +63,8 @@ struct NfcWaveUni
    uint32_t stepped;  /* samples stepped one by one (statistics) */
    uint32_t stopped;  /* 1 retired at rest, 2 handed over */
    uint32_t succ;
+   uint32_t takeKey;  /* stage for which the tile's running sums have been found inside the exact range (nfc_wave_fast); NFC_FK_NONE: not yet */
+   uint32_t succVerify; /* sample at which the successor at hand publishes (nothing to ask it before): 0 = not looked up yet */
    uint32_t at;       /* sample of the tile at hand */
    /* bulk paths (nfc_wave_fast.hpp) */
    uint32_t key;      /* stage the values in sum / s0 / s1 belong to */
@@ -89,6 +91,7 @@ struct NfcWaveLds
    float avg[NFC_LANES];
    float scratch[NFC_LANES];
    uint32_t gate[NFC_LANES];         /* search bank: the detectors' gates per sample of the tile (nfc_wave_search_bits) */
+   uint32_t tileFlags[NFC_LANES];    /* the lane's next 64 tile flag words (one load per 64 tiles instead of one per tile boundary) */
    float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator */
    float s0[6][NFC_LANES];           /* ... and the two differences the detectors look at */
    float s1[6][NFC_LANES];
@@ -595,6 +598,7 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
       lds->u.which = 0xFFFFFFFFu;
       lds->u.whichAt = 0xFFFFFFFFu;
       lds->u.maskValid = 0u;
+      lds->u.takeKey = NFC_FK_NONE;
       if (!allOnGrid)
          lds->u.gridSince = clock + n;
    }
@@ -671,12 +675,18 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
       NFC_WAVE_DEBUG_POINT(lds, fromValues ? 2u : 3u);
 
       {
-         const uint64_t gated = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.gatedHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.gatedLo);
-         const uint32_t next = at + 1u - NFC_WAVE_UNIFORM_U32(lds->u.gatedFrom);
-         /* (only while the decoder stays in the stage the gates were evaluated for) */
          /* (the search bank keeps its gates per detector: asking again is cheap there, and tells which detectors to ask) */
-         again = allowFast && !exact && next < 64u && ((gated >> next) & 1ull) != 0ull && NFC_WAVE_UNIFORM_U32(lds->u.key) != NFC_FK_SEARCH &&
-                 NFC_WAVE_UNIFORM_U32(lds->u.key) == NFC_WAVE_UNIFORM_U32(nfc_wave_stage(NFC_WAVE_STATE(lds), upkeep));
+         const uint32_t keyNow = NFC_WAVE_UNIFORM_U32(lds->u.key);
+
+         again = false;
+
+         if (allowFast && !exact && keyNow != NFC_FK_SEARCH && keyNow != NFC_FK_NONE)
+         {
+            const uint64_t gated = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.gatedHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.gatedLo);
+            const uint32_t next = at + 1u - NFC_WAVE_UNIFORM_U32(lds->u.gatedFrom);
+            /* (only while the decoder stays in the stage the gates were evaluated for) */
+            again = next < 64u && ((gated >> next) & 1ull) != 0ull && keyNow == NFC_WAVE_UNIFORM_U32(nfc_wave_stage(NFC_WAVE_STATE(lds), upkeep));
+         }
       }
    }
 }
@@ -721,7 +731,8 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    it.planes = A.planes + 4u * (uint64_t)it.job->firstTile * NFC_SCAN_TILE;
 
    const uint32_t verifyPos = me->verify;
-   const uint32_t succEnd = it.job->firstWindow + it.job->windows;
+   const uint32_t jobWindows = it.job->windows;
+   const uint32_t succEnd = it.job->firstWindow + jobWindows;
    const uint32_t activate = me->activate;
    const uint32_t warmFront = carry ? 0u : NFC_WINDOW_WARM_FRONT;
    const uint32_t warm = carry ? 0u : NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
@@ -789,6 +800,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       lds->u.stepped = 0;
       lds->u.stopped = 0;
       lds->u.at = 0;
+      lds->u.succVerify = 0u;
       lds->u.succ = carry ? it.job->firstWindow : it.w + 1u;
       if (mode == NFC_WAVE_FINAL || (mode == NFC_WAVE_WINDOWS && (it.w < it.job->firstWindow || it.w >= succEnd)))
          lds->u.succ = succEnd; /* runs on its own */
@@ -824,8 +836,23 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       /* ---- tile boundary: publish, retire, hand over (nfc_window_body) ---- */
       NFC_WAVE_TICK(lds, 0u);
       const bool past = consumed >= warm && consumed > 0;
+
+      /* (the flag words of the next 64 tiles, fetched together: a load per tile boundary is a memory latency per tile) */
+      {
+         const uint32_t tile = consumed / NFC_SCAN_TILE;
+
+         if ((tile % NFC_LANES) == 0u || consumed == 0u)
+         {
+            const uint32_t first = tile / NFC_LANES * NFC_LANES;
+            const uint32_t tilesOfRow = (it.count + NFC_SCAN_TILE - 1u) / NFC_SCAN_TILE;
+            NFC_WAVE_BARRIER();
+            lds->tileFlags[lane] = (jobWindows != 0u && first + lane < tilesOfRow) ? it.tiles[first + lane] : 0u;
+            NFC_WAVE_BARRIER();
+         }
+      }
+
       /* (a stream without windows - NfcScanParams::soloSamples - has nobody to take over from a lane that retires) */
-      const bool mayRetire = past && it.job->windows != 0u && (it.tiles[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) != 0u;
+      const bool mayRetire = past && jobWindows != 0u && (lds->tileFlags[(consumed / NFC_SCAN_TILE) % NFC_LANES] & NFC_TILE_RETIRE_OK) != 0u;
       const bool publishes = pos == verifyPos;
       uint32_t edgeNow = 0;
 
@@ -845,12 +872,15 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
          if (mayRetire && nfc_quiescent(s) && s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
             lds->u.stopped = 1;
 
-         if (!lds->u.stopped && past)
+         /* (the successor is only asked once the lane has reached the sample it publishes at: before that
+          * nfc_lane_handover would find nothing to do, at the price of a trip to memory per tile) */
+         if (!lds->u.stopped && past && pos >= lds->u.succVerify)
          {
             uint32_t succ = lds->u.succ;
             if (nfc_lane_handover(L.windows, *me, succ, succEnd, pos, s, *mem.cold))
                lds->u.stopped = 2;
             lds->u.succ = succ;
+            lds->u.succVerify = succ < succEnd ? L.windows[succ].verify : 0xFFFFFFFFu;
          }
       }
       NFC_WAVE_UNIFORM_END

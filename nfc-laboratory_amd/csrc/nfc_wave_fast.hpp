@@ -743,7 +743,8 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    const bool raw = key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP || key == NFC_FK_A_POLL || key == NFC_FK_F_DATA || key == NFC_FK_F_START || key == NFC_FK_V_POLL;
    bool take = key != NFC_FK_NONE;
 
-   if (raw)
+   /* (looked at once per tile and stage: a sum moves by at most 2 per sample, and NFC_FAST_SUM_LIMIT leaves room for a tile) */
+   if (raw && NFC_WAVE_UNIFORM_U32(lds->u.takeKey) != key)
    {
       if ((uint32_t)(clock0 + 1u - lds->u.gridSince) < NFC_FAST_GRID_BACK)
          take = false;
@@ -755,6 +756,16 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
       }
       else
          take = nfc_abs(s.u.decode.lock.acc) <= NFC_FAST_SUM_LIMIT;
+
+      if (take)
+      {
+         NFC_WAVE_READ_FENCE();
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            lds->u.takeKey = key;
+         }
+         NFC_WAVE_UNIFORM_END
+      }
    }
 
    if (!take)
