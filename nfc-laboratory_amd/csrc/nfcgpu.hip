@@ -1276,6 +1276,26 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    mark("finish");
 
+   if (debugStages && std::atoi(std::getenv("NFCGPU_WINDOW_DEBUG")) >= 3 && nWindows)
+   {
+      /* how much of what the speculative lanes decoded ended up in the stream (the rest was overrun by a lane that could
+       * not hand over, or decoded again in a later pass) */
+      std::vector<NfcWindow> ws(nWindows);
+      HIP_TRY(ctx, hipMemcpy(ws.data(), (const NfcWindow *)ctx->wWindows.ptr + firstWindowSlot, sizeof(NfcWindow) * ws.size(), hipMemcpyDeviceToHost));
+      uint64_t all = 0, live = 0, liveLanes = 0;
+      for (const NfcWindow &w: ws)
+      {
+         all += w.stop - w.start;
+         if (w.live)
+         {
+            live += w.stop - w.start;
+            liveLanes++;
+         }
+      }
+      std::fprintf(stderr, "[nfcgpu] speculative lanes: %zu, %llu samples as they last ran; live in the end: %llu lanes, %llu samples (%.1f %%); submission: %llu samples\n", ws.size(),
+                   (unsigned long long)all, (unsigned long long)liveLanes, (unsigned long long)live, all ? 100.0 * (double)live / (double)all : 0.0, (unsigned long long)totalSamples);
+   }
+
    ctx->stats.windows += nWindows + nJobs;
    ctx->stats.samples += totalSamples;
    ctx->dirty = true;
