@@ -282,7 +282,7 @@ NFC_DEV void nfc_scan_resume(NfcScanLane &w, const NfcScanPoint &p, uint32_t edg
  * the guesses achieved. Returns true when the job is waiting for repairs.
  * chunkEdge[k] = edge-tracker time at the start of chunk k (points without a time of their own inherit it). */
 NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *seams, uint32_t *chunkEdge, uint32_t startEdge, NfcScanChunk *repairs,
-                             uint32_t *repairCount)
+                             uint32_t *repairCount, NfcScanPoint *points = nullptr, uint32_t chunkSamples = 0)
 {
    uint32_t edge = startEdge; /* edge time at the start of the chunk at hand, by the records as they are */
    bool pending = false;
@@ -301,7 +301,49 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
          NFC_SEAM_DEBUG(k, s.start, seams[job.firstChunk + k - 1].end, edge);
 #endif
 
-      if (!sound)
+      if (!sound && points)
+      {
+         /* The carrier zone is a latch: the zone the average was last seen in, kept while the average lies between the two
+          * thresholds. A walk that has not seen the average outside them yet (zone 0: its warm-up and the chunk up to some
+          * sample lie in between - a weak capture can stay there for a million samples) differs from the true walk in
+          * nothing but that: where it says "none yet" the true zone is the one the chunk before ended in. That is put
+          * right here, without a walk: the chunk's start, its stored points up to the first that has a zone, its end if it
+          * never found one. (The tile flag of the first sample outside the thresholds may then mark a change of zone that
+          * is none: a tile looked at for nothing.) Within this loop the corrected end is what the next chunk is held
+          * against, so a run of such chunks settles in one check - they used to be walked again one per round, every
+          * field of them. */
+         const NfcScanPoint &before = seams[job.firstChunk + k - 1].end;
+         const uint32_t zoneBefore = before.zone & NFC_ZONE_MASK;
+
+         if ((s.start.zone & NFC_ZONE_MASK) == 0u && zoneBefore != 0u && nfc_bits(s.start.n1) == nfc_bits(before.n1) && nfc_bits(s.start.mdev) == nfc_bits(before.mdev) &&
+             nfc_bits(s.start.avg) == nfc_bits(before.avg) && nfc_bits(s.start.edgePeak) == nfc_bits(before.edgePeak))
+         {
+            const uint32_t first = k * chunkSamples;
+            const uint32_t last = first + chunkSamples < job.count ? first + chunkSamples : job.count;
+
+            s.start.zone |= zoneBefore;
+
+            bool open = true; /* no zone of the chunk's own yet */
+
+            for (uint32_t pos = first; pos < last && open; pos += NFC_SCAN_POINT)
+            {
+               NfcScanPoint &p = points[job.firstPoint + pos / NFC_SCAN_POINT];
+
+               if ((p.zone & NFC_ZONE_MASK) == 0u)
+                  p.zone |= zoneBefore;
+               else
+                  open = false;
+            }
+
+            if ((s.end.zone & NFC_ZONE_MASK) == 0u)
+               s.end.zone |= zoneBefore;
+         }
+      }
+
+      const bool soundNow = sound || (nfc_point_same(s.start, seams[job.firstChunk + k - 1].end) &&
+                                      (!(s.start.zone & NFC_ZONE_EDGE_KNOWN) || s.start.edgeTime == edge));
+
+      if (!soundNow)
       {
          const NfcScanPoint &before = seams[job.firstChunk + k - 1].end;
 

@@ -908,6 +908,28 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    /* seams: chunks that did not start from the true state are walked again, a round at a time */
    for (uint32_t round = 0;; round++)
    {
+      if (debugStages && std::atoi(std::getenv("NFCGPU_WINDOW_DEBUG")) >= 4)
+      {
+         /* which fields keep seams from verifying (host-side look at the records the seam check is about to judge) */
+         std::vector<NfcScanSeam> sm(nChunks);
+         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+         HIP_TRY(ctx, hipMemcpy(sm.data(), ctx->wSeams.ptr, sizeof(NfcScanSeam) * nChunks, hipMemcpyDeviceToHost));
+         uint32_t n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+         for (uint32_t j = 0; j < nJobs; j++)
+            for (uint32_t k = 1; k < jobs[j].chunks; k++)
+            {
+               const NfcScanPoint &a = sm[jobs[j].firstChunk + k].start, &b = sm[jobs[j].firstChunk + k - 1].end;
+               const bool env = std::memcmp(&a.env, &b.env, 4) != 0 || a.pulseFilter != b.pulseFilter;
+               const bool n1 = std::memcmp(&a.n1, &b.n1, 4) != 0, mdev = std::memcmp(&a.mdev, &b.mdev, 4) != 0, avg = std::memcmp(&a.avg, &b.avg, 4) != 0;
+               const bool peak = std::memcmp(&a.edgePeak, &b.edgePeak, 4) != 0, zone = ((a.zone ^ b.zone) & 0xFFu) != 0;
+               const bool time = (a.zone & 0x100u) && (b.zone & 0x100u) && a.edgeTime != b.edgeTime;
+               n[0] += env; n[1] += n1; n[2] += mdev; n[3] += avg; n[4] += peak; n[5] += zone; n[6] += time;
+               n[7] += (n1 || mdev || avg || peak || zone) ? 1u : 0u;
+            }
+         std::fprintf(stderr, "[nfcgpu]    before round %u, seams that differ in: envelope / counter %u, n1 %u, deviation %u, average %u, edge peak %u, zone %u, known edge times %u; in anything but the envelope %u\n",
+                      round, n[0], n[1], n[2], n[3], n[4], n[5], n[6], n[7]);
+      }
+
       HIP_TRY(ctx, hipMemsetAsync(counters + 7, 0, 4, ctx->stream));
       hipLaunchKernelGGL(nfc_seams_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, round == 0 ? 1u : 0u);
       HIP_TRY(ctx, hipGetLastError());

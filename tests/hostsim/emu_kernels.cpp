@@ -713,7 +713,7 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
             job.status |= NFC_JOB_ALONE;
       }
       if (!(job.status & NFC_JOB_INVALID))
-         nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount);
+         nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples);
       A.jobs[j] = job;
    }
 }
