@@ -38,9 +38,18 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s pe
 
 
 def git_head():
+    """the commit of this tree: from git where there is a repository, otherwise the stamp __graft_entry__.build() left in
+    nfc-laboratory_amd/build/ when it last ran in one (the GPU box gets a snapshot without .git)"""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                              text=True, timeout=10).stdout.strip() or None
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              text=True, timeout=10).stdout.strip()
+        if head:
+            return head
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "nfc-laboratory_amd", "build", "git_head.txt")) as f:
+            return f.read().strip() or None
     except Exception:
         return None
 
@@ -106,11 +115,39 @@ def clamp_used(cursor, dropped, capacity):
     return min(cursor, limit) if dropped else min(cursor, capacity)
 
 
+def headline_layout(steps, warmup, samples, slices):
+    """(slices resident, samples per stream resident) of the headline dataset: SURVEY 8(d) fixes it at L samples per stream
+    (32 GiB for 4096 streams x 2^20) so that the identical data serves every run; `slices` of them are kept (default 2) and
+    step k submits slice k % slices, whatever --steps and --warmup are"""
+    n = max(1, min(steps + warmup, slices))
+    return n, n * samples
+
+
+def headline_sink_words(streams, samples, steps, warmup):
+    """capacity of the held frame sink: dense S1 traffic leaves about 500 words per stream and 2^20 samples (2.04 M words per
+    step of config 5); twice that for every step and warm-up step, at least 16 Mi words"""
+    per_step = 1024 * streams * max(1, samples >> 20) + 65536
+    return max(16 << 20, (steps + warmup) * per_step)
+
+
+def headline_device_bytes(streams, samples, steps, warmup, slices=2, world=1):
+    """device memory one rank of the headline asks for: resident IQ, held sink (+ gather buffer when N > 1) and the library's
+    work buffers of one submission (front-end planes 16 B per sample, tiles / points / lanes < 1 B per sample)"""
+    _, resident = headline_layout(steps, warmup, samples, slices)
+    iq = 8 * streams * resident
+    sink = 4 * headline_sink_words(streams, samples, steps, warmup) * (1 + (world if world > 1 else 0))
+    work = 17 * streams * samples
+    return iq + sink + work
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--slices", type=int, default=2,
+                    help="slices of --samples per stream kept resident (SURVEY 8(d): the dataset is L = 2^20 per stream, 32 GiB for 4096 "
+                         "streams); step k submits slice k %% slices, the decoder's carried state goes on from step to step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("NFC_BENCH_STREAMS", "4096")),
                     help="streams of the headline dataset (BASELINE config 5: 4096); with --scaling strong cut over the ranks, with weak per GPU")
     ap.add_argument("--samples", type=int, default=1 << 20, help="samples per stream per step (headline)")
@@ -122,6 +159,7 @@ def main():
                     help="N > 1: fall back to torch.distributed's all_gather when the C ABI's RCCL communicator does not come up (an error otherwise)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-points", action="store_true", help="headline only")
+    ap.add_argument("--points-budget", type=float, default=780.0, help="no new point is started later than this many seconds after the start")
     ap.add_argument("--points", default="fixtures_single,config5_sparse,config5_idle,share_sparse,share_dense,share_dense_h2d,single_sparse,single_dense,s2_share,saturating")
     ap.add_argument("--saturating-streams", type=int, default=131072, help="streams of the `saturating` point (8192-sample buffers, sequential kernel)")
     ap.add_argument("--share-streams", type=int, default=512, help="streams one GPU holds when BASELINE's 4096 are spread over 8")
@@ -130,6 +168,7 @@ def main():
     ap.add_argument("--config5-samples", type=int, default=1 << 20)
     ap.add_argument("--single-samples", type=int, default=1 << 26)
     args = ap.parse_args()
+    t_start = time.perf_counter()
 
     import numpy as np
     import torch
@@ -168,7 +207,8 @@ def main():
     S, L, K, W = args.streams, args.samples, args.steps, args.warmup
     if args.scaling == "strong":
         S = max(1, args.streams // world)  # the same dataset cut over the ranks
-    T = (K + W) * L
+    NS, T = headline_layout(K, W, L, args.slices)  # slices resident, samples per stream resident
+    order = [k % NS for k in range(W + K)]           # the slice step k submits
 
     template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
     template_dev = torch.from_numpy(template.astype(np.int16)).to(dev)
@@ -181,7 +221,7 @@ def main():
         data[:, :, 0] = 0.25 + noise[None, :]
         data[:, :, 1] = 0.0
 
-    sink_words = 64 << 20
+    sink_words = headline_sink_words(S, L, K, W)
     sink = torch.zeros(sink_words, dtype=torch.int32, device=dev)
     ctl = torch.zeros(4, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
@@ -218,12 +258,12 @@ def main():
             raise SystemExit("bench.py: the frame gather behind the C ABI (nfcgpu_comm_init over RCCL) did not come up on every rank; "
                              "--allow-torch-gather measures with torch.distributed's all_gather instead")
         if abi_gather:
-            gathered = torch.zeros(sink_words, dtype=torch.int32, device=dev)  # room for every rank's records, packed
+            gathered = torch.zeros(sink_words * world, dtype=torch.int32, device=dev)  # room for every rank's records, packed
 
     pitch = T * 8
 
     def step(k):
-        gpu.submit_uniform(first, S, data.data_ptr() + k * L * 8, pitch, L, FS, stride=2)
+        gpu.submit_uniform(first, S, data.data_ptr() + order[k] * L * 8, pitch, L, FS, stride=2)
 
     def fence():
         gpu.sync()
@@ -330,7 +370,8 @@ def main():
             "traffic_source": traffic_source,
             "kernel": dominant,
             "kernel_ms_avg": round(kernel_ms, 4),
-            "kernel_ms_is": "all launches of the kernel in one step (HIP events on the launching streams)",
+            "kernel_ms_is": "sum over all launches of the kernel in one step (HIP events on the launching streams; launches on the "
+                            "library's two streams may overlap, so this is a sum of launch durations, not exclusive time)",
             "kernel_launches_per_step": round((st.wave_launches if dominant == "nfc_wave_kernel" else st.launches) / K, 1),
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "peak_measured_streaming_read": round(read_peak, 1),
@@ -352,10 +393,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         if lib is not None:
             C = min(S, args.cpu_streams)
-            mags = torch.sqrt(data[:C, :, 0] * data[:C, :, 0] + data[:C, :, 1] * data[:C, :, 1]).cpu().numpy()
-            mags = np.ascontiguousarray(mags, dtype=np.float32)
+            # what the decoder saw: slice order[k] of the resident data in step k. The CPU legs are bounded (about
+            # 10-30 s of CPU work): the timing leg takes the first min(K + W, 3) steps of C streams, the parity leg the whole
+            # submission sequence of --check-streams streams
+            base = torch.sqrt(data[:C, :, 0] * data[:C, :, 0] + data[:C, :, 1] * data[:C, :, 1]).cpu().numpy()
+            base = np.ascontiguousarray(base, dtype=np.float32)
+
+            def sequence(rows, steps_taken):
+                return np.ascontiguousarray(np.concatenate([base[rows, order[k] * L:(order[k] + 1) * L] for k in range(steps_taken)], axis=1))
+
+            timed_steps = min(K + W, 3)
+            mags = sequence(slice(0, C), timed_steps)
+            TT = timed_steps * L
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            chunk = 65536 if T >= 65536 else T  # the reference harness's buffer length (TS/main.cpp:163)
+            cpu_model, cpu_physical, cpu_logical = host_cpu()
+            chunk = 65536 if TT >= 65536 else TT  # the reference harness's buffer length (TS/main.cpp:163)
 
             lib.nfcref_decode_many.restype = ctypes.c_long
             lib.nfcref_decode_many.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32,
@@ -363,25 +415,47 @@ def main():
 
             def timed(streams, threads):
                 secs = ctypes.c_double(0)
-                lib.nfcref_decode_many(mags.ctypes.data, T, streams, T, FS, chunk, threads, ctypes.byref(secs))
-                return streams * T / secs.value / 1e6, secs.value
+                lib.nfcref_decode_many(mags.ctypes.data, TT, streams, TT, FS, chunk, threads, ctypes.byref(secs))
+                return streams * TT / secs.value / 1e6, secs.value
 
-            n_single = max(1, min(C, int(150e6 // T)))
+            n_single = max(1, min(C, int(150e6 // TT)))
             single, single_seconds = timed(n_single, 1)
             multi, multi_seconds = timed(C, cores)
+            physical = min(cores, cpu_physical or cores)
+            if physical < cores:
+                multi_phys, multi_phys_seconds = timed(C, physical)
+            else:
+                multi_phys, multi_phys_seconds = multi, multi_seconds
+            del mags
 
             checked = min(C, args.check_streams)
-            outs = []
-            for s in range(checked):
-                fr, _ = TL.reference_decode(mags[s], sample_rate=FS, chunk=L, keep_carrier=True, cap=8192, defined_storage=True)
-                outs.append((s, fr, 0.0))
+            from concurrent.futures import ThreadPoolExecutor
 
-            bad = 0
+            def reference_frames_of(s):
+                full = sequence(slice(s, s + 1), K + W)[0]
+                fr, _ = TL.reference_decode(full, sample_rate=FS, chunk=L, keep_carrier=True, cap=4096 * (K + W), defined_storage=True)
+                return (s, fr, 0.0)
+
+            with ThreadPoolExecutor(max_workers=max(1, min(32, cores))) as pool:  # (as tests/parity_sweep_driver.py does)
+                outs = list(pool.map(reference_frames_of, range(checked)))
+
+            bad, bad_ids, first_diff = 0, [], None
             for s, fr, _ in outs:
-                if frames.get(first + s, []) != fr:
+                mine = frames.get(first + s, [])
+                if mine != fr:
                     bad += 1
+                    bad_ids.append(s)
+                    if first_diff is None:
+                        at = next((i for i, (a, b) in enumerate(zip(mine, fr)) if a != b), min(len(mine), len(fr)))
+                        first_diff = {"stream": s, "frame_index": at, "gpu_frames": len(mine), "reference_frames": len(fr),
+                                      "gpu": repr(mine[at]) if at < len(mine) else None, "reference": repr(fr[at]) if at < len(fr) else None}
+                    dump = os.environ.get("NFC_BENCH_DUMP")
+                    if dump:
+                        os.makedirs(dump, exist_ok=True)
+                        with open(os.path.join(dump, "stream_%d.json" % s), "w") as fh:
+                            json.dump({"stream": s, "order": order, "samples": L, "gpu": [list(map(lambda v: v if not isinstance(v, bytes) else v.hex(), f)) for f in mine],
+                                       "reference": [list(map(lambda v: v if not isinstance(v, bytes) else v.hex(), f)) for f in fr]}, fh)
 
-            cpu_model, cpu_physical, cpu_logical = host_cpu()
             result["cpu_baseline"] = {
                 "value": round(multi, 3),
                 "unit": "Msamples/s",
@@ -392,8 +466,11 @@ def main():
                 "kind": "reference",
                 "sample": "reference lab::NfcDecoder (oracle/_ref, built from /root/reference) on the magnitudes of the first %d "
                           "streams x %d samples (%.1f s), %d-sample buffers, one decoder per stream, %d threads; single thread on %d "
-                          "streams: %.1f Msamples/s (%.1f s)" % (C, T, multi_seconds, chunk, cores, n_single, single, single_seconds),
+                          "streams: %.1f Msamples/s (%.1f s); %d threads (one per physical core): %.1f Msamples/s (%.1f s)" % (
+                              C, TT, multi_seconds, chunk, cores, n_single, single, single_seconds, physical, multi_phys, multi_phys_seconds),
                 "single_thread_value": round(single, 3),
+                "physical_cores_value": round(multi_phys, 3),
+                "physical_cores_threads": physical,
             }
             # BASELINE configs[0]: the reference's RadioDecoderTask itself (subjects + executor + reference decoder, one stream)
             task = os.path.join(ROOT, "oracle", "_ref", "task-ref")
@@ -402,7 +479,7 @@ def main():
                 try:
                     with tempfile.TemporaryDirectory() as tmp:
                         wav = os.path.join(tmp, "plumbing.wav")
-                        one = np.clip(np.rint(mags[0] * 32768.0), -32768, 32767).astype(np.int16)
+                        one = np.clip(np.rint(base[0] * 32768.0), -32768, 32767).astype(np.int16)
                         TL.write_wav(wav, np.tile(one, max(1, int(40e6 // one.size))))
                         out = subprocess.run([task, wav], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300).stdout
                         done = [l.split() for l in out.splitlines() if l.startswith("DONE")]
@@ -439,9 +516,10 @@ def main():
                     result["cpu_baseline"].setdefault("radio_decoder_task_value", None)
                     result["cpu_baseline"]["sample"] += "; RadioDecoderTask run failed: %r" % (exc,)
 
-            result["parity"] = {"streams_checked": checked, "streams_mismatching": bad,
-                                "reference_frames": sum(len(o[1]) for o in outs[:checked])}
-            del mags
+            result["parity"] = {"streams_checked": checked, "streams_mismatching": bad, "submissions_compared": K + W,
+                                "reference_frames": sum(len(o[1]) for o in outs[:checked]), "mismatching_streams": bad_ids,
+                                "first_difference": first_diff}
+            del base
         else:
             result["cpu_baseline"] = None
             result["parity"] = "oracle/_ref not available on this box"
@@ -454,6 +532,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_points:
         segs = synth.sparse_segments(template)
         points = {}
+        point_sink_words = 64 << 20  # (a point is at most 8 submissions)
 
         def run_point(name, n_streams, n_samples, sparse, steps, warm, check, idle=False, offgrid=False, from_host=False):
             total = (steps + warm) * n_samples
@@ -488,7 +567,7 @@ def main():
                     buf[s0:s1, :, 1] = m * torch.sin(phi) + torch.randn(m.shape, device=dev, generator=gen) * 0.002
                     del m
             host = buf.cpu().numpy() if from_host else None  # (the shim's way in: host buffers through the pinned staging of the C ABI)
-            psink = torch.zeros(sink_words, dtype=torch.int32, device=dev)
+            psink = torch.zeros(point_sink_words, dtype=torch.int32, device=dev)
             pctl = torch.zeros(4, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
             torch.cuda.empty_cache()  # what the generators above left in torch's cache is memory the library cannot allocate
@@ -501,7 +580,7 @@ def main():
                 torch.cuda.empty_cache()
 
         def run_point_on(g, name, n_streams, n_samples, sparse, steps, warm, check, idle, offgrid, from_host, buf, host, psink, pctl, total):
-            g.sink_attach(psink.data_ptr(), sink_words, pctl.data_ptr())
+            g.sink_attach(psink.data_ptr(), point_sink_words, pctl.data_ptr())
             g.sink_hold(True)
             g.profile(True)
             f0 = g.open(nfclab_amd.default_params(), count=n_streams)
@@ -527,7 +606,7 @@ def main():
             tb = time.perf_counter()
             ps = g.stats()
             pdrop = int(pctl[1].item())
-            used = clamp_used(int(pctl[0].item()), pdrop, sink_words)
+            used = clamp_used(int(pctl[0].item()), pdrop, point_sink_words)
             pframes = framelib.parse_sink(psink[:used].cpu().numpy(), used, FS)
             point = {
                 "workload": "%d stream(s) x %d samples per step, %s traffic (%s), %s, all four decoders" % (
@@ -611,6 +690,10 @@ def main():
         scan_stats = None
         idle_stats = None
         for name in want:
+            if time.perf_counter() - t_start > args.points_budget:
+                points[name] = {"skipped": "the points' time budget (%d s since start) was used up" % args.points_budget}
+                continue
+            t_point = time.perf_counter()
             try:
                 if name == "fixtures_single":
                     points[name] = run_fixtures()
@@ -636,6 +719,8 @@ def main():
                     points[name], _ = run_point(name, 1, args.single_samples, True, 2, 1, 1)
             except Exception as exc:  # a point that fails must not take the headline with it
                 points[name] = {"error": repr(exc)}
+            if isinstance(points.get(name), dict):
+                points[name]["wall_s"] = round(time.perf_counter() - t_point, 1)
         result["config"]["points"] = points
 
         # the search kernel of the time-parallel path (nfc_scan_kernel): on the idle point it is the whole job; on the sparse
@@ -673,6 +758,14 @@ def main():
                     scan_stats, 2, "config5_sparse (re-walks of chunks whose seams did not verify included in the time)")
 
     if rank == 0:
+        asked = headline_device_bytes(S, L, K, W, args.slices, world)
+        result["consistency"] = {
+            "headline_device_bytes_asked": int(asked),
+            "headline_dataset": "%d slice(s) of %d samples per stream resident (%.1f GiB on this rank), step k submits slice k %% %d" % (
+                NS, L, 8.0 * S * T / 2 ** 30, NS),
+            "fits_in_driver_run": bool(asked < 200 * 2 ** 30),
+            "wall_s": round(time.perf_counter() - t_start, 1),
+        }
         print(json.dumps(result))
 
     if world > 1:

@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 #include <atomic>
+#include <mutex>
 
 #include <hw/SignalType.h>
 #include <hw/SignalBuffer.h>
@@ -213,23 +214,48 @@ long nfcref_decode_after_idle(const float *idle, uint32_t idle_count, uint64_t r
    return decode_capture(samples, count, sample_rate, chunk, params, keep_carrier, 0, out, cap, nullptr, nullptr, &prefix);
 }
 
-/* same, with defined frame storage (see the top of this file); not for timing, single caller at a time */
+/* same, with defined frame storage (see the top of this file); not for timing. May be called from several threads at once
+ * (tests/parity_sweep_driver.py, bench.py's parity leg): the pool is process-wide, so while ANY such decode runs no frame
+ * of any of them goes back to it - the captures' frames are parked until the last of the concurrent decodes has ended -
+ * and every block comes fresh and cleared from posix_memalign. (Round 3 cleared the flag when the first of several
+ * concurrent callers returned: the others then classified truncated frames from uncleared storage, seen as one NFC-F poll
+ * in 37 000 frames with another frame phase than the decoder under test.) Not to be mixed with concurrent nfcref_decode /
+ * nfcref_decode_many calls, which do recycle. */
+static std::mutex definedMutex;
+static int definedActive = 0;
+static std::list<std::list<std::list<lab::RawFrame>>> definedParked;
+
 long nfcref_decode_defined(const float *samples, uint64_t count, uint32_t sample_rate, uint32_t chunk,
                            const nfcref_params *params, int keep_carrier, int send_eof,
                            nfcref_frame *out, uint32_t cap, double *seconds)
 {
    long total;
 
-   rt::Buffer<unsigned char>::heap.cleanup();
-   clearNewStorage = 1;
-
    {
-      std::list<std::list<lab::RawFrame>> kept;
-      total = decode_capture(samples, count, sample_rate, chunk, params, keep_carrier, send_eof, out, cap, seconds, &kept);
+      std::lock_guard<std::mutex> lock(definedMutex);
+
+      if (definedActive++ == 0)
+      {
+         rt::Buffer<unsigned char>::heap.cleanup();
+         clearNewStorage = 1;
+      }
    }
 
-   clearNewStorage = 0;
-   rt::Buffer<unsigned char>::heap.cleanup();
+   std::list<std::list<lab::RawFrame>> kept;
+   total = decode_capture(samples, count, sample_rate, chunk, params, keep_carrier, send_eof, out, cap, seconds, &kept);
+
+   {
+      std::lock_guard<std::mutex> lock(definedMutex);
+
+      definedParked.push_back(std::move(kept));
+
+      if (--definedActive == 0)
+      {
+         definedParked.clear();
+         clearNewStorage = 0;
+         rt::Buffer<unsigned char>::heap.cleanup();
+      }
+   }
 
    return total;
 }

@@ -35,3 +35,19 @@ def test_a_record_of_other_sources_or_another_shape_is_refused(tmp_path, monkeyp
         json.dump(good, f)
     value, source = bench.stored_traffic("nfc_scan_kernel", 4096, 1 << 20)
     assert value is None and "other kernel sources" in source
+
+
+def test_the_headline_of_the_drivers_command_fits_the_gpu():
+    """`bench.py --gpus 1 --steps 20 --warmup 5` asked for 800 GiB (a fresh slice per step). The dataset is
+    SURVEY 8(d)'s L samples per stream, a fixed number of slices of it resident whatever the step count"""
+    gib = float(1 << 30)
+    for steps, warmup in ((2, 1), (20, 5), (200, 50)):
+        slices, resident = bench.headline_layout(steps, warmup, 1 << 20, 2)
+        assert slices <= 2 and resident == slices << 20
+        assert bench.headline_device_bytes(4096, 1 << 20, steps, warmup) < 200 * gib
+    assert bench.headline_layout(1, 0, 1 << 20, 2) == (1, 1 << 20)
+    # the held sink grows with the step count: twice the 2.04 M words a step of config 5 leaves on dense traffic
+    assert bench.headline_sink_words(4096, 1 << 20, 20, 5) >= 25 * 2 * 2040000
+    assert bench.headline_sink_words(512, 1 << 20, 2, 1) >= 16 << 20
+    # N ranks under strong scaling: every rank's share plus a gather buffer for all of them
+    assert bench.headline_device_bytes(512, 1 << 20, 20, 5, world=8) < 40 * gib

@@ -219,6 +219,27 @@ def test_truncated_frames_are_classified_as_with_cleared_reference_storage(built
     assert any(f[1] == trigger[0] and f[-1] == bytes.fromhex(trigger[1]) for f in ref), what
 
 
+def test_defined_reference_storage_holds_under_concurrent_callers(built):
+    """The at-size parity runs (tests/parity_sweep_driver.py, bench.py) call nfcref_decode_defined from a pool of threads.
+    The reference's frame pool is process-wide: round 3's wrapper cleared its flag when the FIRST of several concurrent
+    callers returned, and the others then classified truncated frames from uncleared storage (found by bench.py's parity leg
+    over 25 submissions: one NFC-F poll of one byte in 37 000 frames with another frame phase). Every concurrent caller
+    must see what a lone caller sees."""
+    if T.reference_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    from concurrent.futures import ThreadPoolExecutor
+    captures = [_fuzz_stream(seed, length) for seed, length, _, _ in _TRUNCATED]
+    alone = [T.reference_decode(x, keep_carrier=True, cap=16384, defined_storage=True)[0] for x in captures]
+
+    # (plain decodes first: they leave used frame storage in the allocator and in the pool)
+    for x in captures:
+        T.reference_decode(x, keep_carrier=True, cap=16384)
+    with ThreadPoolExecutor(max_workers=12) as pool:
+        together = list(pool.map(lambda i: T.reference_decode(captures[i % len(captures)], keep_carrier=True, cap=16384, defined_storage=True)[0], range(96)))
+    for i, fr in enumerate(together):
+        assert fr == alone[i % len(captures)], i
+
+
 @pytest.mark.parametrize("rate,step", [(5000000, 2), (2500000, 4)])
 @pytest.mark.parametrize("name", ["test_NFC-A_106kbps_001", "test_NFC-B_106kbps_001", "test_NFC-F_212kbps_002", "test_NFC-V_26kbps_002"])
 def test_step_machine_matches_reference_at_other_sample_rates(built, name, rate, step):
