@@ -155,6 +155,14 @@ __device__ __forceinline__ float nfc_wave_max(float v)
 __global__ __launch_bounds__(64) NFC_WAVE_KERNEL_ATTR void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode)
 {
    __shared__ NfcWaveLds lds;
+#ifdef NFC_WAVE_LDS_PAD
+   /* experiment: more LDS per wave = fewer waves per CU (how much of the throughput is occupancy?) */
+   __shared__ uint32_t pad[NFC_WAVE_LDS_PAD / 4];
+   pad[(threadIdx.x * 97u + mode) % (NFC_WAVE_LDS_PAD / 4)] = blockIdx.x;
+   __syncthreads();
+   if (pad[(blockIdx.x * 31u) % (NFC_WAVE_LDS_PAD / 4)] == 0xFFFFFFFFu)
+      return;
+#endif
 
    NfcConfig cc;
    nfc_wave_config(cfgPtr, cc);

@@ -76,6 +76,14 @@ struct NfcWaveUni
    uint32_t which;    /* search bank: detectors whose gates were up at sample whichAt (bit per detector, nfc_wave_search_gate) */
    uint32_t whichAt;
    uint32_t maskValid; /* search bank: the detectors whose gates over the tile at hand (NfcWaveLds::gate) still stand (bit per detector) */
+   /* what the two ring taps of a sample (nfc_wave_taps) are formed from on demand: the correlators as they stood when the
+    * values of the tile were formed (sample `from`): ring position and running sum of the sample before, whether the ring
+    * entry one sample back is that sum; locked stages (slot 0): ring period, distance of the first tap, ring base, first
+    * clock whose step writes the ring */
+   uint32_t tapPos[6];
+   float tapAcc[6];
+   uint32_t tapPrev;
+   uint32_t tapPeriod, tapShift, tapBase, tapWriteFrom;
    float pass[16];    /* hand-over from single lanes to everybody */
 };
 
@@ -92,9 +100,9 @@ struct NfcWaveLds
    float scratch[NFC_LANES];
    uint32_t gate[NFC_LANES];         /* search bank: the detectors' gates per sample of the tile (nfc_wave_search_bits) */
    uint32_t tileFlags[NFC_LANES];    /* the lane's next 64 tile flag words (one load per 64 tiles instead of one per tile boundary) */
-   float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator */
-   float s0[6][NFC_LANES];           /* ... and the two differences the detectors look at */
-   float s1[6][NFC_LANES];
+   float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator (the two
+                                        differences the detectors look at are formed from it and the ring where they are
+                                        used: nfc_wave_s0s1) */
    /* the run-time part of the configuration (enable mask, thresholds), parked where the step functions find it without a
     * trip to memory: [0] enabled, [1] power, [2] low, [3] high threshold, [4..7] correlation, [8..11] minimum, [12..15] maximum depth */
    uint32_t cfg[16];
@@ -476,7 +484,7 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
             {                                                                                                                                    \
                r.detA[R].acc = lds->sum[R][at];                                                                                                  \
                lds->ring[NFC_R_CORR + c.corrOffset[R] + s.posA[R]] = r.detA[R].acc;                                                              \
-               if (((ask >> R) & 1u) && nfca_detect_decide<R>(c, s, mem, lds->s0[R][at] - lds->s1[R][at],                                        \
+               if (((ask >> R) & 1u) && nfca_detect_decide<R>(c, s, mem, nfc_wave_search_num(c, lds, R, at),                                     \
                                          lds->ring[NFC_R_DEPTH + ((s.clock - c.a[R].delay - c.a[R].p8) & NFC_HMASK)], limit, c.minDepth[0]))     \
                   locked = NFC_TECH_A;                                                                                                           \
             }
@@ -515,14 +523,19 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
             r.detF[0].acc = lds->sum[3][at];
             lds->ring[NFC_R_CORR + c.corrOffset[3] + s.posF[0]] = r.detF[0].acc;
 
-            if (((ask >> 5) & 1u) && nfcf_detect_decide<1>(c, s, mem, lds->s0[3][at], lds->s0[3][at] - lds->s1[3][at], deep, limit))
+            float f0, f1;
+            nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 3u, at, f0, f1);
+
+            if (((ask >> 5) & 1u) && nfcf_detect_decide<1>(c, s, mem, f0, f0 - f1, deep, limit))
                locked = NFC_TECH_F;
             else
             {
                r.detF[1].acc = lds->sum[4][at];
                lds->ring[NFC_R_CORR + c.corrOffset[4] + s.posF[1]] = r.detF[1].acc;
 
-               if (((ask >> 6) & 1u) && nfcf_detect_decide<2>(c, s, mem, lds->s0[4][at], lds->s0[4][at] - lds->s1[4][at], deep, limit))
+               nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 4u, at, f0, f1);
+
+               if (((ask >> 6) & 1u) && nfcf_detect_decide<2>(c, s, mem, f0, f0 - f1, deep, limit))
                   locked = NFC_TECH_F;
             }
          }
@@ -532,7 +545,10 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
             r.detV.acc = lds->sum[5][at];
             lds->ring[NFC_R_CORR + c.corrOffset[5] + s.posV1] = r.detV.acc;
 
-            if (((ask >> 7) & 1u) && nfcv_detect_decide(c, s, mem, lds->s0[5][at], lds->ring[NFC_R_X + ((s.clock - c.v.delay) & NFC_HMASK)]))
+            float v0, v1;
+            nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 5u, at, v0, v1);
+
+            if (((ask >> 7) & 1u) && nfcv_detect_decide(c, s, mem, v0, lds->ring[NFC_R_X + ((s.clock - c.v.delay) & NFC_HMASK)]))
                locked = NFC_TECH_V;
          }
 

@@ -60,43 +60,6 @@ NFC_DEV uint32_t nfc_wave_clock_of(uint32_t clock0)
    return clock0 + 1u + NFC_WAVE_LANE();
 }
 
-/* One raw box-sum correlator over the tile's samples from lane `from` on.
- *   acc      running sum after the sample before lane `from`
- *   pos      ring position of that sample
- *   prevKnown  the ring entry one sample back is the running sum (bank stepped on the previous sample)
- *   writeFrom  first clock whose step writes the ring (NFC-F listen frames: one symbol before the guard ends)
- * Leaves the running sums in lds->sum[slot] and the two taps in c2 / c3. */
-NFC_DEV float nfc_wave_raw(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t clock0, uint32_t from, float acc, uint32_t delay, uint32_t w, uint32_t p1,
-                           uint32_t shift, uint32_t base, uint32_t pos, bool prevKnown, uint32_t writeFrom, float &c2, float &c3)
-{
-   const uint32_t lane = NFC_WAVE_LANE();
-   const bool active = lane >= from;
-   const uint32_t t = nfc_wave_clock_of(clock0);
-   const uint32_t k = lane - from; /* samples after the first of the run */
-
-   const float in = lds->ring[NFC_R_X + ((t - delay) & NFC_HMASK)];
-   const float out = lds->ring[nfc_wave_x_old_index(lds->ring, t - delay - w)];
-
-   const float c = acc + NFC_WAVE_SCAN_ADD_F(active ? in - out : 0.0f);
-
-   NFC_WAVE_BARRIER();
-   lds->sum[slot][lane] = c;
-   NFC_WAVE_BARRIER();
-
-   const uint32_t posj = nfc_wave_wrap3(pos + 1u + (active ? k : 0u), p1);
-
-   /* the entry `shift` samples back: written by the tile if that sample belongs to the run and wrote the ring */
-   const bool c2Here = active && k >= shift && (int32_t)(t - shift - writeFrom) >= 0;
-   const float c2Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - shift, p1)];
-   c2 = c2Here ? lds->sum[slot][c2Here ? lane - shift : lane] : c2Ring;
-
-   const bool c3Here = active && k >= 1u && (int32_t)(t - 1u - writeFrom) >= 0;
-   const float c3Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - 1u, p1)];
-   c3 = c3Here ? lds->sum[slot][c3Here ? lane - 1u : lane] : ((active && k == 0u && prevKnown) ? acc : c3Ring);
-
-   return c;
-}
-
 /* commit of a correlator ring: entries of the samples [from, from + run) (the last `period` of them) */
 NFC_DEV void nfc_wave_ring_commit(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t clock0, uint32_t from, uint32_t run, uint32_t period, uint32_t base,
                                   uint32_t pos, uint32_t writeFrom)
@@ -105,6 +68,70 @@ NFC_DEV void nfc_wave_ring_commit(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, u
 
    if (lane >= from && lane < from + run && lane + period >= from + run && (int32_t)(nfc_wave_clock_of(clock0) - writeFrom) >= 0)
       lds->ring[NFC_R_CORR + base + nfc_wave_wrap3(pos + 1u + (lane - from), period)] = lds->sum[slot][lane];
+}
+
+/* The two ring taps of tile sample `j` of one correlator: the entry `shift` samples back and the entry one sample back.
+ * Either was written by the tile if that sample belongs to the values formed (from `from` on) and wrote the ring - then
+ * it is that sample's sum -, or stands in the ring as the tile found it: no write of the tile can have reached that
+ * position before sample j itself has been dealt with (a ring slot is written again one period later).
+ *   acc / pos    running sum and ring position of the sample before `from`
+ *   prevKnown    the ring entry one sample back from `from` is that running sum (bank stepped on the previous sample)
+ *   writeFrom    first clock whose step writes the ring (NFC-F listen frames: one symbol before the guard ends) */
+NFC_DEV void nfc_wave_taps(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t j, uint32_t clock0, uint32_t from, float acc, uint32_t p1, uint32_t shift,
+                           uint32_t base, uint32_t pos, bool prevKnown, uint32_t writeFrom, float &c2, float &c3)
+{
+   const bool active = j >= from;
+   const uint32_t t = clock0 + 1u + j;
+   const uint32_t k = j - from; /* samples after the first of the run */
+   const uint32_t posj = nfc_wave_wrap3(pos + 1u + (active ? k : 0u), p1);
+
+   const bool c2Here = active && k >= shift && (int32_t)(t - shift - writeFrom) >= 0;
+   const float c2Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - shift, p1)];
+   c2 = c2Here ? lds->sum[slot][c2Here ? j - shift : j] : c2Ring;
+
+   const bool c3Here = active && k >= 1u && (int32_t)(t - 1u - writeFrom) >= 0;
+   const float c3Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - 1u, p1)];
+   c3 = c3Here ? lds->sum[slot][c3Here ? j - 1u : j] : ((active && k == 0u && prevKnown) ? acc : c3Ring);
+}
+
+/* The two differences a detector or symbol stage looks at, at tile sample `j` (a lane's own sample, or the uniform
+ * sample a step is about): S0 and S1 of the reference's correlators (NfcA.cpp:236-255, NfcF.cpp:247-262) - or, where a
+ * stage only looks at one (NFC-V: NfcV.cpp:262-275), that one and zero - from the running sums of the tile
+ * (NfcWaveLds::sum) and the ring, with the correlator as it stood when the sums were formed (NfcWaveUni::tap*).
+ * key: the stage the values belong to; slot: search bank 0..2 NFC-A, 3..4 NFC-F, 5 NFC-V; locked stages 0. */
+NFC_DEV void nfc_wave_s0s1(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t key, uint32_t slot, uint32_t j, float &s0, float &s1)
+{
+   const uint32_t clock0 = lds->u.clock0, from = lds->u.from;
+   const float sum = lds->sum[slot][j];
+   float c2, c3;
+
+   if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
+   {
+      const bool prevKnown = lds->u.tapPrev != 0u;
+      const uint32_t never = clock0 - 0x40000000u;
+      const NfcRate &rt = slot < 3u ? c.a[slot] : (slot < 5u ? c.f[slot - 2u] : c.v);
+
+      nfc_wave_taps(lds, slot, j, clock0, from, lds->u.tapAcc[slot], rt.p1, rt.p1 - rt.p2, c.corrOffset[slot], lds->u.tapPos[slot], prevKnown, never, c2, c3);
+
+      s0 = slot == 5u ? c2 - sum : sum - c2; /* nfcv_detect: num = c2 - sum */
+      s1 = slot == 5u ? 0.0f : c2 - c3;
+      return;
+   }
+
+   nfc_wave_taps(lds, 0u, j, clock0, from, lds->u.tapAcc[0], lds->u.tapPeriod, lds->u.tapShift, lds->u.tapBase, lds->u.tapPos[0], false, lds->u.tapWriteFrom, c2, c3);
+
+   const bool single = key == NFC_FK_V_POLL || key == NFC_FK_V_START || key == NFC_FK_V_SYMBOL;
+
+   s0 = single ? c2 - sum : sum - c2;
+   s1 = single ? 0.0f : c2 - c3;
+}
+
+/* search bank, NFC-A: the correlation of rate R at tile sample j (what nfca_detect_decide is given) */
+NFC_DEV float nfc_wave_search_num(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t j)
+{
+   float s0, s1;
+   nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, slot, j, s0, s1);
+   return s0 - s1;
 }
 
 /* Running sum of a listen-mode integrator, walked in the step's order: sum += in[j]; sum -= out[j] for the samples from
@@ -204,7 +231,7 @@ NFC_DEV bool nfc_wave_gate_a(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    const NfcDetA &m = NFC_WAVE_STATE(lds).u.search.detA[I];
    const NfcRate &rt = c.a[I];
    const float limit = env * c.corrThreshold[0];
-   const float num = lds->s0[I][lane] - lds->s1[I][lane];
+   const float num = nfc_wave_search_num(c, lds, I, lane);
    const bool timeout = m.peakTime && t > m.peakTime + rt.p1;
    bool moves = false;
 
@@ -251,7 +278,7 @@ NFC_DEV bool nfc_wave_gate_f(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    const float deep = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)];
    /* nfcf_detect_rate / nfcf_track_preamble: a correlation above the threshold only changes the record when it is the
     * largest of the pulse so far */
-   const float num = lds->s0[3 + I][lane] - lds->s1[3 + I][lane];
+   const float num = nfc_wave_search_num(c, lds, 3 + I, lane);
    const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.sync | m.peakTime | nfc_bits(m.peak)) == 0u;
    bool moves = false;
 
@@ -275,7 +302,8 @@ NFC_DEV bool nfc_wave_gate_v(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    const float limit = env * c.corrThreshold[3];
    /* nfcv_detect: a pulse correlation above the threshold only changes the record when it is the largest so far or comes
     * with a deeper modulation */
-   const float num = lds->s0[5][lane]; /* c2 - sum */
+   float num, unused;
+   nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 5u, lane, num, unused); /* c2 - sum */
    const bool timeout = m.peakTime && t > m.peakTime + c.v.p0;
    bool moves = false;
 
@@ -352,7 +380,9 @@ NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLd
    return w;
 }
 
-/* running sum of one raw box-sum correlator after each of the tile's samples from lane `from` on (nfc_wave_raw, first half) */
+/* running sum of one raw box-sum correlator after each of the tile's samples from lane `from` on:
+ *   acc    running sum after the sample before lane `from`
+ *   delay  of the correlator's input, w: its window */
 NFC_DEV float nfc_wave_raw_sum(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, float acc, uint32_t delay, uint32_t w)
 {
    const uint32_t lane = NFC_WAVE_LANE();
@@ -362,24 +392,6 @@ NFC_DEV float nfc_wave_raw_sum(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, ui
    const float out = lds->ring[nfc_wave_x_old_index(lds->ring, t - delay - w)];
 
    return acc + NFC_WAVE_SCAN_ADD_F(lane >= from ? in - out : 0.0f);
-}
-
-/* ... and its two ring taps, once the sums of the whole wave are in lds->sum[slot] (second half; every clock writes) */
-NFC_DEV void nfc_wave_raw_taps(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t slot, uint32_t from, float acc, uint32_t p1, uint32_t shift, uint32_t base, uint32_t pos,
-                               bool prevKnown, float &c2, float &c3)
-{
-   const uint32_t lane = NFC_WAVE_LANE();
-   const bool active = lane >= from;
-   const uint32_t k = lane - from;
-   const uint32_t posj = nfc_wave_wrap3(pos + 1u + (active ? k : 0u), p1);
-
-   const bool c2Here = active && k >= shift;
-   const float c2Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - shift, p1)];
-   c2 = c2Here ? lds->sum[slot][c2Here ? lane - shift : lane] : c2Ring;
-
-   const bool c3Here = active && k >= 1u;
-   const float c3Ring = lds->ring[NFC_R_CORR + base + nfc_wave_wrap1(posj + p1 - 1u, p1)];
-   c3 = c3Here ? lds->sum[slot][c3Here ? lane - 1u : lane] : ((active && k == 0u && prevKnown) ? acc : c3Ring);
 }
 
 /* values of the search bank for the tile's samples from `from` on: the six sums, then (one barrier) their taps */
@@ -408,23 +420,25 @@ NFC_DEV void nfc_wave_search_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
    lds->sum[5][lane] = sumV;
    NFC_WAVE_BARRIER();
 
-   float c2, c3;
-
-#define NFC_WAVE_SEARCH_ONE(k, rt, sum, acc, base, pos)                                                        \
-   nfc_wave_raw_taps(lds, (k), from, (acc), (rt).p1, (rt).p1 - (rt).p2, (base), (pos), prevKnown, c2, c3);     \
-   lds->s0[k][lane] = (sum) - c2;                                                                               \
-   lds->s1[k][lane] = c2 - c3;
-
-   NFC_WAVE_SEARCH_ONE(0, c.a[0], sumA0, accA0, c.corrOffset[0], posA0)
-   NFC_WAVE_SEARCH_ONE(1, c.a[1], sumA1, accA1, c.corrOffset[1], posA1)
-   NFC_WAVE_SEARCH_ONE(2, c.a[2], sumA2, accA2, c.corrOffset[2], posA2)
-   NFC_WAVE_SEARCH_ONE(3, c.f[1], sumF0, accF0, c.corrOffset[3], posF0)
-   NFC_WAVE_SEARCH_ONE(4, c.f[2], sumF1, accF1, c.corrOffset[4], posF1)
-#undef NFC_WAVE_SEARCH_ONE
-
-   nfc_wave_raw_taps(lds, 5u, from, accV, c.v.p1, c.v.p1 - c.v.p2, c.corrOffset[5], posV1, prevKnown, c2, c3);
-   lds->s0[5][lane] = c2 - sumV; /* nfcv_detect: num = c2 - sum */
-   lds->s1[5][lane] = 0.0f;
+   /* the taps of a sample are formed where they are used (nfc_wave_s0s1), from the correlators as they stand now */
+   NFC_WAVE_BARRIER();
+   NFC_WAVE_UNIFORM_BEGIN
+   {
+      lds->u.tapPos[0] = posA0;
+      lds->u.tapPos[1] = posA1;
+      lds->u.tapPos[2] = posA2;
+      lds->u.tapPos[3] = posF0;
+      lds->u.tapPos[4] = posF1;
+      lds->u.tapPos[5] = posV1;
+      lds->u.tapAcc[0] = accA0;
+      lds->u.tapAcc[1] = accA1;
+      lds->u.tapAcc[2] = accA2;
+      lds->u.tapAcc[3] = accF0;
+      lds->u.tapAcc[4] = accF1;
+      lds->u.tapAcc[5] = accV;
+      lds->u.tapPrev = prevKnown ? 1u : 0u;
+   }
+   NFC_WAVE_UNIFORM_END
 }
 
 /* ---- locked stages ---- */
@@ -437,9 +451,12 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *l
    const NfcMod &m = d.lock;
    const NfcRate &rt = d.rt;
    const float depth = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)]; /* of this lane's own sample */
-   const float s0 = lds->s0[0][lane];
-   const float s1 = lds->s1[0][lane];
    const float sum = lds->sum[0][lane];
+   float s0 = 0.0f, s1 = 0.0f;
+
+   /* (the stages that look at the correlator's differences) */
+   if (key == NFC_FK_A_ASK_START || key == NFC_FK_F_START || key == NFC_FK_V_POLL || key == NFC_FK_V_START)
+      nfc_wave_s0s1(c, lds, key, 0u, lane, s0, s1);
 
    switch (key)
    {
@@ -556,6 +573,9 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
    const float acc = d.lock.acc, phaseAcc = d.lock.phaseAcc;
    const uint32_t posV0 = s.posV0, posV1 = s.posV1;
 
+   /* the correlator as it stands, for the taps formed on demand (nfc_wave_s0s1) */
+   uint32_t tapPeriod = rt.p1, tapShift = rt.p1 - rt.p2, tapPos = lockPos, tapWriteFrom = never;
+
    switch (key)
    {
       case NFC_FK_A_POLL:
@@ -564,20 +584,25 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
       {
          /* NFC-F listen frames: the box sum runs from the end of the poll frame, the ring only from one symbol before the
           * guard ends (nfcf_listen_start) */
-         const uint32_t writeFrom = key == NFC_FK_F_START ? guardEnd - rt.p1 : never;
-         float c2, c3;
-         const float sum = nfc_wave_raw(lds, 0u, clock0, from, acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, lockBase, lockPos, false, writeFrom, c2, c3);
-         lds->s0[0][lane] = sum - c2;
-         lds->s1[0][lane] = c2 - c3;
+         tapWriteFrom = key == NFC_FK_F_START ? guardEnd - rt.p1 : never;
+
+         const float sum = nfc_wave_raw_sum(lds, clock0, from, acc, rt.delay, rt.p2);
+
+         NFC_WAVE_BARRIER();
+         lds->sum[0][lane] = sum;
+         NFC_WAVE_BARRIER();
          break;
       }
 
       case NFC_FK_V_POLL:
       {
-         float c2, c3;
-         const float sum = nfc_wave_raw(lds, 0u, clock0, from, acc, rt.delay, rt.p2, rt.p1, rt.p1 - rt.p2, lockBase, posV1, false, never, c2, c3);
-         lds->s0[0][lane] = c2 - sum;
-         lds->s1[0][lane] = 0.0f;
+         tapPos = posV1;
+
+         const float sum = nfc_wave_raw_sum(lds, clock0, from, acc, rt.delay, rt.p2);
+
+         NFC_WAVE_BARRIER();
+         lds->sum[0][lane] = sum;
+         NFC_WAVE_BARRIER();
          break;
       }
 
@@ -588,37 +613,16 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
       {
          const bool v15693 = key == NFC_FK_V_START || key == NFC_FK_V_SYMBOL;
          const uint32_t window = v15693 ? rt.p1 : rt.p2;
-         const uint32_t period = v15693 ? rt.p0 : rt.p1;
-         const uint32_t pos = v15693 ? posV0 : lockPos;
-         const uint32_t shift = period - window; /* NFC-V: the entry one symbol half back in the two-symbol ring */
+
+         tapPeriod = v15693 ? rt.p0 : rt.p1;
+         tapPos = v15693 ? posV0 : lockPos;
+         tapShift = tapPeriod - window; /* NFC-V: the entry one symbol half back in the two-symbol ring */
 
          const float v = lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_HMASK)];
          const float sq = v * v * 10.0f;
          const float old = nfc_wave_product(lds, clock0, from, sq, rt.delay, window);
 
          nfc_wave_walk(lds, clock0, from, n, acc, sq, old, never);
-
-         const float sum = lds->sum[0][lane];
-         const bool active = lane >= from;
-         const uint32_t k = lane - from;
-         const uint32_t posj = nfc_wave_wrap3(pos + 1u + (active ? k : 0u), period);
-         const bool c2Here = active && k >= shift;
-         const float c2Ring = lds->ring[NFC_R_CORR + lockBase + nfc_wave_wrap1(posj + period - shift, period)];
-         const float c2 = c2Here ? lds->sum[0][c2Here ? lane - shift : lane] : c2Ring;
-         const bool c3Here = active && k >= 1u;
-         const float c3Ring = lds->ring[NFC_R_CORR + lockBase + nfc_wave_wrap1(posj + period - 1u, period)];
-         const float c3 = c3Here ? lds->sum[0][c3Here ? lane - 1u : lane] : c3Ring;
-
-         if (v15693)
-         {
-            lds->s0[0][lane] = c2 - sum;
-            lds->s1[0][lane] = 0.0f;
-         }
-         else
-         {
-            lds->s0[0][lane] = sum - c2;
-            lds->s1[0][lane] = c2 - c3;
-         }
          break;
       }
 
@@ -639,6 +643,18 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
       default:
          break;
    }
+
+   NFC_WAVE_BARRIER();
+   NFC_WAVE_UNIFORM_BEGIN
+   {
+      lds->u.tapPos[0] = tapPos;
+      lds->u.tapAcc[0] = acc;
+      lds->u.tapPeriod = tapPeriod;
+      lds->u.tapShift = tapShift;
+      lds->u.tapBase = lockBase;
+      lds->u.tapWriteFrom = tapWriteFrom;
+   }
+   NFC_WAVE_UNIFORM_END
 }
 
 /* What the samples [from, from + run) of a gathering symbol stage leave in the locked record (none of them is the
@@ -649,7 +665,7 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
  * not replace it: the comparison is strict). Results in lds->u.pass[8..15] for the uniform part:
  *   [8] 1 when the maximum moved, [9] the maximum, [10] its clock, [11] s0 there;
  *   [12] 1 when the synchronisation sample was in the run, [13] correlation, [14] s0, [15] s1 there. */
-NFC_DEV void nfc_wave_fold(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t key, uint32_t from, uint32_t run)
+NFC_DEV void nfc_wave_fold(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t key, uint32_t from, uint32_t run)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const uint32_t t = nfc_wave_clock_of(clock0);
@@ -657,7 +673,8 @@ NFC_DEV void nfc_wave_fold(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32
    const float thr = d.lock.thr, peak = d.lock.peak;
    const uint32_t winStart = d.lock.winStart, sync = d.lock.sync;
    const float p2 = (float)d.rt.p2;
-   const float s0 = lds->s0[0][lane], s1 = lds->s1[0][lane];
+   float s0, s1;
+   nfc_wave_s0s1(c, lds, key, 0u, lane, s0, s1);
 
    const bool in = lane >= from && lane < from + run && t >= winStart;
 
@@ -1017,7 +1034,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    }
 
    if (gathers)
-      nfc_wave_fold(lds, clock0, key, from, run);
+      nfc_wave_fold(c, lds, clock0, key, from, run);
 
    NFC_WAVE_BARRIER();
 

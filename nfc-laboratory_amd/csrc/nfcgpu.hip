@@ -10,12 +10,17 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nfcgpu.h"
@@ -96,8 +101,21 @@ struct ProfiledLaunch
 
 }
 
+struct nfcgpu_shard;
+
 struct nfcgpu_ctx
 {
+   /* A shard (parent != nullptr) is a context of its own - HIP streams, work buffers of the time-parallel path, event
+    * pool, statistics - that serves a fixed range of its parent's stream slots from a thread of its own (see "shards"
+    * below): the stream table, the configuration table, the launch stamp and every device array of the slots are the
+    * parent's. */
+   explicit nfcgpu_ctx(nfcgpu_ctx *parent_ = nullptr)
+      : parent(parent_), configs(parent_ ? parent_->configs : ownConfigs), streams(parent_ ? parent_->streams : ownStreams),
+        launchSeq(parent_ ? parent_->launchSeq : ownLaunchSeq)
+   {
+   }
+
+   nfcgpu_ctx *parent;
    int device = 0;
    hipStream_t stream = nullptr;
    hipStream_t side = nullptr;       /* the carry lanes of a windowed pass run beside the speculative ones */
@@ -135,15 +153,18 @@ struct nfcgpu_ctx
    uint32_t stageNext = 0;
    bool inflight = false; /* something has been enqueued since the last stream synchronisation */
 
-   std::vector<NfcConfig> configs;
-   std::vector<StreamInfo> streams;
+   std::vector<NfcConfig> ownConfigs;
+   std::vector<StreamInfo> ownStreams;
+   std::atomic<uint32_t> ownLaunchSeq {0};
+   std::vector<NfcConfig> &configs;
+   std::vector<StreamInfo> &streams;
    std::vector<NfcWork> hWorks;
    std::vector<uint32_t> hSink;
 
    bool hold = false;
    bool profile = false;
    bool dirty = false; /* work submitted since last sync */
-   uint32_t launchSeq = 0; /* stamp of the last demodulation launch (NfcLaunch::launchSeq) */
+   std::atomic<uint32_t> &launchSeq; /* stamp of the last demodulation launch (NfcLaunch::launchSeq), one sequence for a context and its shards */
 
    /* ---- time-parallel path (nfc_scan.h): device buffers, grown on demand and kept ---- */
    bool windowed = true;           /* NFCGPU_WINDOWED=0 switches the path off */
@@ -182,6 +203,49 @@ struct nfcgpu_ctx
    std::vector<hipEvent_t> eventPool;
    nfcgpu_stats stats {};
    std::string lastError;
+
+   /* ---- shards: large device-resident uniform submissions are decoded by several host threads, each with a slice of
+    * the slots, so that the latency-bound ends of one slice's submission (repair rounds of the scan, the later decode
+    * passes: a few long lanes each) run beside the throughput-bound middle of another's, and submission k + 1 of a slice
+    * begins as soon as its own submission k is done, whatever the other slices are at (nfcgpu_submit_uniform) ---- */
+   std::vector<std::unique_ptr<nfcgpu_shard>> shards;
+   uint32_t shardCount = 0;        /* NFCGPU_SHARDS (0 or 1: none) */
+   uint32_t shardMinStreams = 128; /* a slice is worth a thread from this many streams on */
+   uint32_t shardSpan = 0;         /* slots per shard: slot / shardSpan is the shard, for the life of the context */
+   bool shardStagger = true;
+   bool asyncInFlight = false;     /* jobs have been handed to shards since the last drain */
+   std::mutex staggerMutex;        /* the first submission after a drain starts the shards one after the other: shard g */
+   std::condition_variable staggerCv; /* waits until g shards before it are through the first decode pass of theirs */
+   uint32_t staggerTicket = 0;
+   bool staggerOwed = false;       /* (shard) this job still owes the parent its ticket */
+   uint32_t sizingStreams = 0;     /* (shard) streams of the whole submission the job at hand is a slice of: chunks and lanes are
+                                      sized for the submission, not for the slice (the machine is shared with the other slices) */
+};
+
+/* one slice of a uniform submission */
+struct nfcgpu_async_job
+{
+   uint32_t first = 0, count = 0;
+   const uint8_t *base = nullptr; /* row of slot `first` */
+   uint64_t pitch = 0;
+   uint32_t n = 0, stride = 0;
+   bool profile = false;
+   bool staggered = false;
+   uint32_t waitTicket = 0;
+   uint32_t submissionStreams = 0;
+};
+
+struct nfcgpu_shard
+{
+   std::unique_ptr<nfcgpu_ctx> ctx;
+   std::thread thread;
+   std::mutex m;
+   std::condition_variable cv;
+   std::deque<nfcgpu_async_job> queue; /* front = the job being run while `running` */
+   bool running = false;
+   bool stop = false;
+   int error = 0; /* first failure since the last drain: later jobs of the shard are dropped */
+   std::string errorText;
 };
 
 namespace {
@@ -419,6 +483,8 @@ hipEvent_t take_event(nfcgpu_ctx *ctx)
    return e;
 }
 
+void stagger_signal(nfcgpu_ctx *ctx);
+
 int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t samples, bool exactPossible, bool exactOnly)
 {
    const uint32_t firstBlock = L.firstSlot / NFC_LANES;
@@ -441,9 +507,12 @@ int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t sample
     * variant (the first buffer of freshly opened streams) does not need the common kernel at all */
    L.forceExact = exactOnly ? 1u : 0u;
 
-   if (++ctx->launchSeq == 0)
-      ctx->launchSeq = 1;
-   L.launchSeq = ctx->launchSeq;
+   {
+      uint32_t stamp = ctx->launchSeq.fetch_add(1u) + 1u;
+      if (stamp == 0)
+         stamp = ctx->launchSeq.fetch_add(1u) + 1u;
+      L.launchSeq = stamp;
+   }
 
    if (!exactOnly)
    {
@@ -714,6 +783,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          for (const WindowedItem &it: items)
             total += it.count;
 
+         /* (a slice of a sharded submission: the chunks of all slices share the machine) */
+         if (ctx->sizingStreams > nJobs)
+            total = total / nJobs * ctx->sizingStreams;
+
          uint64_t chunk = total / 131072u / NFC_SCAN_POINT * NFC_SCAN_POINT;
          if (chunk > 32768u)
             chunk = 32768u;
@@ -762,7 +835,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
     * further apart - fewer warm-ups, fewer hand-overs to go wrong - when that still leaves several lanes per wave slot
     * of the machine (NFCGPU_LANES_WANTED, default 16384 = 8 per slot of 256 CUs x 8 waves) */
    {
-      uint64_t cut = ctx->lanesWanted ? totalSamples / ctx->lanesWanted : 0u;
+      const uint64_t sizingSamples = ctx->sizingStreams > nJobs ? totalSamples / nJobs * ctx->sizingStreams : totalSamples;
+      uint64_t cut = ctx->lanesWanted ? sizingSamples / ctx->lanesWanted : 0u;
       cut = cut / NFC_SCAN_POINT * NFC_SCAN_POINT;
       cut = cut < NFC_WINDOW_CUT ? NFC_WINDOW_CUT : (cut > ctx->cutMax ? ctx->cutMax : cut);
 
@@ -1214,6 +1288,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       HIP_TRY(ctx, hipMemcpyAsync(&again, counters + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
+      stagger_signal(ctx); /* (a shard's first decode pass is through: the next shard of a staggered start may begin) */
+
       if (debugPasses)
       {
          uint32_t ls[3] = {0, 0, 0};
@@ -1504,6 +1580,92 @@ Rccl *rccl()
 
 }
 
+namespace {
+
+/* what a context owns besides the slots: streams, events, the work buffers of the time-parallel path (a shard owns
+ * nothing else) */
+void release_workspace(nfcgpu_ctx *ctx)
+{
+   if (ctx->stream)
+      (void)hipStreamSynchronize(ctx->stream);
+   if (ctx->side)
+      (void)hipStreamSynchronize(ctx->side);
+
+   for (auto *list: {&ctx->timed, &ctx->timedScan, &ctx->timedWindow, &ctx->timedWave, &ctx->timedPlanes})
+   {
+      for (auto &pl: *list)
+      {
+         (void)hipEventDestroy(pl.start);
+         (void)hipEventDestroy(pl.stop);
+      }
+      list->clear();
+   }
+   for (auto e: ctx->eventPool)
+      (void)hipEventDestroy(e);
+   ctx->eventPool.clear();
+
+   for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
+                                &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl, &ctx->vSaveRings, &ctx->vSaveBytes,
+                                &ctx->wPlanes, &ctx->wPlaneChunks})
+   {
+      if (b->ptr)
+         (void)hipFree(b->ptr);
+      b->ptr = nullptr;
+      b->bytes = 0;
+   }
+
+   if (ctx->forkEvent)
+      (void)hipEventDestroy(ctx->forkEvent);
+   if (ctx->joinEvent)
+      (void)hipEventDestroy(ctx->joinEvent);
+   if (ctx->side)
+      (void)hipStreamDestroy(ctx->side);
+   if (ctx->stream)
+      (void)hipStreamDestroy(ctx->stream);
+   ctx->forkEvent = ctx->joinEvent = nullptr;
+   ctx->side = ctx->stream = nullptr;
+}
+
+/* HIP-event spans recorded since the last call -> milliseconds in the context's statistics; the events go back to the pool.
+ * The streams the events were recorded on must have been waited for. */
+void collect_timings(nfcgpu_ctx *ctx)
+{
+   struct Into
+   {
+      std::vector<ProfiledLaunch> *list;
+      double *ms;
+      uint64_t *count;
+   } all[] = {{&ctx->timed, &ctx->stats.kernel_ms, nullptr},
+              {&ctx->timedScan, &ctx->stats.scan_ms, nullptr},
+              {&ctx->timedWindow, &ctx->stats.window_ms, nullptr},
+              {&ctx->timedWave, &ctx->stats.wave_ms, &ctx->stats.wave_launches},
+              {&ctx->timedPlanes, &ctx->stats.planes_ms, nullptr}};
+
+   for (Into &into: all)
+   {
+      for (auto &pl: *into.list)
+      {
+         float ms = 0;
+         if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
+         {
+            *into.ms += ms;
+            if (into.count)
+               ++*into.count;
+         }
+         ctx->eventPool.push_back(pl.start);
+         ctx->eventPool.push_back(pl.stop);
+      }
+      into.list->clear();
+   }
+}
+
+int run_rows(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride);
+int drain_async(nfcgpu_ctx *ctx);
+bool shards_wanted(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, uint32_t n);
+int submit_to_shards(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride);
+
+}
+
 extern "C" {
 
 void nfcgpu_default_params(nfcgpu_params *p)
@@ -1577,6 +1739,13 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    /* busy streams: a wave per lane decodes them where they are; the lane-per-window kernels send them to the sequential ones */
    ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->wave ? 101u : ctx->densePercent);
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);
+   ctx->shardCount = knob("NFCGPU_SHARDS", ctx->shardCount);
+   if (ctx->shardCount > 16)
+      ctx->shardCount = 16;
+   ctx->shardStagger = knob("NFCGPU_SHARD_STAGGER", 1) != 0;
+   ctx->shardMinStreams = knob("NFCGPU_SHARD_MIN", ctx->shardMinStreams);
+   if (ctx->shardMinStreams == 0)
+      ctx->shardMinStreams = 1;
    ctx->blockSamples = knob("NFCGPU_BLOCK_SAMPLES", ctx->blockSamples) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    if (ctx->blockSamples < 65536u)
       ctx->blockSamples = 65536u;
@@ -1656,18 +1825,24 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
 
    (void)hipSetDevice(ctx->device);
 
+   /* the shards first: their threads end once their queues are empty, nothing of their work outlives the slots */
+   for (auto &sh: ctx->shards)
+   {
+      {
+         std::lock_guard<std::mutex> lock(sh->m);
+         sh->stop = true;
+      }
+      sh->cv.notify_all();
+      if (sh->thread.joinable())
+         sh->thread.join();
+      release_workspace(sh->ctx.get());
+   }
+   ctx->shards.clear();
+
    if (ctx->stream)
       (void)hipStreamSynchronize(ctx->stream);
    if (ctx->side)
       (void)hipStreamSynchronize(ctx->side); /* (nothing of its work may outlive the buffers freed below) */
-
-   for (auto &pl: ctx->timed)
-   {
-      (void)hipEventDestroy(pl.start);
-      (void)hipEventDestroy(pl.stop);
-   }
-   for (auto e: ctx->eventPool)
-      (void)hipEventDestroy(e);
 
    (void)hipFree(ctx->dStates);
    (void)hipFree(ctx->dCold);
@@ -1689,31 +1864,7 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
 
    nfcgpu_comm_destroy(ctx);
 
-   for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
-                                &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl, &ctx->vSaveRings, &ctx->vSaveBytes,
-                                &ctx->wPlanes, &ctx->wPlaneChunks})
-   {
-      if (b->ptr)
-         (void)hipFree(b->ptr);
-   }
-
-   for (auto *list: {&ctx->timedScan, &ctx->timedWindow, &ctx->timedWave, &ctx->timedPlanes})
-   {
-      for (auto &pl: *list)
-      {
-         (void)hipEventDestroy(pl.start);
-         (void)hipEventDestroy(pl.stop);
-      }
-   }
-
-   if (ctx->forkEvent)
-      (void)hipEventDestroy(ctx->forkEvent);
-   if (ctx->joinEvent)
-      (void)hipEventDestroy(ctx->joinEvent);
-   if (ctx->side)
-      (void)hipStreamDestroy(ctx->side);
-   if (ctx->stream)
-      (void)hipStreamDestroy(ctx->stream);
+   release_workspace(ctx);
 
    delete ctx;
    return NFCGPU_OK;
@@ -1723,6 +1874,12 @@ int nfcgpu_stream_open_many(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32
 {
    if (!ctx || !first || count == 0)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
 
    /* first fit of `count` contiguous free slots */
    uint32_t run = 0, start = 0;
@@ -1775,6 +1932,12 @@ int nfcgpu_stream_configure(nfcgpu_ctx *ctx, uint32_t id, const nfcgpu_params *p
 {
    if (!ctx || !params)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
@@ -1806,6 +1969,12 @@ int nfcgpu_stream_reset(nfcgpu_ctx *ctx, uint32_t id)
 {
    if (!ctx)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
@@ -1822,6 +1991,12 @@ int nfcgpu_stream_close(nfcgpu_ctx *ctx, uint32_t id)
 {
    if (!ctx)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
@@ -1836,6 +2011,12 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
    if (!ctx || !b || !b->stream_ids || !b->data || !b->n_samples || (b->stride != 1 && b->stride != 2) ||
        (b->location != NFCGPU_LOC_HOST && b->location != NFCGPU_LOC_DEVICE))
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    if (b->n_streams == 0)
       return NFCGPU_OK;
 
@@ -2207,6 +2388,25 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
 
    HIP_TRY(ctx, hipSetDevice(ctx->device));
 
+   /* While earlier submissions are still with the shards, the next one may join them as it is - same streams running on,
+    * nothing to (re)initialise, no table of the context to change -; anything else waits for them first. */
+   {
+      bool joins = ctx->asyncInFlight && location == NFCGPU_LOC_DEVICE && n != 0 && shards_wanted(ctx, first, count, n);
+
+      for (uint32_t i = first; joins && i < first + count; i++)
+      {
+         const StreamInfo &si = ctx->streams[i];
+         joins = si.open && si.initialized && !si.needInit && si.derivedRate != 0 && si.params.sample_rate == sampleRate;
+      }
+
+      if (!joins)
+      {
+         const int drained = drain_async(ctx);
+         if (drained)
+            return drained;
+      }
+   }
+
    /* an empty buffer still stores a new sample rate and re-initialises the stream, like nfcgpu_submit (NfcDecoder.cpp:383-388) */
    for (uint32_t i = first; i < first + count; i++)
    {
@@ -2257,59 +2457,14 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
    if (rc)
       return rc;
 
-   /* contiguous runs of one configuration -> one launch each (normally exactly one) */
-   uint32_t i = first;
+   /* large device-resident submissions: a slice of the slots per shard thread, the call returns with the work handed
+    * over (the header's contract: device memory stays as it is until the next nfcgpu_sync / poll / flush / pending) */
+   if (location == NFCGPU_LOC_DEVICE && shards_wanted(ctx, first, count, n))
+      return submit_to_shards(ctx, first, count, devBase, devPitch, n, stride);
 
-   while (i < first + count)
-   {
-      const uint32_t c = ctx->streams[i].config;
-      uint32_t j = i;
-
-      while (j < first + count && ctx->streams[j].config == c)
-         j++;
-
-      {
-         std::vector<WindowedItem> items(j - i);
-         for (uint32_t k = i; k < j; k++)
-            items[k - i] = WindowedItem {k, devBase + (uint64_t)(k - first) * devPitch, n};
-
-         if (windowed_eligible(ctx, c, items))
-         {
-            rc = run_windowed(ctx, c, items, stride);
-            if (rc)
-               return rc;
-
-            i = j;
-            continue;
-         }
-      }
-
-      NfcLaunch L = base_launch(ctx);
-      L.works = nullptr;
-      L.uniformBase = devBase + (uint64_t)(i - first) * devPitch;
-      L.uniformPitch = devPitch;
-      L.uniformCount = n;
-      L.uniformStride = stride;
-      L.firstSlot = i;
-      L.slotCount = j - i;
-
-      bool exactPossible = false, exactOnly = true;
-      for (uint32_t k = i; k < j; k++)
-      {
-         const bool exact = exact_zone(ctx->streams[k].clock, n);
-         exactPossible = exactPossible || exact;
-         exactOnly = exactOnly && exact;
-      }
-
-      rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i), exactPossible, exactOnly);
-      if (rc)
-         return rc;
-
-      for (uint32_t k = i; k < j; k++)
-         commit_clock(ctx->streams[k], n);
-
-      i = j;
-   }
+   rc = run_rows(ctx, first, count, devBase, devPitch, n, stride);
+   if (rc)
+      return rc;
 
    /* host buffers are never retained past the call: they were copied into the staging slot */
    return NFCGPU_OK;
@@ -2320,6 +2475,12 @@ int nfcgpu_sync(nfcgpu_ctx *ctx)
    if (!ctx)
       return NFCGPU_EINVAL;
 
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
+
    /* nothing enqueued since the last synchronisation and nothing to collect: no device call at all */
    if (!ctx->inflight && !ctx->dirty && ctx->timed.empty() && ctx->timedScan.empty() && ctx->timedWindow.empty() && ctx->timedWave.empty() && ctx->timedPlanes.empty())
       return NFCGPU_OK;
@@ -2328,61 +2489,10 @@ int nfcgpu_sync(nfcgpu_ctx *ctx)
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
    ctx->inflight = false;
 
-   for (auto &pl: ctx->timed)
-   {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
-         ctx->stats.kernel_ms += ms;
-      ctx->eventPool.push_back(pl.start);
-      ctx->eventPool.push_back(pl.stop);
-   }
-   ctx->timed.clear();
-
-   for (auto &pl: ctx->timedScan)
-   {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
-         ctx->stats.scan_ms += ms;
-      ctx->eventPool.push_back(pl.start);
-      ctx->eventPool.push_back(pl.stop);
-   }
-   ctx->timedScan.clear();
-
-   for (auto &pl: ctx->timedWindow)
-   {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
-         ctx->stats.window_ms += ms;
-      ctx->eventPool.push_back(pl.start);
-      ctx->eventPool.push_back(pl.stop);
-   }
-   ctx->timedWindow.clear();
-
    if (!ctx->timedWave.empty() || !ctx->timedPlanes.empty())
       (void)hipStreamSynchronize(ctx->side); /* (carry lanes run beside the windows) */
 
-   for (auto &pl: ctx->timedWave)
-   {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
-      {
-         ctx->stats.wave_ms += ms;
-         ctx->stats.wave_launches++;
-      }
-      ctx->eventPool.push_back(pl.start);
-      ctx->eventPool.push_back(pl.stop);
-   }
-   ctx->timedWave.clear();
-
-   for (auto &pl: ctx->timedPlanes)
-   {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, pl.start, pl.stop) == hipSuccess)
-         ctx->stats.planes_ms += ms;
-      ctx->eventPool.push_back(pl.start);
-      ctx->eventPool.push_back(pl.stop);
-   }
-   ctx->timedPlanes.clear();
+   collect_timings(ctx);
 
    if (!ctx->dirty || ctx->hold)
       return NFCGPU_OK;
@@ -2489,6 +2599,12 @@ int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cu
 {
    if (!ctx)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    if (words)
       *words = ctx->dSink;
    if (cursor)
@@ -2502,6 +2618,12 @@ int nfcgpu_sink_attach(nfcgpu_ctx *ctx, void *words, uint64_t capacityWords, voi
 {
    if (!ctx || (words && (!ctl || capacityWords < 4ull * NFC_FRAME_MAX_WORDS || capacityWords > 0xFFFFFFF0ull)))
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
 
    const bool wasHeld = ctx->hold;
    ctx->hold = false;
@@ -2531,6 +2653,12 @@ int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold)
 {
    if (!ctx)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    ctx->hold = hold != 0;
    return NFCGPU_OK;
 }
@@ -2539,6 +2667,12 @@ int nfcgpu_sink_rewind(nfcgpu_ctx *ctx)
 {
    if (!ctx)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    HIP_TRY(ctx, hipSetDevice(ctx->device));
    HIP_TRY(ctx, hipMemsetAsync(ctx->dSinkCtl, 0, 16, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2619,6 +2753,12 @@ int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords
 {
    if (!ctx || !gathered || !countsHost || !strideWords)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    if (!ctx->comm)
       return fail(ctx, NFCGPU_EINVAL, "nfcgpu_comm_init first");
    if (!ctx->hold)
@@ -2697,6 +2837,12 @@ int nfcgpu_read_bandwidth(nfcgpu_ctx *ctx, const void *ptr, uint64_t bytes, uint
    if (!ctx || !ptr || bytes < 16 || !gbps || ((uintptr_t)ptr & 15))
       return NFCGPU_EINVAL;
 
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
+
    HIP_TRY(ctx, hipSetDevice(ctx->device));
 
    float *out = nullptr;
@@ -2732,6 +2878,12 @@ int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats)
 {
    if (!ctx || !stats)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    std::memcpy(stats, &ctx->stats, NFCGPU_STATS_SIZE_V2); /* a caller built against the older header holds no more */
    return NFCGPU_OK;
 }
@@ -2740,6 +2892,12 @@ int nfcgpu_stats_get_sized(nfcgpu_ctx *ctx, void *stats, uint32_t size)
 {
    if (!ctx || !stats)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    std::memcpy(stats, &ctx->stats, size < sizeof(nfcgpu_stats) ? size : sizeof(nfcgpu_stats));
    return NFCGPU_OK;
 }
@@ -2748,6 +2906,12 @@ int nfcgpu_stats_reset(nfcgpu_ctx *ctx)
 {
    if (!ctx)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    ctx->stats = nfcgpu_stats();
    return NFCGPU_OK;
 }
@@ -2756,6 +2920,12 @@ int nfcgpu_profile(nfcgpu_ctx *ctx, int enable)
 {
    if (!ctx)
       return NFCGPU_EINVAL;
+
+   {
+      const int drained = drain_async(ctx);
+      if (drained)
+         return drained;
+   }
    ctx->profile = enable != 0;
    return NFCGPU_OK;
 }
@@ -2817,6 +2987,356 @@ const char *nfcgpu_version(void)
 #else
    return "nfcgpu 0.1 (gfx950)";
 #endif
+}
+
+}
+
+namespace {
+
+/* rows first .. first + count - 1 of a uniform submission resident on the device: contiguous runs of one configuration ->
+ * one launch each (normally exactly one). Runs on the calling thread, on the streams of `ctx` (a context or a shard). */
+int run_rows(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride)
+{
+   int rc = NFCGPU_OK;
+   uint32_t i = first;
+
+   while (i < first + count)
+   {
+      const uint32_t c = ctx->streams[i].config;
+      uint32_t j = i;
+
+      while (j < first + count && ctx->streams[j].config == c)
+         j++;
+
+      {
+         std::vector<WindowedItem> items(j - i);
+         for (uint32_t k = i; k < j; k++)
+            items[k - i] = WindowedItem {k, devBase + (uint64_t)(k - first) * devPitch, n};
+
+         if (windowed_eligible(ctx, c, items))
+         {
+            rc = run_windowed(ctx, c, items, stride);
+            if (rc)
+               return rc;
+
+            i = j;
+            continue;
+         }
+      }
+
+      NfcLaunch L = base_launch(ctx);
+      L.works = nullptr;
+      L.uniformBase = devBase + (uint64_t)(i - first) * devPitch;
+      L.uniformPitch = devPitch;
+      L.uniformCount = n;
+      L.uniformStride = stride;
+      L.firstSlot = i;
+      L.slotCount = j - i;
+
+      bool exactPossible = false, exactOnly = true;
+      for (uint32_t k = i; k < j; k++)
+      {
+         const bool exact = exact_zone(ctx->streams[k].clock, n);
+         exactPossible = exactPossible || exact;
+         exactOnly = exactOnly && exact;
+      }
+
+      rc = launch_demod(ctx, c, L, (uint64_t)n * (j - i), exactPossible, exactOnly);
+      if (rc)
+         return rc;
+
+      for (uint32_t k = i; k < j; k++)
+         commit_clock(ctx->streams[k], n);
+
+      i = j;
+   }
+
+   return NFCGPU_OK;
+}
+
+/* ---- shards ---- */
+
+/* a shard that owes the parent its ticket hands it in: the next shard of a staggered start may begin */
+void stagger_signal(nfcgpu_ctx *ctx)
+{
+   if (!ctx->parent || !ctx->staggerOwed)
+      return;
+
+   ctx->staggerOwed = false;
+   {
+      std::lock_guard<std::mutex> lock(ctx->parent->staggerMutex);
+      ctx->parent->staggerTicket++;
+   }
+   ctx->parent->staggerCv.notify_all();
+}
+
+int shard_run(nfcgpu_ctx *parent, nfcgpu_shard *sh, const nfcgpu_async_job &job)
+{
+   nfcgpu_ctx *c = sh->ctx.get();
+
+   /* what the parent may have changed since the shard was made */
+   c->profile = job.profile;
+   c->dSink = parent->dSink;
+   c->dSinkCtl = parent->dSinkCtl;
+   c->sinkWords = parent->sinkWords;
+   c->ownSinkWords = parent->ownSinkWords;
+
+   if (job.staggered)
+   {
+      std::unique_lock<std::mutex> lock(parent->staggerMutex);
+      parent->staggerCv.wait(lock, [&] { return parent->staggerTicket >= job.waitTicket; });
+   }
+
+   c->staggerOwed = job.staggered;
+   c->sizingStreams = job.submissionStreams;
+
+   int rc = run_rows(c, job.first, job.count, job.base, job.pitch, job.n, job.stride);
+
+   if (hipStreamSynchronize(c->stream) != hipSuccess && rc == NFCGPU_OK)
+      rc = fail(c, NFCGPU_EHIP, "hipStreamSynchronize (shard)");
+   (void)hipStreamSynchronize(c->side);
+
+   stagger_signal(c); /* (a job that did not get as far as its first decode pass) */
+   return rc;
+}
+
+void shard_main(nfcgpu_ctx *parent, nfcgpu_shard *sh)
+{
+   (void)hipSetDevice(parent->device);
+
+   for (;;)
+   {
+      nfcgpu_async_job job;
+      bool skip;
+
+      {
+         std::unique_lock<std::mutex> lock(sh->m);
+         sh->cv.wait(lock, [&] { return sh->stop || !sh->queue.empty(); });
+
+         if (sh->queue.empty())
+            return;
+
+         job = sh->queue.front();
+         sh->running = true;
+         skip = sh->error != 0;
+      }
+
+      int rc = NFCGPU_OK;
+
+      if (!skip)
+         rc = shard_run(parent, sh, job);
+      else if (job.staggered)
+      {
+         sh->ctx->staggerOwed = true;
+         stagger_signal(sh->ctx.get());
+      }
+
+      {
+         std::lock_guard<std::mutex> lock(sh->m);
+
+         if (rc && !sh->error)
+         {
+            sh->error = rc;
+            sh->errorText = sh->ctx->lastError;
+         }
+
+         sh->queue.pop_front();
+         sh->running = false;
+      }
+      sh->cv.notify_all();
+   }
+}
+
+/* the shards of a context are made when the first submission wants them */
+int make_shards(nfcgpu_ctx *ctx)
+{
+   if (!ctx->shards.empty())
+      return NFCGPU_OK;
+
+   const uint32_t nShards = ctx->shardCount;
+   ctx->shardSpan = ((ctx->maxStreams + nShards - 1) / nShards + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
+
+   for (uint32_t g = 0; g < nShards; g++)
+   {
+      std::unique_ptr<nfcgpu_shard> sh(new (std::nothrow) nfcgpu_shard());
+      if (!sh)
+         return fail(ctx, NFCGPU_ENOMEM, "shard");
+
+      sh->ctx.reset(new (std::nothrow) nfcgpu_ctx(ctx));
+      nfcgpu_ctx *c = sh->ctx.get();
+      if (!c)
+         return fail(ctx, NFCGPU_ENOMEM, "shard context");
+
+      c->device = ctx->device;
+      c->maxStreams = ctx->maxStreams;
+      c->blocks = ctx->blocks;
+      c->dStates = ctx->dStates;
+      c->dCold = ctx->dCold;
+      c->dRings = ctx->dRings;
+      c->dBytes = ctx->dBytes;
+      c->dWorks = ctx->dWorks;
+      c->dConfigs = ctx->dConfigs;
+      c->genericOnly = ctx->genericOnly;
+      c->sideMode = ctx->sideMode;
+      c->windowed = ctx->windowed;
+      c->windowedMinSamples = ctx->windowedMinSamples;
+      c->scanChunk = ctx->scanChunk;
+      c->scanChunkFixed = ctx->scanChunkFixed;
+      c->blockSamples = ctx->blockSamples;
+      c->scanWarm = ctx->scanWarm;
+      c->maxPasses = ctx->maxPasses;
+      c->maxPassesFew = ctx->maxPassesFew;
+      c->densePercent = ctx->densePercent;
+      c->windowWaves = ctx->windowWaves;
+      c->wave = ctx->wave;
+      c->lanesWanted = ctx->lanesWanted;
+      c->cutMax = ctx->cutMax;
+      c->stagingWords = ctx->stagingWords;
+      c->soloSamples = ctx->soloSamples;
+      c->aloneStreams = ctx->aloneStreams;
+      c->alonePercent = ctx->alonePercent;
+      c->shardCount = 0; /* (a shard has none of its own) */
+
+      bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&c->joinEvent, hipEventDisableTiming) == hipSuccess;
+
+      if (!ok)
+      {
+         release_workspace(c);
+         return fail(ctx, NFCGPU_EHIP, "streams of a shard");
+      }
+
+      nfcgpu_shard *raw = sh.get();
+      ctx->shards.push_back(std::move(sh));
+      raw->thread = std::thread(shard_main, ctx, raw);
+   }
+
+   return NFCGPU_OK;
+}
+
+/* does this uniform submission go to the shards? (at least two of them get a slice worth a thread) */
+bool shards_wanted(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, uint32_t n)
+{
+   if (ctx->parent || ctx->shardCount < 2 || !ctx->windowed || n < ctx->windowedMinSamples)
+      return false;
+
+   const uint32_t span = ((ctx->maxStreams + ctx->shardCount - 1) / ctx->shardCount + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
+   uint32_t worth = 0;
+
+   for (uint32_t g = 0; g < ctx->shardCount; g++)
+   {
+      const uint64_t lo = (uint64_t)g * span > first ? (uint64_t)g * span : first;
+      const uint64_t hi = (uint64_t)(g + 1) * span < (uint64_t)first + count ? (uint64_t)(g + 1) * span : (uint64_t)first + count;
+      if (hi > lo && hi - lo >= ctx->shardMinStreams)
+         worth++;
+   }
+
+   return worth >= 2;
+}
+
+int submit_to_shards(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride)
+{
+   int rc = make_shards(ctx);
+   if (rc)
+      return rc;
+
+   /* the slots have been initialised on the context's stream: done before a shard touches them */
+   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+   const bool cold = !ctx->asyncInFlight && ctx->shardStagger; /* first hand-over since the last drain: a staggered start */
+
+   if (cold)
+   {
+      std::lock_guard<std::mutex> lock(ctx->staggerMutex);
+      ctx->staggerTicket = 0;
+   }
+
+   uint32_t ticket = 0;
+
+   for (uint32_t g = 0; g < (uint32_t)ctx->shards.size(); g++)
+   {
+      const uint64_t lo = (uint64_t)g * ctx->shardSpan > first ? (uint64_t)g * ctx->shardSpan : first;
+      const uint64_t hi = (uint64_t)(g + 1) * ctx->shardSpan < (uint64_t)first + count ? (uint64_t)(g + 1) * ctx->shardSpan : (uint64_t)first + count;
+
+      if (hi <= lo)
+         continue;
+
+      nfcgpu_async_job job;
+      job.first = (uint32_t)lo;
+      job.count = (uint32_t)(hi - lo);
+      job.base = devBase + (lo - first) * devPitch;
+      job.pitch = devPitch;
+      job.n = n;
+      job.stride = stride;
+      job.profile = ctx->profile;
+      job.staggered = cold;
+      job.waitTicket = ticket++;
+      job.submissionStreams = count;
+
+      nfcgpu_shard *sh = ctx->shards[g].get();
+      {
+         std::lock_guard<std::mutex> lock(sh->m);
+         sh->queue.push_back(job);
+      }
+      sh->cv.notify_all();
+   }
+
+   ctx->asyncInFlight = true;
+   ctx->inflight = true;
+   ctx->dirty = true;
+   return NFCGPU_OK;
+}
+
+/* waits for everything handed to the shards, takes over their statistics and the first failure */
+int drain_async(nfcgpu_ctx *ctx)
+{
+   if (!ctx->asyncInFlight)
+      return NFCGPU_OK;
+
+   int rc = NFCGPU_OK;
+
+   for (auto &sh: ctx->shards)
+   {
+      {
+         std::unique_lock<std::mutex> lock(sh->m);
+         sh->cv.wait(lock, [&] { return sh->queue.empty() && !sh->running; });
+
+         if (sh->error && rc == NFCGPU_OK)
+         {
+            rc = sh->error;
+            ctx->lastError = sh->errorText;
+         }
+
+         sh->error = 0;
+         sh->errorText.clear();
+      }
+
+      nfcgpu_ctx *c = sh->ctx.get();
+      collect_timings(c); /* (the shard waits for its streams at the end of every job) */
+
+      nfcgpu_stats &a = ctx->stats, &b = c->stats;
+      a.launches += b.launches;
+      a.samples += b.samples;
+      a.kernel_ms += b.kernel_ms;
+      a.scan_ms += b.scan_ms;
+      a.window_ms += b.window_ms;
+      a.scan_samples += b.scan_samples;
+      a.windows += b.windows;
+      a.window_passes += b.window_passes;
+      a.windowed_streams += b.windowed_streams;
+      a.fallback_streams += b.fallback_streams;
+      a.scan_repairs += b.scan_repairs;
+      a.wave_ms += b.wave_ms;
+      a.wave_launches += b.wave_launches;
+      a.planes_ms += b.planes_ms;
+      b = nfcgpu_stats {};
+      c->dirty = false;
+   }
+
+   ctx->asyncInFlight = false;
+   return rc;
 }
 
 }

@@ -15,6 +15,6 @@ $CXX -x c++ -c "$PKG/csrc/nfcgpu.hip" -o "$HERE/emu_nfcgpu.o"
 $CXX -c "$HERE/emu_kernels.cpp" -o "$HERE/emu_kernels.o"
 # the wave decoder's own text, 64 fibres per wave (wavesim.hpp)
 $CXX -c "$HERE/emu_wave.cpp" -o "$HERE/emu_wave.o"
-g++ -shared -o "$HERE/libnfcgpu_emulated.so" "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o"
+g++ -shared -pthread -o "$HERE/libnfcgpu_emulated.so" "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o"
 rm -f "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o"
 echo "built $HERE/libnfcgpu_emulated.so"

@@ -71,6 +71,7 @@ static void emu_carry_debug(const NfcCarry &a, const NfcCarry &b, bool meeting, 
 
 namespace fakehip {
 dim3 launchGrid, launchBlock;
+std::recursive_mutex launchMutex;
 }
 
 static void emu_carry_debug(const NfcCarry &a, const NfcCarry &b, bool meeting, uint32_t tracked)

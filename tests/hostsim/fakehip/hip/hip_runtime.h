@@ -43,8 +43,13 @@ struct float4
    float x, y, z, w;
 };
 
+#include <mutex>
+
 namespace fakehip {
 extern dim3 launchGrid, launchBlock;
+/* the CPU twins keep their working storage in statics (one wave's LDS, the fibres of a wave): one launch at a time,
+ * whatever host thread it comes from (the shards of nfcgpu.hip launch from threads of their own) */
+extern std::recursive_mutex launchMutex;
 }
 
 static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP error"; }
@@ -75,6 +80,7 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
    do                                                              \
    {                                                               \
+      std::lock_guard<std::recursive_mutex> launchLock(fakehip::launchMutex); \
       fakehip::launchGrid = (grid);                                \
       fakehip::launchBlock = (block);                              \
       (kernel)(__VA_ARGS__);                                       \
