@@ -91,19 +91,43 @@ struct NfcLaneMem
    bool linked;          /* frame records are chained per lane in a staging sink (time-parallel path) */
    uint32_t *flags;      /* time-parallel lanes only (linked): what the lane has looked at of the state it inherited, bits of
                             NfcStreamCold::usedTech; kept in fast storage during the run (the sequential kernels track nothing) */
+#ifdef NFC_F_DEEP_CTX
+   NFC_F_DEEP_CTX deep;  /* where NFC_F_DEEP finds what the shortened histories no longer hold */
+#endif
 };
 
+/* The histories of the filtered signal, its mean deviation and the modulation depth may be kept shorter than the raw
+ * samples' (NFC_HIST_F < NFC_HIST: the wave decoder, whose rings are LDS): everything but NFC-V looks back less than 192
+ * samples there (NFC-A 424k BPSK: delay 141 + one symbol of 24; NFC-A / -B depth taps: 153), NFC-V looks back up to 402.
+ * An includer that shortens them provides NFC_F_DEEP(mem, region, sampleClock) for the reads that may reach further
+ * (from the front end's planes in HBM: nfc_wave.hpp). */
+#ifndef NFC_HIST_F
+#define NFC_HIST_F NFC_HIST
+#endif
+
 /* ring regions (in slots) inside a stream block */
-#define NFC_R_X 0u                         /* samplingValue  [NFC_HIST] */
-#define NFC_R_FILT (1u * NFC_HIST)         /* filteredValue  [NFC_HIST] */
-#define NFC_R_MDEV (2u * NFC_HIST)         /* meanDeviation  [NFC_HIST] */
-#define NFC_R_DEPTH (3u * NFC_HIST)        /* modulateDepth  [NFC_HIST] */
-#define NFC_R_PROD (4u * NFC_HIST)         /* listen-mode product ring [NFC_PROD] */
-#define NFC_R_CORR (4u * NFC_HIST + NFC_PROD) /* correlation rings [corrTotal] */
+#define NFC_R_X 0u                                      /* samplingValue  [NFC_HIST]   */
+#define NFC_R_FILT (NFC_HIST)                           /* filteredValue  [NFC_HIST_F] */
+#define NFC_R_MDEV (NFC_HIST + NFC_HIST_F)              /* meanDeviation  [NFC_HIST_F] */
+#define NFC_R_DEPTH (NFC_HIST + 2u * NFC_HIST_F)        /* modulateDepth  [NFC_HIST_F] */
+#define NFC_R_PROD (NFC_HIST + 3u * NFC_HIST_F)         /* listen-mode product ring [NFC_PROD] */
+#define NFC_R_CORR (NFC_HIST + 3u * NFC_HIST_F + NFC_PROD) /* correlation rings [corrTotal] */
 
 /* 32-bit index from a wave-uniform base: the access becomes `global_load v, v_off, s[base]` */
 #define NFC_AT(m, region, slot) ((m).ring[((region) + (uint32_t)(slot)) * NFC_RING_STRIDE + (m).lane])
 #define NFC_HMASK (NFC_HIST - 1u)
+#define NFC_FMASK (NFC_HIST_F - 1u)
+
+/* a read of the filtered / deviation / depth history at the sample of clock `clk`, which may lie further back than the
+ * shortened history holds (NFC-V); `wanted` false: the value is not used (the stream-parallel kernels then read a
+ * harmless row every lane reads anyway, `common`, instead of branching) */
+#ifdef NFC_F_DEEP
+#define NFC_F_AT(mem, region, clk) NFC_F_DEEP((mem), (region), (clk))
+#define NFC_F_TAP(mem, wanted, region, clk, common) ((wanted) ? NFC_F_DEEP((mem), (region), (clk)) : 0.0f)
+#else
+#define NFC_F_AT(mem, region, clk) NFC_AT((mem), (region), (clk) & NFC_FMASK)
+#define NFC_F_TAP(mem, wanted, region, clk, common) NFC_AT((mem), 0u, (wanted) ? (region) + ((clk) & NFC_FMASK) : (common))
+#endif
 
 /* the raw sample of clock `sampleClock`, for the deepest look-back of the path (NFC-V: 472 samples): the wave decoder,
  * which writes a whole tile ahead into a history exactly NFC_HIST_STORED deep, keeps the samples that tile displaced */
@@ -389,9 +413,9 @@ NFC_DEV NfcNow nfc_front_end(const NfcConfig &c, NfcStreamState &s, const NfcLan
    const uint32_t slot = s.clock & NFC_HMASK;
 
    NFC_AT(mem, NFC_R_X, slot) = now.x;
-   NFC_AT(mem, NFC_R_FILT, slot) = now.filt;
-   NFC_AT(mem, NFC_R_MDEV, slot) = now.mdev;
-   NFC_AT(mem, NFC_R_DEPTH, slot) = now.depth;
+   NFC_AT(mem, NFC_R_FILT, s.clock & NFC_FMASK) = now.filt;
+   NFC_AT(mem, NFC_R_MDEV, s.clock & NFC_FMASK) = now.mdev;
+   NFC_AT(mem, NFC_R_DEPTH, s.clock & NFC_FMASK) = now.depth;
 
    return now;
 }
@@ -716,16 +740,17 @@ NFC_DEV NfcDecTaps nfc_load_decode_taps(const NfcLaneMem &mem, const NfcStreamSt
    if (NFC_ANY(raw))
       t.x2 = NFC_AT(mem, 0u, raw ? NFC_X_OLD_INDEX(mem, cur - rt.p2) : common);
    if (NFC_ANY(filt && stored))
-      t.f0 = NFC_AT(mem, 0u, filt && stored ? NFC_R_FILT + (cur & NFC_HMASK) : common);
+      t.f0 = NFC_F_TAP(mem, filt && stored, NFC_R_FILT, cur, common);
    if (NFC_ANY(filt))
    {
-      t.f1 = NFC_AT(mem, 0u, filt ? NFC_R_FILT + ((cur - rt.p1) & NFC_HMASK) : common);
+      /* (one symbol further back: BPSK only, NFC-A / -B, at most 188 samples) */
+      t.f1 = NFC_AT(mem, 0u, filt ? NFC_R_FILT + ((cur - rt.p1) & NFC_FMASK) : common);
       t.pp = NFC_AT(mem, 0u, filt ? NFC_R_PROD + ((cur - window) & NFC_PMASK) : common);
    }
    if (NFC_ANY(stored))
-      t.m0 = NFC_AT(mem, 0u, stored ? NFC_R_MDEV + (cur & NFC_HMASK) : common);
+      t.m0 = NFC_F_TAP(mem, stored, NFC_R_MDEV, cur, common);
    if (NFC_ANY(filt && stored && poll))
-      t.d0 = NFC_AT(mem, 0u, filt && stored && poll ? NFC_R_DEPTH + (cur & NFC_HMASK) : common);
+      t.d0 = NFC_F_TAP(mem, filt && stored && poll, NFC_R_DEPTH, cur, common);
 
    return t;
 }

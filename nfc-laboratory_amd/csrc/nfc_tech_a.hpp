@@ -289,7 +289,7 @@ NFC_DEV void nfca_load_taps_rate(const NfcConfig &c, const NfcStreamState &s, co
    /* read with the others although only needed during a pause: a load inside the detector is waited for with
     * everything else outstanding, the ring stores of the detectors before it included (p8 >= 1: never the slot being
     * written) */
-   taps.deep[R] = NFC_AT(mem, NFC_R_DEPTH, (s.clock - c.a[R].delay - c.a[R].p8) & NFC_HMASK);
+   taps.deep[R] = NFC_AT(mem, NFC_R_DEPTH, (s.clock - c.a[R].delay - c.a[R].p8) & NFC_FMASK);
 }
 
 NFC_DEV void nfca_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsA &taps)

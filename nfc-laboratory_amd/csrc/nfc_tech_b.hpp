@@ -146,8 +146,8 @@ struct NfcTapsB
 
 NFC_DEV void nfcb_load_taps(const NfcConfig &c, const NfcStreamState &s, const NfcLaneMem &mem, NfcTapsB &taps)
 {
-   const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_HMASK;
-   const uint32_t slot1 = (s.clock - c.b[1].delay) & NFC_HMASK;
+   const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_FMASK;
+   const uint32_t slot1 = (s.clock - c.b[1].delay) & NFC_FMASK;
    taps.edge[0] = NFC_AT(mem, NFC_R_FILT, slot0);
    taps.deep[0] = NFC_AT(mem, NFC_R_DEPTH, slot0);
    taps.edge[1] = NFC_AT(mem, NFC_R_FILT, slot1);

@@ -149,7 +149,7 @@ NFC_DEV bool nfcv_detect_decide(const NfcConfig &c, NfcStreamState &s, const Nfc
          }
 
          /* modulation depth one eighth of a symbol back: only needed while a pulse is being tracked */
-         const float deep = NFC_AT(mem, NFC_R_DEPTH, (s.clock - rt.delay - rt.p8) & NFC_HMASK);
+         const float deep = NFC_F_AT(mem, NFC_R_DEPTH, s.clock - rt.delay - rt.p8);
 
          if (deep > m.aux)
             m.aux = deep;

@@ -6,11 +6,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-/* the history is as deep as the stored one; the samples a tile written ahead displaces are kept beside it (nfc_wave.hpp) */
+/* the raw history is as deep as the stored one; the samples a tile written ahead displaces are kept beside it
+ * (nfc_wave.hpp). The histories of the filtered signal, its deviation and the modulation depth are kept 256 deep: what
+ * NFC-V reads further back comes from the front end's planes (nfc_wave_f_deep) */
 #define NFC_X_OLD_INDEX(mem, sampleClock) nfc_wave_x_old_index((mem).ring, (sampleClock))
 #define NFC_RING_STRIDE 1u
 #define NFC_WAVE_LDS __attribute__((address_space(3)))
 #define NFC_RING_FLOAT NFC_WAVE_LDS float
+#define NFC_HIST_F 256u
+struct NfcWaveDeep;
+#define NFC_F_DEEP_CTX const NFC_WAVE_LDS NfcWaveDeep *
+#define NFC_F_DEEP(mem, region, clk) nfc_wave_f_deep((mem), (region), (clk))
+template <class Mem>
+__device__ __forceinline__ float nfc_wave_f_deep(const Mem &mem, uint32_t region, uint32_t clk);
 
 #define NFC_DEV __device__ __forceinline__
 
@@ -32,7 +40,7 @@ __device__ __forceinline__ uint32_t nfc_wave_atomic_add(uint32_t *p, uint32_t v)
  * the tile written ahead has displaced (layout: nfc_wave.hpp, NFC_WAVE_XOLD) */
 __device__ __forceinline__ uint32_t nfc_wave_x_old_index(const NFC_RING_FLOAT *ring, uint32_t clk)
 {
-   const uint32_t displaced = 4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX;
+   const uint32_t displaced = NFC_HIST + 3u * NFC_HIST_F + NFC_PROD + NFC_CORR_MAX;
    const uint32_t clock0 = __builtin_bit_cast(uint32_t, (float)ring[displaced + NFC_LANES]);
    const uint32_t k = clk - (clock0 - (NFC_HIST - 1u)); /* sample clock0 - 511 + j was displaced by tile sample j */
    return k < NFC_LANES ? displaced + k : (clk & (NFC_HIST - 1u));

@@ -51,7 +51,7 @@
 /* behind the regions of nfc_core.hpp: the raw samples the tile at hand displaced in the history (one tile is written ahead
  * into a history NFC_HIST deep; the deepest look-back of the path, NFC-V's 472 samples, reaches them), and the clock of
  * the sample before the tile */
-#define NFC_WAVE_XOLD (4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX)
+#define NFC_WAVE_XOLD (NFC_R_CORR + NFC_CORR_MAX)
 #define NFC_WAVE_XOLD_CLOCK (NFC_WAVE_XOLD + NFC_LANES)
 #define NFC_WAVE_RING_FLOATS (NFC_WAVE_XOLD_CLOCK + 1u)
 
@@ -76,6 +76,7 @@ struct NfcWaveUni
    uint32_t which;    /* search bank: detectors whose gates were up at sample whichAt (bit per detector, nfc_wave_search_gate) */
    uint32_t whichAt;
    uint32_t maskValid; /* search bank: the detectors whose gates over the tile at hand (NfcWaveLds::gate) still stand (bit per detector) */
+   uint32_t retireLo, retireHi; /* may the lane retire at the boundary before tile 64 m + j of its row? bit j (fetched 64 tiles at a time) */
    /* what the two ring taps of a sample (nfc_wave_taps) are formed from on demand: the correlators as they stood when the
     * values of the tile were formed (sample `from`): ring position and running sum of the sample before, whether the ring
     * entry one sample back is that sum; locked stages (slot 0): ring period, distance of the first tap, ring base, first
@@ -87,19 +88,33 @@ struct NfcWaveUni
    float pass[16];    /* hand-over from single lanes to everybody */
 };
 
+/* Where the histories of the filtered signal, its deviation and the modulation depth are found beyond the NFC_HIST_F
+ * samples the rings hold (NFC-V's look-back of up to 402 samples): the front end's planes of the job, the job's samples,
+ * and - before the submission began - the stream's stored history (a carry lane has a copy) */
+struct NfcWaveDeep
+{
+   const float *planes;   /* record of stream position 0 */
+   const uint8_t *data;   /* the job's samples, stream position 0 */
+   const float *stored;   /* [region][NFC_HIST_STORED] rows of `storedPitch` floats: the history up to the submission's first sample */
+   uint64_t storedPitch;
+   uint32_t stride;
+   uint32_t clockBase;    /* clock of the sample before the submission */
+   uint32_t ringEnd;      /* clock of the last sample written to the rings (the tile at hand is written ahead) */
+   uint32_t reserved;
+};
+
 /* LDS of one wave */
 struct NfcWaveLds
 {
    float ring[NFC_WAVE_RING_FLOATS]; /* the regions of nfc_core.hpp (NFC_R_*), one stream */
+   NfcWaveDeep deep;
    NfcStreamCold cold;
    uint8_t bytes[NFC_STREAM_BYTES];
    uint32_t flags;                   /* NfcStreamCold::usedTech while the lane runs */
    NfcWaveUni u;
    float env[NFC_LANES];             /* envelope / average after each sample of the tile at hand */
    float avg[NFC_LANES];
-   float scratch[NFC_LANES];
    uint32_t gate[NFC_LANES];         /* search bank: the detectors' gates per sample of the tile (nfc_wave_search_bits) */
-   uint32_t tileFlags[NFC_LANES];    /* the lane's next 64 tile flag words (one load per 64 tiles instead of one per tile boundary) */
    float sum[6][NFC_LANES];          /* bulk paths: running sum after each sample of the tile, per correlator (the two
                                         differences the detectors look at are formed from it and the ring where they are
                                         used: nfc_wave_s0s1) */
@@ -121,6 +136,50 @@ struct NfcWaveSink
    uint32_t capacity;
    uint32_t streamId;
 };
+
+/* filtered signal / deviation / modulation depth of the sample of clock `clk` from outside the rings */
+template <class Deep>
+NFC_DEV float nfc_wave_deep_fetch(const Deep &dc, uint32_t region, uint32_t clk)
+{
+   const int32_t pos = (int32_t)(clk - dc.clockBase - 1u); /* stream position inside the submission */
+
+   if (pos < 0)
+   {
+      const uint32_t row = region == NFC_R_FILT ? 1u : (region == NFC_R_MDEV ? 2u : 3u);
+      return dc.stored ? dc.stored[(uint64_t)(row * NFC_HIST_STORED + (clk & (NFC_HIST_STORED - 1u))) * dc.storedPitch] : 0.0f;
+   }
+
+   const float *p = dc.planes + 4u * (uint64_t)(uint32_t)pos;
+
+   if (region == NFC_R_FILT)
+      return p[0];
+   if (region == NFC_R_MDEV)
+      return p[2];
+
+   /* modulation depth as the front end forms it (NfcTech.cpp:79-83) */
+   const float x = NFC_SAMPLE_AT(dc.data, dc.stride, (uint32_t)pos);
+   const float env = p[1];
+   const float clamped = (x < 0.0f) ? 0.0f : ((env < x) ? env : x);
+   return (env - clamped) / env;
+}
+
+/* ... of the sample of clock `clk`, wherever it is: in the rings (they hold the NFC_HIST_F samples up to the end of the tile
+ * at hand) or beyond them */
+NFC_DEV float nfc_wave_f_read(const NFC_WAVE_LDS NfcWaveLds *lds, uint32_t region, uint32_t clk)
+{
+   if ((uint32_t)(lds->deep.ringEnd - clk) < NFC_HIST_F)
+      return lds->ring[region + (clk & NFC_FMASK)];
+   return nfc_wave_deep_fetch(lds->deep, region, clk);
+}
+
+/* the step machine's reads (NFC_F_DEEP of nfc_core.hpp) */
+template <class Mem>
+NFC_DEV float nfc_wave_f_deep(const Mem &mem, uint32_t region, uint32_t clk)
+{
+   if ((uint32_t)(mem.deep->ringEnd - clk) < NFC_HIST_F)
+      return mem.ring[region + (clk & NFC_FMASK)];
+   return nfc_wave_deep_fetch(*mem.deep, region, clk);
+}
 
 NFC_DEV bool nfc_wave_exact_span(uint32_t clock, uint32_t count)
 {
@@ -159,6 +218,7 @@ NFC_DEV NfcLaneMem nfc_wave_mem(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveSink 
    mem.streamId = sink.streamId;
    mem.cold = (NfcStreamCold *)&lds->cold;
    mem.tables = cfgPtr;
+   mem.deep = &lds->deep;
    return mem;
 }
 
@@ -174,17 +234,19 @@ NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, co
    uint32_t tracked = (pt.zone & NFC_ZONE_EDGE_KNOWN) ? pt.edgeTime : A.chunkEdge[it.job->firstChunk + (q * NFC_SCAN_POINT) / A.params.chunkSamples];
    float peak = pt.edgePeak;
 
-   for (uint32_t base = q * NFC_SCAN_POINT; base <= last; base += NFC_LANES)
+   /* (16 samples at a time through NfcWaveUni::pass: a rare walk - carrier frames, published and final states) */
+   for (uint32_t base = q * NFC_SCAN_POINT; base <= last; base += 16u)
    {
-      const uint32_t n = last - base + 1u < NFC_LANES ? last - base + 1u : NFC_LANES;
+      const uint32_t n = last - base + 1u < 16u ? last - base + 1u : 16u;
 
       NFC_WAVE_BARRIER();
-      lds->scratch[lane] = lane < n ? nfc_abs(it.planes[4u * (uint64_t)(base + lane)]) : 0.0f;
+      if (lane < 16u)
+         lds->u.pass[lane] = lane < n ? nfc_abs(it.planes[4u * (uint64_t)(base + lane)]) : 0.0f;
       NFC_WAVE_BARRIER();
 
       for (uint32_t k = 0; k < n; k++)
       {
-         const float rectified = lds->scratch[k];
+         const float rectified = lds->u.pass[k];
          const uint32_t clock = it.clockBase + 1u + base + k;
          const bool high = rectified > c.highThreshold;
          const bool top = high && rectified > peak;
@@ -194,6 +256,8 @@ NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, co
          peak = top ? rectified : (low ? 0.0f : peak);
       }
    }
+
+   NFC_WAVE_BARRIER(); /* (pass[] is free again) */
 
    const bool emitValid = lds->cold.emitValid != 0;
    const uint32_t emitClock = lds->cold.emitClock;
@@ -212,17 +276,24 @@ NFC_DEV void nfc_wave_rings_in(NFC_WAVE_LDS NfcWaveLds *lds, const float *src, u
 
    NFC_WAVE_BARRIER();
 
-   for (uint32_t r = 0; r < 4u; r++)
+   for (uint32_t k = lane; k < NFC_HIST_STORED; k += NFC_LANES)
    {
-      for (uint32_t k = lane; k < NFC_HIST_STORED; k += NFC_LANES)
+      const uint32_t t = clock - k; /* sample clock */
+      lds->ring[NFC_R_X + (t & NFC_HMASK)] = src[(uint64_t)(t & (NFC_HIST_STORED - 1u)) * pitch];
+   }
+
+   /* (the shorter histories: the last NFC_HIST_F samples; what lies further back stays where it is, NfcWaveDeep::stored) */
+   for (uint32_t r = 1; r < 4u; r++)
+   {
+      for (uint32_t k = lane; k < NFC_HIST_F; k += NFC_LANES)
       {
-         const uint32_t t = clock - k; /* sample clock */
-         lds->ring[r * NFC_HIST + (t & (NFC_HIST - 1u))] = src[(uint64_t)(r * NFC_HIST_STORED + (t & (NFC_HIST_STORED - 1u))) * pitch];
+         const uint32_t t = clock - k;
+         lds->ring[NFC_R_FILT + (r - 1u) * NFC_HIST_F + (t & NFC_FMASK)] = src[(uint64_t)(r * NFC_HIST_STORED + (t & (NFC_HIST_STORED - 1u))) * pitch];
       }
    }
 
    for (uint32_t k = lane; k < NFC_PROD + corrTotal; k += NFC_LANES)
-      lds->ring[4u * NFC_HIST + k] = src[(uint64_t)(4u * NFC_HIST_STORED + k) * pitch];
+      lds->ring[NFC_R_PROD + k] = src[(uint64_t)(4u * NFC_HIST_STORED + k) * pitch];
 
    NFC_WAVE_BARRIER();
 }
@@ -233,17 +304,30 @@ NFC_DEV void nfc_wave_rings_out(const NFC_WAVE_LDS NfcWaveLds *lds, float *dst, 
 
    NFC_WAVE_BARRIER();
 
-   for (uint32_t r = 0; r < 4u; r++)
+   for (uint32_t k = lane; k < NFC_HIST_STORED; k += NFC_LANES)
    {
+      const uint32_t t = clock - k;
+      dst[(uint64_t)(t & (NFC_HIST_STORED - 1u)) * pitch] = lds->ring[NFC_R_X + (t & NFC_HMASK)];
+   }
+
+   /* the stored histories are NFC_HIST_STORED deep: what the rings no longer hold is fetched where it is kept (a sample
+    * from before the submission is in the stored history already, at the very place: nfc_wave_deep_fetch) */
+   for (uint32_t r = 1; r < 4u; r++)
+   {
+      const uint32_t region = NFC_R_FILT + (r - 1u) * NFC_HIST_F;
+
       for (uint32_t k = lane; k < NFC_HIST_STORED; k += NFC_LANES)
       {
          const uint32_t t = clock - k;
-         dst[(uint64_t)(r * NFC_HIST_STORED + (t & (NFC_HIST_STORED - 1u))) * pitch] = lds->ring[r * NFC_HIST + (t & (NFC_HIST - 1u))];
+         const bool before = (int32_t)(t - lds->deep.clockBase - 1u) < 0;
+
+         if (!before || lds->deep.stored != dst)
+            dst[(uint64_t)(r * NFC_HIST_STORED + (t & (NFC_HIST_STORED - 1u))) * pitch] = nfc_wave_f_read(lds, region, t);
       }
    }
 
    for (uint32_t k = lane; k < NFC_PROD + corrTotal; k += NFC_LANES)
-      dst[(uint64_t)(4u * NFC_HIST_STORED + k) * pitch] = lds->ring[4u * NFC_HIST + k];
+      dst[(uint64_t)(4u * NFC_HIST_STORED + k) * pitch] = lds->ring[NFC_R_PROD + k];
 }
 
 /* The tile at hand: this lane's sample and the front end's results for it, parked where the step reads them. Returns
@@ -292,12 +376,13 @@ NFC_DEV bool nfc_wave_load_tile(const NfcWaveFetch &f, NFC_WAVE_LDS NfcWaveLds *
       const float clamped = (x < 0.0f) ? 0.0f : ((env < x) ? env : x);
 
       const uint32_t slot = (clock + 1u + lane) & NFC_HMASK;
+      const uint32_t slotF = (clock + 1u + lane) & NFC_FMASK;
 
       lds->ring[NFC_WAVE_XOLD + lane] = lds->ring[NFC_R_X + slot]; /* the sample NFC_HIST back */
       lds->ring[NFC_R_X + slot] = x;
-      lds->ring[NFC_R_FILT + slot] = f.filt;
-      lds->ring[NFC_R_MDEV + slot] = f.mdev;
-      lds->ring[NFC_R_DEPTH + slot] = (env - clamped) / env;
+      lds->ring[NFC_R_FILT + slotF] = f.filt;
+      lds->ring[NFC_R_MDEV + slotF] = f.mdev;
+      lds->ring[NFC_R_DEPTH + slotF] = (env - clamped) / env;
       lds->env[lane] = env;
       lds->avg[lane] = f.avg;
 
@@ -308,7 +393,10 @@ NFC_DEV bool nfc_wave_load_tile(const NfcWaveFetch &f, NFC_WAVE_LDS NfcWaveLds *
       lds->ring[NFC_WAVE_XOLD + lane] = lds->ring[NFC_R_X + ((clock + 1u + lane) & NFC_HMASK)]; /* (not displaced: the same value either way) */
 
    if (lane == 0)
+   {
       lds->ring[NFC_WAVE_XOLD_CLOCK] = __builtin_bit_cast(float, clock);
+      lds->deep.ringEnd = clock + n;
+   }
 
    return onGrid;
 }
@@ -393,12 +481,13 @@ NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWa
       NfcStreamState s = *(NfcStreamState *)&lds->u.s;
       const uint32_t at = lds->u.at;
       const uint32_t slot = (s.clock + 1u) & NFC_HMASK;
+      const uint32_t slotF = (s.clock + 1u) & NFC_FMASK;
 
       NfcGiven g;
       g.now.x = lds->ring[NFC_R_X + slot];
-      g.now.filt = lds->ring[NFC_R_FILT + slot];
-      g.now.mdev = lds->ring[NFC_R_MDEV + slot];
-      g.now.depth = lds->ring[NFC_R_DEPTH + slot];
+      g.now.filt = lds->ring[NFC_R_FILT + slotF];
+      g.now.mdev = lds->ring[NFC_R_MDEV + slotF];
+      g.now.depth = lds->ring[NFC_R_DEPTH + slotF];
       g.env = lds->env[at];
       g.avg = lds->avg[at];
 
@@ -452,7 +541,7 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
       s.posV1 = nfc_wave_wrap1(s.posV1 + 1u, c.v.p1);
       s.posV0 = nfc_wave_wrap1(s.posV0 + 1u, c.v.p0);
 
-      const uint32_t slot = s.clock & NFC_HMASK;
+      const uint32_t slot = s.clock & NFC_FMASK; /* (of the filtered / deviation / depth histories) */
 
       s.env = lds->env[at];
       s.avg = lds->avg[at];
@@ -485,7 +574,7 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
                r.detA[R].acc = lds->sum[R][at];                                                                                                  \
                lds->ring[NFC_R_CORR + c.corrOffset[R] + s.posA[R]] = r.detA[R].acc;                                                              \
                if (((ask >> R) & 1u) && nfca_detect_decide<R>(c, s, mem, nfc_wave_search_num(c, lds, R, at),                                     \
-                                         lds->ring[NFC_R_DEPTH + ((s.clock - c.a[R].delay - c.a[R].p8) & NFC_HMASK)], limit, c.minDepth[0]))     \
+                                         lds->ring[NFC_R_DEPTH + ((s.clock - c.a[R].delay - c.a[R].p8) & NFC_FMASK)], limit, c.minDepth[0]))     \
                   locked = NFC_TECH_A;                                                                                                           \
             }
             NFC_WAVE_A_RATE(0)
@@ -496,7 +585,7 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
 
          if (!locked && (c.enabled & 2u))
          {
-            const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_HMASK, slot1 = (s.clock - c.b[1].delay) & NFC_HMASK;
+            const uint32_t slot0 = (s.clock - c.b[0].delay) & NFC_FMASK, slot1 = (s.clock - c.b[1].delay) & NFC_FMASK;
             const int r0 = ((ask >> 3) & 1u) ? nfcb_detect_decide<0>(c, s, mem, lds->ring[NFC_R_FILT + slot0], lds->ring[NFC_R_DEPTH + slot0]) : 0;
 
             if (r0 == 1)
@@ -629,7 +718,7 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
          nfc_wave_advance(cc, lds->u.s, n);
          lds->u.s.env = lds->env[n - 1u];
          lds->u.s.avg = lds->avg[n - 1u];
-         lds->u.s.mdev = lds->ring[NFC_R_MDEV + ((clock + n) & NFC_HMASK)];
+         lds->u.s.mdev = lds->ring[NFC_R_MDEV + ((clock + n) & NFC_FMASK)];
       }
       NFC_WAVE_UNIFORM_END
       return;
@@ -795,6 +884,15 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
    if (lane == 0)
    {
+      lds->deep.planes = it.planes;
+      lds->deep.data = it.job->data;
+      lds->deep.stored = carry ? laneRings : nullptr; /* (only a lane that begins with the submission looks back beyond it) */
+      lds->deep.storedPitch = pitch;
+      lds->deep.stride = stride;
+      lds->deep.clockBase = it.clockBase;
+      lds->deep.ringEnd = startClock;
+      lds->deep.reserved = 0;
+
       lds->cfg[0] = cc.enabled;
       lds->cfg[1] = nfc_bits(cc.powerThreshold);
       lds->cfg[2] = nfc_bits(cc.lowThreshold);
@@ -861,14 +959,22 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
          {
             const uint32_t first = tile / NFC_LANES * NFC_LANES;
             const uint32_t tilesOfRow = (it.count + NFC_SCAN_TILE - 1u) / NFC_SCAN_TILE;
+            const uint32_t word = (jobWindows != 0u && first + lane < tilesOfRow) ? it.tiles[first + lane] : 0u;
+            const uint64_t retire = NFC_WAVE_BALLOT((word & NFC_TILE_RETIRE_OK) != 0u);
+
             NFC_WAVE_BARRIER();
-            lds->tileFlags[lane] = (jobWindows != 0u && first + lane < tilesOfRow) ? it.tiles[first + lane] : 0u;
-            NFC_WAVE_BARRIER();
+            NFC_WAVE_UNIFORM_BEGIN
+            {
+               lds->u.retireLo = (uint32_t)retire;
+               lds->u.retireHi = (uint32_t)(retire >> 32);
+            }
+            NFC_WAVE_UNIFORM_END
          }
       }
 
       /* (a stream without windows - NfcScanParams::soloSamples - has nobody to take over from a lane that retires) */
-      const bool mayRetire = past && jobWindows != 0u && (lds->tileFlags[(consumed / NFC_SCAN_TILE) % NFC_LANES] & NFC_TILE_RETIRE_OK) != 0u;
+      const uint32_t tileBit = (consumed / NFC_SCAN_TILE) % NFC_LANES;
+      const bool mayRetire = past && jobWindows != 0u && (((tileBit < 32u ? lds->u.retireLo : lds->u.retireHi) >> (tileBit & 31u)) & 1u) != 0u;
       const bool publishes = pos == verifyPos;
       uint32_t edgeNow = 0;
 
@@ -1019,6 +1125,14 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       if (mode == NFC_WAVE_WINDOWS)
          me->saved = saved;
 
+#ifdef NFC_WAVE_WHY
+      /* debug build: lanes that stepped most of their samples */
+      if (lds->u.stepped > 20000u)
+         printf("[wave why] slot %u mode %u start %u count %u consumed %u stepped %u lockTech %x stage %u gridSince %u clock %u startClock %u accA %g %g %g accF %g %g accV %g lockacc %g\n", it.w, mode,
+                it.startPos, it.count, consumed, lds->u.stepped, lds->u.s.lockTech, nfc_wave_stage(*(const NfcStreamState *)&lds->u.s, false), lds->u.gridSince, lds->u.s.clock, startClock,
+                (double)lds->u.s.u.search.detA[0].acc, (double)lds->u.s.u.search.detA[1].acc, (double)lds->u.s.u.search.detA[2].acc, (double)lds->u.s.u.search.detF[0].acc,
+                (double)lds->u.s.u.search.detF[1].acc, (double)lds->u.s.u.search.detV.acc, (double)lds->u.s.u.decode.lock.acc);
+#endif
       const uint32_t tilesStepped = (lds->u.stepped + NFC_LANES - 1u) / NFC_LANES;
       NFC_WAVE_STAT_ADD(L.laneStats, tilesStepped);
       NFC_WAVE_STAT_MAX(L.laneStats + 1, tilesStepped);

@@ -238,7 +238,7 @@ NFC_DEV bool nfc_wave_gate_a(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    if (nfc_may_exceed(num, (float)rt.p2, limit))
    {
       const float sd = num / (float)rt.p2;
-      const float deep = lds->ring[NFC_R_DEPTH + ((t - rt.delay - rt.p8) & NFC_HMASK)];
+      const float deep = lds->ring[NFC_R_DEPTH + ((t - rt.delay - rt.p8) & NFC_FMASK)];
       moves = !m.symStart ? (sd < -limit && (sd < m.peak || deep > m.aux)) : (sd > limit && sd > m.peak);
    }
 
@@ -249,7 +249,7 @@ NFC_DEV bool nfc_wave_gate_a(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
 template <int I>
 NFC_DEV bool nfc_wave_gate_b(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, const NfcDetB &m, uint32_t t, float env)
 {
-   const uint32_t slot = (t - c.b[I].delay) & NFC_HMASK;
+   const uint32_t slot = (t - c.b[I].delay) & NFC_FMASK;
    const float edge = lds->ring[NFC_R_FILT + slot], deep = lds->ring[NFC_R_DEPTH + slot];
    const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.auxTime | nfc_bits(m.aux)) == 0u;
    const bool reset = (deep > c.maxDepth[1] || (m.auxTime && t > m.auxTime + c.b[I].p1)) && !clear;
@@ -275,7 +275,7 @@ NFC_DEV bool nfc_wave_gate_f(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    const NfcDetF &m = NFC_WAVE_STATE(lds).u.search.detF[I];
    const NfcRate &rt = c.f[I + 1];
    const float limit = env * c.corrThreshold[2];
-   const float deep = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)];
+   const float deep = lds->ring[NFC_R_DEPTH + (t & NFC_FMASK)];
    /* nfcf_detect_rate / nfcf_track_preamble: a correlation above the threshold only changes the record when it is the
     * largest of the pulse so far */
    const float num = nfc_wave_search_num(c, lds, 3 + I, lane);
@@ -310,7 +310,7 @@ NFC_DEV bool nfc_wave_gate_v(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    if (nfc_may_exceed(num, (float)c.v.p2, limit))
    {
       const float q = num / (float)c.v.p2;
-      const float deep = lds->ring[NFC_R_DEPTH + ((t - c.v.delay - c.v.p8) & NFC_HMASK)];
+      const float deep = nfc_wave_f_read(lds, NFC_R_DEPTH, t - c.v.delay - c.v.p8); /* (402 samples back: beyond the rings) */
       moves = q > limit && (q > m.peak || deep > m.aux);
    }
 
@@ -450,7 +450,7 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *l
    const NfcDecodeRegs &d = NFC_WAVE_STATE(lds).u.decode;
    const NfcMod &m = d.lock;
    const NfcRate &rt = d.rt;
-   const float depth = lds->ring[NFC_R_DEPTH + (t & NFC_HMASK)]; /* of this lane's own sample */
+   const float depth = lds->ring[NFC_R_DEPTH + (t & NFC_FMASK)]; /* of this lane's own sample */
    const float sum = lds->sum[0][lane];
    float s0 = 0.0f, s1 = 0.0f;
 
@@ -498,7 +498,7 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *l
 
       case NFC_FK_B_POLL:
       {
-         const float edge = nfc_abs(lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_HMASK)]);
+         const float edge = nfc_abs(lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_FMASK)]);
          return (t > m.winStart && t < m.winEnd && edge > m.thr && m.aux < edge) || t == m.sync;
       }
 
@@ -520,6 +520,9 @@ NFC_DEV bool nfc_wave_locked_gate(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *l
       case NFC_FK_F_START:
       {
          const float sd = nfc_abs(s0 - s1) / (float)rt.p2;
+#ifdef NFC_WAVE_DEBUG_FSTART
+         NFC_WAVE_DEBUG_FSTART(t, d, m, sd);
+#endif
          if (t < d.guardEnd)
             return false;
          if (t == d.guardEnd || t > d.waitingEnd)
@@ -618,7 +621,7 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
          tapPos = v15693 ? posV0 : lockPos;
          tapShift = tapPeriod - window; /* NFC-V: the entry one symbol half back in the two-symbol ring */
 
-         const float v = lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_HMASK)];
+         const float v = nfc_wave_f_read(lds, NFC_R_FILT, t - rt.delay); /* (NFC-V: 378 samples back, beyond the rings) */
          const float sq = v * v * 10.0f;
          const float old = nfc_wave_product(lds, clock0, from, sq, rt.delay, window);
 
@@ -631,8 +634,8 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
       case NFC_FK_B_START:
       case NFC_FK_B_SYMBOL:
       {
-         const float a = lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_HMASK)];
-         const float b = lds->ring[NFC_R_FILT + ((t - rt.delay - rt.p1) & NFC_HMASK)];
+         const float a = lds->ring[NFC_R_FILT + ((t - rt.delay) & NFC_FMASK)];
+         const float b = lds->ring[NFC_R_FILT + ((t - rt.delay - rt.p1) & NFC_FMASK)];
          const float in = a * b * 10.0f;
          const float out = nfc_wave_product(lds, clock0, from, in, rt.delay, rt.p4);
          /* NFC-A integrates from the end of the guard time on (nfca_listen_bpsk_start returns before it until then) */
@@ -877,7 +880,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
             if (on0)
             {
-               const uint32_t slot = (clk - c.b[0].delay) & NFC_HMASK;
+               const uint32_t slot = (clk - c.b[0].delay) & NFC_FMASK;
                NfcDetB m = *(NfcDetB *)&lds->u.s.u.search.detB[0];
                (void)nfcb_track<0>(c, m, clk, envAt, lds->ring[NFC_R_FILT + slot], lds->ring[NFC_R_DEPTH + slot]);
                *(NfcDetB *)&lds->u.s.u.search.detB[0] = m;
@@ -885,7 +888,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
             if (on1)
             {
-               const uint32_t slot = (clk - c.b[1].delay) & NFC_HMASK;
+               const uint32_t slot = (clk - c.b[1].delay) & NFC_FMASK;
                NfcDetB m = *(NfcDetB *)&lds->u.s.u.search.detB[1];
                (void)nfcb_track<1>(c, m, clk, envAt, lds->ring[NFC_R_FILT + slot], lds->ring[NFC_R_DEPTH + slot]);
                *(NfcDetB *)&lds->u.s.u.search.detB[1] = m;
@@ -1107,7 +1110,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
       w.clock += run;
       w.env = lds->env[last];
       w.avg = lds->avg[last];
-      w.mdev = lds->ring[NFC_R_MDEV + (w.clock & NFC_HMASK)];
+      w.mdev = lds->ring[NFC_R_MDEV + (w.clock & NFC_FMASK)];
 
       lds->u.at = from + run;
    }

@@ -16,6 +16,12 @@
 #define NFC_RING_STRIDE 1u
 #define NFC_WAVE_LDS
 #define NFC_RING_FLOAT float
+#define NFC_HIST_F 256u
+struct NfcWaveDeep;
+#define NFC_F_DEEP_CTX const NfcWaveDeep *
+#define NFC_F_DEEP(mem, region, clk) nfc_wave_f_deep((mem), (region), (clk))
+template <class Mem>
+static inline float nfc_wave_f_deep(const Mem &mem, uint32_t region, uint32_t clk);
 
 #define NFC_DEV static inline
 static inline uint32_t emu_add(uint32_t *p, uint32_t v) { uint32_t old = *p; *p += v; return old; }
@@ -27,7 +33,7 @@ static inline uint32_t emu_add(uint32_t *p, uint32_t v) { uint32_t old = *p; *p 
  * the tile written ahead has displaced (layout: nfc_wave.hpp, NFC_WAVE_XOLD) */
 static inline uint32_t nfc_wave_x_old_index(const NFC_RING_FLOAT *ring, uint32_t clk)
 {
-   const uint32_t displaced = 4u * NFC_HIST + NFC_PROD + NFC_CORR_MAX;
+   const uint32_t displaced = NFC_HIST + 3u * NFC_HIST_F + NFC_PROD + NFC_CORR_MAX;
    const uint32_t clock0 = __builtin_bit_cast(uint32_t, (float)ring[displaced + NFC_LANES]);
    const uint32_t k = clk - (clock0 - (NFC_HIST - 1u)); /* sample clock0 - 511 + j was displaced by tile sample j */
    return k < NFC_LANES ? displaced + k : (clk & (NFC_HIST - 1u));
@@ -117,6 +123,10 @@ static bool emu_watch_armed;
       std::fprintf(stderr, "[watch] ring[%d] changed to %g (was %g) after phase %u (1 bulk call, 2 search step, 3 step, 4 load, 5 end), fibre %u at %u clock %u key %u\n", emu_watch_index, \
                    (lds)->ring[emu_watch_index], emu_watch_value, (unsigned)(tag), wavesim::lane(), (lds)->u.at, (lds)->u.s.clock, (lds)->u.key); emu_watch_value = (lds)->ring[emu_watch_index]; } } while (0)
 #include <cstring>
+#define NFC_WAVE_DEBUG_FSTART(t, d, m, sd) do { static const bool on = std::getenv("NFC_EMU_DEBUG_FSTART") != nullptr; static unsigned long shown = 0; \
+   const bool hit = (t) >= (d).guardEnd && ((t) == (d).guardEnd || (t) > (d).waitingEnd || ((t) >= (m).winStart && (((sd) >= (m).thr && (sd) > (m).peak) || (t) == (m).sync || (t) == (m).winEnd))); \
+   if (on && hit && wavesim::lane() == lds->u.at && (shown++ % 997) < 3 && shown < 200000) std::fprintf(stderr, "[fstart] t %u guardEnd %u waitingEnd %u winStart %u winEnd %u sync %u sd %g thr %g peak %g stage %u pulses %u symStart %u symEnd %u\n", \
+   (t), (d).guardEnd, (d).waitingEnd, (m).winStart, (m).winEnd, (m).sync, (double)(sd), (double)(m).thr, (double)(m).peak, (m).stage, (m).pulses, (m).symStart, (m).symEnd); } while (0)
 #include "../../nfc-laboratory_amd/csrc/nfc_wave.hpp"
 
 static int emu_verify_mode()
@@ -242,7 +252,7 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
       const NfcStreamState &a = fastLds.u.s, &b = lds->u.s;
 
       const bool same = std::memcmp(&a, &b, sizeof(a)) == 0 && fastLds.u.at == lds->u.at && std::memcmp(&ca, &cb, sizeof(ca)) == 0 &&
-                        std::memcmp(fastLds.ring, lds->ring, sizeof(float) * 4u * NFC_HIST) == 0 &&
+                        std::memcmp(fastLds.ring, lds->ring, sizeof(float) * NFC_R_PROD) == 0 &&
                         std::memcmp(fastLds.ring + NFC_R_CORR, lds->ring + NFC_R_CORR, sizeof(float) * NFC_CORR_MAX) == 0 &&
                         std::memcmp(fastLds.bytes, lds->bytes, NFC_STREAM_BYTES) == 0 && fastLds.flags == lds->flags;
 
@@ -263,7 +273,7 @@ static void emu_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const 
                std::fprintf(stderr, "   corr ring %u: bulk %g stepped %g\n", i, fastLds.ring[NFC_R_CORR + i], lds->ring[NFC_R_CORR + i]);
          std::fprintf(stderr, "   at: bulk %u stepped %u; n %u; env[0] %g %g env[n-1] %g %g; fetched.env (fibre 0) %g; stepped count %u %u\n", fastLds.u.at, lds->u.at, n, fastLds.env[0], lds->env[0],
                       fastLds.env[n - 1], lds->env[n - 1], fetched.env, fastLds.u.stepped, lds->u.stepped);
-         for (uint32_t i = 0; i < 4u * NFC_HIST; i++)
+         for (uint32_t i = 0; i < NFC_R_PROD; i++)
             if (std::memcmp(&fastLds.ring[i], &lds->ring[i], 4) != 0)
                std::fprintf(stderr, "   history ring %u (region %u slot %u): bulk %g stepped %g\n", i, i / NFC_HIST, i % NFC_HIST, fastLds.ring[i], lds->ring[i]);
          for (uint32_t i = 0; i < NFC_STREAM_BYTES; i++)
