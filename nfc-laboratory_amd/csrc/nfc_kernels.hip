@@ -878,8 +878,11 @@ __global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restr
 
    A.tiles[i] = flags;
 
+   /* Off the capture grid a running sum depends on everything that was ever added to it: no lane that starts inside the
+    * stream can be in the decoder's state. The carry lane is (it continues the stream's own sums), so it decodes such a
+    * stream alone; the lane-per-window kernels have no way of walking the sums and leave it to the sequential ones. */
    if (flags & NFC_TILE_OFFGRID)
-      atomicOr(&A.jobs[lo].status, NFC_JOB_OFFGRID);
+      atomicOr(&A.jobs[lo].status, A.params.offGridAlone ? (NFC_JOB_ALONE | NFC_JOB_OFFGRID_SEEN) : NFC_JOB_OFFGRID);
 
    if ((flags & NFC_TILE_BUSY) && !(flags & NFC_TILE_DARK))
       atomicAdd(&A.jobs[lo].busyTiles, 1u);

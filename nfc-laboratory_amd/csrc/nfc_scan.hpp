@@ -30,6 +30,8 @@ struct NfcScanParams
    uint32_t soloSamples;   /* streams of at most this many samples get no speculative windows: their carry lane decodes them alone, in one pass */
    uint32_t aloneStreams;  /* ... and so do the busy streams of a submission of at least this many streams (0: never): there are lanes enough */
    uint32_t alonePercent;  /* busy: more than this share of the tiles has something for the decoder to do */
+   uint32_t offGridAlone;  /* a stream with samples off the capture grid is decoded by its carry lane alone (the wave decoder walks the
+                              running sums in the step's order there: nfc_wave_fast.hpp); 0: it takes the sequential kernels */
 };
 
 /* bit-for-bit equality of two records (word by word through memcpy: no library call on the device, and no loads through

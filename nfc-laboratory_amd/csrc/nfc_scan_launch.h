@@ -19,6 +19,8 @@ struct NfcScanParams
    uint32_t soloSamples;
    uint32_t aloneStreams;
    uint32_t alonePercent;
+   uint32_t offGridAlone; /* a stream with samples off the capture grid is decoded by its carry lane alone (the wave decoder walks
+                             the running sums in the step's order there: nfc_wave_fast.hpp); 0: it takes the sequential kernels */
 };
 #endif
 

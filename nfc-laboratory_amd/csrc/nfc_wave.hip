@@ -143,6 +143,7 @@ __device__ __forceinline__ float nfc_wave_max(float v)
 #define NFC_WAVE_MAX_F(v) nfc_wave_max(v)
 #define NFC_WAVE_PICK_F(reg, array, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)(reg)), (int)(j)))
 #define NFC_WAVE_PICK_U32(reg, array, j) ((uint32_t)__builtin_amdgcn_readlane((int)(reg), (int)(j)))
+#define NFC_WAVE_SHFL_F(reg, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)(reg)), (int)(j)))
 #define NFC_WAVE_CONFIG(cfgPtr, lds, cc) nfc_wave_config_parked((lds)->cfg, (cc))
 /* experiments: -DNFC_WAVE_STEP_INLINE (the steps inlined into the tile loop), -DNFC_WAVE_WAVES=n (register budget for n waves per SIMD) */
 #ifdef NFC_WAVE_STEP_INLINE

@@ -63,7 +63,8 @@ struct NfcWaveUni
    uint32_t stepped;  /* samples stepped one by one (statistics) */
    uint32_t stopped;  /* 1 retired at rest, 2 handed over */
    uint32_t succ;
-   uint32_t takeKey;  /* stage for which the tile's running sums have been found inside the exact range (nfc_wave_fast); NFC_FK_NONE: not yet */
+   uint32_t takeKey;  /* stage for which the tile's running sums have been looked at (nfc_wave_fast): inside the exact range or not; NFC_FK_NONE: not yet */
+   uint32_t walked;   /* ... and what was found: 1 = the raw sums of that stage are walked in the step's order (off the grid, or out of the exact range) */
    uint32_t succVerify; /* sample at which the successor at hand publishes (nothing to ask it before): 0 = not looked up yet */
    uint32_t at;       /* sample of the tile at hand */
    /* bulk paths (nfc_wave_fast.hpp) */
@@ -704,6 +705,7 @@ NFC_DEV void nfc_wave_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const N
       lds->u.whichAt = 0xFFFFFFFFu;
       lds->u.maskValid = 0u;
       lds->u.takeKey = NFC_FK_NONE;
+      lds->u.walked = 0u;
       if (!allOnGrid)
          lds->u.gridSince = clock + n;
    }

@@ -12,7 +12,8 @@
  *   raw    box sums of the raw signal (search bank; NFC-A / NFC-V poll frames, all of NFC-F): on the capture grid
  *          (multiples of 2^-15, |x| <= 1, |sum| <= 128 + window) every partial sum is exact in fp32, so the running sum
  *          after each sample of the tile is the sum before the tile plus a wave prefix sum of (entering - leaving), bit
- *          for bit what the step's add-then-subtract leaves; off the grid the path is not taken.
+ *          for bit what the step's add-then-subtract leaves; off the grid (real radio input: float IQ) the
+ *          sums are walked like the integrators below (nfc_wave_raw_walked).
  *   power  10 * filtered^2 over a window (NFC-A 106k and NFC-V listen frames), phase: 10 * filtered * filtered one symbol
  *          back (BPSK listen frames): not on a grid, so the running sum is walked sample by sample in the step's own order
  *          (one dependent add and subtract per sample, every lane the same walk), everything around it is per lane.
@@ -394,8 +395,36 @@ NFC_DEV float nfc_wave_raw_sum(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, ui
    return acc + NFC_WAVE_SCAN_ADD_F(lane >= from ? in - out : 0.0f);
 }
 
+/* The same off the capture grid (or with a sum beyond the range in which grid values add exactly): the running sum walked
+ * in the step's own order - sum += entering; sum -= leaving (nfc_corr_apply) -, every lane the same walk, a lane keeping
+ * the sum after its own sample. n: samples of the tile. */
+NFC_DEV float nfc_wave_raw_walked(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, uint32_t n, float acc, uint32_t delay, uint32_t w)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+   const uint32_t t = nfc_wave_clock_of(clock0);
+
+   const float in = lds->ring[NFC_R_X + ((t - delay) & NFC_HMASK)];
+   const float out = lds->ring[nfc_wave_x_old_index(lds->ring, t - delay - w)];
+
+   float mine = acc;
+
+   for (uint32_t j = from; j < n; j++)
+   {
+      acc += NFC_WAVE_SHFL_F(in, j);
+      acc -= NFC_WAVE_SHFL_F(out, j);
+      mine = lane == j ? acc : mine;
+   }
+
+   return mine;
+}
+
+NFC_DEV float nfc_wave_raw_any(NFC_WAVE_LDS NfcWaveLds *lds, bool walked, uint32_t clock0, uint32_t from, uint32_t n, float acc, uint32_t delay, uint32_t w)
+{
+   return walked ? nfc_wave_raw_walked(lds, clock0, from, n, acc, delay, w) : nfc_wave_raw_sum(lds, clock0, from, acc, delay, w);
+}
+
 /* values of the search bank for the tile's samples from `from` on: the six sums, then (one barrier) their taps */
-NFC_DEV void nfc_wave_search_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from)
+NFC_DEV void nfc_wave_search_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, uint32_t n, bool walked)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const NfcStreamState &s = NFC_WAVE_STATE(lds);
@@ -404,12 +433,12 @@ NFC_DEV void nfc_wave_search_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
    const uint32_t posA0 = s.posA[0], posA1 = s.posA[1], posA2 = s.posA[2], posF0 = s.posF[0], posF1 = s.posF[1], posV1 = s.posV1;
    const float accA0 = r.detA[0].acc, accA1 = r.detA[1].acc, accA2 = r.detA[2].acc, accF0 = r.detF[0].acc, accF1 = r.detF[1].acc, accV = r.detV.acc;
 
-   const float sumA0 = nfc_wave_raw_sum(lds, clock0, from, accA0, c.a[0].delay, c.a[0].p2);
-   const float sumA1 = nfc_wave_raw_sum(lds, clock0, from, accA1, c.a[1].delay, c.a[1].p2);
-   const float sumA2 = nfc_wave_raw_sum(lds, clock0, from, accA2, c.a[2].delay, c.a[2].p2);
-   const float sumF0 = nfc_wave_raw_sum(lds, clock0, from, accF0, c.f[1].delay, c.f[1].p2);
-   const float sumF1 = nfc_wave_raw_sum(lds, clock0, from, accF1, c.f[2].delay, c.f[2].p2);
-   const float sumV = nfc_wave_raw_sum(lds, clock0, from, accV, c.v.delay, c.v.p2);
+   const float sumA0 = nfc_wave_raw_any(lds, walked, clock0, from, n, accA0, c.a[0].delay, c.a[0].p2);
+   const float sumA1 = nfc_wave_raw_any(lds, walked, clock0, from, n, accA1, c.a[1].delay, c.a[1].p2);
+   const float sumA2 = nfc_wave_raw_any(lds, walked, clock0, from, n, accA2, c.a[2].delay, c.a[2].p2);
+   const float sumF0 = nfc_wave_raw_any(lds, walked, clock0, from, n, accF0, c.f[1].delay, c.f[1].p2);
+   const float sumF1 = nfc_wave_raw_any(lds, walked, clock0, from, n, accF1, c.f[2].delay, c.f[2].p2);
+   const float sumV = nfc_wave_raw_any(lds, walked, clock0, from, n, accV, c.v.delay, c.v.p2);
 
    NFC_WAVE_BARRIER();
    lds->sum[0][lane] = sumA0;
@@ -564,7 +593,7 @@ NFC_DEV float nfc_wave_product(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, ui
    return lds->ring[NFC_R_PROD + ((cur - window) & NFC_PMASK)];
 }
 
-NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, uint32_t n, uint32_t key)
+NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t from, uint32_t n, uint32_t key, bool walked)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const uint32_t t = nfc_wave_clock_of(clock0);
@@ -589,7 +618,7 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
           * guard ends (nfcf_listen_start) */
          tapWriteFrom = key == NFC_FK_F_START ? guardEnd - rt.p1 : never;
 
-         const float sum = nfc_wave_raw_sum(lds, clock0, from, acc, rt.delay, rt.p2);
+         const float sum = nfc_wave_raw_any(lds, walked, clock0, from, n, acc, rt.delay, rt.p2);
 
          NFC_WAVE_BARRIER();
          lds->sum[0][lane] = sum;
@@ -601,7 +630,7 @@ NFC_DEV void nfc_wave_locked_values(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds 
       {
          tapPos = posV1;
 
-         const float sum = nfc_wave_raw_sum(lds, clock0, from, acc, rt.delay, rt.p2);
+         const float sum = nfc_wave_raw_any(lds, walked, clock0, from, n, acc, rt.delay, rt.p2);
 
          NFC_WAVE_BARRIER();
          lds->sum[0][lane] = sum;
@@ -758,42 +787,47 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
          key = NFC_FK_UNARMED;
    }
 
-   /* the raw box sums are only order-independent on the grid, and while they stay far inside the range in which
-    * multiples of 2^-15 are exact */
+   /* The raw box sums are only order-independent on the grid, and while they stay far inside the range in which multiples
+    * of 2^-15 are exact: there the running sums of a tile are a wave prefix sum away. Anywhere else - a sample off the
+    * grid within the correlators' reach, a sum that has drifted out of that range - they are walked in the step's order
+    * (nfc_wave_raw_walked). Looked at once per tile and stage: a sum moves by at most 2 per sample, and NFC_FAST_SUM_LIMIT
+    * leaves room for a tile. */
    const bool raw = key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP || key == NFC_FK_A_POLL || key == NFC_FK_F_DATA || key == NFC_FK_F_START || key == NFC_FK_V_POLL;
-   bool take = key != NFC_FK_NONE;
+   const bool take = key != NFC_FK_NONE;
 
-   /* (looked at once per tile and stage: a sum moves by at most 2 per sample, and NFC_FAST_SUM_LIMIT leaves room for a tile) */
    if (raw && NFC_WAVE_UNIFORM_U32(lds->u.takeKey) != key)
    {
-      if ((uint32_t)(clock0 + 1u - lds->u.gridSince) < NFC_FAST_GRID_BACK)
-         take = false;
+      bool exact;
+
+      /* (signed: a tile with a sample off the grid sets gridSince to its own end) */
+      if ((int32_t)(clock0 + 1u - lds->u.gridSince) < (int32_t)NFC_FAST_GRID_BACK)
+         exact = false;
       else if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
       {
          const NfcSearchRegs &r = s.u.search;
-         take = nfc_abs(r.detA[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[2].acc) <= NFC_FAST_SUM_LIMIT &&
-                nfc_abs(r.detF[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detF[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detV.acc) <= NFC_FAST_SUM_LIMIT;
+         exact = nfc_abs(r.detA[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detA[2].acc) <= NFC_FAST_SUM_LIMIT &&
+                 nfc_abs(r.detF[0].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detF[1].acc) <= NFC_FAST_SUM_LIMIT && nfc_abs(r.detV.acc) <= NFC_FAST_SUM_LIMIT;
       }
       else
-         take = nfc_abs(s.u.decode.lock.acc) <= NFC_FAST_SUM_LIMIT;
+         exact = nfc_abs(s.u.decode.lock.acc) <= NFC_FAST_SUM_LIMIT;
 
-      if (take)
+      NFC_WAVE_READ_FENCE();
+      NFC_WAVE_UNIFORM_BEGIN
       {
-         NFC_WAVE_READ_FENCE();
-         NFC_WAVE_UNIFORM_BEGIN
-         {
-            lds->u.takeKey = key;
-         }
-         NFC_WAVE_UNIFORM_END
+         lds->u.takeKey = key;
+         lds->u.walked = exact ? 0u : 1u;
       }
+      NFC_WAVE_UNIFORM_END
    }
+
+   const bool walked = raw && NFC_WAVE_UNIFORM_U32(lds->u.walked) != 0u;
 
    if (!take)
    {
       NFC_WAVE_COUNT(46u, 0u, 1u); /* bulk paths not taken */
       NFC_WAVE_COUNT(key, 1u, 0u);
 #ifdef NFC_WAVE_COUNT_NOT_TAKEN
-      NFC_WAVE_COUNT_NOT_TAKEN(key, raw && (uint32_t)(clock0 + 1u - lds->u.gridSince) < NFC_FAST_GRID_BACK);
+      NFC_WAVE_COUNT_NOT_TAKEN(key, false);
 #endif
       /* stepping goes on without the values being kept up */
       NFC_WAVE_UNIFORM_BEGIN
@@ -813,12 +847,16 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
       if (key == NFC_FK_SEARCH || key == NFC_FK_UPKEEP)
       {
          NFC_WAVE_COUNT(41u, 0u, 1u); /* search values formed */
-         nfc_wave_search_values(c, lds, clock0, from);
+         if (walked)
+            NFC_WAVE_COUNT(48u, 0u, 1u); /* values with walked sums */
+         nfc_wave_search_values(c, lds, clock0, from, n, walked);
       }
       else if (key != NFC_FK_UNARMED && key != NFC_FK_B_POLL)
       {
          NFC_WAVE_COUNT(42u, 0u, 1u); /* locked values formed */
-         nfc_wave_locked_values(c, lds, clock0, from, n, key);
+         if (walked)
+            NFC_WAVE_COUNT(48u, 0u, 1u);
+         nfc_wave_locked_values(c, lds, clock0, from, n, key, walked);
       }
 
       NFC_WAVE_BARRIER();

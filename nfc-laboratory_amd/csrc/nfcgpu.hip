@@ -773,6 +773,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       sp.soloSamples = ctx->wave ? ctx->soloSamples : 0u; /* (the lane-per-window kernels let carry lanes retire) */
       sp.aloneStreams = ctx->wave ? ctx->aloneStreams : 0u;
       sp.alonePercent = ctx->alonePercent;
+      sp.offGridAlone = ctx->wave ? 1u : 0u;
 
       /* Every chunk pays the warm-up again, so chunks should be as long as the machine allows: one lane per chunk, and
        * 131072 lanes (256 CUs x 4 SIMDs x 2 waves of the scan kernel's 204 registers x 64) are resident at a time.

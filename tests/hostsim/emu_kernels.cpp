@@ -732,7 +732,7 @@ void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint3
          const uint32_t flags = nfc_tile_flags(*cfgPtr, A.params, A.tileStats + job.firstTile, i);
          A.tiles[job.firstTile + i] = flags;
          if (flags & NFC_TILE_OFFGRID)
-            job.status |= NFC_JOB_OFFGRID;
+            job.status |= A.params.offGridAlone ? (NFC_JOB_ALONE | NFC_JOB_OFFGRID_SEEN) : NFC_JOB_OFFGRID;
          if ((flags & NFC_TILE_BUSY) && !(flags & NFC_TILE_DARK))
             job.busyTiles++;
          rewalked += (flags & NFC_TILE_REWALKED) ? 1 : 0;

@@ -65,6 +65,7 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 #define NFC_WAVE_READ_FENCE() wavesim::barrier()
 #define NFC_WAVE_PICK_F(reg, array, j) ((array)[(j)])
 #define NFC_WAVE_PICK_U32(reg, array, j) (wavesim::shfl((reg), (j)))
+#define NFC_WAVE_SHFL_F(reg, j) (wavesim::shfl((reg), (j)))
 #define NFC_WAVE_CONFIG(cfgPtr, lds, cc) ((cc) = *(cfgPtr))
 #define NFC_WAVE_NOINLINE static __attribute__((noinline))
 #define NFC_WAVE_STAT_ADD(p, v) (*(p) += (v))
@@ -158,8 +159,8 @@ struct CountPrinter
       std::fprintf(stderr, "[emu wave] NFC-B detectors stepped on their own %llu, steps in the wake of another %llu, bulk paths not taken %llu, unarmed / carrier steps %llu\n",
                    (unsigned long long)emu_wave_counts[44][0], (unsigned long long)emu_wave_counts[45][0], (unsigned long long)emu_wave_counts[46][0],
                    (unsigned long long)emu_wave_counts[47][0]);
-      std::fprintf(stderr, "[emu wave] bulk-path calls %llu, search values formed %llu, locked values formed %llu, tiles %llu\n", (unsigned long long)emu_wave_counts[40][0],
-                   (unsigned long long)emu_wave_counts[41][0], (unsigned long long)emu_wave_counts[42][0], (unsigned long long)emu_wave_counts[43][0]);
+      std::fprintf(stderr, "[emu wave] bulk-path calls %llu, search values formed %llu, locked values formed %llu (with walked sums: %llu), tiles %llu\n", (unsigned long long)emu_wave_counts[40][0],
+                   (unsigned long long)emu_wave_counts[41][0], (unsigned long long)emu_wave_counts[42][0], (unsigned long long)emu_wave_counts[48][0], (unsigned long long)emu_wave_counts[43][0]);
       for (uint32_t k = 0; k < 17; k++)
          if (emu_wave_counts[k][0] | emu_wave_counts[k][1])
             std::fprintf(stderr, "[emu wave] %-14s bulk %12llu stepped %10llu\n", names[k], (unsigned long long)emu_wave_counts[k][0],

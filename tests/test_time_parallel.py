@@ -102,10 +102,14 @@ def test_random_multi_submission_scenarios_emulated(emulated):
 
 
 @needs_reference
-def test_input_off_the_grid_takes_the_sequential_path_emulated(emulated):
-    res = _run(["offgrid"], True)
-    _check(res, windowed=False)
-    assert res[0]["stats"]["fallback"] == 1 and res[0]["stats"]["windowed"] == 0
+def test_input_off_the_grid_is_decoded_by_carry_lanes_with_walked_sums_emulated(emulated):
+    """float input off the int16 grid (what a radio delivers) stays on the path: no speculative windows - off the grid no lane
+    that starts inside a stream can be in the decoder's state - but the stream's carry lane decodes it, one wavefront per
+    stream, the raw running sums walked in the step's order; every tile decoded twice (bulk / stepped) and compared"""
+    res = _run(["offgrid"], True, {"NFC_EMU_WAVE_VERIFY": "1"})
+    _check(res)
+    for r in res:
+        assert r["stats"]["fallback"] == 0, r
 
 
 @needs_reference
@@ -128,6 +132,8 @@ def test_buffers_synthetic_quiet_and_offgrid_on_the_gpu(built):
     res = _run(["buffers", "synthetic", "quiet", "carried"], False)
     _check(res)
     res = _run(["offgrid"], False)
-    _check(res, windowed=False)
+    _check(res)  # (off the grid: carry lanes with walked sums, nothing decoded by the sequential kernels)
+    for r in res:
+        assert r["stats"]["fallback"] == 0, r
     res = _run(["buffers"], False, {"NFCGPU_SCAN_CHUNK": "8192", "NFCGPU_SCAN_WARM": "1024"})
     _check(res)

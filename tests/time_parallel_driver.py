@@ -87,8 +87,20 @@ def main():
 
     if not which or "offgrid" in which:
         mag = np.abs(T.load_fixture("test_NFC-A_106kbps_001")).astype(np.float32)
-        mag = (mag * np.float32(1.0000153)).astype(np.float32)  # off the int16 grid: sequential path
+        mag = (mag * np.float32(1.0000153)).astype(np.float32)  # off the int16 grid: the carry lane alone, running sums walked
         out.append(case("off-grid magnitudes", [mag]))
+        # what a radio delivers (set S2): every technology's captures scaled off the grid with white noise on top,
+        # in two submissions (the sums a stream carries are not on a grid either)
+        rng = np.random.default_rng(11)
+        streams = []
+        for name, gain in (("test_NFC-B_106kbps_001", 0.83), ("test_NFC-F_212kbps_001", 1.07), ("test_NFC-V_26kbps_002", 0.91), ("test_NFC-A_424kbps_001", 0.77),
+                           ("test_POLL_ABF_001", 1.0)):
+            m = np.abs(T.load_fixture(name)).astype(np.float32)
+            streams.append(np.abs(m * np.float32(gain) + rng.normal(0.0, 0.0007, m.size).astype(np.float32)).astype(np.float32))
+        out.append(case("captures off the grid with noise, 2 buffers", streams, buffers=2))
+        streams = [np.abs(synth.magnitude_f32(template, 40 + s, 0, 1 << 18) * np.float32(0.93) + rng.normal(0.0, 0.0005, 1 << 18).astype(np.float32)).astype(np.float32)
+                   for s in range(3)]
+        out.append(case("3 dense synthetic streams x 2^18 off the grid, IQ entry, 2 buffers", streams, buffers=2, stride=2))
 
     if not which or "quiet" in which:
         # long quiet carrier around one exchange: the case the path is for (nearly everything skipped)
