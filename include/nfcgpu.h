@@ -221,11 +221,16 @@ int nfcgpu_comm_destroy(nfcgpu_ctx *ctx);
 /* All-gather of every rank's packed frame records (the context's frame sink as it stands: nfcgpu_sink_hold must be on,
  * so that nothing has been drained - NFCGPU_EINVAL otherwise): one ncclAllGather of (word count, receive capacity) per
  * rank, on which every rank takes the same go / no-go decision (NFCGPU_ENOMEM everywhere when some rank's buffer is too
- * small for the total), then the records at their exact sizes (one ncclBroadcast per rank, grouped). `gathered` is a
- * device buffer of capacity_words words; the records are packed: rank r's start at the sum of counts_host[0 .. r-1],
- * counts_host[r] words of them, and *stride_words is set to 0 (round 2 padded every rank to a common stride instead).
+ * small), then the records at their exact sizes (one ncclBroadcast per rank, grouped). `gathered` is a device buffer of
+ * capacity_words words; counts_host[r] = words of rank r.
+ *   nfcgpu_gather_frames_packed  rank r's records start at the sum of counts_host[0 .. r-1] (needs the sum of the counts);
+ *   nfcgpu_gather_frames         the layout of rounds 1-2: rank r's records start at r * *stride_words, *stride_words = the
+ *                                largest count (needs n_ranks times that). Round 3 returned the packed layout with a stride
+ *                                of 0 under this symbol; a caller built against the older header reads every rank at
+ *                                r * stride, so the padded layout is what this symbol keeps.
  * Record format of the sink: [stream, tech, type, flags, phase, rate, start, end, length, payload words]. */
 int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacity_words, uint32_t *counts_host, uint64_t *stride_words);
+int nfcgpu_gather_frames_packed(nfcgpu_ctx *ctx, void *gathered, uint64_t capacity_words, uint32_t *counts_host);
 
 /* streaming-read bandwidth of this GPU over `bytes` of device memory (16-byte loads per lane, grid sized to the chip):
  * the measured denominator of the HBM roofline, next to the vendor peak. Best of `repeats` passes, GB/s. */

@@ -558,6 +558,15 @@ int grow(nfcgpu_ctx *ctx, nfcgpu_ctx::DevBuf &b, size_t bytes)
    if (bytes <= b.bytes)
       return NFCGPU_OK;
 
+#ifdef NFCGPU_EMULATED_TEST_BUILD
+   /* (test build: a device that cannot give the front-end planes more than this - the fallbacks of run_windowed) */
+   if (const char *limit = std::getenv("NFCGPU_TEST_ALLOC_LIMIT"))
+   {
+      if (&b == &ctx->wPlanes && bytes > std::strtoull(limit, nullptr, 10))
+         return fail(ctx, NFCGPU_ENOMEM, "device allocation for the time-parallel path failed (test limit)");
+   }
+#endif
+
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
    if (b.ptr)
@@ -716,18 +725,22 @@ void record_span(nfcgpu_ctx *ctx, std::vector<ProfiledLaunch> &into, ProfiledLau
 }
 
 int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride);
+int launch_sequential(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride);
 
-/* the same submission, `blockSamples` at a time */
-int run_in_blocks(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride)
+/* the same submission, `blockSamples` at a time (0: the context's block length) */
+int run_in_blocks(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride, uint32_t blockSamples = 0)
 {
    uint32_t longest = 0;
    for (const WindowedItem &it: items)
       longest = it.count > longest ? it.count : longest;
 
+   if (!blockSamples)
+      blockSamples = ctx->blockSamples;
+
    int rc = NFCGPU_OK;
    ctx->inBlocks = true;
 
-   for (uint64_t at = 0; at < longest && rc == NFCGPU_OK; at += ctx->blockSamples)
+   for (uint64_t at = 0; at < longest && rc == NFCGPU_OK; at += blockSamples)
    {
       std::vector<WindowedItem> block;
 
@@ -736,7 +749,7 @@ int run_in_blocks(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIt
          if (it.count > at)
          {
             const uint64_t left = it.count - at;
-            block.push_back(WindowedItem {it.slot, it.data + (size_t)at * stride * 4, (uint32_t)(left < ctx->blockSamples ? left : ctx->blockSamples)});
+            block.push_back(WindowedItem {it.slot, it.data + (size_t)at * stride * 4, (uint32_t)(left < blockSamples ? left : blockSamples)});
          }
       }
 
@@ -1074,7 +1087,28 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    if (ctx->wave)
    {
       if ((rc = grow(ctx, ctx->wPlanes, (size_t)tiles * NFC_SCAN_TILE * 16u)) || (rc = grow(ctx, ctx->wPlaneChunks, sizeof(NfcScanChunk) * nChunks)))
-         return rc;
+      {
+         /* The planes are 16 bytes per sample of the submission (64 GiB for 4096 streams x 2^20): where the device cannot
+          * give that, the submission is decoded a quarter of its length at a time (a quarter of the planes), and if that
+          * does not fit either by the sequential kernels, which need no work buffers. Nothing has been touched yet: the scan
+          * only reads. */
+         if (rc != NFCGPU_ENOMEM)
+            return rc;
+
+         (void)hipGetLastError();
+
+         uint32_t longest = 0;
+         for (const WindowedItem &it: items)
+            longest = it.count > longest ? it.count : longest;
+
+         const uint32_t quarter = longest / 4u / NFC_SCAN_POINT * NFC_SCAN_POINT;
+
+         if (!ctx->inBlocks && quarter >= 65536u && quarter >= ctx->windowedMinSamples)
+            return run_in_blocks(ctx, config, items, stride, quarter);
+
+         ctx->stats.fallback_streams += nJobs;
+         return launch_sequential(ctx, config, items, stride);
+      }
 
       std::vector<NfcScanChunk> all(chunks);
       for (NfcScanChunk &c: all)
@@ -1531,6 +1565,22 @@ struct IdByValue
    char internal[NFCGPU_UNIQUE_ID_BYTES];
 };
 
+#ifdef NFCGPU_EMULATED_TEST_BUILD
+struct FakeNcclId
+{
+   char internal[NFCGPU_UNIQUE_ID_BYTES];
+};
+extern "C" {
+int fake_ncclGetUniqueId(void *id);
+int fake_ncclCommInitRank(void **comm, int nRanks, FakeNcclId id, int rank);
+int fake_ncclCommDestroy(void *comm);
+int fake_ncclAllGather(const void *send, void *recv, size_t count, int type, void *comm, void *stream);
+int fake_ncclBroadcast(const void *send, void *recv, size_t count, int type, int root, void *comm, void *stream);
+int fake_ncclGroupStart();
+int fake_ncclGroupEnd();
+}
+#endif
+
 namespace {
 
 struct Rccl
@@ -1554,7 +1604,22 @@ Rccl *rccl()
    if (!tried)
    {
       tried = true;
-#ifndef NFCGPU_EMULATED_TEST_BUILD
+#ifdef NFCGPU_EMULATED_TEST_BUILD
+      /* the emulated test build has no RCCL; with NFCGPU_FAKE_RCCL=1 it takes an in-process stand-in (tests/hostsim/
+       * fake_rccl.cpp: ranks are threads of one process) so that the rank logic of the gather runs without GPUs */
+      if (std::getenv("NFCGPU_FAKE_RCCL"))
+      {
+         r.handle = (void *)&r;
+         r.getUniqueId = fake_ncclGetUniqueId;
+         r.commInitRank = (int (*)(void **, int, IdByValue, int))fake_ncclCommInitRank;
+         r.commDestroy = fake_ncclCommDestroy;
+         r.allGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))fake_ncclAllGather;
+         r.broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))fake_ncclBroadcast;
+         r.groupStart = fake_ncclGroupStart;
+         r.groupEnd = fake_ncclGroupEnd;
+         r.getErrorString = nullptr;
+      }
+#else
       for (const char *name: {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
       {
          r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -2750,9 +2815,11 @@ int nfcgpu_comm_destroy(nfcgpu_ctx *ctx)
    return NFCGPU_OK;
 }
 
-int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords, uint32_t *countsHost, uint64_t *strideWords)
+/* both forms of the gather: `packed` - rank r's records start at the sum of the counts before it; otherwise at r * stride,
+ * stride = the largest count (the layout of rounds 1-2, kept under the old symbol) */
+static int gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords, uint32_t *countsHost, uint64_t *strideWords, bool packed)
 {
-   if (!ctx || !gathered || !countsHost || !strideWords)
+   if (!ctx || !gathered || !countsHost || (!packed && !strideWords))
       return NFCGPU_EINVAL;
 
    {
@@ -2799,18 +2866,22 @@ int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords
    HIP_TRY(ctx, hipMemcpyAsync(pairs.data(), ctx->dCounts, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
-   uint64_t total = 0, smallest = ~0ull;
+   uint64_t total = 0, smallest = ~0ull, largest = 0;
    for (int i = 0; i < n; i++)
    {
       countsHost[i] = pairs[2 * i];
       total += pairs[2 * i];
+      largest = pairs[2 * i] > largest ? pairs[2 * i] : largest;
       smallest = pairs[2 * i + 1] < smallest ? pairs[2 * i + 1] : smallest;
    }
 
-   /* packed: rank i's records start at the sum of the counts before it */
-   *strideWords = 0;
+   const uint64_t stride = packed ? 0 : largest;
+   const uint64_t needed = packed ? total : largest * (uint64_t)n;
 
-   if (total > smallest)
+   if (strideWords)
+      *strideWords = stride;
+
+   if (needed > smallest)
       return fail(ctx, NFCGPU_ENOMEM, "a rank's gather buffer is too small for all ranks' records (the same verdict on every rank)");
 
    /* records, exact sizes: one broadcast per rank into its place, all in one group */
@@ -2819,7 +2890,7 @@ int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords
    for (int i = 0; i < n && rc == 0; i++)
    {
       if (countsHost[i])
-         rc = r->broadcast(ctx->dSink, (uint32_t *)gathered + at, countsHost[i], /* ncclUint32 */ 3, i, ctx->comm, ctx->stream);
+         rc = r->broadcast(ctx->dSink, (uint32_t *)gathered + (packed ? at : (uint64_t)i * stride), countsHost[i], /* ncclUint32 */ 3, i, ctx->comm, ctx->stream);
       at += countsHost[i];
    }
    const int rcEnd = r->groupEnd();
@@ -2831,6 +2902,16 @@ int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
    return ctl[1] ? NFCGPU_EOVERFLOW : NFCGPU_OK;
+}
+
+int nfcgpu_gather_frames_packed(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords, uint32_t *countsHost)
+{
+   return gather_frames(ctx, gathered, capacityWords, countsHost, nullptr, true);
+}
+
+int nfcgpu_gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords, uint32_t *countsHost, uint64_t *strideWords)
+{
+   return gather_frames(ctx, gathered, capacityWords, countsHost, strideWords, false);
 }
 
 int nfcgpu_read_bandwidth(nfcgpu_ctx *ctx, const void *ptr, uint64_t bytes, uint32_t repeats, double *gbps)

@@ -146,6 +146,7 @@ def load_library(path=LIB_PATH):
     lib.nfcgpu_comm_init.argtypes = [vp, vp, i32, i32]
     lib.nfcgpu_comm_destroy.argtypes = [vp]
     lib.nfcgpu_gather_frames.argtypes = [vp, vp, ctypes.c_uint64, P(ctypes.c_uint32), P(ctypes.c_uint64)]
+    lib.nfcgpu_gather_frames_packed.argtypes = [vp, vp, ctypes.c_uint64, P(ctypes.c_uint32)]
     lib.nfcgpu_read_bandwidth.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, P(ctypes.c_double)]
     lib.nfcgpu_hip_stream.argtypes = [vp]
     lib.nfcgpu_hip_stream.restype = vp
@@ -309,9 +310,14 @@ class NfcGpu:
     def comm_destroy(self):
         self._check(self.lib.nfcgpu_comm_destroy(self.ctx))
 
-    def gather_frames(self, gathered_ptr, capacity_words):
-        """ncclAllGather of every rank's frame sink into the device buffer at gathered_ptr; returns (counts, stride)"""
+    def gather_frames(self, gathered_ptr, capacity_words, packed=True):
+        """every rank's frame records into the device buffer at gathered_ptr (RCCL behind the C ABI); returns (counts, stride):
+        packed (nfcgpu_gather_frames_packed): rank r's records start at sum(counts[:r]), stride 0; otherwise
+        (nfcgpu_gather_frames, the layout of rounds 1-2) at r * stride, stride = max(counts)"""
         counts = (ctypes.c_uint32 * self._n_ranks)()
+        if packed:
+            self._check(self.lib.nfcgpu_gather_frames_packed(self.ctx, gathered_ptr, capacity_words, counts), allow=(-6,))
+            return list(counts), 0
         stride = ctypes.c_uint64()
         self._check(self.lib.nfcgpu_gather_frames(self.ctx, gathered_ptr, capacity_words, counts, ctypes.byref(stride)), allow=(-6,))
         return list(counts), int(stride.value)

@@ -15,6 +15,8 @@ $CXX -x c++ -c "$PKG/csrc/nfcgpu.hip" -o "$HERE/emu_nfcgpu.o"
 $CXX -c "$HERE/emu_kernels.cpp" -o "$HERE/emu_kernels.o"
 # the wave decoder's own text, 64 fibres per wave (wavesim.hpp)
 $CXX -c "$HERE/emu_wave.cpp" -o "$HERE/emu_wave.o"
-g++ -shared -pthread -o "$HERE/libnfcgpu_emulated.so" "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o"
-rm -f "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o"
+# in-process stand-in for RCCL (ranks are threads): the gather's rank logic without GPUs (NFCGPU_FAKE_RCCL=1)
+$CXX -c "$HERE/fake_rccl.cpp" -o "$HERE/fake_rccl.o"
+g++ -shared -pthread -o "$HERE/libnfcgpu_emulated.so" "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o" "$HERE/fake_rccl.o"
+rm -f "$HERE/emu_nfcgpu.o" "$HERE/emu_kernels.o" "$HERE/emu_wave.o" "$HERE/fake_rccl.o"
 echo "built $HERE/libnfcgpu_emulated.so"

@@ -52,3 +52,12 @@ def test_dense_streams_in_two_submissions_match_the_reference(built):
 @pytest.mark.gpu
 def test_many_dense_streams_of_short_submissions_match_the_reference(built):
     _check(_sweep("dense", 2048, 1 << 18, 2))
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_config5_dense_every_stream_matches_the_reference(built):
+    """the headline of bench.py as it is submitted: 4096 dense streams x 2^20 samples in one submission (16 384+ lanes, lanes up
+    to 131072 samples apart: another lane geometry than the 512-stream case above), default knobs, every stream compared"""
+    res = _check(_sweep("dense", 4096, 1 << 20, 1))
+    assert res["time_parallel_streams"] + res["sequential_streams"] == 4096 and res["sequential_streams"] <= 32, res

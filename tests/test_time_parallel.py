@@ -90,15 +90,42 @@ def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emul
 
 
 @needs_reference
+def test_planes_that_do_not_fit_the_device_are_not_fatal_emulated(emulated):
+    """the wave path's front-end planes are 16 bytes per sample of the submission; when the device cannot give
+    them the submission used to fail with NFCGPU_ENOMEM. It is now decoded a quarter of its length at a time (a quarter of
+    the planes) and, if that does not fit either, by the sequential kernels - same frames either way."""
+    full = 2 * (1 << 19) * 16
+    res = _run(["planes"], True, {"NFCGPU_TEST_ALLOC_LIMIT": str(full // 2)})       # the quarter fits
+    _check(res)
+    assert res[0]["stats"]["windowed"] == 4 * 2 and res[0]["stats"]["fallback"] == 0, res   # four blocks of two streams
+    res = _run(["planes"], True, {"NFCGPU_TEST_ALLOC_LIMIT": str(full // 8)})       # nothing fits: sequential kernels
+    _check(res, windowed=False)
+    assert res[0]["stats"]["windowed"] == 0 and res[0]["stats"]["fallback"] == 4 * 2, res   # (counted per block)
+
+
+@needs_reference
 def test_random_multi_submission_scenarios_emulated(emulated):
     """a short run of profiles/tools/r02/emulated_fuzz.py (random mixes of sparse and dense streams cut into submissions at
     random samples: both paths, carried state, final-state fix-ups) - the long runs are in profiles/r02/emulated_fuzz.json"""
     fuzz = os.path.join(T.ROOT, "profiles", "tools", "r02", "emulated_fuzz.py")
     env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_DENSE_PERCENT="100", NFCGPU_WINDOWED_MIN="32768")
-    run = subprocess.run([sys.executable, fuzz, "5", "30"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    run = subprocess.run([sys.executable, fuzz, "5", "45", "small"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-2000:]
     res = json.loads(run.stdout.strip().splitlines()[-1])
-    assert res["rounds"] >= 1 and res["mismatches"] == [], res
+    assert res["rounds"] >= 3 and res["mismatches"] == [], res
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_random_multi_submission_scenarios_on_the_gpu(built):
+    """a minute of the same generator on the real library (full-size scenarios: up to 23 streams of up to 1.3 M samples, cut
+    into up to five submissions at random samples, a quarter of them off the int16 grid), default knobs"""
+    fuzz = os.path.join(T.ROOT, "profiles", "tools", "r02", "emulated_fuzz.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("NFCGPU_")}
+    run = subprocess.run([sys.executable, fuzz, "2026", "60"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    res = json.loads(run.stdout.strip().splitlines()[-1])
+    assert res["rounds"] >= 5 and res["mismatches"] == [], res
 
 
 @needs_reference

@@ -102,6 +102,11 @@ def main():
                    for s in range(3)]
         out.append(case("3 dense synthetic streams x 2^18 off the grid, IQ entry, 2 buffers", streams, buffers=2, stride=2))
 
+    if "planes" in which:
+        # (tests/test_time_parallel.py: the front-end planes - 16 bytes per sample - do not fit the device)
+        streams = [synth.magnitude_f32(template, 60 + s, 0, 1 << 19) for s in range(2)]
+        out.append(case("2 dense synthetic streams x 2^19", streams))
+
     if not which or "quiet" in which:
         # long quiet carrier around one exchange: the case the path is for (nearly everything skipped)
         rng = np.random.default_rng(5)
