@@ -1175,80 +1175,6 @@ NFC_DEV void nfc_step_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLan
    s.bankClock = s.clock;
 }
 
-/* A locked NFC-F decoder that is waiting for an answer with a clear preamble tracker (nfcf_listen_start after the guard
- * time): per sample it keeps its box sum and ring and looks whether |S0 - S1| / p2 reaches the threshold or the waiting
- * time is over; nothing else can change its state (NfcF.cpp:815-933: without a value above the threshold the tracker
- * only waits for its sync and window-end clocks, which are not set). The wait can be as long as 217 k samples at
- * 10 MS/s; on the int16 grid what the correlator will see is known exactly from the samples (nfc_scan.hpp). */
-NFC_DEV bool nfc_fwait_idle(const NfcStreamState &s)
-{
-   if (s.lockTech != NFC_TECH_F || s.unlock)
-      return false;
-
-   const NfcDecodeRegs &d = s.u.decode;
-   const NfcMod &m = d.lock;
-
-   if (d.frameType != NFC_FRAME_LISTEN || d.frameStart != 0 || d.pendType != 0)
-      return false;
-
-   /* threshold set (guard over), every ring entry in use written since, waiting time not over */
-   if ((int32_t)(s.clock - d.guardEnd) <= (int32_t)d.rt.p1 || (int32_t)(d.waitingEnd - s.clock) <= 0)
-      return false;
-
-   if (m.winStart | m.winEnd | m.sync | m.symStart | m.symEnd | m.pulses | m.peakTime | nfc_bits(m.peak))
-      return false;
-
-   return m.thr > 0.0f;
-}
-
-/* warm-up steps of a lane that lands in the middle of such a wait (nfc_lane_fwait_jump): front end only (refills the
- * sample history) ... */
-template <bool EXACT>
-NFC_DEV void nfc_step_lock_front(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
-{
-   NfcLaneMem mem = lane;
-   mem.exact = EXACT;
-
-   ++s.clock;
-   ++s.pulseFilter;
-
-   nfc_advance_positions(c, s, mem);
-   nfc_advance_lock_pos(s, mem);
-   (void)nfc_front_end(c, s, mem, value);
-}
-
-/* ... then front end + the listen correlator's box sum and ring entry, no decisions (the samples have been checked:
- * nothing reaches the threshold here). The sum starts from zero where the lane landed: its offset never shows, S0 and
- * S1 are differences of ring entries written from here on. */
-template <bool EXACT>
-NFC_DEV void nfc_step_fwait_upkeep(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &lane, float value)
-{
-   NfcLaneMem mem = lane;
-   mem.exact = EXACT;
-
-   ++s.clock;
-   ++s.pulseFilter;
-
-   nfc_advance_positions(c, s, mem);
-   nfc_advance_lock_pos(s, mem);
-
-   const NfcRate &rt = s.u.decode.rt;
-   const uint32_t cur = s.clock - rt.delay;
-
-   const float out = NFC_AT(mem, NFC_R_X, (cur - rt.p2) & NFC_HMASK);
-   float in = NFC_AT(mem, NFC_R_X, cur & NFC_HMASK);
-
-   const NfcNow now = nfc_front_end(c, s, mem, value);
-
-   if (rt.delay == 0)
-      in = now.x;
-
-   NfcMod &m = s.u.decode.lock;
-   m.acc += in;
-   m.acc -= out;
-   NFC_AT(mem, NFC_R_CORR, s.u.decode.lockBase + nfc_lock_pos(s)) = m.acc;
-}
-
 /* True when the decoder is searching and every detector record is what a cleared record is, apart from the running
  * sums, from fields that are rewritten before they are next read (NFC-B: thr, recomputed on every sample of the idle
  * detector; NFC-F: syncValue, c0, lastValue, lastPhase, set by the first pulse of the next preamble before they can

@@ -827,23 +827,7 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
    NfcScanJob job = A.jobs[j];
 
    if (first)
-   {
       job.passes = 0;
-
-      /* routing, from the tile tests on the unrepaired scan (an estimate is all it takes): where most of the signal is
-       * busy the lanes would be long and their hand-overs many; such a stream is decoded sequentially */
-      const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-      if (A.nJobs >= NFC_LANES && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
-      {
-         job.status |= NFC_JOB_DENSE; /* (fewer streams than a wave has lanes: the sequential kernel would crawl, cut them anyway) */
-         atomicAdd(A.denseCount, 1u);
-      }
-
-      /* Speculative lanes buy parallelism inside a stream with warm-ups, hand-overs that fail and further passes. A
-       * submission of hundreds of busy streams has lanes enough without: one lane per stream, start to end, one pass. */
-      if (A.params.aloneStreams && A.nJobs >= A.params.aloneStreams && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.params.alonePercent)
-         job.status |= NFC_JOB_ALONE;
-   }
 
    if (!(job.status & NFC_JOB_INVALID))
       nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples);
@@ -1143,660 +1127,8 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
    A.works[wi] = work;
 }
 
-/* Stage the next 64 samples of every lane's own row (rowBase: where the lane's next sample is, left: samples it has
- * left, 0 for a lane that takes none) into LDS as magnitudes, transposed: tile row r = lane r. One wave-wide load
- * fetches 64 consecutive samples of one lane (512 B of IQ, 256 B of magnitude), NFC_STAGE_ROWS loads in flight. */
-__device__ __forceinline__ void nfc_stage_lanes(const NfcLaunch &L, const uint8_t *rowBase, uint32_t left, uint32_t lane, float *tile)
-{
-   if (!left)
-      rowBase = (const uint8_t *)L.rings; /* read (and discard) something that is always there */
-
-#pragma clang loop unroll(disable)
-   for (uint32_t r0 = 0; r0 < NFC_LANES; r0 += NFC_STAGE_ROWS)
-   {
-      float re[NFC_STAGE_ROWS], im[NFC_STAGE_ROWS];
-      uint32_t count[NFC_STAGE_ROWS];
-
-#pragma unroll
-      for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
-      {
-         const int q = (int)(r0 + j);
-         const uint64_t p = ((uint64_t)(uint32_t)__shfl((int)((uint64_t)rowBase >> 32), q, 64) << 32) |
-                            (uint32_t)__shfl((int)(uint32_t)(uint64_t)rowBase, q, 64);
-         const uint32_t n = (uint32_t)__shfl((int)left, q, 64);
-         const uint32_t at = n ? (lane < n ? lane : n - 1u) : 0u;
-
-         count[j] = n;
-
-         if (L.uniformStride == 2)
-         {
-            const float2 iq = reinterpret_cast<const float2 *>(p)[at];
-            re[j] = iq.x;
-            im[j] = iq.y;
-         }
-         else
-         {
-            re[j] = reinterpret_cast<const float *>(p)[at];
-            im[j] = 0.0f;
-         }
-      }
-
-#pragma unroll
-      for (uint32_t j = 0; j < NFC_STAGE_ROWS; j++)
-      {
-         const float v = L.uniformStride == 2 ? nfc_iq_magnitude(re[j], im[j]) : re[j];
-         tile[(r0 + j) * TILE_PITCH + lane] = lane < count[j] ? v : 0.0f;
-      }
-   }
-}
-
-/* nfc_fwait_first_hot for the whole wave: 64 samples per step. The samples go through an inclusive wave scan (grid units,
- * 32-bit wrap-around arithmetic: only differences over at most p1 samples are used); `pp` (192 words of LDS) holds the
- * prefix sums of the 128 samples before the block at hand and of the block, so that lane i finds W(k) = pp[k] - pp[k-p2]
- * for the three windows of its sample's step. Every argument is wave-uniform; requires delay + p1 <= NFC_FWAIT_LOOKBACK
- * and from >= NFC_FWAIT_LOOKBACK. */
-__device__ uint32_t nfc_wave_first_hot(const uint8_t *data, uint32_t stride, uint32_t count, uint32_t from, uint32_t limit, uint32_t p1, uint32_t p2,
-                                       uint32_t delay, float thr, uint32_t *pp)
-{
-   const uint32_t lane = threadIdx.x;
-   uint32_t carry = 0u;
-
-   __syncthreads();
-   pp[lane] = 0u;
-   pp[64u + lane] = 0u;
-   pp[128u + lane] = 0u;
-   __syncthreads();
-
-   for (uint32_t t0 = from - NFC_FWAIT_LOOKBACK; t0 < limit; t0 += 64u)
-   {
-      const uint32_t a = pp[64u + lane], b = pp[128u + lane];
-      __syncthreads();
-      pp[lane] = a;
-      pp[64u + lane] = b;
-
-      const uint32_t idx = t0 + lane;
-      uint32_t v = idx < count ? (uint32_t)nfc_grid_units(data, stride, idx) : 0u;
-
-      for (uint32_t off = 1u; off < 64u; off <<= 1)
-      {
-         const uint32_t other = (uint32_t)__shfl_up((int)v, (int)off, 64);
-         if (lane >= off)
-            v += other;
-      }
-
-      v += carry;
-      carry = (uint32_t)__shfl((int)v, 63, 64);
-
-      pp[128u + lane] = v;
-      __syncthreads();
-
-      if (t0 >= from)
-      {
-         const uint32_t n = t0 + lane;
-         const uint32_t cur = 128u + lane - delay; /* pp index of the decode point of sample n's step */
-         const uint32_t d = p1 - p2;
-
-         const int32_t w0 = (int32_t)(pp[cur] - pp[cur - p2]);
-         const int32_t wd = (int32_t)(pp[cur - d] - pp[cur - d - p2]);
-         const int32_t w1 = (int32_t)(pp[cur - 1u] - pp[cur - 1u - p2]);
-
-         const uint64_t hot = __ballot(n < limit && nfc_fwait_hot(w0, wd, w1, p2, thr));
-
-         if (hot)
-            return t0 + (uint32_t)__builtin_ctzll(hot);
-      }
-   }
-
-   return limit;
-}
-
-/* Lanes of the wave whose decoder is an idle waiting NFC-F decoder: one after the other the wave looks ahead for them
- * (nfc_wave_first_hot) and the lane jumps (nfc_lane_fwait_jump). `pos`: the lane's stream position (tile boundary);
- * lockFrontUntil / lockUpkeepUntil / nextWaitScan: the lane's own bookkeeping (stream positions). Called by all lanes. */
-__device__ __forceinline__ uint32_t nfc_wave_fwait(const NfcConfig &cc, const NfcScanArgs &A, const NfcWindow *windows, bool candidate, uint32_t w,
-                                                   uint32_t pos, uint32_t stride, NfcStreamState &s, const NfcStreamCold *cold, uint32_t &lockFrontUntil,
-                                                   uint32_t &lockUpkeepUntil, uint32_t &nextWaitScan, uint32_t *pp)
-{
-   const uint32_t lane = threadIdx.x;
-   uint32_t landed = pos;
-
-   /* what the wave needs to know about the lane */
-   uint32_t jobIndex = 0u, limit = 0u, p1 = 0u, p2 = 0u, delay = 0u;
-   float thr = 0.0f;
-
-   if (candidate)
-   {
-      const NfcRate &rt = s.u.decode.rt;
-      p1 = rt.p1;
-      p2 = rt.p2;
-      delay = rt.delay;
-      thr = s.u.decode.lock.thr;
-      jobIndex = windows[w].job;
-
-      const NfcScanJob &job = A.jobs[jobIndex];
-      uint64_t end = (uint64_t)pos + (uint32_t)(s.u.decode.waitingEnd - s.clock);
-      limit = end > job.count ? job.count : (uint32_t)end;
-
-      candidate = delay + p1 <= NFC_FWAIT_LOOKBACK && pos >= NFC_FWAIT_LOOKBACK + NFC_SCAN_TILE && p2 != 0u && p1 > p2;
-   }
-
-   uint64_t todo = __ballot(candidate);
-
-   while (todo)
-   {
-      const int who = (int)__builtin_ctzll(todo);
-      todo &= todo - 1ull;
-
-      const uint32_t j = (uint32_t)__shfl((int)jobIndex, who, 64);
-      const uint32_t from = (uint32_t)__shfl((int)pos, who, 64);
-      const uint32_t lim = (uint32_t)__shfl((int)limit, who, 64);
-      const uint32_t q1 = (uint32_t)__shfl((int)p1, who, 64);
-      const uint32_t q2 = (uint32_t)__shfl((int)p2, who, 64);
-      const uint32_t dl = (uint32_t)__shfl((int)delay, who, 64);
-      const float th = __shfl(thr, who, 64);
-
-      const NfcScanJob &job = A.jobs[j];
-
-      const uint32_t firstHot = nfc_wave_first_hot(job.data, stride, job.count, from, lim, q1, q2, dl, th, pp);
-
-      if ((int)lane == who)
-      {
-         const uint32_t land = nfc_lane_fwait_jump(cc, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, pos, firstHot, s, *cold);
-
-         if (land != pos)
-         {
-            landed = land;
-            lockFrontUntil = land + NFC_WINDOW_WARM_FRONT;
-            lockUpkeepUntil = land + NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
-         }
-         else
-            nextWaitScan = firstHot + NFC_SCAN_TILE;
-      }
-   }
-
-   return landed;
-}
-
-/* The windowed decode: nfc_demod_body with lanes that stop on their own. A lane consumes its row tile by tile: front
- * end only, then correlator upkeep (both lengths are the launch's), then the full step machine; at a tile boundary it
- * retires when the decoder is at rest, the rings hold nothing from before its last unlock and the scan found nothing
- * ahead (NFC_TILE_RETIRE_OK). CARRY lanes continue a stream from its own state (no warm-up, exact-modulo ring positions
- * where the clock asks for them). */
-template <bool CARRY>
-__device__ __forceinline__ void nfc_window_body(const NfcConfig *__restrict__ cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, float *tile, uint32_t *waitScan)
-{
-   const uint32_t lane = threadIdx.x;
-   const uint32_t block = L.firstBlock + blockIdx.x;
-   const uint32_t slot = block * NFC_LANES + lane;
-
-   uint32_t mineCount = 0;
-   const uint32_t *flags = nullptr;
-
-   if (slot >= L.firstSlot && slot < L.firstSlot + L.slotCount)
-   {
-      mineCount = L.works[slot].count;
-      flags = L.works[slot].tiles;
-   }
-
-   uint32_t longest = mineCount;
-   for (int off = 32; off > 0; off >>= 1)
-   {
-      uint32_t other = __shfl_xor(longest, off, 64);
-      longest = other > longest ? other : longest;
-   }
-
-   longest = __builtin_amdgcn_readfirstlane(longest);
-
-   if (longest == 0)
-      return;
-
-   NfcStreamState s = L.states[slot];
-
-   NfcLaneMem mem;
-   mem.ring = L.rings + (uint64_t)block * L.ringBlockFloats;
-   mem.lane = lane;
-   mem.exact = false;
-   mem.linked = true;
-   mem.flags = waitScan + 192 + lane; /* (the wave's LDS words behind the look-ahead buffer) */
-   waitScan[192 + lane] = 0u;
-   mem.bytes = L.bytes + (uint64_t)slot * NFC_STREAM_BYTES;
-   mem.sink = L.sink;
-   mem.sinkCursor = L.sinkCtl;
-   mem.sinkDropped = L.sinkCtl + 1;
-   mem.sinkWords = L.sinkWords;
-   mem.streamId = slot;
-   mem.cold = L.cold + slot;
-   mem.tables = cfgPtr;
-
-   NFC_DRAIN();
-
-   NfcConfig cc;
-   nfc_fixed_runtime_config(cfgPtr, cc);
-
-   const uint32_t warm = L.warmFront + L.warmCorr;
-   bool stopped = mineCount == 0;
-   uint32_t consumed = 0;
-   uint32_t stepped = 0;
-   uint32_t handed = 0;
-
-   /* the lanes after this one on the same stream (nfc_lane_handover) */
-   uint32_t startPos = 0, verifyPos = 0xFFFFFFFFu, succ = 0, succEnd = 0;
-
-   if (mineCount)
-   {
-      const NfcWindow &me = L.windows[slot];
-      const NfcScanJob &job = L.jobs[me.job];
-      startPos = me.start;
-      verifyPos = me.verify;
-      succ = CARRY ? job.firstWindow : slot + 1u;
-      succEnd = job.firstWindow + job.windows;
-      if (!CARRY && (slot < job.firstWindow || slot >= succEnd))
-         succ = succEnd; /* a final lane (regenerates a state): runs on its own */
-   }
-
-   /* `base`: samples of the row this lane has consumed (lanes may jump ahead through dark signal: nfc_lane_dark_jump, and
-    * through the wait of an NFC-F decoder: nfc_lane_fwait_jump) */
-   uint32_t base = 0;
-   uint32_t lockFrontUntil = 0, lockUpkeepUntil = 0, nextWaitScan = 0; /* stream positions */
-
-   for (;;)
-   {
-      if (!stopped && base >= mineCount)
-         stopped = true;
-
-      if (__any(!stopped) == 0)
-         break;
-
-      if (!stopped && startPos + base == verifyPos)
-         nfc_lane_publish(L.windows[slot], s, *mem.cold);
-
-      /* retire? (tile boundary: TILE == NFC_SCAN_TILE and every lane starts on a tile boundary of its stream) */
-      if (!stopped && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_quiescent(s) &&
-          s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
-         stopped = true;
-
-      if (!stopped && base >= warm && base > 0 && nfc_lane_handover(L.windows, L.windows[slot], succ, succEnd, startPos + base, s, *mem.cold))
-      {
-         stopped = true;
-         handed = 1;
-      }
-
-      if (!stopped && base >= warm && (flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT) >= NFC_DARK_JUMP)
-      {
-         const NfcScanJob &job = L.jobs[L.windows[slot].job];
-         base = nfc_lane_dark_jump(cc, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, startPos + base,
-                                   flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - startPos;
-      }
-
-      /* a waiting NFC-F decoder: skip to where its correlator can next reach the threshold */
-      {
-         const uint32_t pos = startPos + base;
-         const bool waiting = !stopped && base >= warm && pos >= lockUpkeepUntil && pos >= nextWaitScan && nfc_fwait_idle(s) &&
-                              !nfc_exact_span(s.clock, TILE);
-
-         if (__any(waiting))
-            base = nfc_wave_fwait(cc, A, L.windows, waiting, slot, pos, L.uniformStride, s, mem.cold, lockFrontUntil, lockUpkeepUntil, nextWaitScan,
-                                  waitScan) - startPos;
-      }
-
-      if (__any(!stopped) == 0)
-         break;
-
-      nfc_stage_lanes(L, stopped ? nullptr : L.works[slot].data + (uint64_t)base * L.uniformStride * 4u, stopped ? 0u : mineCount - base, lane, tile);
-
-      __syncthreads();
-
-      if (!stopped)
-      {
-         const uint32_t left = mineCount - base;
-         const uint32_t n = left < TILE ? left : TILE;
-
-         if (base < L.warmFront)
-         {
-            for (uint32_t k = 0; k < n; k++)
-               nfc_step_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-         }
-         else if (base < warm)
-         {
-            for (uint32_t k = 0; k < n; k++)
-               nfc_step_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-         }
-         else if (startPos + base < lockFrontUntil)
-         {
-            for (uint32_t k = 0; k < n; k++)
-               nfc_step_lock_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-         }
-         else if (startPos + base < lockUpkeepUntil)
-         {
-            for (uint32_t k = 0; k < n; k++)
-               nfc_step_fwait_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-         }
-         else if (CARRY && __any(nfc_exact_span(s.clock, n)) != 0)
-         {
-            for (uint32_t k = 0; k < n; k++)
-               nfc_step_as<true>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-         }
-         else
-         {
-            for (uint32_t k = 0; k < n; k++)
-               nfc_step_as<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-         }
-
-         base += n;
-         consumed = base;
-         stepped += n;
-      }
-
-      __syncthreads();
-   }
-
-   if (mineCount)
-   {
-      mem.cold->usedTech = *mem.flags;
-      L.states[slot] = s;
-      L.windows[slot].stop = L.windows[slot].start + consumed;
-      /* out of samples in a state the closing window can take over from (nfc_lane_comparable): as good as stopped at rest,
-       * and the stream's final state is then the closing window's (768 samples to run again instead of this lane) */
-      const bool closing = L.windows[slot].activate >= L.windows[slot].start + mineCount;
-      L.windows[slot].retired = handed ? 2u : ((consumed < mineCount || (!closing && nfc_lane_comparable(s, *mem.cold))) ? 1u : 0u);
-
-      atomicAdd(L.laneStats, (stepped + TILE - 1) / TILE);
-      atomicMax(L.laneStats + 1, (stepped + TILE - 1) / TILE);
-      atomicAdd(L.laneStats + 2, 1u);
-   }
-}
-
-/* one lane per job, warm-up as a window: regenerates the state (rings included) of a job's last lane in the job's own
- * lane slot once the chain is settled (the persistent waves below do not keep a finished lane's rings) */
-__global__ __launch_bounds__(64) void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
-{
-   __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ uint32_t waitScan[192 + NFC_LANES];
-   nfc_window_body<false>(cfgPtr, L, A, tile, waitScan);
-}
-
-/* The windowed decode of the speculative lanes: persistent waves that refill their lanes. A wave keeps 64 windows in
- * flight, one per lane, all stepping one sample per step; a lane that finishes (retired at rest, or out of samples)
- * stores its result and, at the next multiple of 512 steps, takes the next window off the run list. Joining only there,
- * and numbering the joining lane's correlation rings from the wave's current common positions (the ring phase labels
- * say how that relates to the reference's numbering), keeps every ring access of the wave on one row: window starts are
- * multiples of 512 samples, so clock & 511 is the same for all lanes of a wave as long as the submissions are. The ring
- * storage belongs to the (wave, lane), not to the window: a lane's rings are rebuilt by its warm-up. */
-__global__ __launch_bounds__(64) NFC_PINNED void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
-{
-   __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ uint32_t waitScan[192 + NFC_LANES];
-
-   const uint32_t lane = threadIdx.x;
-   const uint32_t ringBlock = A.firstWindowSlot / NFC_LANES + blockIdx.x;
-
-   NfcLaneMem mem;
-   mem.ring = L.rings + (uint64_t)ringBlock * L.ringBlockFloats;
-   mem.lane = lane;
-   mem.exact = false;
-   mem.linked = true;
-   mem.flags = waitScan + 192 + lane;
-   waitScan[192 + lane] = 0u;
-   mem.bytes = L.bytes + ((uint64_t)ringBlock * NFC_LANES + lane) * NFC_STREAM_BYTES;
-   mem.sink = L.sink;
-   mem.sinkCursor = L.sinkCtl;
-   mem.sinkDropped = L.sinkCtl + 1;
-   mem.sinkWords = L.sinkWords;
-   mem.streamId = 0;
-   mem.cold = L.cold;
-   mem.tables = cfgPtr;
-
-   NfcConfig cc;
-   nfc_fixed_runtime_config(cfgPtr, cc);
-
-   const uint32_t warm = L.warmFront + L.warmCorr;
-   const uint32_t total = *A.runCount;
-
-   NfcStreamState s;
-   __builtin_memset(&s, 0, sizeof(s));
-
-   bool active = false;
-   uint32_t w = 0, consumed = 0, mineCount = 0, stepped = 0;
-   uint32_t startPos = 0, verifyPos = 0xFFFFFFFFu, succ = 0, succEnd = 0;
-   uint32_t lockFrontUntil = 0, lockUpkeepUntil = 0, nextWaitScan = 0; /* stream positions (nfc_lane_fwait_jump) */
-   const uint8_t *data = nullptr;
-   const uint32_t *flags = nullptr;
-   uint32_t steps = 0; /* steps of this wave since its lanes last all started together (multiple of 512 at a join) */
-
-   for (;;)
-   {
-      /* ---- join: free lanes take the next windows off the run list ---- */
-      const uint64_t freeMask = __ballot(!active);
-
-      if (freeMask == ~0ull)
-         steps = 0; /* nobody to stay in step with */
-
-      if (freeMask)
-      {
-         const uint32_t leader = (uint32_t)__builtin_ctzll(freeMask);
-         uint32_t base = 0;
-
-         if (lane == leader)
-            base = atomicAdd(A.runNext, (uint32_t)__builtin_popcountll(freeMask));
-
-         base = (uint32_t)__shfl((int)base, (int)leader, 64);
-
-         const uint32_t mine = base + (uint32_t)__builtin_popcountll(freeMask & ((1ull << lane) - 1ull));
-
-         if (!active && mine < total)
-         {
-            w = A.runList[mine];
-            s = L.states[w];
-            NFC_DRAIN();
-
-            const NfcWork work = L.works[w];
-            data = work.data;
-            mineCount = work.count;
-            flags = work.tiles;
-            consumed = 0;
-            stepped = 0;
-            active = mineCount != 0;
-            lockFrontUntil = 0;
-            lockUpkeepUntil = 0;
-            nextWaitScan = 0;
-            *mem.flags = 0u;
-
-            mem.cold = L.cold + w;
-            mem.streamId = w;
-
-            {
-               const NfcWindow &me = L.windows[w];
-               const NfcScanJob &job = A.jobs[me.job];
-               startPos = me.start;
-               verifyPos = me.verify;
-               succ = w + 1u;
-               succEnd = job.firstWindow + job.windows;
-            }
-
-            /* number the rings from where the wave's other lanes are */
-            s.posA[0] = steps % cc.a[0].p1;
-            s.posA[1] = steps % cc.a[1].p1;
-            s.posA[2] = steps % cc.a[2].p1;
-            s.posF[0] = steps % cc.f[1].p1;
-            s.posF[1] = steps % cc.f[2].p1;
-            s.posV1 = steps % cc.v.p1;
-            s.posV0 = steps % cc.v.p0;
-
-            mem.cold->label[0] = nfc_label(s.clock, cc.a[0].delay, cc.a[0].p1, s.posA[0]);
-            mem.cold->label[1] = nfc_label(s.clock, cc.a[1].delay, cc.a[1].p1, s.posA[1]);
-            mem.cold->label[2] = nfc_label(s.clock, cc.a[2].delay, cc.a[2].p1, s.posA[2]);
-            mem.cold->label[3] = nfc_label(s.clock, cc.f[1].delay, cc.f[1].p1, s.posF[0]);
-            mem.cold->label[4] = nfc_label(s.clock, cc.f[2].delay, cc.f[2].p1, s.posF[1]);
-            mem.cold->label[5] = nfc_label(s.clock, cc.v.delay, cc.v.p1, s.posV1);
-            mem.cold->label[6] = nfc_label(s.clock, cc.v.delay, cc.v.p0, s.posV0);
-         }
-      }
-
-      if (__any(active) == 0)
-         break; /* run list exhausted and every lane done */
-
-      /* ---- one epoch: 512 steps, lanes may finish at any tile boundary ---- */
-      for (uint32_t t = 0; t < NFC_SCAN_POINT / TILE; t++)
-      {
-         if (active)
-         {
-            bool done = consumed >= mineCount;
-            uint32_t how = done ? 0u : 1u;
-
-            /* out of samples, but not the closing window, in a state that one can take over from: see nfc_window_body */
-            if (done && L.windows[w].activate < startPos + mineCount && nfc_lane_comparable(s, *mem.cold))
-               how = 1u;
-
-            if (!done && startPos + consumed == verifyPos)
-               nfc_lane_publish(L.windows[w], s, *mem.cold);
-
-            if (!done && consumed >= warm && (flags[consumed / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_quiescent(s) &&
-                s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
-               done = true;
-
-            if (!done && consumed >= warm && nfc_lane_handover(L.windows, L.windows[w], succ, succEnd, startPos + consumed, s, *mem.cold))
-            {
-               done = true;
-               how = 2u;
-            }
-
-            if (done)
-            {
-               mem.cold->usedTech = *mem.flags;
-               L.states[w] = s;
-               L.windows[w].stop = startPos + consumed;
-               L.windows[w].retired = how;
-               active = false;
-
-               /* ran to the end of the submission with nobody to take over: may be the stream's last lane. Its rings are
-                * about to be reused by the next window this lane of the wave takes: leave a copy (NfcScanArgs::saveRings) */
-               if (how == 0u && L.windows[w].activate < startPos + mineCount)
-               {
-                  const uint32_t slot = atomicAdd(A.saveNext, 1u);
-
-                  if (slot < A.saveRoom)
-                  {
-                     const uint32_t rows = L.ringBlockFloats / NFC_LANES;
-                     const float *src = mem.ring + lane;
-                     float *dst = A.saveRings + (uint64_t)slot * rows;
-
-                     for (uint32_t i = 0; i < rows; i++)
-                        dst[i] = src[(uint64_t)i * NFC_LANES];
-
-                     const uint32_t *bs = (const uint32_t *)mem.bytes;
-                     uint32_t *bd = (uint32_t *)(A.saveBytes + (uint64_t)slot * NFC_STREAM_BYTES);
-
-                     for (uint32_t i = 0; i < NFC_STREAM_BYTES / 4; i++)
-                        bd[i] = bs[i];
-
-                     L.windows[w].saved = slot + 1u;
-                  }
-               }
-
-               atomicAdd(L.laneStats, (stepped + TILE - 1) / TILE);
-               atomicMax(L.laneStats + 1, (stepped + TILE - 1) / TILE);
-               atomicAdd(L.laneStats + 2, 1u);
-            }
-         }
-
-         /* dark signal ahead: jump */
-         if (active && consumed >= warm && (flags[consumed / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT) >= NFC_DARK_JUMP)
-         {
-            const NfcScanJob &job = A.jobs[L.windows[w].job];
-            consumed = nfc_lane_dark_jump(cc, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, startPos + consumed,
-                                          flags[consumed / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - startPos;
-         }
-
-         /* a waiting NFC-F decoder: skip to where its correlator can next reach the threshold */
-         {
-            const uint32_t pos = startPos + consumed;
-            const bool waiting = active && consumed >= warm && consumed < mineCount && pos >= lockUpkeepUntil && pos >= nextWaitScan && nfc_fwait_idle(s);
-
-            if (__any(waiting))
-               consumed = nfc_wave_fwait(cc, A, L.windows, waiting, w, pos, L.uniformStride, s, mem.cold, lockFrontUntil, lockUpkeepUntil, nextWaitScan,
-                                         waitScan) - startPos;
-         }
-
-         /* stage: row r = the next 64 samples of lane r's window */
-         nfc_stage_lanes(L, active ? data + (uint64_t)consumed * L.uniformStride * 4u : nullptr, active ? mineCount - consumed : 0u, lane, tile);
-
-         __syncthreads();
-
-         {
-            const uint32_t left = active ? mineCount - consumed : 0u;
-            const uint32_t n = left < TILE ? left : TILE;
-
-            const bool front = active && consumed < L.warmFront;
-            const bool upkeep = active && !front && consumed < warm;
-            const bool lockFront = active && !front && !upkeep && startPos + consumed < lockFrontUntil;
-            const bool lockUpkeep = active && !front && !upkeep && !lockFront && startPos + consumed < lockUpkeepUntil;
-            const bool full = active && !front && !upkeep && !lockFront && !lockUpkeep;
-
-            if (__any(front))
-            {
-               for (uint32_t k = 0; k < TILE; k++)
-               {
-                  if (front && k < n)
-                     nfc_step_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-               }
-            }
-
-            if (__any(upkeep))
-            {
-               for (uint32_t k = 0; k < TILE; k++)
-               {
-                  if (upkeep && k < n)
-                     nfc_step_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-               }
-            }
-
-            if (__any(lockFront))
-            {
-               for (uint32_t k = 0; k < TILE; k++)
-               {
-                  if (lockFront && k < n)
-                     nfc_step_lock_front<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-               }
-            }
-
-            if (__any(lockUpkeep))
-            {
-               for (uint32_t k = 0; k < TILE; k++)
-               {
-                  if (lockUpkeep && k < n)
-                     nfc_step_fwait_upkeep<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-               }
-            }
-
-            if (__any(full))
-            {
-               for (uint32_t k = 0; k < TILE; k++)
-               {
-                  if (full && k < n)
-                     nfc_step_as<false>(cc, s, mem, tile[lane * TILE_PITCH + k]);
-               }
-            }
-
-            consumed += n;
-            stepped += n;
-         }
-
-         __syncthreads();
-      }
-
-      steps += NFC_SCAN_POINT;
-   }
-}
-
-__global__ __launch_bounds__(64) void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
-{
-   __shared__ float tile[NFC_LANES * TILE_PITCH];
-   __shared__ uint32_t waitScan[192 + NFC_LANES];
-   nfc_window_body<true>(cfgPtr, L, A, tile, waitScan);
-}
-
 /* once the chain is settled: jobs whose last lane is a speculative window get that window set up again in their own
- * final-lane slot (A.finalLaneSlot + job), to be run by nfc_window_final_kernel */
+ * final-lane slot (A.finalLaneSlot + job), to be run by the wave decoder (nfc_wave_kernel, mode NFC_WAVE_FINAL) */
 __global__ __launch_bounds__(64) void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes)
 {
    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -109,10 +109,9 @@ struct NfcScanJob
 #define NFC_JOB_RERUN 0x04u     /* the chain kernel asked for another pass */
 #define NFC_JOB_GIVEUP 0x08u    /* too many passes: sequential path */
 #define NFC_JOB_OVERFLOW 0x10u  /* window table full: sequential path */
-#define NFC_JOB_DENSE 0x20u     /* so much of the signal is busy that cutting it into lanes does not pay: sequential path */
-#define NFC_JOB_ALONE 0x40u     /* busy signal in a submission of many streams: the stream's carry lane decodes it alone (no windows, one pass) */
+#define NFC_JOB_ALONE 0x40u     /* the stream's carry lane decodes it alone (no windows, one pass): samples off the capture grid */
 #define NFC_JOB_OFFGRID_SEEN 0x80u /* samples off the int16 grid in a stream that stays on the path (NfcScanParams::offGridAlone): no windows */
-#define NFC_JOB_INVALID (NFC_JOB_OFFGRID | NFC_JOB_SEAM | NFC_JOB_GIVEUP | NFC_JOB_OVERFLOW | NFC_JOB_DENSE)
+#define NFC_JOB_INVALID (NFC_JOB_OFFGRID | NFC_JOB_SEAM | NFC_JOB_GIVEUP | NFC_JOB_OVERFLOW)
 
 struct NfcScanChunk
 {

@@ -28,8 +28,6 @@ struct NfcScanParams
    uint32_t chunkSamples;  /* samples per chunk (multiple of NFC_SCAN_POINT) */
    uint32_t warmSamples;   /* samples walked before a chunk to reach the true front-end state (multiple of NFC_SCAN_POINT) */
    uint32_t soloSamples;   /* streams of at most this many samples get no speculative windows: their carry lane decodes them alone, in one pass */
-   uint32_t aloneStreams;  /* ... and so do the busy streams of a submission of at least this many streams (0: never): there are lanes enough */
-   uint32_t alonePercent;  /* busy: more than this share of the tiles has something for the decoder to do */
    uint32_t offGridAlone;  /* a stream with samples off the capture grid is decoded by its carry lane alone (the wave decoder walks the
                               running sums in the step's order there: nfc_wave_fast.hpp); 0: it takes the sequential kernels */
 };
@@ -498,15 +496,6 @@ NFC_DEV uint32_t nfc_windows_build(const NfcScanJob &job, uint32_t jobIndex, uin
 NFC_DEV uint64_t nfc_bits_from(uint64_t lo, uint64_t hi, uint32_t l)
 {
    return l == 0u ? lo : ((lo >> l) | (hi << (64u - l)));
-}
-
-NFC_DEV uint64_t nfc_group_valid(uint32_t nTiles, uint32_t g)
-{
-   const uint32_t first = g * 64u;
-   if (first >= nTiles)
-      return 0ull;
-   const uint32_t n = nTiles - first;
-   return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
 }
 
 /* a lane may retire at tile l of the group: tiles l .. l+15 exist and are not busy (`blocked`: busy or beyond the end) */
@@ -1002,143 +991,6 @@ NFC_DEV bool nfc_lane_handover(NfcWindow *windows, NfcWindow &me, uint32_t &succ
    me.stopDigest[0] = h[0];
    me.stopDigest[1] = h[1];
    return true;
-}
-
-/* A searching lane at tile boundary `pos` with `run` dark tiles ahead: through them the decoder does nothing but its front
- * end (no detector is stepped, the carrier detector has nothing to do: NFC_TILE_DARK), and the front end has been
- * scanned. The lane lands NFC_SCAN_POINT samples (rounded up to a stored point) before the dark tiles end, with the
- * scanned front end; detector records, running sums and correlation rings stay as they are (the reference's are frozen
- * too), the ring positions move on by the samples skipped, and the samples left before the dark ends refill the
- * history rings. Returns the sample the lane continues at (== pos: no jump). */
-NFC_DEV uint32_t nfc_lane_dark_jump(const NfcConfig &c, const NfcScanJob &job, const NfcScanPoint *points, const uint32_t *chunkEdge, uint32_t chunkSamples,
-                                    uint32_t clockBase, uint32_t pos, uint32_t run, NfcStreamState &s, const NfcStreamCold &cold)
-{
-   if (s.lockTech || s.unlock || run < NFC_DARK_JUMP)
-      return pos;
-
-   const uint32_t land = (pos + run * NFC_SCAN_TILE - NFC_SCAN_POINT) / NFC_SCAN_POINT * NFC_SCAN_POINT;
-
-   if (land <= pos + NFC_SCAN_POINT || land >= job.count)
-      return pos;
-
-   const NfcScanPoint &p = points[job.firstPoint + land / NFC_SCAN_POINT];
-   const uint32_t tracked = (p.zone & NFC_ZONE_EDGE_KNOWN) ? p.edgeTime : chunkEdge[job.firstChunk + land / chunkSamples];
-   const uint32_t skipped = land - pos;
-
-   s.clock = clockBase + land;
-   s.pulseFilter = p.pulseFilter;
-   s.env = p.env;
-   s.n1 = p.n1;
-   s.mdev = p.mdev;
-   s.avg = p.avg;
-   s.edgePeak = p.edgePeak;
-   s.edgeTime = (cold.emitValid && (int32_t)(tracked - cold.emitClock) <= 0) ? 0u : tracked;
-
-   s.posA[0] = (s.posA[0] + skipped) % c.a[0].p1;
-   s.posA[1] = (s.posA[1] + skipped) % c.a[1].p1;
-   s.posA[2] = (s.posA[2] + skipped) % c.a[2].p1;
-   s.posF[0] = (s.posF[0] + skipped) % c.f[1].p1;
-   s.posF[1] = (s.posF[1] + skipped) % c.f[2].p1;
-   s.posV1 = (s.posV1 + skipped) % c.v.p1;
-   s.posV0 = (s.posV0 + skipped) % c.v.p0;
-
-   return land;
-}
-
-/* ------------------------------------------------------------------------------------------ */
-/* waiting NFC-F decoder: what its correlator will see, exactly                                */
-/* ------------------------------------------------------------------------------------------ */
-
-/* nfcf_listen_start at the step that takes sample n (decode point cur = n - delay): acc = W(cur) + const with
- * W(k) = x[k-p2+1] + .. + x[k]; c2 = ring entry written p1 - p2 steps before, c3 = the one written the step before;
- * s0 = acc - c2, s1 = c2 - c3, sd = |s0 - s1| / p2, compared with the threshold taken at the end of the guard time. On the
- * int16 grid every W is an integer number of 1/32768 that a float holds exactly, so the three differences below are the
- * decoder's own values (int -> float rounds as the float subtraction would) and the rest is the decoder's arithmetic. */
-NFC_DEV bool nfc_fwait_hot(int32_t w0, int32_t wd, int32_t w1, uint32_t p2, float thr)
-{
-   const float s0 = (float)(w0 - wd) * (1.0f / 32768.0f);
-   const float s1 = (float)(wd - w1) * (1.0f / 32768.0f);
-   const float sd = nfc_abs(s0 - s1) / (float)p2;
-   return sd >= thr;
-}
-
-/* grid units of sample i of a stream (the scan has established that the stream is on the grid) */
-NFC_DEV int32_t nfc_grid_units(const uint8_t *data, uint32_t stride, uint32_t i)
-{
-   return (int32_t)(NFC_SAMPLE_AT(data, stride, i) * 32768.0f);
-}
-
-/* first sample in [from, limit) at whose step the waiting decoder's correlation reaches `thr`, or `limit`: the statement
- * of the rule, sample by sample (the kernels evaluate 64 samples at a time from prefix sums: nfc_wave_first_hot) */
-NFC_DEV uint32_t nfc_fwait_first_hot(const uint8_t *data, uint32_t stride, uint32_t from, uint32_t limit, uint32_t p1, uint32_t p2, uint32_t delay, float thr)
-{
-   for (uint32_t n = from; n < limit; n++)
-   {
-      const uint32_t cur = n - delay;
-      int32_t w0 = 0, wd = 0, w1 = 0;
-
-      for (uint32_t j = 0; j < p2; j++)
-      {
-         w0 += nfc_grid_units(data, stride, cur - j);
-         wd += nfc_grid_units(data, stride, cur - (p1 - p2) - j);
-         w1 += nfc_grid_units(data, stride, cur - 1u - j);
-      }
-
-      if (nfc_fwait_hot(w0, wd, w1, p2, thr))
-         return n;
-   }
-
-   return limit;
-}
-
-/* how far back from a sample the correlator of its step looks: the caller needs that much of the stream before `from` */
-#define NFC_FWAIT_LOOKBACK 128u
-
-/* A lane at tile boundary `pos` whose decoder is an idle waiting NFC-F decoder (nfc_fwait_idle), and `firstHot`: the
- * first sample from `pos` on whose step can change that (correlation at the threshold, waiting time over, end of the
- * submission). The lane lands 768 samples before it with the scanned front end, lets the front end refill the sample
- * history (512 samples, nfc_step_lock_front) and the correlator its ring (256, nfc_step_fwait_upkeep) and is then exactly
- * where the reference's decoder is. Detector records, their rings and sums stay frozen as in the reference (a locked
- * decoder does not step them); ring positions move on by the samples skipped. Returns the sample the lane continues at
- * (== pos: no jump). */
-NFC_DEV uint32_t nfc_lane_fwait_jump(const NfcConfig &c, const NfcScanJob &job, const NfcScanPoint *points, const uint32_t *chunkEdge, uint32_t chunkSamples,
-                                     uint32_t clockBase, uint32_t pos, uint32_t firstHot, NfcStreamState &s, const NfcStreamCold &cold)
-{
-   const uint32_t warm = NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
-
-   if (firstHot < pos + warm + 2u * NFC_SCAN_POINT || firstHot > job.count)
-      return pos;
-
-   const uint32_t land = (firstHot - warm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
-
-   if (land <= pos + NFC_SCAN_POINT)
-      return pos;
-
-   const NfcScanPoint &p = points[job.firstPoint + land / NFC_SCAN_POINT];
-   const uint32_t tracked = (p.zone & NFC_ZONE_EDGE_KNOWN) ? p.edgeTime : chunkEdge[job.firstChunk + land / chunkSamples];
-   const uint32_t skipped = land - pos;
-
-   s.clock = clockBase + land;
-   s.pulseFilter = p.pulseFilter;
-   s.env = p.env;
-   s.n1 = p.n1;
-   s.mdev = p.mdev;
-   s.avg = p.avg;
-   s.edgePeak = p.edgePeak;
-   s.edgeTime = (cold.emitValid && (int32_t)(tracked - cold.emitClock) <= 0) ? 0u : tracked;
-
-   s.posA[0] = (s.posA[0] + skipped) % c.a[0].p1;
-   s.posA[1] = (s.posA[1] + skipped) % c.a[1].p1;
-   s.posA[2] = (s.posA[2] + skipped) % c.a[2].p1;
-   s.posF[0] = (s.posF[0] + skipped) % c.f[1].p1;
-   s.posF[1] = (s.posF[1] + skipped) % c.f[2].p1;
-   s.posV1 = (s.posV1 + skipped) % c.v.p1;
-   s.posV0 = (s.posV0 + skipped) % c.v.p0;
-
-   s.u.decode.lockPos = (s.u.decode.lockPos + skipped) % s.u.decode.rt.p1;
-   s.u.decode.lock.acc = 0.0f;
-
-   return land;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -17,8 +17,6 @@ struct NfcScanParams
    uint32_t chunkSamples;
    uint32_t warmSamples;
    uint32_t soloSamples;
-   uint32_t aloneStreams;
-   uint32_t alonePercent;
    uint32_t offGridAlone; /* a stream with samples off the capture grid is decoded by its carry lane alone (the wave decoder walks
                              the running sums in the step's order there: nfc_wave_fast.hpp); 0: it takes the sequential kernels */
 };
@@ -32,7 +30,6 @@ struct NfcScanArgs
    uint32_t nChunks;
    uint32_t stride;            /* floats per sample of every job: 1 magnitude, 2 IQ */
    NfcScanParams params;
-   uint32_t densePercent;      /* streams with more than this share of busy tiles are decoded sequentially (> 100: never) */
    const NfcStreamState *states; /* the streams' own slots (state a submission starts from) */
    NfcScanPoint *points;
    NfcScanSeam *seams;         /* [nChunks] */
@@ -48,7 +45,6 @@ struct NfcScanArgs
    uint32_t *rerunCount;       /* jobs that need another decode pass (device counter) */
    NfcScanChunk *repairs;      /* chunks to walk again (nfc_seams_check), at most one per job and round */
    uint32_t *repairCount;
-   uint32_t *denseCount;       /* jobs routed to the sequential kernels (device counter) */
    uint32_t *runList;          /* speculative lanes to run in the coming pass (indices into the lane arrays) */
    uint32_t *runCount;         /* entries of runList (device counter) */
    uint32_t *runNext;          /* next entry a persistent wave takes (device counter) */

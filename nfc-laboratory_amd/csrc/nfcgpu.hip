@@ -10,17 +10,12 @@
 
 #include <dlfcn.h>
 
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
-#include <memory>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/nfcgpu.h"
@@ -47,10 +42,7 @@ __global__ void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanAr
 __global__ void nfc_windows_kernel(NfcScanArgs A);
 __global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint32_t pass);
 __global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass);
-__global__ void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
-__global__ void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
 __global__ void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes);
-__global__ void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A);
 __global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses);
 __global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
 __global__ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restrict__ out);
@@ -101,21 +93,8 @@ struct ProfiledLaunch
 
 }
 
-struct nfcgpu_shard;
-
 struct nfcgpu_ctx
 {
-   /* A shard (parent != nullptr) is a context of its own - HIP streams, work buffers of the time-parallel path, event
-    * pool, statistics - that serves a fixed range of its parent's stream slots from a thread of its own (see "shards"
-    * below): the stream table, the configuration table, the launch stamp and every device array of the slots are the
-    * parent's. */
-   explicit nfcgpu_ctx(nfcgpu_ctx *parent_ = nullptr)
-      : parent(parent_), configs(parent_ ? parent_->configs : ownConfigs), streams(parent_ ? parent_->streams : ownStreams),
-        launchSeq(parent_ ? parent_->launchSeq : ownLaunchSeq)
-   {
-   }
-
-   nfcgpu_ctx *parent;
    int device = 0;
    hipStream_t stream = nullptr;
    hipStream_t side = nullptr;       /* the carry lanes of a windowed pass run beside the speculative ones */
@@ -153,18 +132,15 @@ struct nfcgpu_ctx
    uint32_t stageNext = 0;
    bool inflight = false; /* something has been enqueued since the last stream synchronisation */
 
-   std::vector<NfcConfig> ownConfigs;
-   std::vector<StreamInfo> ownStreams;
-   std::atomic<uint32_t> ownLaunchSeq {0};
-   std::vector<NfcConfig> &configs;
-   std::vector<StreamInfo> &streams;
+   std::vector<NfcConfig> configs;
+   std::vector<StreamInfo> streams;
    std::vector<NfcWork> hWorks;
    std::vector<uint32_t> hSink;
 
    bool hold = false;
    bool profile = false;
    bool dirty = false; /* work submitted since last sync */
-   std::atomic<uint32_t> &launchSeq; /* stamp of the last demodulation launch (NfcLaunch::launchSeq), one sequence for a context and its shards */
+   uint32_t launchSeq = 0; /* stamp of the last demodulation launch (NfcLaunch::launchSeq) */
 
    /* ---- time-parallel path (nfc_scan.h): device buffers, grown on demand and kept ---- */
    bool windowed = true;           /* NFCGPU_WINDOWED=0 switches the path off */
@@ -182,16 +158,12 @@ struct nfcgpu_ctx
       size_t bytes = 0;
    };
    DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
-   uint32_t densePercent = 8;  /* streams busier than this go the sequential way (NFCGPU_DENSE_PERCENT, > 100: never) */
-   uint32_t windowWaves = 2048; /* persistent waves of the windowed decode (NFCGPU_WINDOW_WAVES) */
+   uint32_t busyPercent = 8;   /* a stream with more than this share of busy tiles is "busy": few long busy streams are decoded in blocks */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
-   bool wave = true;               /* lanes are decoded by the wave decoder (nfc_wave.hpp); NFCGPU_WAVE=0: by the lane-per-window kernels */
    uint32_t lanesWanted = 16384;    /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart) */
    uint32_t cutMax = 1u << 17;      /* ... but never further apart than this (NFCGPU_CUT_MAX) */
    uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
    uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
-   uint32_t aloneStreams = 0;       /* ... and so are the busy streams of a submission of at least this many streams (NFCGPU_ALONE_STREAMS; 0, the default: never - measured on MI355X a lone lane does 2.4 MS/s of busy signal, so 2^20 samples take longer than the passes they save) */
-   uint32_t alonePercent = 25;      /* busy: more than this share of a stream's tiles has work for the decoder (NFCGPU_ALONE_PERCENT) */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
 
@@ -204,48 +176,6 @@ struct nfcgpu_ctx
    nfcgpu_stats stats {};
    std::string lastError;
 
-   /* ---- shards: large device-resident uniform submissions are decoded by several host threads, each with a slice of
-    * the slots, so that the latency-bound ends of one slice's submission (repair rounds of the scan, the later decode
-    * passes: a few long lanes each) run beside the throughput-bound middle of another's, and submission k + 1 of a slice
-    * begins as soon as its own submission k is done, whatever the other slices are at (nfcgpu_submit_uniform) ---- */
-   std::vector<std::unique_ptr<nfcgpu_shard>> shards;
-   uint32_t shardCount = 0;        /* NFCGPU_SHARDS (0 or 1: none) */
-   uint32_t shardMinStreams = 128; /* a slice is worth a thread from this many streams on */
-   uint32_t shardSpan = 0;         /* slots per shard: slot / shardSpan is the shard, for the life of the context */
-   bool shardStagger = true;
-   bool asyncInFlight = false;     /* jobs have been handed to shards since the last drain */
-   std::mutex staggerMutex;        /* the first submission after a drain starts the shards one after the other: shard g */
-   std::condition_variable staggerCv; /* waits until g shards before it are through the first decode pass of theirs */
-   uint32_t staggerTicket = 0;
-   bool staggerOwed = false;       /* (shard) this job still owes the parent its ticket */
-   uint32_t sizingStreams = 0;     /* (shard) streams of the whole submission the job at hand is a slice of: chunks and lanes are
-                                      sized for the submission, not for the slice (the machine is shared with the other slices) */
-};
-
-/* one slice of a uniform submission */
-struct nfcgpu_async_job
-{
-   uint32_t first = 0, count = 0;
-   const uint8_t *base = nullptr; /* row of slot `first` */
-   uint64_t pitch = 0;
-   uint32_t n = 0, stride = 0;
-   bool profile = false;
-   bool staggered = false;
-   uint32_t waitTicket = 0;
-   uint32_t submissionStreams = 0;
-};
-
-struct nfcgpu_shard
-{
-   std::unique_ptr<nfcgpu_ctx> ctx;
-   std::thread thread;
-   std::mutex m;
-   std::condition_variable cv;
-   std::deque<nfcgpu_async_job> queue; /* front = the job being run while `running` */
-   bool running = false;
-   bool stop = false;
-   int error = 0; /* first failure since the last drain: later jobs of the shard are dropped */
-   std::string errorText;
 };
 
 namespace {
@@ -483,8 +413,6 @@ hipEvent_t take_event(nfcgpu_ctx *ctx)
    return e;
 }
 
-void stagger_signal(nfcgpu_ctx *ctx);
-
 int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t samples, bool exactPossible, bool exactOnly)
 {
    const uint32_t firstBlock = L.firstSlot / NFC_LANES;
@@ -507,12 +435,9 @@ int launch_demod(nfcgpu_ctx *ctx, uint32_t config, NfcLaunch &L, uint64_t sample
     * variant (the first buffer of freshly opened streams) does not need the common kernel at all */
    L.forceExact = exactOnly ? 1u : 0u;
 
-   {
-      uint32_t stamp = ctx->launchSeq.fetch_add(1u) + 1u;
-      if (stamp == 0)
-         stamp = ctx->launchSeq.fetch_add(1u) + 1u;
-      L.launchSeq = stamp;
-   }
+   if (++ctx->launchSeq == 0)
+      ctx->launchSeq = 1;
+   L.launchSeq = ctx->launchSeq;
 
    if (!exactOnly)
    {
@@ -783,10 +708,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       sp.deepK = 0.98f * deep;
       sp.chunkSamples = ctx->scanChunk;
       sp.warmSamples = ctx->scanWarm;
-      sp.soloSamples = ctx->wave ? ctx->soloSamples : 0u; /* (the lane-per-window kernels let carry lanes retire) */
-      sp.aloneStreams = ctx->wave ? ctx->aloneStreams : 0u;
-      sp.alonePercent = ctx->alonePercent;
-      sp.offGridAlone = ctx->wave ? 1u : 0u;
+      sp.soloSamples = ctx->soloSamples;
+      sp.offGridAlone = 1u;
 
       /* Every chunk pays the warm-up again, so chunks should be as long as the machine allows: one lane per chunk, and
        * 131072 lanes (256 CUs x 4 SIMDs x 2 waves of the scan kernel's 204 registers x 64) are resident at a time.
@@ -796,10 +719,6 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          uint64_t total = 0;
          for (const WindowedItem &it: items)
             total += it.count;
-
-         /* (a slice of a sharded submission: the chunks of all slices share the machine) */
-         if (ctx->sizingStreams > nJobs)
-            total = total / nJobs * ctx->sizingStreams;
 
          uint64_t chunk = total / 131072u / NFC_SCAN_POINT * NFC_SCAN_POINT;
          if (chunk > 32768u)
@@ -849,8 +768,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
     * further apart - fewer warm-ups, fewer hand-overs to go wrong - when that still leaves several lanes per wave slot
     * of the machine (NFCGPU_LANES_WANTED, default 16384 = 8 per slot of 256 CUs x 8 waves) */
    {
-      const uint64_t sizingSamples = ctx->sizingStreams > nJobs ? totalSamples / nJobs * ctx->sizingStreams : totalSamples;
-      uint64_t cut = ctx->lanesWanted ? sizingSamples / ctx->lanesWanted : 0u;
+      uint64_t cut = ctx->lanesWanted ? totalSamples / ctx->lanesWanted : 0u;
       cut = cut / NFC_SCAN_POINT * NFC_SCAN_POINT;
       cut = cut < NFC_WINDOW_CUT ? NFC_WINDOW_CUT : (cut > ctx->cutMax ? ctx->cutMax : cut);
 
@@ -875,7 +793,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    /* records per lane slot (carry lanes, final lanes, one per window); ring and frame-assembly storage per carry lane,
     * final lane and per lane of the persistent waves that run the windows */
-   const size_t storageLanes = (size_t)firstWindowSlot + (size_t)ctx->windowWaves * NFC_LANES;
+   const size_t storageLanes = (size_t)firstWindowSlot; /* (a speculative window's rings live in LDS; one that runs to the end leaves a copy in the save area) */
 
    auto growLanes = [&](uint32_t lanesWanted) -> int {
       const size_t lanes = ((size_t)lanesWanted + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
@@ -926,7 +844,6 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.nChunks = nChunks;
    A.stride = stride;
    A.params = sp;
-   A.densePercent = ctx->densePercent;
    A.states = ctx->dStates;
    A.points = (NfcScanPoint *)ctx->wPoints.ptr;
    A.seams = (NfcScanSeam *)ctx->wSeams.ptr;
@@ -945,7 +862,6 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.runList = (uint32_t *)ctx->wRunList.ptr;
    A.repairs = (NfcScanChunk *)ctx->wRepairs.ptr;
    A.repairCount = counters + 7;
-   A.denseCount = counters + 9;
 
    /* save area for lanes that run to the end of the submission (nfc_scan_launch.h): a few per stream */
    {
@@ -1022,8 +938,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       hipLaunchKernelGGL(nfc_seams_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, round == 0 ? 1u : 0u);
       HIP_TRY(ctx, hipGetLastError());
 
-      uint32_t word[3] = {0, 0, 0}; /* repairs, (save area), dense jobs */
-      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 12, hipMemcpyDeviceToHost, ctx->stream));
+      uint32_t word[1] = {0}; /* chunks to walk again */
+      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
 
       /* (a small submission: how busy are its streams? the tile tests have counted) */
       const bool small = round == 0 && nJobs < NFC_LANES && !ctx->inBlocks;
@@ -1044,20 +960,12 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          for (uint32_t j = 0; j < nJobs; j++)
          {
             const uint64_t nTiles = ((uint64_t)jobs[j].count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-            busy = busy || (uint64_t)jobs[j].busyTiles * 100u > nTiles * ctx->densePercent;
+            busy = busy || (uint64_t)jobs[j].busyTiles * 100u > nTiles * ctx->busyPercent;
             longest = jobs[j].count > longest ? jobs[j].count : longest;
          }
 
          if (busy && longest > ctx->blockSamples)
             return run_in_blocks(ctx, config, items, stride);
-      }
-
-      /* The sequential kernels take as long for one stream as for a hundred thousand (one lane each): once half of the
-       * submission goes there anyway, cutting the other half into lanes first only adds its time on top. */
-      if (round == 0 && (uint64_t)word[2] * 2u >= nJobs)
-      {
-         ctx->stats.fallback_streams += nJobs;
-         return launch_sequential(ctx, config, items, stride);
       }
 
       if (debugStages)
@@ -1084,7 +992,6 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    /* The wave decoder takes the front end's results per sample instead of walking it again: a second walk of every
     * chunk from its verified start state (the repair form of the scan: no warm-up) writes them. */
-   if (ctx->wave)
    {
       if ((rc = grow(ctx, ctx->wPlanes, (size_t)tiles * NFC_SCAN_TILE * 16u)) || (rc = grow(ctx, ctx->wPlaneChunks, sizeof(NfcScanChunk) * nChunks)))
       {
@@ -1193,17 +1100,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       L.warmFront = carry ? 0u : NFC_WINDOW_WARM_FRONT;
       L.warmCorr = carry ? 0u : NFC_WINDOW_WARM_CORR;
 
-      const uint32_t blocks = (firstSlot % NFC_LANES + slotCount + NFC_LANES - 1) / NFC_LANES;
-
-      if (ctx->wave)
-      {
-         ProfiledLaunch wl {nullptr, nullptr};
-         record_span(ctx, ctx->timedWave, wl, true, on);
-         hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
-         record_span(ctx, ctx->timedWave, wl, false, on);
-      }
-      else
-         hipLaunchKernelGGL(carry ? nfc_window_carry_kernel : nfc_window_final_kernel, dim3(blocks), dim3(NFC_LANES), 0, on, dCfg, L, A);
+      ProfiledLaunch wl {nullptr, nullptr};
+      record_span(ctx, ctx->timedWave, wl, true, on);
+      hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
+      record_span(ctx, ctx->timedWave, wl, false, on);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
       return NFCGPU_OK;
@@ -1215,19 +1115,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       L.warmFront = NFC_WINDOW_WARM_FRONT;
       L.warmCorr = NFC_WINDOW_WARM_CORR;
 
-      uint32_t waves = (nWindows + NFC_LANES - 1) / NFC_LANES;
-      if (waves > ctx->windowWaves)
-         waves = ctx->windowWaves;
-
-      if (ctx->wave)
-      {
-         ProfiledLaunch wl {nullptr, nullptr};
-         record_span(ctx, ctx->timedWave, wl, true);
-         hipLaunchKernelGGL(nfc_wave_kernel, dim3(nWindows), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
-         record_span(ctx, ctx->timedWave, wl, false);
-      }
-      else
-         hipLaunchKernelGGL(nfc_window_kernel, dim3(waves), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A);
+      ProfiledLaunch wl {nullptr, nullptr};
+      record_span(ctx, ctx->timedWave, wl, true);
+      hipLaunchKernelGGL(nfc_wave_kernel, dim3(nWindows), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
+      record_span(ctx, ctx->timedWave, wl, false);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
       return NFCGPU_OK;
@@ -1322,8 +1213,6 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       uint32_t again = 0;
       HIP_TRY(ctx, hipMemcpyAsync(&again, counters + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-
-      stagger_signal(ctx); /* (a shard's first decode pass is through: the next shard of a staggered start may begin) */
 
       if (debugPasses)
       {
@@ -1648,8 +1537,7 @@ Rccl *rccl()
 
 namespace {
 
-/* what a context owns besides the slots: streams, events, the work buffers of the time-parallel path (a shard owns
- * nothing else) */
+/* what a context owns besides the slots: streams, events, the work buffers of the time-parallel path */
 void release_workspace(nfcgpu_ctx *ctx)
 {
    if (ctx->stream)
@@ -1726,9 +1614,6 @@ void collect_timings(nfcgpu_ctx *ctx)
 }
 
 int run_rows(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride);
-int drain_async(nfcgpu_ctx *ctx);
-bool shards_wanted(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, uint32_t n);
-int submit_to_shards(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride);
 
 }
 
@@ -1792,31 +1677,16 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
    ctx->maxPassesFew = knob("NFCGPU_WINDOW_PASSES_FEW", knob("NFCGPU_WINDOW_PASSES", ctx->maxPassesFew));
-   ctx->windowWaves = knob("NFCGPU_WINDOW_WAVES", ctx->windowWaves);
-   ctx->wave = knob("NFCGPU_WAVE", 1) != 0;
    ctx->soloSamples = knob("NFCGPU_SOLO_SAMPLES", ctx->soloSamples);
    ctx->stagingWords = knob("NFCGPU_STAGING_WORDS", ctx->stagingWords);
    ctx->lanesWanted = knob("NFCGPU_LANES_WANTED", ctx->lanesWanted);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;
-   ctx->aloneStreams = knob("NFCGPU_ALONE_STREAMS", ctx->aloneStreams);
-   ctx->alonePercent = knob("NFCGPU_ALONE_PERCENT", ctx->alonePercent);
-   /* busy streams: a wave per lane decodes them where they are; the lane-per-window kernels send them to the sequential ones */
-   ctx->densePercent = knob("NFCGPU_DENSE_PERCENT", ctx->wave ? 101u : ctx->densePercent);
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);
-   ctx->shardCount = knob("NFCGPU_SHARDS", ctx->shardCount);
-   if (ctx->shardCount > 16)
-      ctx->shardCount = 16;
-   ctx->shardStagger = knob("NFCGPU_SHARD_STAGGER", 1) != 0;
-   ctx->shardMinStreams = knob("NFCGPU_SHARD_MIN", ctx->shardMinStreams);
-   if (ctx->shardMinStreams == 0)
-      ctx->shardMinStreams = 1;
    ctx->blockSamples = knob("NFCGPU_BLOCK_SAMPLES", ctx->blockSamples) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    if (ctx->blockSamples < 65536u)
       ctx->blockSamples = 65536u;
-   if (ctx->windowWaves == 0)
-      ctx->windowWaves = 1;
 
    if (ctx->scanWarm < NFC_SCAN_POINT)
       ctx->scanWarm = NFC_SCAN_POINT;
@@ -1891,20 +1761,6 @@ int nfcgpu_shutdown(nfcgpu_ctx *ctx)
 
    (void)hipSetDevice(ctx->device);
 
-   /* the shards first: their threads end once their queues are empty, nothing of their work outlives the slots */
-   for (auto &sh: ctx->shards)
-   {
-      {
-         std::lock_guard<std::mutex> lock(sh->m);
-         sh->stop = true;
-      }
-      sh->cv.notify_all();
-      if (sh->thread.joinable())
-         sh->thread.join();
-      release_workspace(sh->ctx.get());
-   }
-   ctx->shards.clear();
-
    if (ctx->stream)
       (void)hipStreamSynchronize(ctx->stream);
    if (ctx->side)
@@ -1941,11 +1797,6 @@ int nfcgpu_stream_open_many(nfcgpu_ctx *ctx, const nfcgpu_params *params, uint32
    if (!ctx || !first || count == 0)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
 
    /* first fit of `count` contiguous free slots */
    uint32_t run = 0, start = 0;
@@ -1999,11 +1850,6 @@ int nfcgpu_stream_configure(nfcgpu_ctx *ctx, uint32_t id, const nfcgpu_params *p
    if (!ctx || !params)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
@@ -2036,11 +1882,6 @@ int nfcgpu_stream_reset(nfcgpu_ctx *ctx, uint32_t id)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
@@ -2058,11 +1899,6 @@ int nfcgpu_stream_close(nfcgpu_ctx *ctx, uint32_t id)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
@@ -2078,11 +1914,6 @@ int nfcgpu_submit_batch(nfcgpu_ctx *ctx, const nfcgpu_batch *b)
        (b->location != NFCGPU_LOC_HOST && b->location != NFCGPU_LOC_DEVICE))
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    if (b->n_streams == 0)
       return NFCGPU_OK;
 
@@ -2454,25 +2285,6 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
 
    HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-   /* While earlier submissions are still with the shards, the next one may join them as it is - same streams running on,
-    * nothing to (re)initialise, no table of the context to change -; anything else waits for them first. */
-   {
-      bool joins = ctx->asyncInFlight && location == NFCGPU_LOC_DEVICE && n != 0 && shards_wanted(ctx, first, count, n);
-
-      for (uint32_t i = first; joins && i < first + count; i++)
-      {
-         const StreamInfo &si = ctx->streams[i];
-         joins = si.open && si.initialized && !si.needInit && si.derivedRate != 0 && si.params.sample_rate == sampleRate;
-      }
-
-      if (!joins)
-      {
-         const int drained = drain_async(ctx);
-         if (drained)
-            return drained;
-      }
-   }
-
    /* an empty buffer still stores a new sample rate and re-initialises the stream, like nfcgpu_submit (NfcDecoder.cpp:383-388) */
    for (uint32_t i = first; i < first + count; i++)
    {
@@ -2523,11 +2335,6 @@ int nfcgpu_submit_uniform(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const
    if (rc)
       return rc;
 
-   /* large device-resident submissions: a slice of the slots per shard thread, the call returns with the work handed
-    * over (the header's contract: device memory stays as it is until the next nfcgpu_sync / poll / flush / pending) */
-   if (location == NFCGPU_LOC_DEVICE && shards_wanted(ctx, first, count, n))
-      return submit_to_shards(ctx, first, count, devBase, devPitch, n, stride);
-
    rc = run_rows(ctx, first, count, devBase, devPitch, n, stride);
    if (rc)
       return rc;
@@ -2541,11 +2348,6 @@ int nfcgpu_sync(nfcgpu_ctx *ctx)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
 
    /* nothing enqueued since the last synchronisation and nothing to collect: no device call at all */
    if (!ctx->inflight && !ctx->dirty && ctx->timed.empty() && ctx->timedScan.empty() && ctx->timedWindow.empty() && ctx->timedWave.empty() && ctx->timedPlanes.empty())
@@ -2666,11 +2468,6 @@ int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cu
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    if (words)
       *words = ctx->dSink;
    if (cursor)
@@ -2685,11 +2482,6 @@ int nfcgpu_sink_attach(nfcgpu_ctx *ctx, void *words, uint64_t capacityWords, voi
    if (!ctx || (words && (!ctl || capacityWords < 4ull * NFC_FRAME_MAX_WORDS || capacityWords > 0xFFFFFFF0ull)))
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
 
    const bool wasHeld = ctx->hold;
    ctx->hold = false;
@@ -2720,11 +2512,6 @@ int nfcgpu_sink_hold(nfcgpu_ctx *ctx, int hold)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    ctx->hold = hold != 0;
    return NFCGPU_OK;
 }
@@ -2734,11 +2521,6 @@ int nfcgpu_sink_rewind(nfcgpu_ctx *ctx)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    HIP_TRY(ctx, hipSetDevice(ctx->device));
    HIP_TRY(ctx, hipMemsetAsync(ctx->dSinkCtl, 0, 16, ctx->stream));
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2822,11 +2604,6 @@ static int gather_frames(nfcgpu_ctx *ctx, void *gathered, uint64_t capacityWords
    if (!ctx || !gathered || !countsHost || (!packed && !strideWords))
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    if (!ctx->comm)
       return fail(ctx, NFCGPU_EINVAL, "nfcgpu_comm_init first");
    if (!ctx->hold)
@@ -2919,11 +2696,6 @@ int nfcgpu_read_bandwidth(nfcgpu_ctx *ctx, const void *ptr, uint64_t bytes, uint
    if (!ctx || !ptr || bytes < 16 || !gbps || ((uintptr_t)ptr & 15))
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
 
    HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -2961,11 +2733,6 @@ int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats)
    if (!ctx || !stats)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    std::memcpy(stats, &ctx->stats, NFCGPU_STATS_SIZE_V2); /* a caller built against the older header holds no more */
    return NFCGPU_OK;
 }
@@ -2975,11 +2742,6 @@ int nfcgpu_stats_get_sized(nfcgpu_ctx *ctx, void *stats, uint32_t size)
    if (!ctx || !stats)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    std::memcpy(stats, &ctx->stats, size < sizeof(nfcgpu_stats) ? size : sizeof(nfcgpu_stats));
    return NFCGPU_OK;
 }
@@ -2989,11 +2751,6 @@ int nfcgpu_stats_reset(nfcgpu_ctx *ctx)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    ctx->stats = nfcgpu_stats();
    return NFCGPU_OK;
 }
@@ -3003,11 +2760,6 @@ int nfcgpu_profile(nfcgpu_ctx *ctx, int enable)
    if (!ctx)
       return NFCGPU_EINVAL;
 
-   {
-      const int drained = drain_async(ctx);
-      if (drained)
-         return drained;
-   }
    ctx->profile = enable != 0;
    return NFCGPU_OK;
 }
@@ -3076,7 +2828,7 @@ const char *nfcgpu_version(void)
 namespace {
 
 /* rows first .. first + count - 1 of a uniform submission resident on the device: contiguous runs of one configuration ->
- * one launch each (normally exactly one). Runs on the calling thread, on the streams of `ctx` (a context or a shard). */
+ * one launch each (normally exactly one) */
 int run_rows(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride)
 {
    int rc = NFCGPU_OK;
@@ -3134,291 +2886,6 @@ int run_rows(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *dev
    }
 
    return NFCGPU_OK;
-}
-
-/* ---- shards ---- */
-
-/* a shard that owes the parent its ticket hands it in: the next shard of a staggered start may begin */
-void stagger_signal(nfcgpu_ctx *ctx)
-{
-   if (!ctx->parent || !ctx->staggerOwed)
-      return;
-
-   ctx->staggerOwed = false;
-   {
-      std::lock_guard<std::mutex> lock(ctx->parent->staggerMutex);
-      ctx->parent->staggerTicket++;
-   }
-   ctx->parent->staggerCv.notify_all();
-}
-
-int shard_run(nfcgpu_ctx *parent, nfcgpu_shard *sh, const nfcgpu_async_job &job)
-{
-   nfcgpu_ctx *c = sh->ctx.get();
-
-   /* what the parent may have changed since the shard was made */
-   c->profile = job.profile;
-   c->dSink = parent->dSink;
-   c->dSinkCtl = parent->dSinkCtl;
-   c->sinkWords = parent->sinkWords;
-   c->ownSinkWords = parent->ownSinkWords;
-
-   if (job.staggered)
-   {
-      std::unique_lock<std::mutex> lock(parent->staggerMutex);
-      parent->staggerCv.wait(lock, [&] { return parent->staggerTicket >= job.waitTicket; });
-   }
-
-   c->staggerOwed = job.staggered;
-   c->sizingStreams = job.submissionStreams;
-
-   int rc = run_rows(c, job.first, job.count, job.base, job.pitch, job.n, job.stride);
-
-   if (hipStreamSynchronize(c->stream) != hipSuccess && rc == NFCGPU_OK)
-      rc = fail(c, NFCGPU_EHIP, "hipStreamSynchronize (shard)");
-   (void)hipStreamSynchronize(c->side);
-
-   stagger_signal(c); /* (a job that did not get as far as its first decode pass) */
-   return rc;
-}
-
-void shard_main(nfcgpu_ctx *parent, nfcgpu_shard *sh)
-{
-   (void)hipSetDevice(parent->device);
-
-   for (;;)
-   {
-      nfcgpu_async_job job;
-      bool skip;
-
-      {
-         std::unique_lock<std::mutex> lock(sh->m);
-         sh->cv.wait(lock, [&] { return sh->stop || !sh->queue.empty(); });
-
-         if (sh->queue.empty())
-            return;
-
-         job = sh->queue.front();
-         sh->running = true;
-         skip = sh->error != 0;
-      }
-
-      int rc = NFCGPU_OK;
-
-      if (!skip)
-         rc = shard_run(parent, sh, job);
-      else if (job.staggered)
-      {
-         sh->ctx->staggerOwed = true;
-         stagger_signal(sh->ctx.get());
-      }
-
-      {
-         std::lock_guard<std::mutex> lock(sh->m);
-
-         if (rc && !sh->error)
-         {
-            sh->error = rc;
-            sh->errorText = sh->ctx->lastError;
-         }
-
-         sh->queue.pop_front();
-         sh->running = false;
-      }
-      sh->cv.notify_all();
-   }
-}
-
-/* the shards of a context are made when the first submission wants them */
-int make_shards(nfcgpu_ctx *ctx)
-{
-   if (!ctx->shards.empty())
-      return NFCGPU_OK;
-
-   const uint32_t nShards = ctx->shardCount;
-   ctx->shardSpan = ((ctx->maxStreams + nShards - 1) / nShards + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
-
-   for (uint32_t g = 0; g < nShards; g++)
-   {
-      std::unique_ptr<nfcgpu_shard> sh(new (std::nothrow) nfcgpu_shard());
-      if (!sh)
-         return fail(ctx, NFCGPU_ENOMEM, "shard");
-
-      sh->ctx.reset(new (std::nothrow) nfcgpu_ctx(ctx));
-      nfcgpu_ctx *c = sh->ctx.get();
-      if (!c)
-         return fail(ctx, NFCGPU_ENOMEM, "shard context");
-
-      c->device = ctx->device;
-      c->maxStreams = ctx->maxStreams;
-      c->blocks = ctx->blocks;
-      c->dStates = ctx->dStates;
-      c->dCold = ctx->dCold;
-      c->dRings = ctx->dRings;
-      c->dBytes = ctx->dBytes;
-      c->dWorks = ctx->dWorks;
-      c->dConfigs = ctx->dConfigs;
-      c->genericOnly = ctx->genericOnly;
-      c->sideMode = ctx->sideMode;
-      c->windowed = ctx->windowed;
-      c->windowedMinSamples = ctx->windowedMinSamples;
-      c->scanChunk = ctx->scanChunk;
-      c->scanChunkFixed = ctx->scanChunkFixed;
-      c->blockSamples = ctx->blockSamples;
-      c->scanWarm = ctx->scanWarm;
-      c->maxPasses = ctx->maxPasses;
-      c->maxPassesFew = ctx->maxPassesFew;
-      c->densePercent = ctx->densePercent;
-      c->windowWaves = ctx->windowWaves;
-      c->wave = ctx->wave;
-      c->lanesWanted = ctx->lanesWanted;
-      c->cutMax = ctx->cutMax;
-      c->stagingWords = ctx->stagingWords;
-      c->soloSamples = ctx->soloSamples;
-      c->aloneStreams = ctx->aloneStreams;
-      c->alonePercent = ctx->alonePercent;
-      c->shardCount = 0; /* (a shard has none of its own) */
-
-      bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-      ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
-      ok = ok && hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming) == hipSuccess;
-      ok = ok && hipEventCreateWithFlags(&c->joinEvent, hipEventDisableTiming) == hipSuccess;
-
-      if (!ok)
-      {
-         release_workspace(c);
-         return fail(ctx, NFCGPU_EHIP, "streams of a shard");
-      }
-
-      nfcgpu_shard *raw = sh.get();
-      ctx->shards.push_back(std::move(sh));
-      raw->thread = std::thread(shard_main, ctx, raw);
-   }
-
-   return NFCGPU_OK;
-}
-
-/* does this uniform submission go to the shards? (at least two of them get a slice worth a thread) */
-bool shards_wanted(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, uint32_t n)
-{
-   if (ctx->parent || ctx->shardCount < 2 || !ctx->windowed || n < ctx->windowedMinSamples)
-      return false;
-
-   const uint32_t span = ((ctx->maxStreams + ctx->shardCount - 1) / ctx->shardCount + NFC_LANES - 1) / NFC_LANES * NFC_LANES;
-   uint32_t worth = 0;
-
-   for (uint32_t g = 0; g < ctx->shardCount; g++)
-   {
-      const uint64_t lo = (uint64_t)g * span > first ? (uint64_t)g * span : first;
-      const uint64_t hi = (uint64_t)(g + 1) * span < (uint64_t)first + count ? (uint64_t)(g + 1) * span : (uint64_t)first + count;
-      if (hi > lo && hi - lo >= ctx->shardMinStreams)
-         worth++;
-   }
-
-   return worth >= 2;
-}
-
-int submit_to_shards(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride)
-{
-   int rc = make_shards(ctx);
-   if (rc)
-      return rc;
-
-   /* the slots have been initialised on the context's stream: done before a shard touches them */
-   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-
-   const bool cold = !ctx->asyncInFlight && ctx->shardStagger; /* first hand-over since the last drain: a staggered start */
-
-   if (cold)
-   {
-      std::lock_guard<std::mutex> lock(ctx->staggerMutex);
-      ctx->staggerTicket = 0;
-   }
-
-   uint32_t ticket = 0;
-
-   for (uint32_t g = 0; g < (uint32_t)ctx->shards.size(); g++)
-   {
-      const uint64_t lo = (uint64_t)g * ctx->shardSpan > first ? (uint64_t)g * ctx->shardSpan : first;
-      const uint64_t hi = (uint64_t)(g + 1) * ctx->shardSpan < (uint64_t)first + count ? (uint64_t)(g + 1) * ctx->shardSpan : (uint64_t)first + count;
-
-      if (hi <= lo)
-         continue;
-
-      nfcgpu_async_job job;
-      job.first = (uint32_t)lo;
-      job.count = (uint32_t)(hi - lo);
-      job.base = devBase + (lo - first) * devPitch;
-      job.pitch = devPitch;
-      job.n = n;
-      job.stride = stride;
-      job.profile = ctx->profile;
-      job.staggered = cold;
-      job.waitTicket = ticket++;
-      job.submissionStreams = count;
-
-      nfcgpu_shard *sh = ctx->shards[g].get();
-      {
-         std::lock_guard<std::mutex> lock(sh->m);
-         sh->queue.push_back(job);
-      }
-      sh->cv.notify_all();
-   }
-
-   ctx->asyncInFlight = true;
-   ctx->inflight = true;
-   ctx->dirty = true;
-   return NFCGPU_OK;
-}
-
-/* waits for everything handed to the shards, takes over their statistics and the first failure */
-int drain_async(nfcgpu_ctx *ctx)
-{
-   if (!ctx->asyncInFlight)
-      return NFCGPU_OK;
-
-   int rc = NFCGPU_OK;
-
-   for (auto &sh: ctx->shards)
-   {
-      {
-         std::unique_lock<std::mutex> lock(sh->m);
-         sh->cv.wait(lock, [&] { return sh->queue.empty() && !sh->running; });
-
-         if (sh->error && rc == NFCGPU_OK)
-         {
-            rc = sh->error;
-            ctx->lastError = sh->errorText;
-         }
-
-         sh->error = 0;
-         sh->errorText.clear();
-      }
-
-      nfcgpu_ctx *c = sh->ctx.get();
-      collect_timings(c); /* (the shard waits for its streams at the end of every job) */
-
-      nfcgpu_stats &a = ctx->stats, &b = c->stats;
-      a.launches += b.launches;
-      a.samples += b.samples;
-      a.kernel_ms += b.kernel_ms;
-      a.scan_ms += b.scan_ms;
-      a.window_ms += b.window_ms;
-      a.scan_samples += b.scan_samples;
-      a.windows += b.windows;
-      a.window_passes += b.window_passes;
-      a.windowed_streams += b.windowed_streams;
-      a.fallback_streams += b.fallback_streams;
-      a.scan_repairs += b.scan_repairs;
-      a.wave_ms += b.wave_ms;
-      a.wave_launches += b.wave_launches;
-      a.planes_ms += b.planes_ms;
-      b = nfcgpu_stats {};
-      c->dirty = false;
-   }
-
-   ctx->asyncInFlight = false;
-   return rc;
 }
 
 }

@@ -1,5 +1,5 @@
 """Randomised parity of the host runtime + time-parallel path on the emulated runtime (test infrastructure; see profiles/r02/emulated_fuzz.json).
-usage: NFCGPU_LIB=tests/hostsim/libnfcgpu_emulated.so NFCGPU_DENSE_PERCENT=100 python profiles/tools/r02/emulated_fuzz.py <seed> <seconds> [small]
+usage: NFCGPU_LIB=tests/hostsim/libnfcgpu_emulated.so python profiles/tools/r02/emulated_fuzz.py <seed> <seconds> [small]
 (small: at most 6 streams of at most 9 x 32768 samples per scenario - what the CPU suite runs; round 4: a quarter of the scenarios is taken off the
 int16 grid - a gain and white noise, what a radio delivers -: carry lanes with walked sums)"""
 import os, sys, json, time

@@ -25,7 +25,7 @@ with nfclab_amd.NfcGpu(device=0, max_streams=max(64, len(streams))) as gpu:
 TECH = {"101": "NFC-A", "102": "NFC-B", "103": "NFC-F", "104": "NFC-V", "0": "searching"}
 
 def run(kind, S, L, extra=None):
-    env = dict(os.environ, NFCGPU_LIB=os.path.join(ROOT, "tests", "hostsim", "libnfcgpu_emulated.so"), NFCGPU_NO_TORCH="1", NFCGPU_DENSE_PERCENT="101",
+    env = dict(os.environ, NFCGPU_LIB=os.path.join(ROOT, "tests", "hostsim", "libnfcgpu_emulated.so"), NFCGPU_NO_TORCH="1",
                NFCGPU_WINDOW_DEBUG="1", NFC_EMU_DEBUG5="1")
     out = subprocess.run([sys.executable, "-c", DRIVER, kind, str(S), str(L)] + (extra or []), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stderr
     passes, blocked = [], collections.Counter()

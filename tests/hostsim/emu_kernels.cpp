@@ -316,207 +316,6 @@ void copy_lane(const NfcLaunch &from, uint32_t a, const NfcLaunch &to, uint32_t 
    std::memcpy(to.bytes + (uint64_t)b * NFC_STREAM_BYTES, from.bytes + (uint64_t)a * NFC_STREAM_BYTES, NFC_STREAM_BYTES);
 }
 
-bool emu_persistent = false; /* window_lane called for a lane of the persistent waves (ring storage not the lane's own) */
-
-/* one lane: record slot `slot` (state, cold, work, window), ring / frame-assembly storage of lane slot `storage` */
-void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, bool carry, uint32_t slot, uint32_t storage);
-
-void window_decode(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, bool carry)
-{
-   for (uint32_t slot = L.firstSlot; slot < L.firstSlot + L.slotCount; slot++)
-      window_lane(cfgPtr, L, A, carry, slot, slot);
-}
-
-void window_lane(const NfcConfig *cfgPtr, const NfcLaunch &L, const NfcScanArgs &A, bool carry, uint32_t slot, uint32_t storage)
-{
-   {
-      const uint32_t mineCount = L.works[slot].count;
-
-      if (!mineCount)
-         return;
-
-      const uint32_t *flags = L.works[slot].tiles;
-      const uint8_t *data = L.works[slot].data;
-
-      NfcStreamState s = L.states[slot];
-
-      NfcLaneMem mem;
-      mem.ring = L.rings + (uint64_t)(storage / NFC_LANES) * L.ringBlockFloats;
-      mem.lane = storage % NFC_LANES;
-      mem.exact = false;
-      mem.linked = true;
-      uint32_t laneFlags = 0;
-      mem.flags = &laneFlags;
-      mem.bytes = L.bytes + (uint64_t)storage * NFC_STREAM_BYTES;
-      mem.sink = L.sink;
-      mem.sinkCursor = L.sinkCtl;
-      mem.sinkDropped = L.sinkCtl + 1;
-      mem.sinkWords = L.sinkWords;
-      mem.streamId = slot;
-      mem.cold = L.cold + slot;
-      mem.tables = cfgPtr;
-
-      const uint32_t warm = L.warmFront + L.warmCorr;
-      uint32_t consumed = 0;
-      uint32_t stepped = 0;
-      uint32_t handed = 0;
-      uint32_t lockFrontUntil = 0, lockUpkeepUntil = 0, nextWaitScan = 0; /* stream positions (nfc_lane_fwait_jump) */
-
-      NfcWindow &me = L.windows[slot];
-      const NfcScanJob &job = L.jobs[me.job];
-      uint32_t succ = carry ? job.firstWindow : slot + 1u;
-      const uint32_t succEnd = job.firstWindow + job.windows;
-      if (!carry && (slot < job.firstWindow || slot >= succEnd))
-         succ = succEnd;
-
-      for (uint32_t base = 0; base < mineCount;)
-      {
-         auto dump = [&](const char *what) {
-            if (!std::getenv("NFC_EMU_DEBUG4"))
-               return;
-            const NfcSearchRegs &r = s.u.search;
-            std::fprintf(stderr, "[emu] %s lane %u pos %u clock %u lock %x comparable %d bankRun %u | A0 %u %u %u %g %g %u | A1 %u %u %u | A2 %u %u %u | B0 %u %u %u %u %g %u thr %g | B1 %u %u %u %u %g %u | F0 ws %u we %u sy %u ss %u se %u pk %g pt %u pulses %u thr %g | F1 ws %u we %u sy %u ss %u se %u pk %g pt %u pulses %u thr %g | V %u %u %u %g %g %u\n",
-                         what, slot, me.start + base, s.clock, s.lockTech, (int)nfc_lane_comparable(s, *mem.cold), mem.cold->bankRun,
-                         r.detA[0].winStart, r.detA[0].winEnd, r.detA[0].symStart, r.detA[0].peak, r.detA[0].aux, r.detA[0].peakTime,
-                         r.detA[1].winStart, r.detA[1].winEnd, r.detA[1].symStart, r.detA[2].winStart, r.detA[2].winEnd, r.detA[2].symStart,
-                         r.detB[0].winStart, r.detB[0].winEnd, r.detB[0].symStart, r.detB[0].symEnd, r.detB[0].aux, r.detB[0].auxTime, r.detB[0].thr,
-                         r.detB[1].winStart, r.detB[1].winEnd, r.detB[1].symStart, r.detB[1].symEnd, r.detB[1].aux, r.detB[1].auxTime,
-                         r.detF[0].winStart, r.detF[0].winEnd, r.detF[0].sync, r.detF[0].symStart, r.detF[0].symEnd, r.detF[0].peak, r.detF[0].peakTime, r.detF[0].pulses, r.detF[0].thr,
-                         r.detF[1].winStart, r.detF[1].winEnd, r.detF[1].sync, r.detF[1].symStart, r.detF[1].symEnd, r.detF[1].peak, r.detF[1].peakTime, r.detF[1].pulses, r.detF[1].thr,
-                         r.detV.winStart, r.detV.winEnd, r.detV.symStart, r.detV.peak, r.detV.aux, r.detV.peakTime);
-         };
-
-         if (me.start + base == me.verify)
-         {
-            nfc_lane_publish(me, s, *mem.cold);
-            dump("publish");
-         }
-
-         if (base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK) && nfc_quiescent(s) &&
-             s.bankClock == s.clock && (uint32_t)(s.clock - mem.cold->bankRun) >= NFC_WINDOW_SETTLE)
-            break;
-
-         if (std::getenv("NFC_EMU_DEBUG5") && base >= warm && base > 0)
-         {
-            uint32_t k = succ;
-            while (k < succEnd && L.windows[k].verify < me.start + base)
-               k++;
-            if (k < succEnd && L.windows[k].verify == me.start + base && !nfc_lane_comparable(s, *mem.cold))
-               std::fprintf(stderr, "[emu] lane %u (start %u) at %u (after %u steps) not comparable: lock %x unlock %x bank %d run %u env %g type %u fstart %u towait %d\n", slot, me.start,
-                            me.start + base, base, s.lockTech, s.unlock, (int)(s.bankClock == s.clock), (uint32_t)(s.clock - mem.cold->bankRun), s.env,
-                            s.lockTech ? s.u.decode.frameType : 0u, s.lockTech ? s.u.decode.frameStart : 0u,
-                            s.lockTech ? (int)(s.u.decode.waitingEnd - s.clock) : 0);
-         }
-
-         if (base >= warm && base > 0 && nfc_lane_handover(L.windows, me, succ, succEnd, me.start + base, s, *mem.cold))
-         {
-            dump("handover");
-            handed = 1;
-            break;
-         }
-
-         if (std::getenv("NFC_EMU_DEBUG2") && base >= warm && base > 0 && (flags[base / NFC_SCAN_TILE] & NFC_TILE_RETIRE_OK))
-         {
-            static uint64_t shown = 0;
-            if (shown++ % 500 == 0)
-            {
-               const NfcSearchRegs &r = s.u.search;
-               std::fprintf(stderr, "[emu] lane %u base %u cannot retire: lock %x unlock %x settle %u | A %u %u %u %u | B %u %u | F ws %u we %u sync %u pulses %u thr %g ss %u se %u peak %g pt %u | F2 pulses %u thr %g ws %u | V %u %u\n",
-                            slot, base, s.lockTech, s.unlock, (uint32_t)(s.clock - mem.cold->bankRun),
-                            r.detA[0].winStart, r.detA[0].peakTime, r.detA[1].winStart, r.detA[2].winStart, r.detB[0].symStart, r.detB[1].symStart,
-                            r.detF[0].winStart, r.detF[0].winEnd, r.detF[0].sync, r.detF[0].pulses, r.detF[0].thr, r.detF[0].symStart, r.detF[0].symEnd, r.detF[0].peak, r.detF[0].peakTime,
-                            r.detF[1].pulses, r.detF[1].thr, r.detF[1].winStart, r.detV.winStart, r.detV.peakTime);
-            }
-         }
-
-         if (base >= warm && (flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT) >= NFC_DARK_JUMP)
-            base = nfc_lane_dark_jump(*cfgPtr, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, me.start + base,
-                                      flags[base / NFC_SCAN_TILE] >> NFC_TILE_DARK_RUN_SHIFT, s, *mem.cold) - me.start;
-
-         /* a waiting NFC-F decoder: skip to where its correlator can next reach the threshold */
-         if (base >= warm && me.start + base >= lockUpkeepUntil && me.start + base >= nextWaitScan && nfc_fwait_idle(s) &&
-             !exact_span(s.clock, NFC_SCAN_TILE) && !std::getenv("NFC_EMU_NO_FWAIT"))
-         {
-            const NfcRate &rt = s.u.decode.rt;
-            const uint32_t pos = me.start + base;
-
-            if (rt.delay + rt.p1 <= NFC_FWAIT_LOOKBACK && pos >= NFC_FWAIT_LOOKBACK + NFC_SCAN_TILE)
-            {
-               /* the step that takes sample n has clock s.clock + 1 + (n - pos): the waiting time is over at the first n with clock > waitingEnd */
-               uint64_t limit = (uint64_t)pos + (uint32_t)(s.u.decode.waitingEnd - s.clock);
-               if (limit > job.count)
-                  limit = job.count;
-
-               const uint32_t firstHot = nfc_fwait_first_hot(job.data, L.uniformStride, pos, (uint32_t)limit, rt.p1, rt.p2, rt.delay, s.u.decode.lock.thr);
-               const uint32_t land = nfc_lane_fwait_jump(*cfgPtr, job, A.points, A.chunkEdge, A.params.chunkSamples, A.states[job.slot].clock, pos, firstHot, s, *mem.cold);
-
-               if (land != pos)
-               {
-                  base = land - me.start;
-                  lockFrontUntil = land + NFC_WINDOW_WARM_FRONT;
-                  lockUpkeepUntil = land + NFC_WINDOW_WARM_FRONT + NFC_WINDOW_WARM_CORR;
-               }
-               else
-                  nextWaitScan = firstHot + NFC_SCAN_TILE;
-            }
-         }
-
-         const uint32_t left = mineCount - base;
-         const uint32_t n = left < NFC_SCAN_TILE ? left : NFC_SCAN_TILE;
-         const bool exact = carry && exact_span(s.clock, n);
-
-         for (uint32_t k = 0; k < n; k++)
-         {
-            const float v = sample_of(data, L.uniformStride, base + k);
-
-            if (base < L.warmFront)
-               nfc_step_front<false>(*cfgPtr, s, mem, v);
-            else if (base < warm)
-               nfc_step_upkeep<false>(*cfgPtr, s, mem, v);
-            else if (me.start + base < lockFrontUntil)
-               nfc_step_lock_front<false>(*cfgPtr, s, mem, v);
-            else if (me.start + base < lockUpkeepUntil)
-               nfc_step_fwait_upkeep<false>(*cfgPtr, s, mem, v);
-            else if (exact)
-               nfc_step_as<true>(*cfgPtr, s, mem, v);
-            else
-               nfc_step_as<false>(*cfgPtr, s, mem, v);
-         }
-
-         consumed = base + n;
-         base += n;
-         stepped += n;
-      }
-
-      mem.cold->usedTech = laneFlags;
-      L.states[slot] = s;
-      L.windows[slot].stop = L.windows[slot].start + consumed;
-      const bool closing = L.windows[slot].activate >= L.windows[slot].start + mineCount;
-      L.windows[slot].retired = handed ? 2u : ((consumed < mineCount || (!closing && nfc_lane_comparable(s, *mem.cold))) ? 1u : 0u);
-
-      /* nfc_window_kernel: a speculative lane that ran to the end leaves a copy of its rings in the save area */
-      if (emu_persistent && !carry && L.windows[slot].retired == 0u && !closing)
-      {
-         const uint32_t to = emu_add(A.saveNext, 1u);
-
-         if (to < A.saveRoom)
-         {
-            const uint32_t rows = L.ringBlockFloats / NFC_LANES;
-            const float *src = mem.ring + mem.lane;
-            for (uint32_t i = 0; i < rows; i++)
-               A.saveRings[(uint64_t)to * rows + i] = src[(uint64_t)i * NFC_LANES];
-            std::memcpy(A.saveBytes + (uint64_t)to * NFC_STREAM_BYTES, mem.bytes, NFC_STREAM_BYTES);
-            L.windows[slot].saved = to + 1u;
-         }
-      }
-
-      emu_add(L.laneStats, (stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE);
-      if ((stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE > L.laneStats[1])
-         L.laneStats[1] = (stepped + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-      emu_add(L.laneStats + 2, 1u);
-   }
-}
-
 }
 
 void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
@@ -705,14 +504,7 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
    {
       NfcScanJob job = A.jobs[j];
       if (first)
-      {
          job.passes = 0;
-         const uint32_t nTiles = (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
-         if (A.nJobs >= NFC_LANES && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.densePercent)
-            { job.status |= NFC_JOB_DENSE; emu_add(A.denseCount, 1u); }
-         if (A.params.aloneStreams && A.nJobs >= A.params.aloneStreams && (uint64_t)job.busyTiles * 100u > (uint64_t)nTiles * A.params.alonePercent)
-            job.status |= NFC_JOB_ALONE;
-      }
       if (!(job.status & NFC_JOB_INVALID))
          nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples);
       A.jobs[j] = job;
@@ -983,24 +775,6 @@ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A
       A.works[wi] = work;
    }
 }
-
-/* the persistent waves: here one lane after the other, every window in the ring storage of the first wave's first lane
- * (as on the device, a window does not own ring storage: its warm-up rebuilds what it needs) */
-void nfc_window_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A)
-{
-   /* later windows first: on the device the lanes of a stream run side by side and a lane reaches the sample its successor
-    * published for long after the successor did; one after the other, that order has to be arranged */
-   std::vector<uint32_t> order(A.runList, A.runList + *A.runCount);
-   std::sort(order.begin(), order.end());
-   emu_persistent = true;
-   for (uint32_t i = (uint32_t)order.size(); i-- > 0;)
-      window_lane(cfgPtr, L, A, false, order[i], A.firstWindowSlot + (i % NFC_LANES));
-   emu_persistent = false;
-   *A.runNext = *A.runCount;
-}
-
-void nfc_window_final_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A) { window_decode(cfgPtr, L, A, false); }
-void nfc_window_carry_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A) { window_decode(cfgPtr, L, A, true); }
 
 void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes)
 {

@@ -162,71 +162,6 @@ def test_uniform_layout_submissions_on_the_emulated_runtime(emulated, tmp_path):
     assert out["bad"] == [] and out["bad_sink"] == [] and out["dropped"] == 0 and out["frames"] > 200, out
 
 
-SHARD_DRIVER = r'''
-import sys, json, os
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
-import numpy as np
-import nfc_testlib as T, nfclab_amd, synth, frames as framelib
-S, L, K = 160, 16384, 4
-template = synth.load_template(os.path.join(T.ROOT, "tests", "golden"))
-data = np.stack([synth.magnitude_f32(template, 100 + s, 0, L * K) for s in range(S)]).astype(np.float32)
-sink = np.zeros(1 << 23, np.int32)
-ctl = np.zeros(4, np.int32)
-out = {}
-with nfclab_amd.NfcGpu(device=0, max_streams=192, frame_sink_bytes=1 << 20) as gpu:
-    gpu.sink_attach(sink.ctypes.data, sink.size, ctl.ctypes.data)
-    gpu.sink_hold(True)
-    first = gpu.open(count=S)
-    # two submissions handed to the shards back to back (the second joins the first while it is in flight) ...
-    for k in range(2):
-        gpu.submit_uniform(first, S, data.ctypes.data + k * L * 4, L * K * 4, L, 10000000, stride=1, location=nfclab_amd.LOC_DEVICE)
-    # ... a call that needs them done (statistics), a new threshold for one stream (its own configuration: the slice of
-    # that shard becomes three launches), and two more
-    st = gpu.stats()
-    out["windowed_after_two"] = int(st.windowed_streams) + int(st.fallback_streams)
-    p = nfclab_amd.default_params()
-    p.corr_threshold[1] = 0.45
-    gpu.configure(first + 77, p)
-    for k in range(2, K):
-        gpu.submit_uniform(first, S, data.ctypes.data + k * L * 4, L * K * 4, L, 10000000, stride=1, location=nfclab_amd.LOC_DEVICE)
-    gpu.sync()
-    st = gpu.stats()
-    out["streams_served"] = int(st.windowed_streams) + int(st.fallback_streams)
-    parsed = framelib.parse_sink(sink, int(ctl[0]), 10000000)
-    out["dropped"] = int(ctl[1])
-bad, frames = [], 0
-for s in range(S):
-    # (NFC-B is not in this set's first samples: the changed NFC-B threshold of stream 77 only has to be carried, and the
-    # reference is run with it from the point it was set)
-    ref, _ = T.reference_decode(data[s], chunk=L, keep_carrier=True, cap=8192, defined_storage=True)
-    frames += len(ref)
-    if s != 77 and parsed.get(first + s, []) != ref:
-        bad.append(s)
-out["bad"] = bad
-out["frames"] = frames
-out["stream_77_frames"] = len(parsed.get(first + 77, []))
-print(json.dumps(out))
-'''
-
-
-def test_large_uniform_submissions_go_through_the_shards_emulated(emulated, tmp_path):
-    """Large device-resident uniform submissions are handed to shard threads (a slice of the slots each, submissions of a
-    slice pipelined behind each other): back-to-back submissions, a call in between that has to wait for them, a stream
-    reconfigured in between; every stream against the reference."""
-    import json
-    if T.reference_lib() is None:
-        pytest.skip("oracle/_ref not built")
-    with open(tmp_path / "driver.py", "w") as f:
-        f.write(SHARD_DRIVER)
-    run = subprocess.run([sys.executable, str(tmp_path / "driver.py"), os.path.join(T.ROOT, "nfc-laboratory_amd"), os.path.join(T.ROOT, "tests")],
-                         env=dict(os.environ, NFCGPU_LIB=emulated, NFCGPU_NO_TORCH="1", NFCGPU_SHARDS="3", NFCGPU_SHARD_MIN="32", NFCGPU_WINDOWED_MIN="8192"),
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
-    assert run.returncode == 0, run.stderr[-3000:]
-    out = json.loads(run.stdout.splitlines()[-1])
-    assert out["bad"] == [] and out["dropped"] == 0 and out["frames"] > 200, out
-    assert out["windowed_after_two"] == 2 * 160 and out["streams_served"] == 4 * 160 and out["stream_77_frames"] > 0, out
-
-
 CONFIG_DRIVER = r'''
 import sys, json
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])

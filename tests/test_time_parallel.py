@@ -1,7 +1,6 @@
 """The time-parallel path (scan kernel -> windows -> windowed decode -> chain, nfc_scan.h) against the reference decoder:
 every fixture in one submission and split over buffers, synthetic streams through the IQ entry, input off the int16 grid
-(sequential fallback), a long quiet capture. The routing that sends busy streams the sequential way is switched off
-(NFCGPU_DENSE_PERCENT=101) so that the path itself is what is tested. Without a GPU the cases run on the emulated
+(carry lanes alone, running sums walked), a long quiet capture. Without a GPU the cases run on the emulated
 runtime of tests/hostsim (the product's host runtime and device code on a stand-in HIP); with `-m gpu` on the real
 library and kernels."""
 import json
@@ -22,7 +21,7 @@ needs_reference = pytest.mark.skipif(T.reference_lib() is None, reason="oracle/_
 def _run(cases, emulated, extra=None):
     # (NFCGPU_SOLO_SAMPLES=0: speculative windows also on the short captures - by default a stream of up to 2^18 samples is
     # decoded by its carry lane alone)
-    env = dict(os.environ, NFCGPU_DENSE_PERCENT="101", NFCGPU_WINDOWED_MIN="4096", NFCGPU_SCAN_CHUNK="32768", NFCGPU_SOLO_SAMPLES="0")
+    env = dict(os.environ, NFCGPU_WINDOWED_MIN="4096", NFCGPU_SCAN_CHUNK="32768", NFCGPU_SOLO_SAMPLES="0")
     if emulated:
         env["NFCGPU_LIB"] = EMU
         env["NFCGPU_NO_TORCH"] = "1"
@@ -73,7 +72,7 @@ def test_small_chunks_force_repairs_emulated(emulated):
 def test_long_busy_submissions_of_few_streams_are_decoded_in_blocks_emulated(emulated):
     """a few long busy streams: the runtime cuts the submission into blocks of NFCGPU_BLOCK_SAMPLES and settles one after the
     other (the passes a submission needs grow with its length); same frames"""
-    res = _run(["carried"], True, {"NFCGPU_BLOCK_SAMPLES": "131072", "NFCGPU_DENSE_PERCENT": "8"})
+    res = _run(["carried"], True, {"NFCGPU_BLOCK_SAMPLES": "131072"})
     _check(res)
     dense = [r for r in res if r["name"].startswith("3 dense")][0]
     assert dense["stats"]["windowed"] > 9, dense  # 3 streams x 3 submissions, each in several blocks
@@ -108,7 +107,7 @@ def test_random_multi_submission_scenarios_emulated(emulated):
     """a short run of profiles/tools/r02/emulated_fuzz.py (random mixes of sparse and dense streams cut into submissions at
     random samples: both paths, carried state, final-state fix-ups) - the long runs are in profiles/r02/emulated_fuzz.json"""
     fuzz = os.path.join(T.ROOT, "profiles", "tools", "r02", "emulated_fuzz.py")
-    env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_DENSE_PERCENT="100", NFCGPU_WINDOWED_MIN="32768")
+    env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="32768")
     run = subprocess.run([sys.executable, fuzz, "5", "45", "small"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-2000:]
     res = json.loads(run.stdout.strip().splitlines()[-1])
@@ -137,14 +136,6 @@ def test_input_off_the_grid_is_decoded_by_carry_lanes_with_walked_sums_emulated(
     _check(res)
     for r in res:
         assert r["stats"]["fallback"] == 0, r
-
-
-@needs_reference
-def test_busy_streams_are_routed_to_the_sequential_path_emulated(emulated):
-    """routing applies to submissions of at least 64 streams (a wave of sequential lanes)"""
-    res = _run(["routing"], True, {"NFCGPU_DENSE_PERCENT": "5"})
-    _check(res, windowed=False)
-    assert sum(r["stats"]["fallback"] for r in res) > 0
 
 
 @needs_reference

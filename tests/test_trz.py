@@ -103,3 +103,131 @@ def test_trace_against_the_reference_trace_storage_task(tmp_path):
         assert tar.getnames() == ["frame.json"]
         ref_entries = json.load(tar.extractfile(tar.getmember("frame.json")))["frames"]
     assert ref_entries == entries
+
+
+# ---- the writer behind the C ABI (nfc-laboratory_amd/csrc/nfc_trace.hip): nfcgpu_trace_write_frames / nfcgpu_trace_write ----
+
+def _c_frames(frames):
+    import nfclab_amd
+    arr = (nfclab_amd.Frame * len(frames))()
+    for a, (tech, ftype, flags, phase, rate, start, end, fs, payload) in zip(arr, frames):
+        a.tech_type, a.frame_type, a.frame_flags, a.frame_phase, a.frame_rate = tech, ftype, flags, phase, rate
+        a.sample_start, a.sample_end, a.sample_rate, a.length = start, end, fs, len(payload)
+        for i, b in enumerate(payload):
+            a.data[i] = b
+    return arr
+
+
+def _read_entries(path):
+    with tarfile.open(path, "r:gz") as tar:
+        assert tar.getnames() == ["frame.json"]
+        return json.load(tar.extractfile(tar.getmember("frame.json")))["frames"]
+
+
+EMU = os.path.join(T.ROOT, "tests", "hostsim", "libnfcgpu_emulated.so")
+
+
+def _abi():
+    """the C ABI without a device: the trace writer is host code, the emulated test build of the library exports it too"""
+    import ctypes
+    if not os.path.exists(EMU):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(T.ROOT, "tests", "hostsim", "build_emulated.sh")])
+    lib = ctypes.CDLL(EMU)
+    lib.nfcgpu_trace_write_frames.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                              ctypes.POINTER(ctypes.c_uint32)]
+    return lib
+
+
+def test_c_abi_writer_writes_what_the_python_writer_writes(tmp_path):
+    import ctypes
+    frames = T.load_golden("test_POLL_ABF_001") + T.load_golden("test_NFC-V_26kbps_001") + [(0x100, 0x101, 0, 0x101, 0, 77, 77, 10000000, b"")]
+    mine, theirs = str(tmp_path / "c.trz"), str(tmp_path / "py.trz")
+    written = ctypes.c_uint32()
+    arr = _c_frames(frames)
+    assert _abi().nfcgpu_trace_write_frames(mine.encode(), ctypes.byref(arr), len(frames), 1700000000, 0.0, 0.0, ctypes.byref(written)) == 0
+    assert written.value == len(frames)
+    trz.write_trz(theirs, frames, stream_time=1700000000)
+    assert _read_entries(mine) == _read_entries(theirs)
+
+
+def test_c_abi_writer_keeps_the_frames_of_a_time_range_and_shifts_them(tmp_path):
+    """TraceStorageTask.cpp:461-483: frames that start before the range or end after it are left out, the others move to
+    its start (times, sample numbers); dateTime stays"""
+    import ctypes
+    frames = T.load_golden("test_NFC-A_106kbps_001")
+    t0 = frames[3][5] / 1e7 - 1e-4
+    t1 = frames[9][6] / 1e7 + 1e-4
+    path = str(tmp_path / "range.trz")
+    written = ctypes.c_uint32()
+    arr = _c_frames(frames)
+    assert _abi().nfcgpu_trace_write_frames(path.encode(), ctypes.byref(arr), len(frames), 5, t0, t1, ctypes.byref(written)) == 0
+    entries = _read_entries(path)
+    assert written.value == len(entries) == 7
+    offset = int(1e7 * t0)
+    for e, f in zip(entries, frames[3:10]):
+        assert e["sampleStart"] == f[5] - offset and e["sampleEnd"] == f[6] - offset
+        assert e["timeStart"] == f[5] / 1e7 - t0 and e["dateTime"] == 5 + f[5] / 1e7
+
+
+def test_c_abi_trace_opens_with_the_reference_python_reader(tmp_path):
+    import ctypes
+    tools = os.path.join(os.environ.get("NFC_REFERENCE_ROOT", "/root/reference"), "tools")
+    if not os.path.isdir(os.path.join(tools, "py_nfclab")):
+        pytest.skip("reference tree not present")
+    sys.path.insert(0, tools)
+    try:
+        from py_nfclab.readers import read_trz
+    except Exception as exc:
+        pytest.skip("py_nfclab not importable here: %r" % (exc,))
+    frames = T.load_golden("test_NFC-B_106kbps_001") + T.load_golden("test_NFC-F_212kbps_001")
+    path = str(tmp_path / "c.trz")
+    arr = _c_frames(frames)
+    assert _abi().nfcgpu_trace_write_frames(path.encode(), ctypes.byref(arr), len(frames), 0, 0.0, 0.0, None) == 0
+    got = read_trz(path)
+    assert len(got) == len(frames)
+    for g, f in zip(got, frames):
+        assert (int(g.tech_type), int(g.frame_type), g.sample_start, g.sample_end, g.sample_rate, g.frame_rate) == (f[0], f[1], f[5], f[6], f[7], f[4])
+        assert bytes(g.data) == f[8]
+
+
+@pytest.mark.skipif(not os.path.exists(TRACE_REF), reason="trace-ref not built (needs the reference tree and zlib at build time)")
+def test_c_abi_trace_is_read_by_the_reference_trace_storage_task(tmp_path):
+    """the reference's own task (tar + zlib inflate of the reference) reads the archive the C ABI wrote - a gzip member of
+    stored deflate blocks - and publishes the same frames"""
+    import ctypes
+    import subprocess
+    frames = T.load_golden("test_POLL_ABF_001")
+    path = str(tmp_path / "c.trz")
+    arr = _c_frames(frames)
+    assert _abi().nfcgpu_trace_write_frames(path.encode(), ctypes.byref(arr), len(frames), 1700000000, 0.0, 0.0, None) == 0
+    run = subprocess.run([TRACE_REF, "read", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = run.stdout.splitlines()
+    assert len(got) == len(frames)
+    for line, f in zip(got, frames):
+        w = line.split()
+        assert [int(v) for v in w[:8]] == list(f[:8])
+        assert (bytes.fromhex(w[11]) if w[11] != "-" else b"") == f[8]
+
+
+@pytest.mark.gpu
+def test_trace_of_device_decoded_frames_through_the_c_abi(built, tmp_path):
+    """nfcgpu_trace_write: the frames the device decoded for a stream (waiting in its queue) as a .trz - the capture decoded
+    on the GPU, the trace equal to what the golden frames give"""
+    import numpy as np
+    import nfclab_amd
+    name = "test_NFC-A_106kbps_001"
+    mag = np.abs(T.load_fixture(name)).astype(np.float32)
+    path = str(tmp_path / "gpu.trz")
+    with nfclab_amd.NfcGpu(device=0, max_streams=64) as gpu:
+        sid = gpu.open()
+        for pos in range(0, mag.size, 65536):
+            gpu.submit(sid, mag[pos:pos + 65536], 10000000)
+        n = gpu.trace_write(sid, path)
+        queued = gpu.poll(sid)          # (a trace does not take the frames out of the queue)
+    want = [f for f in queued]
+    assert n == len(want) and [f for f in want if f[1] in (0x102, 0x103)] == T.load_golden(name)
+    ref = str(tmp_path / "py.trz")
+    trz.write_trz(ref, want)
+    assert _read_entries(path) == _read_entries(ref)

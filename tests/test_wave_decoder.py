@@ -64,12 +64,6 @@ def test_stepping_alone_decodes_the_same_frames(emulated):
 
 
 @needs_reference
-def test_lane_per_window_kernels_still_decode(emulated):
-    """NFCGPU_WAVE=0: the round-2 kernels (one lane per window, rings in HBM) stay available behind the knob"""
-    _run(["fixture:test_NFC-A_106kbps_002", "quiet"], {"NFCGPU_WAVE": "0", "NFCGPU_DENSE_PERCENT": "101"})
-
-
-@needs_reference
 def test_short_streams_are_decoded_by_their_carry_lane_alone(emulated):
     """the default: a stream of up to 2^18 samples gets no speculative windows - one lane, one pass"""
     env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096")
@@ -79,15 +73,3 @@ def test_short_streams_are_decoded_by_their_carry_lane_alone(emulated):
     for r in json.loads(run.stdout.strip().splitlines()[-1]):
         assert r["mismatching"] == [] and r["frames"] > 0, r
         assert r["stats"]["windowed"] == 1 and r["stats"]["passes"] == 1 and r["stats"]["windows"] == 1, r
-
-
-@needs_reference
-def test_busy_streams_of_a_large_submission_are_decoded_alone(emulated):
-    """NFCGPU_ALONE_STREAMS (default 256; 2 here): in a submission of that many streams the busy ones get no speculative
-    windows - a lane per stream, start to end - while the quiet ones keep theirs; state carried across submissions"""
-    env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096", NFCGPU_ALONE_STREAMS="2", NFCGPU_SOLO_SAMPLES="0")
-    run = subprocess.run([sys.executable, DRIVER, "synthetic"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
-    assert run.returncode == 0, run.stderr[-3000:]
-    for r in json.loads(run.stdout.strip().splitlines()[-1]):
-        assert r["mismatching"] == [] and r["frames"] > 0, r
-        assert r["stats"]["fallback"] == 0, r

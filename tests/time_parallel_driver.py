@@ -81,10 +81,6 @@ def main():
         streams = [synth.sparse_magnitude_f32(template, segs, s, 0, 1 << 20) for s in range(24)]
         out.append(case("24 sparse synthetic streams x 2^20 in 4 buffers", streams, buffers=4))
 
-    if "routing" in which:
-        streams = [synth.magnitude_f32(template, s, 0, 1 << 16) for s in range(64)]
-        out.append(case("64 synthetic streams x 2^16 (dense: sequential path when routing is on)", streams))
-
     if not which or "offgrid" in which:
         mag = np.abs(T.load_fixture("test_NFC-A_106kbps_001")).astype(np.float32)
         mag = (mag * np.float32(1.0000153)).astype(np.float32)  # off the int16 grid: the carry lane alone, running sums walked
