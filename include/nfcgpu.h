@@ -197,6 +197,18 @@ int nfcgpu_sync(nfcgpu_ctx *ctx);
 int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t stream_id, nfcgpu_frame *out, uint32_t capacity, uint32_t *count);
 int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t stream_id, uint32_t *count);
 
+/* Trace files: decoded frames in the format the reference application opens ("open trace") and
+ * tools/py_nfclab reads - a gzip-compressed tar archive with one entry frame.json, as TraceStorageTask writes it
+ * (lab-tasks/src/main/cpp/tasks/TraceStorageTask.cpp:461-520; read back by :380-449). range_start / range_end in seconds of
+ * stream time keep the frames inside the range and shift their times and sample numbers to its start (:461-483, the
+ * range of the "write file" command :211-240); 0, 0 = every frame. *written (may be NULL) = frames in the file.
+ *   nfcgpu_trace_write_frames  any frames the caller holds (no context, no device);
+ *   nfcgpu_trace_write         the frames the device has decoded for a stream and that wait in its queue (nfcgpu_poll
+ *                              order; implies nfcgpu_sync); they stay queued. dateTime = the stream's stream_time + timeStart. */
+int nfcgpu_trace_write_frames(const char *path, const nfcgpu_frame *frames, uint32_t count, int64_t stream_time, double range_start, double range_end,
+                              uint32_t *written);
+int nfcgpu_trace_write(nfcgpu_ctx *ctx, uint32_t stream_id, const char *path, double range_start, double range_end, uint32_t *written);
+
 /* device-resident view of the frames produced since the last sync: packed records of 32-bit words
  * [stream_id, tech, type, flags, phase, rate, start, end, length, payload...]; used for RCCL frame gathers */
 int nfcgpu_sink_device_view(nfcgpu_ctx *ctx, const void **words, const void **cursor_words, uint64_t *capacity_words);

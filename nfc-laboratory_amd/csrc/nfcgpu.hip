@@ -2451,6 +2451,29 @@ int nfcgpu_poll(nfcgpu_ctx *ctx, uint32_t id, nfcgpu_frame *out, uint32_t capaci
    return rc;
 }
 
+/* the frames the device has decoded for a stream, as the trace file the reference application opens
+ * (TraceStorageTask.cpp:211-240 the range of "write file", 461-520 the entries). The frames stay in the stream's queue. */
+int nfcgpu_trace_write(nfcgpu_ctx *ctx, uint32_t id, const char *path, double rangeStart, double rangeEnd, uint32_t *written)
+{
+   if (!ctx || !path)
+      return NFCGPU_EINVAL;
+   if (id >= ctx->maxStreams || !ctx->streams[id].open)
+      return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
+
+   int rc = nfcgpu_sync(ctx);
+   if (rc && rc != NFCGPU_EOVERFLOW)
+      return rc;
+
+   const StreamInfo &si = ctx->streams[id];
+   std::vector<nfcgpu_frame> frames(si.queue.begin(), si.queue.end());
+
+   const int wrote = nfcgpu_trace_write_frames(path, frames.data(), (uint32_t)frames.size(), si.params.stream_time, rangeStart, rangeEnd, written);
+   if (wrote)
+      return fail(ctx, wrote, "the trace file could not be written");
+
+   return rc;
+}
+
 int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t id, uint32_t *count)
 {
    if (!ctx || !count)

@@ -147,6 +147,8 @@ def load_library(path=LIB_PATH):
     lib.nfcgpu_comm_destroy.argtypes = [vp]
     lib.nfcgpu_gather_frames.argtypes = [vp, vp, ctypes.c_uint64, P(ctypes.c_uint32), P(ctypes.c_uint64)]
     lib.nfcgpu_gather_frames_packed.argtypes = [vp, vp, ctypes.c_uint64, P(ctypes.c_uint32)]
+    lib.nfcgpu_trace_write.argtypes = [vp, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_double, ctypes.c_double, P(ctypes.c_uint32)]
+    lib.nfcgpu_trace_write_frames.argtypes = [ctypes.c_char_p, vp, ctypes.c_uint32, ctypes.c_int64, ctypes.c_double, ctypes.c_double, P(ctypes.c_uint32)]
     lib.nfcgpu_read_bandwidth.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, P(ctypes.c_double)]
     lib.nfcgpu_hip_stream.argtypes = [vp]
     lib.nfcgpu_hip_stream.restype = vp
@@ -321,6 +323,12 @@ class NfcGpu:
         stride = ctypes.c_uint64()
         self._check(self.lib.nfcgpu_gather_frames(self.ctx, gathered_ptr, capacity_words, counts, ctypes.byref(stride)), allow=(-6,))
         return list(counts), int(stride.value)
+
+    def trace_write(self, stream_id, path, range_start=0.0, range_end=0.0):
+        """the frames decoded for a stream (still queued) as a .trz the reference application opens; returns the frame count"""
+        n = ctypes.c_uint32()
+        self._check(self.lib.nfcgpu_trace_write(self.ctx, stream_id, os.fsencode(path), range_start, range_end, ctypes.byref(n)), allow=(-6,))
+        return int(n.value)
 
     def read_bandwidth(self, device_ptr, n_bytes, repeats=5):
         """streaming-read GB/s over a device buffer (16-byte loads): the measured HBM roofline denominator"""
