@@ -633,6 +633,15 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
                w.fe.env = seam.start.env;
                w.fe.pulseFilter = seam.start.pulseFilter;
                begun = true;
+
+               /* the point stored where the chunk begins carries the true start too (the full second walk rewrites it;
+                * this one left the first walk's guess there) */
+               if (pos == start && (start % NFC_SCAN_POINT) == 0)
+               {
+                  NfcScanPoint &first = A.points[job->firstPoint + start / NFC_SCAN_POINT];
+                  first.env = seam.start.env;
+                  first.pulseFilter = seam.start.pulseFilter;
+               }
             }
 
             if (pos > start && (pos % NFC_SCAN_POINT) == 0)

@@ -344,6 +344,13 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
          float lo = NFC_SCAN_BIG, hi = -NFC_SCAN_BIG;
          bool merged = false;
 
+         if ((start % NFC_SCAN_POINT) == 0)
+         {
+            NfcScanPoint &first = A.points[job->firstPoint + start / NFC_SCAN_POINT];
+            first.env = seam.start.env;
+            first.pulseFilter = seam.start.pulseFilter;
+         }
+
          for (uint32_t sp = start; sp < end; sp++)
          {
             if (sp > start && (sp % NFC_SCAN_POINT) == 0)

@@ -89,6 +89,25 @@ def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emul
 
 
 @needs_reference
+@pytest.mark.parametrize("knobs,expect", [
+    ({"NFCGPU_WINDOWED": "0"}, "sequential"),                                  # the path switched off: sequential kernels only
+    ({"NFCGPU_WINDOW_PASSES": "1", "NFCGPU_WINDOW_PASSES_FEW": "1"}, "any"),   # one pass and no more: streams that need another go the sequential way
+    ({"NFCGPU_LANES_WANTED": "0", "NFCGPU_CUT_MAX": "16384"}, "windowed"),     # lanes 16384 samples apart whatever the submission
+    ({"NFCGPU_SIDE_STREAM": "0"}, "windowed"),                                 # carry lanes on the stream of the windows
+])
+def test_remaining_knobs_at_non_default_values_emulated(emulated, knobs, expect):
+    """every knob that is left (INTEGRATION.md lists them) decodes the same frames at a value that is not its
+    default - three dense synthetic streams in three submissions"""
+    res = _run(["carried_dense"], True, knobs)
+    for r in res:
+        assert r["mismatching"] == [] and r["frames"] > 0, r
+        if expect == "sequential":
+            assert r["stats"]["windowed"] == 0 and r["stats"]["fallback"] >= 1, r
+        elif expect == "windowed":
+            assert r["stats"]["windowed"] >= 1 and r["stats"]["fallback"] == 0, r
+
+
+@needs_reference
 def test_planes_that_do_not_fit_the_device_are_not_fatal_emulated(emulated):
     """the wave path's front-end planes are 16 bytes per sample of the submission; when the device cannot give
     them the submission used to fail with NFCGPU_ENOMEM. It is now decoded a quarter of its length at a time (a quarter of

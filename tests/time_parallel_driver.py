@@ -98,6 +98,10 @@ def main():
                    for s in range(3)]
         out.append(case("3 dense synthetic streams x 2^18 off the grid, IQ entry, 2 buffers", streams, buffers=2, stride=2))
 
+    if "carried_dense" in which:
+        streams = [synth.magnitude_f32(template, s, 0, 3 << 17) for s in (29, 5, 17)]
+        out.append(case("3 dense synthetic streams x 3 * 2^17 in 3 buffers", streams, buffers=3))
+
     if "planes" in which:
         # (tests/test_time_parallel.py: the front-end planes - 16 bytes per sample - do not fit the device)
         streams = [synth.magnitude_f32(template, 60 + s, 0, 1 << 19) for s in range(2)]
