@@ -77,6 +77,7 @@ struct NfcWaveUni
    uint32_t which;    /* search bank: detectors whose gates were up at sample whichAt (bit per detector, nfc_wave_search_gate) */
    uint32_t whichAt;
    uint32_t maskValid; /* search bank: the detectors whose gates over the tile at hand (NfcWaveLds::gate) still stand (bit per detector) */
+   uint32_t aloneLocked; /* search bank: an NFC-F tracker applied on its own found its preamble complete (the sample is the step's) */
    uint32_t retireLo, retireHi; /* may the lane retire at the boundary before tile 64 m + j of its row? bit j (fetched 64 tiles at a time) */
    /* what the two ring taps of a sample (nfc_wave_taps) are formed from on demand: the correlators as they stood when the
     * values of the tile were formed (sample `from`): ring position and running sum of the sample before, whether the ring

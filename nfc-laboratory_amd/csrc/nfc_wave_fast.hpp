@@ -322,8 +322,7 @@ NFC_DEV bool nfc_wave_gate_v(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
  * evaluated for stand: bits 0..2 NFC-A, 3..4 NFC-B, 5..6 NFC-F, 7 NFC-V, 8..9 the NFC-F reset marks, 10..11 where the
  * NFC-F detectors look at their records (nfc_wave_gate_f). `valid`: the detectors whose bits still stand (a step clears
  * the bits of the detectors it asked). */
-#define NFC_WAVE_GATE_HARD 0xE7u /* a gate of these detectors is a sample to step */
-#define NFC_WAVE_GATE_B 0x18u    /* NFC-B detectors before their second edge are stepped on their own (nfc_wave_fast) */
+/* (bits 0 .. 7: the detectors are shown their records where their gates are up, in place: nfc_wave_fast) */
 #define NFC_WAVE_GATE_OTHER 0x1000u /* bit 12: the bank is not armed at this sample, or a carrier frame is due */
 
 NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t valid, uint32_t w)
@@ -759,6 +758,50 @@ NFC_DEV void nfc_wave_fold(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    NFC_WAVE_BARRIER();
 }
 
+/* The marks the NFC-F detectors leave on samples [lo, end) of a run although nothing else happens there (bits 8 .. 11 of the
+ * lanes' gate words: asked to reset a clear record; looked at a record the lane inherited before the lane has reset it,
+ * NfcStreamCold::usedTech bits 16 + i / 14 + i), as nfcf_detect_rate leaves them sample after sample */
+NFC_DEV uint32_t nfc_wave_f_marks(NFC_WAVE_LDS NfcWaveLds *lds, uint32_t bits, uint32_t lo, uint32_t end)
+{
+   const uint32_t lane = NFC_WAVE_LANE();
+   const bool mine = lane >= lo && lane < end;
+   uint32_t marks = 0;
+
+   for (uint32_t i = 0; i < 2u; i++)
+   {
+      const uint64_t asked = NFC_WAVE_BALLOT(mine && ((bits >> (8u + i)) & 1u)), looked = NFC_WAVE_BALLOT(mine && ((bits >> (10u + i)) & 1u));
+
+      /* (a detector that looks at its record before the lane has reset it: NfcStreamCold::usedTech, bit 14 + i) */
+      if (looked && !((lds->flags >> (16u + i)) & 1u) && (!asked || __builtin_ctzll(looked) < __builtin_ctzll(asked)))
+         marks |= 1u << (14u + i);
+      if (asked)
+         marks |= 1u << (16u + i);
+   }
+
+   return marks;
+}
+
+/* what the step functions need of the lane's memory when they are only shown a detector record (no frame can be emitted) */
+NFC_DEV NfcLaneMem nfc_wave_mem_records(NFC_WAVE_LDS NfcWaveLds *lds)
+{
+   NfcLaneMem mem;
+   mem.ring = (NFC_RING_FLOAT *)lds->ring;
+   mem.lane = 0;
+   mem.exact = false;
+   mem.linked = true;
+   mem.flags = (uint32_t *)&lds->flags;
+   mem.bytes = (uint8_t *)lds->bytes;
+   mem.sink = nullptr;
+   mem.sinkCursor = nullptr;
+   mem.sinkDropped = nullptr;
+   mem.sinkWords = 0;
+   mem.streamId = 0;
+   mem.cold = (NfcStreamCold *)&lds->cold;
+   mem.tables = nullptr;
+   mem.deep = &lds->deep;
+   return mem;
+}
+
 /* Commits the samples from lds->u.at on that change nothing but sums and rings (at most up to n) and advances
  * lds->u.at past them; false: the sample at lds->u.at has to be stepped. Called by every lane. */
 NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t n, bool upkeep)
@@ -874,6 +917,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    uint32_t run;
    uint64_t gated;   /* bit j: sample from + j is gated */
    uint32_t bits = 0; /* search: this lane's gate word */
+   uint32_t marksFrom = from; /* search: first sample of the run whose NFC-F marks have not been left yet */
 
    /* a carrier frame is due (NfcDecoder.cpp:472-523: search mode only) */
    const bool carrier = (avg > c.highThreshold) ? !s.carrierOn : ((avg < c.lowThreshold) && !s.carrierOff);
@@ -887,8 +931,16 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
       bits = nfc_wave_search_bits(c, lds, clock0, formed ? 0u : NFC_WAVE_UNIFORM_U32(lds->u.maskValid), formed ? 0u : lds->gate[lane]);
       bits = (bits & ~NFC_WAVE_GATE_OTHER) | ((!armed || carrier) ? NFC_WAVE_GATE_OTHER : 0u);
 
-      const uint64_t hard = NFC_WAVE_BALLOT((bits & (NFC_WAVE_GATE_HARD | NFC_WAVE_GATE_OTHER)) != 0u) & range;
-      uint64_t soft = NFC_WAVE_BALLOT((bits & NFC_WAVE_GATE_B) != 0u) & range;
+      /* Only a sample at which the bank is not armed, or a carrier frame is due, is the step machine's from the start. Where a
+       * detector's gate is up, the wave shows that detector its own record: its decision function (nfc*_detect_decide, the
+       * statement of what the reference's detector does there) runs on a copy of the record, in the order of the bank (NFC-A
+       * 106 / 212 / 424, NFC-B 106 / 212, NFC-F 212 / 424, NFC-V: NfcDecoder.cpp:401-417). Nearly always it moves the record and
+       * nothing else - a pause being tracked, an edge, a pulse of a preamble -: the copies go back and the run goes on. When one
+       * of them recognises its start of frame, the copies are dropped and the sample is the search step's (nfc_wave_search_step),
+       * which decides again from the records as they were and locks; what the first decision has left outside the records - the
+       * lane's marks and bounds of the NFC-F trackers, the decode set a locking detector prepares - it leaves again, the same. */
+      const uint64_t hard = NFC_WAVE_BALLOT((bits & NFC_WAVE_GATE_OTHER) != 0u) & range;
+      uint64_t soft = NFC_WAVE_BALLOT((bits & 0xFFu) != 0u) & range;
       uint32_t at = from, g = n;
 
       for (;;)
@@ -901,52 +953,182 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
             break;
 
          const uint32_t here = NFC_WAVE_PICK_U32(bits, lds->gate, g);
-         const bool on0 = (here & 8u) != 0u, on1 = (here & 16u) != 0u;
+         const bool onF0 = (here & 0x20u) != 0u, onF1 = (here & 0x40u) != 0u;
 
-         if ((on0 && s.u.search.detB[0].symEnd) || (on1 && s.u.search.detB[1].symEnd))
-            break;
+         /* the marks of the samples before it (NFC-F: what its detectors leave where nothing else happens) are left first,
+          * in the order the step machine would: the tracker below may reset a record */
+         const uint32_t before = (onF0 || onF1) ? nfc_wave_f_marks(lds, bits, marksFrom, g) : 0u;
 
          NFC_WAVE_READ_FENCE(); /* (the records are about to change) */
 
-         NFC_WAVE_COUNT(44u, 0u, 1u); /* NFC-B detectors stepped on their own */
          NFC_WAVE_TICK(lds, 10u);
 
          NFC_WAVE_UNIFORM_BEGIN
          {
             const uint32_t clk = clock0 + 1u + g;
             const float envAt = lds->env[g];
+            const NfcLaneMem mem = nfc_wave_mem_records(lds);
 
-            if (on0)
+            NfcStreamState shown; /* what the detectors are shown: the clock, the envelope and the records they are asked about */
+            shown.clock = clk;
+            shown.env = envAt;
+            shown.posA[0] = shown.posA[1] = shown.posA[2] = 0u; /* (positions: only a lock looks at them) */
+            shown.posF[0] = shown.posF[1] = 0u;
+            shown.posV1 = shown.posV0 = 0u;
+
+            bool locks = false;
+
+            if (c.enabled & 1u)
             {
-               const uint32_t slot = (clk - c.b[0].delay) & NFC_FMASK;
-               NfcDetB m = *(NfcDetB *)&lds->u.s.u.search.detB[0];
-               (void)nfcb_track<0>(c, m, clk, envAt, lds->ring[NFC_R_FILT + slot], lds->ring[NFC_R_DEPTH + slot]);
-               *(NfcDetB *)&lds->u.s.u.search.detB[0] = m;
+               const float limit = envAt * c.corrThreshold[0];
+
+#define NFC_WAVE_A_ALONE(R)                                                                                                              \
+               if (!locks && ((here >> R) & 1u))                                                                                         \
+               {                                                                                                                         \
+                  shown.u.search.detA[R] = *(const NfcDetA *)&lds->u.s.u.search.detA[R];                                                 \
+                  locks = nfca_detect_decide<R>(c, shown, mem, nfc_wave_search_num(c, lds, R, g),                                        \
+                                                lds->ring[NFC_R_DEPTH + ((clk - c.a[R].delay - c.a[R].p8) & NFC_FMASK)], limit, c.minDepth[0]); \
+               }
+               NFC_WAVE_A_ALONE(0)
+               NFC_WAVE_A_ALONE(1)
+               NFC_WAVE_A_ALONE(2)
+#undef NFC_WAVE_A_ALONE
             }
 
-            if (on1)
+            if (!locks && (c.enabled & 2u))
             {
-               const uint32_t slot = (clk - c.b[1].delay) & NFC_FMASK;
-               NfcDetB m = *(NfcDetB *)&lds->u.s.u.search.detB[1];
-               (void)nfcb_track<1>(c, m, clk, envAt, lds->ring[NFC_R_FILT + slot], lds->ring[NFC_R_DEPTH + slot]);
-               *(NfcDetB *)&lds->u.s.u.search.detB[1] = m;
+               const uint32_t slot0 = (clk - c.b[0].delay) & NFC_FMASK, slot1 = (clk - c.b[1].delay) & NFC_FMASK;
+               int r0 = 0;
+
+               if ((here >> 3) & 1u)
+               {
+                  shown.u.search.detB[0] = *(const NfcDetB *)&lds->u.s.u.search.detB[0];
+                  r0 = nfcb_detect_decide<0>(c, shown, mem, lds->ring[NFC_R_FILT + slot0], lds->ring[NFC_R_DEPTH + slot0]);
+               }
+
+               if (r0 == 1)
+                  locks = true;
+               else if ((here >> 4) & 1u)
+               {
+                  /* (r0 == 2: the rate is skipped on this sample - its record is not looked at and goes back as it came) */
+                  shown.u.search.detB[1] = *(const NfcDetB *)&lds->u.s.u.search.detB[1];
+                  if (r0 == 0 && nfcb_detect_decide<1>(c, shown, mem, lds->ring[NFC_R_FILT + slot1], lds->ring[NFC_R_DEPTH + slot1]) == 1)
+                     locks = true;
+               }
             }
+
+            if (!locks && (c.enabled & 4u) && (onF0 || onF1))
+            {
+               const float limit = envAt * c.corrThreshold[2];
+               const float deep = lds->ring[NFC_R_DEPTH + (clk & NFC_FMASK)];
+
+               lds->flags |= before;
+
+               /* (what the search step leaves of the detectors it does not ask: nfc_wave_search_step) */
+               lds->flags |= ((here >> 8) & 1u) << 16 | ((here >> 9) & 1u) << 17;
+               const uint32_t seen = lds->flags;
+               lds->flags = seen | (((here >> 10) & 1u & ~(seen >> 16)) << 14) | (((here >> 11) & 1u & ~(seen >> 17)) << 15);
+
+               if (onF0)
+               {
+                  float f0, f1;
+                  nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 3u, g, f0, f1);
+                  shown.u.search.detF[0] = *(const NfcDetF *)&lds->u.s.u.search.detF[0];
+                  locks = nfcf_detect_decide<1>(c, shown, mem, f0, f0 - f1, deep, limit);
+               }
+
+               if (!locks && onF1)
+               {
+                  float f0, f1;
+                  nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 4u, g, f0, f1);
+                  shown.u.search.detF[1] = *(const NfcDetF *)&lds->u.s.u.search.detF[1];
+                  locks = nfcf_detect_decide<2>(c, shown, mem, f0, f0 - f1, deep, limit);
+               }
+            }
+
+            if (!locks && (c.enabled & 8u) && ((here >> 7) & 1u))
+            {
+               float v0, v1;
+               nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 5u, g, v0, v1);
+               shown.u.search.detV = *(const NfcDetV *)&lds->u.s.u.search.detV;
+               locks = nfcv_detect_decide(c, shown, mem, v0, lds->ring[NFC_R_X + ((clk - c.v.delay) & NFC_HMASK)]);
+            }
+
+            /* every record that was shown, or none (the step decides about all of them again) */
+            if (!locks)
+            {
+               if ((c.enabled & 1u) && (here & 1u))
+                  *(NfcDetA *)&lds->u.s.u.search.detA[0] = shown.u.search.detA[0];
+               if ((c.enabled & 1u) && (here & 2u))
+                  *(NfcDetA *)&lds->u.s.u.search.detA[1] = shown.u.search.detA[1];
+               if ((c.enabled & 1u) && (here & 4u))
+                  *(NfcDetA *)&lds->u.s.u.search.detA[2] = shown.u.search.detA[2];
+               if ((c.enabled & 2u) && (here & 8u))
+                  *(NfcDetB *)&lds->u.s.u.search.detB[0] = shown.u.search.detB[0];
+               if ((c.enabled & 2u) && (here & 16u))
+                  *(NfcDetB *)&lds->u.s.u.search.detB[1] = shown.u.search.detB[1];
+               if ((c.enabled & 4u) && onF0)
+                  *(NfcDetF *)&lds->u.s.u.search.detF[0] = shown.u.search.detF[0];
+               if ((c.enabled & 4u) && onF1)
+                  *(NfcDetF *)&lds->u.s.u.search.detF[1] = shown.u.search.detF[1];
+               if ((c.enabled & 8u) && (here & 128u))
+                  *(NfcDetV *)&lds->u.s.u.search.detV = shown.u.search.detV;
+            }
+
+            lds->u.aloneLocked = locks ? 1u : 0u;
          }
          NFC_WAVE_UNIFORM_END
 
+         if (NFC_WAVE_UNIFORM_U32(lds->u.aloneLocked))
+            break; /* a start of frame: the sample is the search step's (nothing has been moved) */
+
+         NFC_WAVE_COUNT(44u, 0u, 1u); /* detectors shown their records in place */
+
          /* their gates over the rest of the tile, for the records as they now stand */
-         if (on0)
+         if (lane > g)
          {
-            const NfcDetB m = s.u.search.detB[0];
-            bits = (bits & ~8u) | (nfc_wave_gate_b<0>(c, lds, m, t, env) ? 8u : 0u);
-         }
-         if (on1)
-         {
-            const NfcDetB m = s.u.search.detB[1];
-            bits = (bits & ~16u) | (nfc_wave_gate_b<1>(c, lds, m, t, env) ? 16u : 0u);
+            if (c.enabled & 1u)
+            {
+               if (here & 1u)
+                  bits = (bits & ~1u) | (nfc_wave_gate_a<0>(c, lds, t, env) ? 1u : 0u);
+               if (here & 2u)
+                  bits = (bits & ~2u) | (nfc_wave_gate_a<1>(c, lds, t, env) ? 2u : 0u);
+               if (here & 4u)
+                  bits = (bits & ~4u) | (nfc_wave_gate_a<2>(c, lds, t, env) ? 4u : 0u);
+            }
+            if (c.enabled & 2u)
+            {
+               if (here & 8u)
+               {
+                  const NfcDetB m = s.u.search.detB[0];
+                  bits = (bits & ~8u) | (nfc_wave_gate_b<0>(c, lds, m, t, env) ? 8u : 0u);
+               }
+               if (here & 16u)
+               {
+                  const NfcDetB m = s.u.search.detB[1];
+                  bits = (bits & ~16u) | (nfc_wave_gate_b<1>(c, lds, m, t, env) ? 16u : 0u);
+               }
+            }
+            if ((c.enabled & 4u) && onF0)
+            {
+               bool asked, looked;
+               const bool gate = nfc_wave_gate_f<0>(c, lds, t, env, asked, looked);
+               bits = (bits & ~0x520u) | (gate ? 0x20u : 0u) | (asked ? 0x100u : 0u) | (looked ? 0x400u : 0u);
+            }
+            if ((c.enabled & 4u) && onF1)
+            {
+               bool asked, looked;
+               const bool gate = nfc_wave_gate_f<1>(c, lds, t, env, asked, looked);
+               bits = (bits & ~0xA40u) | (gate ? 0x40u : 0u) | (asked ? 0x200u : 0u) | (looked ? 0x800u : 0u);
+            }
+            if ((c.enabled & 8u) && (here & 128u))
+               bits = (bits & ~128u) | (nfc_wave_gate_v(c, lds, t, env) ? 128u : 0u);
          }
 
-         soft = NFC_WAVE_BALLOT((bits & NFC_WAVE_GATE_B) != 0u) & range;
+         if (onF0 || onF1)
+            marksFrom = g + 1u;
+
+         soft = NFC_WAVE_BALLOT((bits & 0xFFu) != 0u) & range;
          at = g + 1u;
       }
 
@@ -981,6 +1163,53 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
       gated = NFC_WAVE_BALLOT(gate && lane >= from && lane < n) >> from;
       run = gated ? (uint32_t)__builtin_ctzll(gated) : n - from;
+
+      /* A waiting NFC-F decoder whose preamble tracker follows what the signal does (nfcf_listen_start between the guard
+       * and the waiting time): after a pulse that did not hold the tracker starts over with a threshold of zero, and every
+       * wiggle of the noise is a pulse to it for as long as the wait lasts (up to 217 k samples) - a step machine step per
+       * sample. Such a sample touches the tracker's record and nothing else, so the wave applies the tracker itself
+       * (nfcf_track_preamble, the decoder's own function, on a copy of the record) and goes on with the run, as it does for
+       * the NFC-B detectors of the search bank; a preamble that completes is left to the step. */
+      while (key == NFC_FK_F_START && from + run < n)
+      {
+         const uint32_t g = from + run;
+         const uint32_t clk = clock0 + 1u + g;
+         const NfcDecodeRegs &d = s.u.decode;
+
+         /* (nfcf_listen_start's own comparisons: past the guard time, the threshold seeded; not timed out; window open) */
+         if (!(clk > d.guardEnd && clk <= d.waitingEnd && clk >= d.lock.winStart))
+            break;
+
+         float g0, g1;
+         nfc_wave_s0s1(c, lds, key, 0u, g, g0, g1);
+         const float sd = nfc_abs(g0 - g1) / (float)d.rt.p2;
+
+         NfcMod m = *(const NfcMod *)&lds->u.s.u.decode.lock;
+         NfcStreamState at;
+         at.clock = clk;
+         uint32_t polarity = 0;
+         const NfcRate rt = d.rt;
+
+         if (nfcf_track_preamble(at, m, rt, sd, g0, sd >= m.thr, polarity, nullptr))
+            break; /* start of frame: the step's */
+
+         NFC_WAVE_READ_FENCE(); /* (the record is about to change) */
+         NFC_WAVE_COUNT(49u, 0u, 1u);
+
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            m.acc = lds->u.s.u.decode.lock.acc; /* (the running sum is the commit's) */
+            *(NfcMod *)&lds->u.s.u.decode.lock = m;
+         }
+         NFC_WAVE_UNIFORM_END
+
+         /* the gates of the samples behind it, for the record as it now stands */
+         const bool again = nfc_wave_locked_gate(c, lds, clock0, key);
+         const uint64_t rest = NFC_WAVE_BALLOT(again && lane > g && lane < n);
+
+         gated = rest >> from;
+         run = rest ? (uint32_t)__builtin_ctzll(rest) - from : n - from;
+      }
    }
 
    /* kept for the caller: the sample after a stepped one is stepped too when it was gated here */
@@ -1059,20 +1288,7 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
    /* NFC-F detectors asked to reset (a clear record) somewhere in the run: the mark nfcf_detect_rate leaves */
    uint32_t marks = 0;
    if (key == NFC_FK_SEARCH)
-   {
-      const bool mine = lane >= from && lane <= last;
-
-      for (uint32_t i = 0; i < 2u; i++)
-      {
-         const uint64_t asked = NFC_WAVE_BALLOT(mine && ((bits >> (8u + i)) & 1u)), looked = NFC_WAVE_BALLOT(mine && ((bits >> (10u + i)) & 1u));
-
-         /* (a detector that looks at its record before the lane has reset it: NfcStreamCold::usedTech, bit 14 + i) */
-         if (looked && !((lds->flags >> (16u + i)) & 1u) && (!asked || __builtin_ctzll(looked) < __builtin_ctzll(asked)))
-            marks |= 1u << (14u + i);
-         if (asked)
-            marks |= 1u << (16u + i);
-      }
-   }
+      marks = nfc_wave_f_marks(lds, bits, marksFrom, last + 1u);
 
    if (gathers)
       nfc_wave_fold(c, lds, clock0, key, from, run);

@@ -159,6 +159,8 @@ struct CountPrinter
       std::fprintf(stderr, "[emu wave] NFC-B detectors stepped on their own %llu, steps in the wake of another %llu, bulk paths not taken %llu, unarmed / carrier steps %llu\n",
                    (unsigned long long)emu_wave_counts[44][0], (unsigned long long)emu_wave_counts[45][0], (unsigned long long)emu_wave_counts[46][0],
                    (unsigned long long)emu_wave_counts[47][0]);
+      std::fprintf(stderr, "[emu wave] NFC-F listen tracker applied in place %llu, NFC-F detectors stepped on their own %llu\n", (unsigned long long)emu_wave_counts[49][0],
+                   (unsigned long long)emu_wave_counts[50][0]);
       std::fprintf(stderr, "[emu wave] bulk-path calls %llu, search values formed %llu, locked values formed %llu (with walked sums: %llu), tiles %llu\n", (unsigned long long)emu_wave_counts[40][0],
                    (unsigned long long)emu_wave_counts[41][0], (unsigned long long)emu_wave_counts[42][0], (unsigned long long)emu_wave_counts[48][0], (unsigned long long)emu_wave_counts[43][0]);
       for (uint32_t k = 0; k < 17; k++)

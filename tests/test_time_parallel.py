@@ -97,12 +97,12 @@ def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emul
 ])
 def test_remaining_knobs_at_non_default_values_emulated(emulated, knobs, expect):
     """every knob that is left (INTEGRATION.md lists them) decodes the same frames at a value that is not its
-    default - three dense synthetic streams in three submissions"""
+    default - two dense synthetic streams in three submissions"""
     res = _run(["carried_dense"], True, knobs)
     for r in res:
         assert r["mismatching"] == [] and r["frames"] > 0, r
         if expect == "sequential":
-            assert r["stats"]["windowed"] == 0 and r["stats"]["fallback"] >= 1, r
+            assert r["stats"]["windowed"] == 0 and r["stats"]["passes"] == 0, r   # (the path is not tried at all)
         elif expect == "windowed":
             assert r["stats"]["windowed"] >= 1 and r["stats"]["fallback"] == 0, r
 
@@ -127,7 +127,7 @@ def test_random_multi_submission_scenarios_emulated(emulated):
     random samples: both paths, carried state, final-state fix-ups) - the long runs are in profiles/r02/emulated_fuzz.json"""
     fuzz = os.path.join(T.ROOT, "profiles", "tools", "r02", "emulated_fuzz.py")
     env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="32768")
-    run = subprocess.run([sys.executable, fuzz, "5", "45", "small"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    run = subprocess.run([sys.executable, fuzz, "5", "35", "small"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-2000:]
     res = json.loads(run.stdout.strip().splitlines()[-1])
     assert res["rounds"] >= 3 and res["mismatches"] == [], res
@@ -151,7 +151,8 @@ def test_input_off_the_grid_is_decoded_by_carry_lanes_with_walked_sums_emulated(
     """float input off the int16 grid (what a radio delivers) stays on the path: no speculative windows - off the grid no lane
     that starts inside a stream can be in the decoder's state - but the stream's carry lane decodes it, one wavefront per
     stream, the raw running sums walked in the step's order; every tile decoded twice (bulk / stepped) and compared"""
-    res = _run(["offgrid"], True, {"NFC_EMU_WAVE_VERIFY": "1"})
+    # (the CPU run: three of the five captures and one synthetic stream; the GPU test below takes all of them)
+    res = _run(["offgrid"], True, {"NFC_EMU_WAVE_VERIFY": "1", "NFC_TEST_OFFGRID_CAPTURES": "3", "NFC_TEST_OFFGRID_SYNTHETIC": "1"})
     _check(res)
     for r in res:
         assert r["stats"]["fallback"] == 0, r

@@ -90,17 +90,18 @@ def main():
         rng = np.random.default_rng(11)
         streams = []
         for name, gain in (("test_NFC-B_106kbps_001", 0.83), ("test_NFC-F_212kbps_001", 1.07), ("test_NFC-V_26kbps_002", 0.91), ("test_NFC-A_424kbps_001", 0.77),
-                           ("test_POLL_ABF_001", 1.0)):
+                           ("test_POLL_ABF_001", 1.0))[:int(os.environ.get("NFC_TEST_OFFGRID_CAPTURES", "5"))]:
             m = np.abs(T.load_fixture(name)).astype(np.float32)
             streams.append(np.abs(m * np.float32(gain) + rng.normal(0.0, 0.0007, m.size).astype(np.float32)).astype(np.float32))
         out.append(case("captures off the grid with noise, 2 buffers", streams, buffers=2))
+        n_syn = int(os.environ.get("NFC_TEST_OFFGRID_SYNTHETIC", "3"))
         streams = [np.abs(synth.magnitude_f32(template, 40 + s, 0, 1 << 18) * np.float32(0.93) + rng.normal(0.0, 0.0005, 1 << 18).astype(np.float32)).astype(np.float32)
-                   for s in range(3)]
-        out.append(case("3 dense synthetic streams x 2^18 off the grid, IQ entry, 2 buffers", streams, buffers=2, stride=2))
+                   for s in range(n_syn)]
+        out.append(case("%d dense synthetic streams x 2^18 off the grid, IQ entry, 2 buffers" % n_syn, streams, buffers=2, stride=2))
 
     if "carried_dense" in which:
-        streams = [synth.magnitude_f32(template, s, 0, 3 << 17) for s in (29, 5, 17)]
-        out.append(case("3 dense synthetic streams x 3 * 2^17 in 3 buffers", streams, buffers=3))
+        streams = [synth.magnitude_f32(template, s, 0, 3 << 16) for s in (29, 5)]
+        out.append(case("2 dense synthetic streams x 3 * 2^16 in 3 buffers", streams, buffers=3))
 
     if "planes" in which:
         # (tests/test_time_parallel.py: the front-end planes - 16 bytes per sample - do not fit the device)
