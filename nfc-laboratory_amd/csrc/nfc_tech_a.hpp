@@ -592,6 +592,57 @@ NFC_DEV void nfca_poll_frame(const NfcConfig &c, NfcStreamState &s, const NfcLan
 }
 
 /* ---- listen SOF, 106k OOK subcarrier, NfcA.cpp:939-1090 ---- */
+/* The pulse tracker of the listen-frame start (NfcA.cpp:976-1060): a rising correlation above the threshold opens a
+ * pulse, its largest value half a symbol on marks the start, the falling one its end; true when a pulse of one symbol's
+ * width has just ended (the start of frame, pattern D: the caller sets the symbol up from the record), false while it is
+ * still looking - then the record is all it has touched. On its own because the wave decoder applies it in place
+ * (nfc_wave_fast.hpp) where the window between guard and waiting time is open and the modulation is not too deep. */
+NFC_DEV bool nfca_listen_ask_track(NfcMod &m, const NfcRate &rt, uint32_t clock, float s0)
+{
+   if (!m.symStart)
+   {
+      if (s0 > m.thr && s0 > m.peak)
+      {
+         m.peak = s0;
+         m.peakTime = clock;
+         m.winEnd = clock + rt.p4;
+      }
+   }
+   else if (s0 < -m.thr && s0 < m.peak)
+   {
+      m.peak = s0;
+      m.peakTime = clock;
+   }
+
+   if (clock != m.winEnd)
+      return false;
+
+   if (!m.symStart)
+   {
+      m.sync = m.peakTime + rt.p2;
+      m.winEnd = m.winEnd + rt.p2;
+      m.symStart = m.peakTime - rt.p2;
+      m.peakTime = 0;
+      m.peak = 0;
+      return false;
+   }
+
+   m.symEnd = m.peakTime;
+   m.pulses = m.symEnd - m.symStart;
+
+   const uint32_t minimumWidth = rt.p1 - rt.p8;
+   const uint32_t maximumWidth = rt.p1 + rt.p8;
+
+   if (m.peakTime == 0 || m.pulses < minimumWidth || m.pulses > maximumWidth)
+   {
+      m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
+      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
+      return false;
+   }
+
+   return true;
+}
+
 NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem &mem, const NfcNow &now, const NfcDecTaps &taps)
 {
    const NfcRate &rt = s.u.decode.rt;
@@ -627,46 +678,8 @@ NFC_DEV uint32_t nfca_listen_ask_start(const NfcConfig &c, NfcStreamState &s, co
    if (deep > c.minDepth[0])
       return SYM_TIMEOUT;
 
-   if (!m.symStart)
-   {
-      if (s0 > m.thr && s0 > m.peak)
-      {
-         m.peak = s0;
-         m.peakTime = s.clock;
-         m.winEnd = s.clock + rt.p4;
-      }
-   }
-   else if (s0 < -m.thr && s0 < m.peak)
-   {
-      m.peak = s0;
-      m.peakTime = s.clock;
-   }
-
-   if (s.clock != m.winEnd)
+   if (!nfca_listen_ask_track(m, rt, s.clock, s0))
       return SYM_NONE;
-
-   if (!m.symStart)
-   {
-      m.sync = m.peakTime + rt.p2;
-      m.winEnd = m.winEnd + rt.p2;
-      m.symStart = m.peakTime - rt.p2;
-      m.peakTime = 0;
-      m.peak = 0;
-      return SYM_NONE;
-   }
-
-   m.symEnd = m.peakTime;
-   m.pulses = m.symEnd - m.symStart;
-
-   const uint32_t minimumWidth = rt.p1 - rt.p8;
-   const uint32_t maximumWidth = rt.p1 + rt.p8;
-
-   if (m.peakTime == 0 || m.pulses < minimumWidth || m.pulses > maximumWidth)
-   {
-      m.symStart = 0; m.symEnd = 0; m.sync = 0; m.winStart = 0; m.winEnd = 0; m.pulses = 0;
-      m.peakTime = 0; m.peak = 0; m.auxTime = 0; m.aux = 0;
-      return SYM_NONE;
-   }
 
    m.sync = m.symEnd + rt.p1;
    m.winStart = m.sync - rt.p8;

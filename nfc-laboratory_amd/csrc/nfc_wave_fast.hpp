@@ -1170,6 +1170,210 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
        * sample. Such a sample touches the tracker's record and nothing else, so the wave applies the tracker itself
        * (nfcf_track_preamble, the decoder's own function, on a copy of the record) and goes on with the run, as it does for
        * the NFC-B detectors of the search bank; a preamble that completes is left to the step. */
+      /* BPSK listen symbols (nfca_listen_bpsk_symbol, nfcb_listen_symbol): once per symbol the integrated phase changes sign,
+       * which re-times the symbol - three fields of the record -; the decision at the synchronisation sample is the step's.
+       * (Left to the step, the samples behind a zero crossing were stepped one after the other: their gates had been
+       * evaluated against the phase of the symbol before.) */
+      while ((key == NFC_FK_A_BPSK_SYMBOL || key == NFC_FK_B_SYMBOL) && from + run < n)
+      {
+         const uint32_t g = from + run;
+         const uint32_t clk = clock0 + 1u + g;
+         const NfcDecodeRegs &d = s.u.decode;
+         const float phase = lds->sum[0][g];
+         const float lastPhase = d.lock.lastPhase;
+
+         const bool cross = !d.lock.auxTime && ((phase > 0.0f && lastPhase < 0.0f) || (phase < 0.0f && lastPhase > 0.0f));
+
+         if (!cross || clk == d.lock.sync)
+            break; /* the synchronisation sample: the step's */
+
+         const uint32_t p2 = d.rt.p2;
+
+         NFC_WAVE_READ_FENCE(); /* (the record is about to change) */
+         NFC_WAVE_COUNT(49u, 0u, 1u);
+
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            lds->u.s.u.decode.lock.auxTime = clk;
+            lds->u.s.u.decode.lock.sync = clk + p2;
+            lds->u.s.u.decode.lock.lastPhase = phase;
+         }
+         NFC_WAVE_UNIFORM_END
+
+         const bool again = nfc_wave_locked_gate(c, lds, clock0, key);
+         const uint64_t rest = NFC_WAVE_BALLOT(again && lane > g && lane < n);
+
+         gated = rest >> from;
+         run = rest ? (uint32_t)__builtin_ctzll(rest) - from : n - from;
+      }
+
+      /* The start of an NFC-A BPSK answer (nfca_listen_bpsk_start): while the integrated phase stays above the threshold -
+       * the three or four bit periods of the preamble - every sample notes where the burst began (once) and pushes the end of
+       * its window half a symbol on, nothing else; the window cannot end, nor the phase turn negative, on such a sample. A run
+       * of them leaves what its last one leaves. */
+      while (key == NFC_FK_A_BPSK_START && from + run < n)
+      {
+         const uint32_t g = from + run;
+         const NfcDecodeRegs &d = s.u.decode;
+         const float phase = lds->sum[0][lane];
+         const float deepAt = lds->ring[NFC_R_DEPTH + (t & NFC_FMASK)];
+
+         const bool plain = t > d.guardEnd && t <= d.waitingEnd && !(deepAt > c.minDepth[0]) && phase > d.lock.thr && !(phase < 0.0f);
+         const uint64_t ok = NFC_WAVE_BALLOT(plain && lane >= g && lane < n) >> g;
+         const uint32_t many = (ok & 1ull) ? (~ok ? (uint32_t)__builtin_ctzll(~ok) : 64u) : 0u; /* samples g .. g + many - 1 */
+
+         if (many == 0u)
+            break;
+
+         const uint32_t first = clock0 + 1u + g, last = clock0 + g + many;
+         const uint32_t p2 = d.rt.p2;
+
+         NFC_WAVE_READ_FENCE();
+         NFC_WAVE_COUNT(49u, 0u, many);
+
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            if (!lds->u.s.u.decode.lock.symStart)
+               lds->u.s.u.decode.lock.symStart = first;
+            lds->u.s.u.decode.lock.winEnd = last + p2;
+         }
+         NFC_WAVE_UNIFORM_END
+
+         const bool again = nfc_wave_locked_gate(c, lds, clock0, key);
+         const uint64_t rest = NFC_WAVE_BALLOT(again && lane >= g + many && lane < n);
+
+         gated = rest >> from;
+         run = rest ? (uint32_t)__builtin_ctzll(rest) - from : n - from;
+      }
+
+      /* NFC-V poll frames (nfcv_poll_symbol): a pulse correlation above the threshold that is the largest so far moves the
+       * record's maximum and, with it, the end of the window; what the window holds is decided at its end, by the step */
+      while (key == NFC_FK_V_POLL && from + run < n)
+      {
+         const uint32_t g = from + run;
+         const uint32_t clk = clock0 + 1u + g;
+         const NfcDecodeRegs &d = s.u.decode;
+
+         if (clk < d.lock.winStart || clk == d.lock.winEnd)
+            break;
+
+         float g0, g1;
+         nfc_wave_s0s1(c, lds, key, 0u, g, g0, g1);
+         const float q = g0 / (float)d.rt.p2; /* (c2 - sum) / p2: nfcv_pulse_apply */
+
+         if (!(q > d.lock.thr && q > d.lock.peak))
+            break; /* (nothing to do here after all: the step finds that out as well) */
+
+         const uint32_t p4 = d.rt.p4;
+
+         NFC_WAVE_READ_FENCE();
+         NFC_WAVE_COUNT(49u, 0u, 1u);
+
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            lds->u.s.u.decode.lock.peak = q;
+            lds->u.s.u.decode.lock.peakTime = clk;
+            lds->u.s.u.decode.lock.winEnd = clk + p4;
+         }
+         NFC_WAVE_UNIFORM_END
+
+         const bool again = nfc_wave_locked_gate(c, lds, clock0, key);
+         const uint64_t rest = NFC_WAVE_BALLOT(again && lane > g && lane < n);
+
+         gated = rest >> from;
+         run = rest ? (uint32_t)__builtin_ctzll(rest) - from : n - from;
+      }
+
+      /* the start of an NFC-V answer (nfcv_listen_start): a burst correlation beyond the threshold on either side that is
+       * the largest so far moves the record's extreme and the end of its window; the window's end is the step's */
+      while (key == NFC_FK_V_START && from + run < n)
+      {
+         const uint32_t g = from + run;
+         const uint32_t clk = clock0 + 1u + g;
+         const NfcDecodeRegs &d = s.u.decode;
+         const float deepAt = lds->ring[NFC_R_DEPTH + (clk & NFC_FMASK)];
+
+         if (!(clk > d.guardEnd && clk <= d.waitingEnd && !(deepAt > c.maxDepth[3]) && clk >= d.lock.winStart))
+            break;
+
+         float g0, g1;
+         nfc_wave_s0s1(c, lds, key, 0u, g, g0, g1);
+
+         float peak = d.lock.peak;
+         bool moved = false;
+
+         if (g0 < -d.lock.thr && g0 < peak)
+         {
+            peak = g0;
+            moved = true;
+         }
+         if (g0 > d.lock.thr && g0 > peak)
+         {
+            peak = g0;
+            moved = true;
+         }
+
+         if (!moved)
+            break; /* (the end of the window, or nothing at all: the step's) */
+
+         const uint32_t p8 = d.rt.p8;
+
+         NFC_WAVE_READ_FENCE();
+         NFC_WAVE_COUNT(49u, 0u, 1u);
+
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            lds->u.s.u.decode.lock.peak = peak;
+            lds->u.s.u.decode.lock.peakTime = clk;
+            lds->u.s.u.decode.lock.winEnd = clk + p8;
+         }
+         NFC_WAVE_UNIFORM_END
+
+         const bool again = nfc_wave_locked_gate(c, lds, clock0, key);
+         const uint64_t rest = NFC_WAVE_BALLOT(again && lane > g && lane < n);
+
+         gated = rest >> from;
+         run = rest ? (uint32_t)__builtin_ctzll(rest) - from : n - from;
+      }
+
+      /* the same for the pulse tracker of an NFC-A 106 k listen-frame start (nfca_listen_ask_track): inside the waiting time,
+       * past the sample that seeds the threshold, modulation not deeper than a card's */
+      while (key == NFC_FK_A_ASK_START && from + run < n)
+      {
+         const uint32_t g = from + run;
+         const uint32_t clk = clock0 + 1u + g;
+         const NfcDecodeRegs &d = s.u.decode;
+         const float deepAt = lds->ring[NFC_R_DEPTH + (clk & NFC_FMASK)];
+
+         if (!(clk > d.guardEnd && clk <= d.waitingEnd && !(deepAt > c.minDepth[0])))
+            break;
+
+         float g0, g1;
+         nfc_wave_s0s1(c, lds, key, 0u, g, g0, g1);
+
+         NfcMod m = *(const NfcMod *)&lds->u.s.u.decode.lock;
+         const NfcRate rt = d.rt;
+
+         if (nfca_listen_ask_track(m, rt, clk, g0))
+            break; /* start of frame: the step's */
+
+         NFC_WAVE_READ_FENCE(); /* (the record is about to change) */
+         NFC_WAVE_COUNT(49u, 0u, 1u);
+
+         NFC_WAVE_UNIFORM_BEGIN
+         {
+            m.acc = lds->u.s.u.decode.lock.acc; /* (the running sum is the commit's) */
+            *(NfcMod *)&lds->u.s.u.decode.lock = m;
+         }
+         NFC_WAVE_UNIFORM_END
+
+         const bool again = nfc_wave_locked_gate(c, lds, clock0, key);
+         const uint64_t rest = NFC_WAVE_BALLOT(again && lane > g && lane < n);
+
+         gated = rest >> from;
+         run = rest ? (uint32_t)__builtin_ctzll(rest) - from : n - from;
+      }
+
       while (key == NFC_FK_F_START && from + run < n)
       {
          const uint32_t g = from + run;
