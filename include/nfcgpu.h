@@ -131,6 +131,10 @@ typedef struct nfcgpu_stats
    double wave_ms;
    uint64_t wave_launches;
    double planes_ms;
+   /* round 4: the time the wave decoder's kernel was running at all since nfcgpu_stats_reset - the union of its launch
+    * intervals (the carry lanes of a pass run on a second HIP stream beside the speculative lanes, so wave_ms, the sum of
+    * the launch durations, counts the overlap twice). Profiling on; measured from the reset on. */
+   double wave_busy_ms;
 } nfcgpu_stats;
 
 #define NFCGPU_STATS_SIZE_V2 104u /* bytes of nfcgpu_stats up to and including scan_repairs: what nfcgpu_stats_get writes */

@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/nfcgpu.h"
@@ -166,6 +168,8 @@ struct nfcgpu_ctx
    uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
+   hipEvent_t epoch = nullptr;      /* recorded when the statistics start over: the time base of the launch intervals below */
+   std::vector<std::pair<float, float>> waveSpans; /* [start, stop) of every wave decoder launch since, ms after `epoch` */
 
    /* ---- frame gather over RCCL (nfcgpu_comm_*) ---- */
    void *comm = nullptr;
@@ -1568,6 +1572,9 @@ void release_workspace(nfcgpu_ctx *ctx)
       b->bytes = 0;
    }
 
+   if (ctx->epoch)
+      (void)hipEventDestroy(ctx->epoch);
+   ctx->epoch = nullptr;
    if (ctx->forkEvent)
       (void)hipEventDestroy(ctx->forkEvent);
    if (ctx->joinEvent)
@@ -1605,6 +1612,12 @@ void collect_timings(nfcgpu_ctx *ctx)
             *into.ms += ms;
             if (into.count)
                ++*into.count;
+
+            /* the wave decoder's launches run on two streams side by side: where they lie in time, for the time the kernel
+             * was running at all (nfcgpu_stats::wave_busy_ms) */
+            float at = 0;
+            if (into.list == &ctx->timedWave && ctx->epoch && hipEventElapsedTime(&at, ctx->epoch, pl.start) == hipSuccess)
+               ctx->waveSpans.push_back(std::make_pair(at, at + ms));
          }
          ctx->eventPool.push_back(pl.start);
          ctx->eventPool.push_back(pl.stop);
@@ -2751,6 +2764,38 @@ int nfcgpu_read_bandwidth(nfcgpu_ctx *ctx, const void *ptr, uint64_t bytes, uint
    return NFCGPU_OK;
 }
 
+namespace {
+
+/* total length of the union of the wave decoder's launch intervals */
+void close_wave_spans(nfcgpu_ctx *ctx)
+{
+   std::vector<std::pair<float, float>> &v = ctx->waveSpans;
+   std::sort(v.begin(), v.end());
+
+   double busy = 0.0;
+   float lo = 0, hi = -1.0f;
+
+   for (const auto &span: v)
+   {
+      if (hi < lo || span.first > hi)
+      {
+         if (hi >= lo)
+            busy += hi - lo;
+         lo = span.first;
+         hi = span.second;
+      }
+      else if (span.second > hi)
+         hi = span.second;
+   }
+
+   if (hi >= lo)
+      busy += hi - lo;
+
+   ctx->stats.wave_busy_ms = busy;
+}
+
+}
+
 int nfcgpu_stats_get(nfcgpu_ctx *ctx, nfcgpu_stats *stats)
 {
    if (!ctx || !stats)
@@ -2765,6 +2810,8 @@ int nfcgpu_stats_get_sized(nfcgpu_ctx *ctx, void *stats, uint32_t size)
    if (!ctx || !stats)
       return NFCGPU_EINVAL;
 
+   close_wave_spans(ctx);
+
    std::memcpy(stats, &ctx->stats, size < sizeof(nfcgpu_stats) ? size : sizeof(nfcgpu_stats));
    return NFCGPU_OK;
 }
@@ -2775,6 +2822,14 @@ int nfcgpu_stats_reset(nfcgpu_ctx *ctx)
       return NFCGPU_EINVAL;
 
    ctx->stats = nfcgpu_stats();
+   ctx->waveSpans.clear();
+
+   /* the time base of the launch intervals: an event on the context's stream, now */
+   if (!ctx->epoch)
+      (void)hipEventCreate(&ctx->epoch);
+   if (ctx->epoch)
+      (void)hipEventRecord(ctx->epoch, ctx->stream);
+
    return NFCGPU_OK;
 }
 

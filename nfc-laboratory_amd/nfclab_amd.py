@@ -89,6 +89,7 @@ class Stats(ctypes.Structure):
         ("wave_ms", ctypes.c_double),
         ("wave_launches", ctypes.c_uint64),
         ("planes_ms", ctypes.c_double),
+        ("wave_busy_ms", ctypes.c_double),
     ]
 
 
