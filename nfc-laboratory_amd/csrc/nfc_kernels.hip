@@ -1075,15 +1075,37 @@ __global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcL
 }
 
 /* speculative lanes: all of them (pass 0: every window assumes what the stream's state holds now), or those marked */
-__global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass)
+/* The waves take the run list in order, and the long lanes of a pass are what its last waves wait for: the lanes go on the
+ * list longest first, by classes of their distance to the successor's start (what a lane decodes before it can hand over).
+ * order: 0 every lane that runs goes on the list as it comes; 1 all lanes are set up, those of [lenLo, lenHi) go on the
+ * list; 2 (launched after 1, class by class) those of [lenLo, lenHi) follow. */
+__global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass, uint32_t order,
+                                                               uint32_t lenLo, uint32_t lenHi)
 {
    const uint32_t wi = A.firstWindowSlot + blockIdx.x * blockDim.x + threadIdx.x;
+   const uint32_t wEnd = A.firstWindowSlot + (*A.windowCount < A.windowRoom ? *A.windowCount : A.windowRoom);
 
-   if (wi >= A.firstWindowSlot + *A.windowCount || wi >= A.firstWindowSlot + A.windowRoom)
+   if (wi >= wEnd)
       return;
 
    NfcWindow w = A.windows[wi];
    const NfcScanJob *job = A.jobs + w.job;
+
+   bool listed = true;
+   if (order != 0u)
+   {
+      const uint32_t next = (wi + 1u < wEnd && A.windows[wi + 1u].job == w.job) ? A.windows[wi + 1u].start : job->count;
+      const uint32_t len = next - w.start;
+      listed = len >= lenLo && len < lenHi;
+   }
+
+   if (order == 2u)
+   {
+      /* (set up by the first launch; `rerun` has been cleared there: the work record says whether the lane runs) */
+      if (listed && A.works[wi].count != 0u)
+         A.runList[atomicAdd(A.runCount, 1u)] = wi;
+      return;
+   }
 
    NfcWork work;
    work.data = job->data + (uint64_t)w.start * A.stride * 4u;
@@ -1130,7 +1152,8 @@ __global__ __launch_bounds__(64) void nfc_window_lanes_kernel(const NfcConfig *_
 
       work.count = job->count - w.start;
 
-      A.runList[atomicAdd(A.runCount, 1u)] = wi;
+      if (listed)
+         A.runList[atomicAdd(A.runCount, 1u)] = wi;
    }
 
    A.works[wi] = work;

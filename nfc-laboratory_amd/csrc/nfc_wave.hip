@@ -139,17 +139,24 @@ __device__ __forceinline__ float nfc_wave_max(float v)
 #define NFC_WAVE_UNIFORM_BEGIN {
 #define NFC_WAVE_UNIFORM_END }
 #define NFC_WAVE_UNIFORM_U32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+/* a word a uniform block hands to the code after it: every lane has computed it (no trip through LDS) */
+#define NFC_WAVE_UNIFORM_LEAVE(slot, value) ((void)0)
+#define NFC_WAVE_UNIFORM_TAKE(slot, value) ((value) = (uint32_t)__builtin_amdgcn_readfirstlane((int)(value)))
 #define NFC_WAVE_SCAN_ADD_F(v) nfc_wave_scan_add(v)
 #define NFC_WAVE_MAX_F(v) nfc_wave_max(v)
 #define NFC_WAVE_PICK_F(reg, array, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)(reg)), (int)(j)))
 #define NFC_WAVE_PICK_U32(reg, array, j) ((uint32_t)__builtin_amdgcn_readlane((int)(reg), (int)(j)))
 #define NFC_WAVE_SHFL_F(reg, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)(reg)), (int)(j)))
 #define NFC_WAVE_CONFIG(cfgPtr, lds, cc) nfc_wave_config_parked((lds)->cfg, (cc))
-/* experiments: -DNFC_WAVE_STEP_INLINE (the steps inlined into the tile loop), -DNFC_WAVE_WAVES=n (register budget for n waves per SIMD) */
-#ifdef NFC_WAVE_STEP_INLINE
+/* The two step functions are inlined into the tile loop and work on the decoder state where it lies in LDS (round 4: as
+ * functions of their own that took the 91-word state into registers they used every register of the wave, and the 66
+ * callee-saved ones went to scratch and back on every call: two thirds of the kernel's HBM writes).
+ * Experiments: -DNFC_WAVE_STEP_CALL (functions of their own), -DNFC_WAVE_STEP_COPY (state into registers and back),
+ * -DNFC_WAVE_WAVES=n (register budget for n waves per SIMD) */
+#ifndef NFC_WAVE_STEP_CALL
 #define NFC_WAVE_NOINLINE __device__ __forceinline__
 #else
-#define NFC_WAVE_NOINLINE __device__ __attribute__((noinline))
+#define NFC_WAVE_NOINLINE static __device__ __attribute__((noinline))
 #endif
 #ifdef NFC_WAVE_WAVES
 #define NFC_WAVE_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(NFC_WAVE_WAVES, NFC_WAVE_WAVES)))

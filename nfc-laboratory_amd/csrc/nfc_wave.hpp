@@ -480,7 +480,11 @@ NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWa
 
    NFC_WAVE_UNIFORM_BEGIN
    {
+#ifdef NFC_WAVE_STEP_COPY
       NfcStreamState s = *(NfcStreamState *)&lds->u.s;
+#else
+      NfcStreamState &s = *(NfcStreamState *)&lds->u.s;
+#endif
       const uint32_t at = lds->u.at;
       const uint32_t slot = (s.clock + 1u) & NFC_HMASK;
       const uint32_t slotF = (s.clock + 1u) & NFC_FMASK;
@@ -507,7 +511,9 @@ NFC_WAVE_NOINLINE void nfc_wave_step(const NfcConfig *cfgPtr, NFC_WAVE_LDS NfcWa
 
       NFC_WAVE_TICK(lds, 14u);
 
+#ifdef NFC_WAVE_STEP_COPY
       *(NfcStreamState *)&lds->u.s = s;
+#endif
       lds->u.maskValid = 0u;
       lds->u.at = at + 1u;
       lds->u.stepped++;
@@ -530,7 +536,11 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
    {
       /* (in registers for the step: the detectors touch most of the record, and every access in place is an LDS round
        * trip the next one waits for) */
+#ifdef NFC_WAVE_SEARCH_IN_PLACE
+      NfcStreamState &s = *(NfcStreamState *)&lds->u.s;
+#else
       NfcStreamState s = *(NfcStreamState *)&lds->u.s;
+#endif
       const uint32_t at = lds->u.at;
 
       ++s.clock;
@@ -662,7 +672,9 @@ NFC_WAVE_NOINLINE void nfc_wave_search_step(const NfcConfig *cfgPtr, NFC_WAVE_LD
       /* the gates of the detectors that were asked no longer stand (NFC-F: the marks with them) */
       lds->u.maskValid &= ~(ask & 0xFFu);
 
+#ifndef NFC_WAVE_SEARCH_IN_PLACE
       *(NfcStreamState *)&lds->u.s = s;
+#endif
       lds->u.at = at + 1u;
       lds->u.stepped++;
    }

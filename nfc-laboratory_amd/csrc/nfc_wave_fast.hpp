@@ -963,6 +963,8 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
          NFC_WAVE_TICK(lds, 10u);
 
+         uint32_t lockedHere = 0u; /* (the verdict of the uniform block: every lane computes it on the GPU) */
+
          NFC_WAVE_UNIFORM_BEGIN
          {
             const uint32_t clk = clock0 + 1u + g;
@@ -1075,14 +1077,27 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
                   *(NfcDetV *)&lds->u.s.u.search.detV = shown.u.search.detV;
             }
 
-            lds->u.aloneLocked = locks ? 1u : 0u;
+            lockedHere = locks ? 1u : 0u;
+            NFC_WAVE_UNIFORM_LEAVE(lds->u.aloneLocked, lockedHere);
          }
          NFC_WAVE_UNIFORM_END
 
-         if (NFC_WAVE_UNIFORM_U32(lds->u.aloneLocked))
+         NFC_WAVE_UNIFORM_TAKE(lds->u.aloneLocked, lockedHere);
+#ifdef NFC_WAVE_PROFILE_VISITS
+         NFC_WAVE_TICK(lds, 15u); /* (profile build: the gates after a visit on their own) */
+#endif
+
+         if (lockedHere)
             break; /* a start of frame: the sample is the search step's (nothing has been moved) */
 
          NFC_WAVE_COUNT(44u, 0u, 1u); /* detectors shown their records in place */
+#ifdef NFC_WAVE_COUNT_VISITS
+         for (uint32_t kk = 0; kk < 8u; kk++)
+            if ((here >> kk) & 1u)
+               NFC_WAVE_COUNT(51u + kk, 0u, 1u);
+         if ((here & 0xFFu & ~0x18u) == 0u)
+            NFC_WAVE_COUNT(59u, 0u, 1u); /* NFC-B only */
+#endif
 
          /* their gates over the rest of the tile, for the records as they now stand */
          if (lane > g)

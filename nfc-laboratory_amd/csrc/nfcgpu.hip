@@ -43,7 +43,7 @@ __global__ void nfc_seams_kernel(NfcScanArgs A, uint32_t first);
 __global__ void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t nTilesTotal);
 __global__ void nfc_windows_kernel(NfcScanArgs A);
 __global__ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint32_t pass);
-__global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass);
+__global__ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass, uint32_t order, uint32_t lenLo, uint32_t lenHi);
 __global__ void nfc_final_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes);
 __global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPasses);
 __global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
@@ -162,6 +162,7 @@ struct nfcgpu_ctx
    DevBuf wRepairs, wJobs, wChunks, wPoints, wSeams, wChunkEdge, wTiles, wTileStats, wWindows, wWorks, wCounters, wRunList;
    uint32_t busyPercent = 8;   /* a stream with more than this share of busy tiles is "busy": few long busy streams are decoded in blocks */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
+   uint32_t longFirst = 32768;      /* the run list of a pass takes its lanes longest first, by classes of their length down to this one (NFCGPU_LONG_FIRST; 0: as they come) */
    uint32_t lanesWanted = 16384;    /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart) */
    uint32_t cutMax = 1u << 17;      /* ... but never further apart than this (NFCGPU_CUT_MAX) */
    uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
@@ -1160,8 +1161,28 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (nWindows)
       {
          HIP_TRY(ctx, hipMemsetAsync(counters + 2, 0, 8, ctx->stream)); /* run list: count and next */
-         hipLaunchKernelGGL(nfc_window_lanes_kernel, dim3(windowBlocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, A, lanes, pass);
-         HIP_TRY(ctx, hipGetLastError());
+         if (!ctx->longFirst)
+         {
+            hipLaunchKernelGGL(nfc_window_lanes_kernel, dim3(windowBlocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, A, lanes, pass, 0u, 0u, 0xFFFFFFFFu);
+            HIP_TRY(ctx, hipGetLastError());
+         }
+         else
+         {
+            /* longest lanes first: classes of 65536 samples and more, then halving down to NFCGPU_LONG_FIRST, then the rest */
+            uint32_t hi = 0xFFFFFFFFu, lo = 65536u > ctx->longFirst ? 65536u : ctx->longFirst;
+
+            for (uint32_t order = 1u;; order = 2u)
+            {
+               hipLaunchKernelGGL(nfc_window_lanes_kernel, dim3(windowBlocks), dim3(NFC_LANES), 0, ctx->stream, dCfg, A, lanes, pass, order, lo, hi);
+               HIP_TRY(ctx, hipGetLastError());
+
+               if (lo == 0u)
+                  break;
+
+               hi = lo;
+               lo = lo / 2u >= ctx->longFirst ? lo / 2u : 0u;
+            }
+         }
       }
 
       /* the carry lanes (later passes: those the chain kernel sent on): from the stream's own state, which has not
@@ -1236,8 +1257,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
                all += v;
             if (all)
                std::fprintf(stderr, "[nfcgpu]    wave cycles x 2^10: boundary %u, tile load %u, values %u, search gates %u, commit %u, step %u, search step %u, set-up %u, "
-                                    "prologue %u, locked gates %u, NFC-B alone %u, between %u, step: state in %u, machine %u, state out %u\n", prof[0], prof[1], prof[2], prof[3], prof[4], prof[5],
-                            prof[6], prof[7], prof[8], prof[9], prof[10], prof[11], prof[12], prof[13], prof[14]);
+                                    "prologue %u, locked gates %u, detectors shown their records %u (gates after it: %u), between %u, step: state in %u, machine %u, state out %u\n", prof[0], prof[1], prof[2], prof[3], prof[4], prof[5],
+                            prof[6], prof[7], prof[8], prof[9], prof[10], prof[15], prof[11], prof[12], prof[13], prof[14]);
          }
          if (std::atoi(std::getenv("NFCGPU_WINDOW_DEBUG")) >= 2 && nWindows)
          {
@@ -1693,6 +1714,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->soloSamples = knob("NFCGPU_SOLO_SAMPLES", ctx->soloSamples);
    ctx->stagingWords = knob("NFCGPU_STAGING_WORDS", ctx->stagingWords);
    ctx->lanesWanted = knob("NFCGPU_LANES_WANTED", ctx->lanesWanted);
+   ctx->longFirst = knob("NFCGPU_LONG_FIRST", ctx->longFirst);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;

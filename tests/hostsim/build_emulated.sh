@@ -10,7 +10,7 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 PKG="$HERE/../../nfc-laboratory_amd"
 make -s -C "$PKG" build/nfc_config_fixed.inc
-CXX="g++ -std=c++17 -O2 -fno-strict-aliasing -ffp-contract=off -msse3 -mno-avx -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -I$HERE/fakehip -I$PKG/build -DNFCGPU_EMULATED_TEST_BUILD"
+CXX="g++ -std=c++17 -O2 -fno-strict-aliasing -ffp-contract=off -msse3 -mno-avx -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -I$HERE/fakehip -I$PKG/build -DNFCGPU_EMULATED_TEST_BUILD $EMU_DEFS"
 $CXX -x c++ -c "$PKG/csrc/nfcgpu.hip" -o "$HERE/emu_nfcgpu.o"
 $CXX -x c++ -c "$PKG/csrc/nfc_trace.hip" -o "$HERE/emu_trace.o"
 $CXX -c "$HERE/emu_kernels.cpp" -o "$HERE/emu_kernels.o"

@@ -726,14 +726,30 @@ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint
    }
 }
 
-void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass)
+void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, NfcLaunch lanes, uint32_t pass, uint32_t order, uint32_t lenLo, uint32_t lenHi)
 {
    const uint32_t n = *A.windowCount < A.windowRoom ? *A.windowCount : A.windowRoom;
+   const uint32_t wEnd = A.firstWindowSlot + n;
 
-   for (uint32_t wi = A.firstWindowSlot; wi < A.firstWindowSlot + n; wi++)
+   for (uint32_t wi = A.firstWindowSlot; wi < wEnd; wi++)
    {
       NfcWindow w = A.windows[wi];
       const NfcScanJob *job = A.jobs + w.job;
+
+      /* (the order of the run list: nfc_kernels.hip) */
+      bool listed = true;
+      if (order != 0u)
+      {
+         const uint32_t next = (wi + 1u < wEnd && A.windows[wi + 1u].job == w.job) ? A.windows[wi + 1u].start : job->count;
+         listed = next - w.start >= lenLo && next - w.start < lenHi;
+      }
+
+      if (order == 2u)
+      {
+         if (listed && A.works[wi].count != 0u)
+            A.runList[emu_add(A.runCount, 1u)] = wi;
+         continue;
+      }
 
       NfcWork work;
       work.data = job->data + (uint64_t)w.start * A.stride * 4u;
@@ -776,7 +792,8 @@ void nfc_window_lanes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A
 
          work.count = job->count - w.start;
 
-         A.runList[emu_add(A.runCount, 1u)] = wi;
+         if (listed)
+            A.runList[emu_add(A.runCount, 1u)] = wi;
       }
 
       A.works[wi] = work;

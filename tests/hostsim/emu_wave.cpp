@@ -62,6 +62,8 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 #define NFC_WAVE_UNIFORM_BEGIN if (wavesim::lane() == 0) {
 #define NFC_WAVE_UNIFORM_END } wavesim::barrier();
 #define NFC_WAVE_UNIFORM_U32(x) ((uint32_t)(x))
+#define NFC_WAVE_UNIFORM_LEAVE(slot, value) ((slot) = (value))
+#define NFC_WAVE_UNIFORM_TAKE(slot, value) ((value) = (slot))
 #define NFC_WAVE_READ_FENCE() wavesim::barrier()
 #define NFC_WAVE_PICK_F(reg, array, j) ((array)[(j)])
 #define NFC_WAVE_PICK_U32(reg, array, j) (wavesim::shfl((reg), (j)))
@@ -159,6 +161,9 @@ struct CountPrinter
       std::fprintf(stderr, "[emu wave] NFC-B detectors stepped on their own %llu, steps in the wake of another %llu, bulk paths not taken %llu, unarmed / carrier steps %llu\n",
                    (unsigned long long)emu_wave_counts[44][0], (unsigned long long)emu_wave_counts[45][0], (unsigned long long)emu_wave_counts[46][0],
                    (unsigned long long)emu_wave_counts[47][0]);
+      for (uint32_t k = 0; k < 9; k++)
+         if (emu_wave_counts[51 + k][0])
+            std::fprintf(stderr, "[emu wave] shown in place: %-5s %10llu\n", k < 8 ? det[k] : "B only", (unsigned long long)emu_wave_counts[51 + k][0]);
       std::fprintf(stderr, "[emu wave] NFC-F listen tracker applied in place %llu, NFC-F detectors stepped on their own %llu\n", (unsigned long long)emu_wave_counts[49][0],
                    (unsigned long long)emu_wave_counts[50][0]);
       std::fprintf(stderr, "[emu wave] bulk-path calls %llu, search values formed %llu, locked values formed %llu (with walked sums: %llu), tiles %llu\n", (unsigned long long)emu_wave_counts[40][0],
