@@ -764,7 +764,7 @@ def main():
                 "frac_of_measured_peak": line["frac_of_measured_peak"],
                 "workload": line["workload"],
                 "note": "the per-sample search kernel of the time-parallel path: exact front end + tile tests over every sample; it reads "
-                        "every sample once plus the warm-up overlap of its chunks (6144 samples per chunk of up to 32768: 1.19 x the "
+                        "every sample once plus the warm-up overlap of its chunks (4096 samples per chunk of up to 32768: 1.125 x the "
                         "algorithmic bytes at this size). Two timed launches, HIP events on the library's stream.",
             }
             if scan_stats is not None and scan_stats.scan_ms > 0:

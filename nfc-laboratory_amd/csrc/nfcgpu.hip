@@ -151,7 +151,7 @@ struct nfcgpu_ctx
    bool scanChunkFixed = false;    /* NFCGPU_SCAN_CHUNK given: no sizing by the submission */
    uint32_t blockSamples = 1u << 23; /* a few long busy streams are decoded this many samples at a time (NFCGPU_BLOCK_SAMPLES) */
    bool inBlocks = false;
-   uint32_t scanWarm = 6144;       /* samples walked ahead of a chunk */
+   uint32_t scanWarm = 4096;       /* samples walked ahead of a chunk (round 4: 6144 -> 4096; config 5 dense: scan and second walks 94 -> 79 ms per step, as many chunks walked again) */
    uint32_t maxPasses = 12;        /* decode passes before a stream of a large submission gives up (sequential path) */
    uint32_t maxPassesFew = 48;     /* the same for submissions of fewer streams than a wave has lanes: the sequential path would crawl */
    struct DevBuf
