@@ -148,11 +148,14 @@ struct nfcgpu_ctx
    bool windowed = true;           /* NFCGPU_WINDOWED=0 switches the path off */
    uint32_t windowedMinSamples = 32768; /* shortest submission (per stream) worth cutting into windows */
    uint32_t scanChunk = 8192;      /* samples per scan chunk, at least: short chunks = many lanes (the walk is latency-bound per wave) */
+   uint32_t scanLanes = 32768;     /* chunks a large submission is cut into, at least (NFCGPU_SCAN_LANES) */
    bool scanChunkFixed = false;    /* NFCGPU_SCAN_CHUNK given: no sizing by the submission */
    uint32_t blockSamples = 1u << 23; /* a few long busy streams are decoded this many samples at a time (NFCGPU_BLOCK_SAMPLES) */
    bool inBlocks = false;
    uint32_t scanWarm = 4096;       /* samples walked ahead of a chunk (round 4: 6144 -> 4096; config 5 dense: scan and second walks 94 -> 79 ms per step, as many chunks walked again) */
-   uint32_t maxPasses = 12;        /* decode passes before a stream of a large submission gives up (sequential path) */
+   uint32_t maxPasses = 32;        /* decode passes before a stream of a large submission gives up (sequential path). Round 4: 12 -> 32: a late pass of a
+                                      few lanes is 10-20 ms, the sequential kernels take seconds for a stream of 2^20 samples (256 dense streams x 2^20
+                                      cut into 64 lanes each: one stream in 768 needed a thirteenth pass, and the step took 1035 instead of 305 ms) */
    uint32_t maxPassesFew = 48;     /* the same for submissions of fewer streams than a wave has lanes: the sequential path would crawl */
    struct DevBuf
    {
@@ -163,7 +166,7 @@ struct nfcgpu_ctx
    uint32_t busyPercent = 8;   /* a stream with more than this share of busy tiles is "busy": few long busy streams are decoded in blocks */
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    uint32_t longFirst = 32768;      /* the run list of a pass takes its lanes longest first, by classes of their length down to this one (NFCGPU_LONG_FIRST; 0: as they come) */
-   uint32_t lanesWanted = 16384;    /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart) */
+   uint32_t lanesWanted = 4096;     /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart). Round 4: 16384 -> 4096: longer lanes need fewer passes (512 dense streams x 2^20: 320 -> 273 ms per step; 4096 streams are at NFCGPU_CUT_MAX either way) */
    uint32_t cutMax = 1u << 17;      /* ... but never further apart than this (NFCGPU_CUT_MAX) */
    uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
    uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
@@ -725,7 +728,11 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          for (const WindowedItem &it: items)
             total += it.count;
 
-         uint64_t chunk = total / 131072u / NFC_SCAN_POINT * NFC_SCAN_POINT;
+         /* (round 4: a sixteenth of that is enough lanes. What a submission of 2^29 samples - 512 busy streams, an eighth of
+          * config 5 - pays for are the rounds of second walks, a launch and a trip to the host each, and a chain of chunks that
+          * inherit a wrong envelope from each other is as many rounds as it has chunks: 27 rounds of 4096-sample chunks, 8 of
+          * 32768. 512 / 1024 dense streams x 2^20: 352 -> 321 ms per step.) */
+         uint64_t chunk = total / ctx->scanLanes / NFC_SCAN_POINT * NFC_SCAN_POINT;
          if (chunk > 32768u)
             chunk = 32768u;
          if (chunk > sp.chunkSamples)
@@ -1708,6 +1715,9 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->windowedMinSamples = knob("NFCGPU_WINDOWED_MIN", ctx->windowedMinSamples);
    ctx->scanChunkFixed = std::getenv("NFCGPU_SCAN_CHUNK") != nullptr && std::getenv("NFCGPU_SCAN_CHUNK")[0] != 0;
    ctx->scanChunk = knob("NFCGPU_SCAN_CHUNK", ctx->scanChunk) / NFC_SCAN_POINT * NFC_SCAN_POINT;
+   ctx->scanLanes = knob("NFCGPU_SCAN_LANES", ctx->scanLanes);
+   if (ctx->scanLanes == 0u)
+      ctx->scanLanes = 1u;
    ctx->scanWarm = knob("NFCGPU_SCAN_WARM", ctx->scanWarm) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->maxPasses = knob("NFCGPU_WINDOW_PASSES", ctx->maxPasses);
    ctx->maxPassesFew = knob("NFCGPU_WINDOW_PASSES_FEW", knob("NFCGPU_WINDOW_PASSES", ctx->maxPassesFew));

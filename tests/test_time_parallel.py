@@ -94,6 +94,7 @@ def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emul
     ({"NFCGPU_WINDOW_PASSES": "1", "NFCGPU_WINDOW_PASSES_FEW": "1"}, "any"),   # one pass and no more: streams that need another go the sequential way
     ({"NFCGPU_LANES_WANTED": "0", "NFCGPU_CUT_MAX": "16384"}, "windowed"),     # lanes 16384 samples apart whatever the submission
     ({"NFCGPU_SIDE_STREAM": "0"}, "windowed"),                                 # carry lanes on the stream of the windows
+    ({"NFCGPU_SCAN_LANES": "1"}, "windowed"),                                  # scan chunks as long as they get (32768 samples)
     ({"NFCGPU_LONG_FIRST": "0"}, "windowed"),                                  # the run list of a pass in stream order
     ({"NFCGPU_LONG_FIRST": "2048", "NFCGPU_LANES_WANTED": "0", "NFCGPU_CUT_MAX": "16384"}, "windowed"),  # ... in six classes of length
 ])
