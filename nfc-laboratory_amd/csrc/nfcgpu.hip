@@ -169,7 +169,8 @@ struct nfcgpu_ctx
    uint32_t lanesWanted = 4096;     /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart). Round 4: 16384 -> 4096: longer lanes need fewer passes (512 dense streams x 2^20: 320 -> 273 ms per step; 4096 streams are at NFCGPU_CUT_MAX either way) */
    uint32_t cutMax = 1u << 17;      /* ... but never further apart than this (NFCGPU_CUT_MAX) */
    uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
-   uint32_t soloSamples = 1u << 18; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES) */
+   uint32_t soloSamples = 1u << 16; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES). Round 4: 2^18 -> 2^16,
+                                       the lanes being what they now are: the bundled captures of 100 k - 200 k samples 25 / 39 / 49 -> 17 / 27 / 37 ms */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
    hipEvent_t epoch = nullptr;      /* recorded when the statistics start over: the time base of the launch intervals below */

@@ -19,7 +19,7 @@ needs_reference = pytest.mark.skipif(T.reference_lib() is None, reason="oracle/_
 
 
 def _run(cases, emulated, extra=None):
-    # (NFCGPU_SOLO_SAMPLES=0: speculative windows also on the short captures - by default a stream of up to 2^18 samples is
+    # (NFCGPU_SOLO_SAMPLES=0: speculative windows also on the short captures - by default a stream of up to 2^16 samples is
     # decoded by its carry lane alone)
     env = dict(os.environ, NFCGPU_WINDOWED_MIN="4096", NFCGPU_SCAN_CHUNK="32768", NFCGPU_SOLO_SAMPLES="0")
     if emulated:
