@@ -65,11 +65,16 @@ def test_stepping_alone_decodes_the_same_frames(emulated):
 
 @needs_reference
 def test_short_streams_are_decoded_by_their_carry_lane_alone(emulated):
-    """the default: a stream of up to 2^18 samples gets no speculative windows - one lane, one pass"""
+    """the default (NFCGPU_SOLO_SAMPLES = 2^16 since round 4, 2^18 before): a stream of up to 2^16 samples gets no speculative
+    windows - one lane, one pass; a longer one does (every bundled capture is longer: the short ones are their first samples)"""
     env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096")
-    run = subprocess.run([sys.executable, DRIVER, "fixture:test_NFC-A_106kbps_002", "fixture:test_NFC-B_106kbps_001"], env=env, stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True, timeout=900)
+    run = subprocess.run([sys.executable, DRIVER, "fixture:test_NFC-A_106kbps_002@61000", "fixture:test_NFC-B_106kbps_001@65536", "fixture:test_NFC-A_106kbps_002"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
-    for r in json.loads(run.stdout.strip().splitlines()[-1]):
+    results = json.loads(run.stdout.strip().splitlines()[-1])
+    assert len(results) == 3
+    for r in results:
         assert r["mismatching"] == [] and r["frames"] > 0, r
+    for r in results[:2]:
         assert r["stats"]["windowed"] == 1 and r["stats"]["passes"] == 1 and r["stats"]["windows"] == 1, r
+    assert results[2]["stats"]["windowed"] == 1 and results[2]["stats"]["windows"] > 1, results[2]

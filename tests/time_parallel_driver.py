@@ -53,10 +53,15 @@ def main():
     out = []
     template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
 
-    # "fixture:<name>": one capture
+    # "fixture:<name>": one capture; "fixture:<name>@<n>": its first n samples
     for name in [w.split(":", 1)[1] for w in which if w.startswith("fixture:")]:
+        head = None
+        if "@" in name:
+            name, head = name.split("@", 1)
         mag = np.abs(T.load_fixture(name)).astype(np.float32)
-        out.append(case(name, [mag]))
+        if head is not None:
+            mag = np.ascontiguousarray(mag[:int(head)])
+        out.append(case(name if head is None else "%s@%s" % (name, head), [mag]))
 
     if not which or "fixtures" in which:
         for name in T.fixture_names():
