@@ -54,14 +54,19 @@ def git_head():
         return None
 
 
+# files under csrc/ that are not part of the kernels the stored counter figures are about (nfc_wave_kernel, nfc_scan_kernel,
+# nfc_demod_fixed_kernel): the host runtime, and the kernel of the envelope tracker's second walks (round 4, a translation unit
+# of its own that includes the others' headers and changes none of them)
+NOT_IN_DIGEST = ("nfcgpu.hip", "nfc_envelope.hip", "nfc_envelope.hpp")
+
+
 def sources_digest():
-    """sha1 over the kernel sources - everything under csrc/ but the host runtime nfcgpu.hip - : what a stored counter
-    figure belongs to"""
+    """sha1 over the sources of the kernels the stored counter figures belong to: everything under csrc/ but NOT_IN_DIGEST"""
     import hashlib
     src = os.path.join(ROOT, "nfc-laboratory_amd", "csrc")
     h = hashlib.sha1()
     for f in sorted(os.listdir(src)):
-        if not f.endswith((".h", ".hpp", ".hip")) or f == "nfcgpu.hip":
+        if not f.endswith((".h", ".hpp", ".hip")) or f in NOT_IN_DIGEST:
             continue
         with open(os.path.join(src, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())

@@ -49,6 +49,7 @@ __global__ void nfc_chain_kernel(NfcScanArgs A, NfcLaunch lanes, uint32_t maxPas
 __global__ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes);
 __global__ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restrict__ out);
 __global__ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
+__global__ void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode);
 
 namespace {
@@ -172,6 +173,11 @@ struct nfcgpu_ctx
    uint32_t soloSamples = 1u << 16; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES). Round 4: 2^18 -> 2^16,
                                        the lanes being what they now are: the bundled captures of 100 k - 200 k samples 25 / 39 / 49 -> 17 / 27 / 37 ms */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
+   DevBuf wRepairsEnv;             /* the chunks of a round whose envelope tracker alone is walked again (nfc_envelope_kernel) */
+   uint32_t envelopeMax = 64;      /* ... when the round lists at most this many chunks (NFCGPU_ENVELOPE_KERNEL; 0: never). Measured on the MI355X
+                                      (profiles/r04/ab_envelope): a lane that fetches its own chunk is what a short capture wants - its 10 - 20
+                                      rounds of a few 4096-sample chunks 10.2 / 20.4 -> 8.0 / 16.0 ms - and what a large submission does not:
+                                      thousands of lanes reading 32768-sample chunks a cache line each, 79 -> 122 ms per step of the headline */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
    hipEvent_t epoch = nullptr;      /* recorded when the statistics start over: the time base of the launch intervals below */
    std::vector<std::pair<float, float>> waveSpans; /* [start, stop) of every wave decoder launch since, ms after `epoch` */
@@ -798,7 +804,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
        (rc = grow(ctx, ctx->wPoints, sizeof(NfcScanPoint) * (size_t)points)) || (rc = grow(ctx, ctx->wSeams, sizeof(NfcScanSeam) * nChunks)) ||
        (rc = grow(ctx, ctx->wChunkEdge, 4 * (size_t)nChunks)) || (rc = grow(ctx, ctx->wTiles, 4 * (size_t)tiles)) ||
        (rc = grow(ctx, ctx->wTileStats, sizeof(NfcScanTile) * (size_t)tiles)) ||
-       (rc = grow(ctx, ctx->wCounters, 256)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nChunks)))
+       (rc = grow(ctx, ctx->wCounters, 256)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nChunks)) ||
+       (rc = grow(ctx, ctx->wRepairsEnv, sizeof(NfcScanChunk) * nChunks)))
       return rc;
 
    /* lanes: a first guess (one window per 8192 samples); the window kernel reports what it needs */
@@ -923,6 +930,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    HIP_TRY(ctx, hipGetLastError());
 
    /* seams: chunks that did not start from the true state are walked again, a round at a time */
+   std::vector<NfcScanChunk> listed, listedWhole, listedAlone; /* a round's list as the seam check left it, and sorted by what is walked again */
+
    for (uint32_t round = 0;; round++)
    {
       if (debugStages && std::atoi(std::getenv("NFCGPU_WINDOW_DEBUG")) >= 4)
@@ -987,14 +996,62 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (!repairs)
          break;
 
-      NfcScanArgs R = A;
-      R.chunks = A.repairs;
-      R.nChunks = repairs;
+      /* A short list (a capture, a receiver's block: rounds of a few chunks, and the latency of a round is what the caller waits
+       * for): the chunks whose envelope tracker alone started wrong - from the second round on that is all of them: chains of
+       * chunks that inherit a wrong envelope from each other, a chunk per round - go to a kernel that does nothing else
+       * (nfc_envelope.hpp); the others to the scan kernel, from their true starts. The list is sorted on the host. A long
+       * list, or one of long chunks (what has been measured are the 4096-sample chunks of small submissions), stays with the
+       * scan kernel as it is (its envelope-only branch; see nfcgpu_ctx::envelopeMax). */
+      uint32_t whole = repairs, alone = 0;
+
+      if (repairs <= ctx->envelopeMax && sp.chunkSamples <= 4096u)
+      {
+         listed.resize(repairs);
+         HIP_TRY(ctx, hipMemcpyAsync(listed.data(), A.repairs, sizeof(NfcScanChunk) * repairs, hipMemcpyDeviceToHost, ctx->stream));
+         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+         listedWhole.clear();
+         listedAlone.clear();
+
+         for (const NfcScanChunk &c: listed)
+            ((c.index & NFC_CHUNK_ENVELOPE) ? listedAlone : listedWhole).push_back(c);
+
+         whole = (uint32_t)listedWhole.size();
+         alone = (uint32_t)listedAlone.size();
+
+         /* (both vectors outlive the copies: the next thing that touches them comes after the next round's synchronisation) */
+         if (alone && whole)
+            HIP_TRY(ctx, hipMemcpyAsync((void *)A.repairs, listedWhole.data(), sizeof(NfcScanChunk) * whole, hipMemcpyHostToDevice, ctx->stream));
+         if (alone)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->wRepairsEnv.ptr, listedAlone.data(), sizeof(NfcScanChunk) * alone, hipMemcpyHostToDevice, ctx->stream));
+      }
+
+      if (debugStages && alone)
+         std::fprintf(stderr, "[nfcgpu]    ... %u of them the envelope tracker's alone, by the envelope kernel\n", alone);
 
       ProfiledLaunch pr {nullptr, nullptr};
       record_span(ctx, ctx->timedScan, pr, true);
-      hipLaunchKernelGGL(nfc_scan_kernel, dim3((repairs + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
-      HIP_TRY(ctx, hipGetLastError());
+
+      if (whole)
+      {
+         NfcScanArgs R = A;
+         R.chunks = A.repairs;
+         R.nChunks = whole;
+
+         hipLaunchKernelGGL(nfc_scan_kernel, dim3((whole + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
+         HIP_TRY(ctx, hipGetLastError());
+      }
+
+      if (alone)
+      {
+         NfcScanArgs R = A;
+         R.chunks = (const NfcScanChunk *)ctx->wRepairsEnv.ptr;
+         R.nChunks = alone;
+
+         hipLaunchKernelGGL(nfc_envelope_kernel, dim3((alone + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
+         HIP_TRY(ctx, hipGetLastError());
+      }
+
       record_span(ctx, ctx->timedScan, pr, false);
       ctx->stats.scan_repairs += repairs;
    }
@@ -1591,7 +1648,7 @@ void release_workspace(nfcgpu_ctx *ctx)
       (void)hipEventDestroy(e);
    ctx->eventPool.clear();
 
-   for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
+   for (nfcgpu_ctx::DevBuf *b: {&ctx->wRepairs, &ctx->wRepairsEnv, &ctx->wJobs, &ctx->wChunks, &ctx->wPoints, &ctx->wSeams, &ctx->wChunkEdge, &ctx->wTiles, &ctx->wTileStats, &ctx->wWindows, &ctx->wRunList,
                                 &ctx->wWorks, &ctx->wCounters, &ctx->vStates, &ctx->vCold, &ctx->vRings, &ctx->vBytes, &ctx->vSink, &ctx->vSinkCtl, &ctx->vSaveRings, &ctx->vSaveBytes,
                                 &ctx->wPlanes, &ctx->wPlaneChunks})
    {
@@ -1726,6 +1783,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->stagingWords = knob("NFCGPU_STAGING_WORDS", ctx->stagingWords);
    ctx->lanesWanted = knob("NFCGPU_LANES_WANTED", ctx->lanesWanted);
    ctx->longFirst = knob("NFCGPU_LONG_FIRST", ctx->longFirst);
+   ctx->envelopeMax = knob("NFCGPU_ENVELOPE_KERNEL", ctx->envelopeMax);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;

@@ -68,6 +68,7 @@ static void emu_carry_debug(const NfcCarry &a, const NfcCarry &b, bool meeting, 
 #include "../../nfc-laboratory_amd/csrc/nfc_scan.hpp"
 #include "../../nfc-laboratory_amd/csrc/nfc_launch.h"
 #include "../../nfc-laboratory_amd/csrc/nfc_scan_launch.h"
+#include "../../nfc-laboratory_amd/csrc/nfc_envelope.hpp"
 
 namespace fakehip {
 dim3 launchGrid, launchBlock;
@@ -469,6 +470,13 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
          seam.start = A.seams[g].start;
       A.seams[g] = seam;
    }
+}
+
+/* the envelope tracker's second walks: the kernel's own text, a chunk after the other */
+void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
+{
+   for (uint32_t listed = 0; listed < A.nChunks; listed++)
+      nfc_envelope_rewalk(*cfgPtr, A, A.chunks[listed]);
 }
 
 /* the second walk of the scan (repair form, from the verified chunk starts): front-end planes only */

@@ -97,6 +97,7 @@ def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emul
     ({"NFCGPU_SCAN_LANES": "1"}, "windowed"),                                  # scan chunks as long as they get (32768 samples)
     ({"NFCGPU_LONG_FIRST": "0"}, "windowed"),                                  # the run list of a pass in stream order
     ({"NFCGPU_LONG_FIRST": "2048", "NFCGPU_LANES_WANTED": "0", "NFCGPU_CUT_MAX": "16384"}, "windowed"),  # ... in six classes of length
+    ({"NFCGPU_ENVELOPE_KERNEL": "0"}, "windowed"),                             # the envelope tracker's second walks left to the scan kernel
 ])
 def test_remaining_knobs_at_non_default_values_emulated(emulated, knobs, expect):
     """every knob that is left (INTEGRATION.md lists them) decodes the same frames at a value that is not its
@@ -108,6 +109,25 @@ def test_remaining_knobs_at_non_default_values_emulated(emulated, knobs, expect)
             assert r["stats"]["windowed"] == 0 and r["stats"]["passes"] == 0, r   # (the path is not tried at all)
         elif expect == "windowed":
             assert r["stats"]["windowed"] >= 1 and r["stats"]["fallback"] == 0, r
+
+
+@needs_reference
+def test_envelope_kernel_walks_the_short_lists_of_small_submissions_emulated(emulated):
+    """A capture with the default knobs is scanned in chunks of 4096 samples, and after the first round its second walks are the
+    envelope tracker's alone: nfc_envelope_kernel takes them (NFCGPU_ENVELOPE_KERNEL, default 64 chunks per round). Same frames,
+    same chunks walked again, same windows and passes as with the scan kernel's envelope-only branch (knob 0)."""
+    cases = ["fixture:test_NFC-A_424kbps_001", "fixture:test_NFC-B_106kbps_001", "fixture:test_NFC-F_212kbps_004"]
+    outs = {}
+    for knob in ("64", "0"):
+        env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096", NFCGPU_WINDOW_DEBUG="1", NFCGPU_ENVELOPE_KERNEL=knob)
+        run = subprocess.run([sys.executable, DRIVER] + cases, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert run.returncode == 0, run.stderr[-3000:]
+        outs[knob] = (json.loads(run.stdout.strip().splitlines()[-1]), run.stderr.count("by the envelope kernel"))
+    for r in outs["64"][0] + outs["0"][0]:
+        assert r["mismatching"] == [] and r["frames"] > 0, r
+    assert outs["64"][1] > 0 and outs["0"][1] == 0, (outs["64"][1], outs["0"][1])
+    assert [r["stats"] for r in outs["64"][0]] == [r["stats"] for r in outs["0"][0]]
+    assert sum(r["stats"]["repairs"] for r in outs["64"][0]) > 0
 
 
 @needs_reference
