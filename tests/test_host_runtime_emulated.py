@@ -36,6 +36,15 @@ def test_c_abi_parity_suite_on_the_emulated_runtime(emulated):
     env = dict(os.environ, NFCGPU_LIB=emulated, NFCGPU_NO_TORCH="1")
     cmd = [sys.executable, "-m", "pytest", os.path.join(T.ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
            "-p", "no:cacheprovider"]
+    # the tests of that file are independent of each other (a context of its own per test module and worker): a few of them
+    # at a time where pytest-xdist is there (ten minutes -> four on eight cores: this is the longest test of the CPU suite)
+    try:
+        import xdist  # noqa: F401
+        workers = max(1, min(4, (os.cpu_count() or 2) // 2))
+        if workers > 1:
+            cmd += ["-n", str(workers)]
+    except ImportError:
+        pass
     for name in NEEDS_GPU:
         cmd += ["--deselect", "tests/test_gpu_parity.py::" + name]
     run = subprocess.run(cmd, cwd=T.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
