@@ -963,6 +963,15 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       uint32_t word[1] = {0}; /* chunks to walk again */
       HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
 
+      /* (where a short list would go to the envelope kernel - below - its first entries come with the count: one trip to
+       * the host per round instead of two) */
+      const uint32_t early = (sp.chunkSamples <= 4096u && ctx->envelopeMax) ? (ctx->envelopeMax < nChunks ? ctx->envelopeMax : nChunks) : 0u;
+      if (early)
+      {
+         listed.resize(early);
+         HIP_TRY(ctx, hipMemcpyAsync(listed.data(), A.repairs, sizeof(NfcScanChunk) * early, hipMemcpyDeviceToHost, ctx->stream));
+      }
+
       /* (a small submission: how busy are its streams? the tile tests have counted) */
       const bool small = round == 0 && nJobs < NFC_LANES && !ctx->inBlocks;
       if (small)
@@ -1006,9 +1015,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       if (repairs <= ctx->envelopeMax && sp.chunkSamples <= 4096u)
       {
-         listed.resize(repairs);
-         HIP_TRY(ctx, hipMemcpyAsync(listed.data(), A.repairs, sizeof(NfcScanChunk) * repairs, hipMemcpyDeviceToHost, ctx->stream));
-         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+         listed.resize(repairs); /* (fetched with the count: repairs <= early, the list holds at most one entry per chunk) */
 
          listedWhole.clear();
          listedAlone.clear();
