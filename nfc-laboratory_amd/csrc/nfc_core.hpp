@@ -511,6 +511,7 @@ NFC_DEV void nfc_detect_carrier(const NfcConfig &c, NfcStreamState &s, const Nfc
          s.edgeTime = 0;
          mem.cold->emitClock = s.clock;
          mem.cold->emitValid = 1;
+         mem.cold->emitOwn = 1;
       }
    }
    else if (s.avg < c.lowThreshold)
@@ -523,6 +524,7 @@ NFC_DEV void nfc_detect_carrier(const NfcConfig &c, NfcStreamState &s, const Nfc
          s.edgeTime = 0;
          mem.cold->emitClock = s.clock;
          mem.cold->emitValid = 1;
+         mem.cold->emitOwn = 1;
       }
    }
 }
@@ -760,6 +762,59 @@ NFC_DEV void nfc_command_written(const NfcLaneMem &mem, uint32_t k)
 {
    if (mem.linked)
       *mem.flags |= 1u << (8u + k);
+}
+
+/* ---- what a lane of the time-parallel path requires of a waiting time it inherited (NfcStreamCold::waitUsed) ---- */
+
+/* nfc*_process of a poll frame has just taken the waiting time from the technology's protoWaitingTime */
+NFC_DEV void nfc_wait_from_proto(const NfcLaneMem &mem, uint32_t k)
+{
+   if (mem.linked)
+   {
+      const uint32_t f = mem.cold->waitFlags;
+      mem.cold->waitFlags = (f & ~(1u << k)) | (((f >> (4u + k)) & 1u) ? 0u : (1u << k));
+   }
+}
+
+/* ... and replaced it by a constant of the command at hand (REQA, SELECT, RATS, REQB, ATTRIB, REQC) */
+NFC_DEV void nfc_wait_overridden(const NfcLaneMem &mem, uint32_t k)
+{
+   if (mem.linked)
+      mem.cold->waitFlags &= ~(1u << k);
+}
+
+/* the lane has set protoWaitingTime of technology k */
+NFC_DEV void nfc_wait_proto_written(const NfcLaneMem &mem, uint32_t k)
+{
+   if (mem.linked)
+      mem.cold->waitFlags |= 1u << (4u + k);
+}
+
+/* The search for the start of an answer of technology k has ended on this sample: by the time running out (ranOut: the
+ * comparison `clock > waitingEnd` itself), or by anything else - a start of frame, a modulation deeper than a card's - with
+ * the comparison false up to and including this sample. */
+NFC_DEV void nfc_wait_ended(const NfcLaneMem &mem, const NfcStreamState &s, uint32_t k, bool ranOut)
+{
+   if (!mem.linked)
+      return;
+
+   const uint32_t f = mem.cold->waitFlags;
+
+   if (!((f >> k) & 1u))
+      return; /* (a waiting time of the command's own, or one the lane has set itself) */
+
+   if (ranOut)
+      mem.cold->waitFlags = (f & ~(1u << k)) | (1u << (8u + k));
+   else
+   {
+      /* waitingEnd = (sample the waiting time counts from) + waitingTime: what of it had passed by now */
+      const uint32_t used = mem.cold->tim[k].waitingTime - (s.u.decode.waitingEnd - s.clock);
+
+      if (used > mem.cold->waitUsed[k])
+         mem.cold->waitUsed[k] = used;
+
+      mem.cold->waitFlags = f & ~(1u << k);
+   }
 }
 
 /* a frame has been assembled on this sample: remember it; classification (process*), emission and the mode change

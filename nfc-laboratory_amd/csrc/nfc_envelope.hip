@@ -1,11 +1,11 @@
 /*
- * nfc_envelope.hip — gfx950 kernel of the envelope tracker's second walks (nfc_envelope.hpp): one lane per listed chunk,
- * 64 chunks per wave, no LDS, no barrier; a lane reads its own chunk (8 B of IQ or 4 B of magnitude per sample, a group of
- * sixteen samples ahead of the one it walks) and carries two words of state.
+ * nfc_envelope.hip — gfx950 kernel of the envelope tracker's second walks (nfc_envelope.hpp): one wavefront per listed chunk
+ * (round 5; round 4: one lane per chunk), no LDS, no barrier; lane j loads sample j of a tile (8 B of IQ or 4 B of magnitude,
+ * one coalesced load per tile, two tiles ahead of the one being walked), every lane walks the tile's 64 steps on values handed
+ * round with v_readlane.
  *
- * Bound: the latency of one lane's dependent arithmetic (the tracker is a recurrence: sample k needs the envelope sample
- * k - 1 left), a chunk of 32768 samples per round of a large submission, 4096 of a capture; HBM traffic is the listed
- * chunks' samples once. The path is only taken at the sample rate whose constants are compiled in (nfcgpu.hip:
+ * Bound: the latency of the tracker's dependent arithmetic (a recurrence: sample k needs the envelope sample k - 1 left), a
+ * chunk of 32768 samples per round of a large submission, 4096 of a capture; HBM traffic is the listed chunks' samples once. The path is only taken at the sample rate whose constants are compiled in (nfcgpu.hip:
  * windowed_eligible), so the tracker's three constants are literals.
  */
 #include <hip/hip_runtime.h>
@@ -38,11 +38,18 @@ __device__ __forceinline__ float nfc_envelope_sample_at(const uint8_t *data, uin
 #define NFC_FIXED_FN __device__ __forceinline__
 #include "nfc_config_fixed.inc"
 
+#define NFC_ENVELOPE_WAVE
+#define NFC_ENVELOPE_READLANE_F(v, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (int)(j)))
+/* (a value the compiler may know nothing about: in a vector register, and not to be reasoned about as uniform) */
+#define NFC_ENVELOPE_OPAQUE_F(v) asm volatile("" : "+v"(v))
+#define NFC_ENVELOPE_OPAQUE_U(v) asm volatile("" : "+v"(v))
+
 #include "nfc_envelope.hpp"
 
+/* one wavefront per listed chunk (nfc_envelope_rewalk_wave) */
 __global__ __launch_bounds__(64) void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 {
-   const uint32_t listed = blockIdx.x * NFC_LANES + threadIdx.x;
+   const uint32_t listed = blockIdx.x;
 
    if (listed >= A.nChunks)
       return;
@@ -52,5 +59,5 @@ __global__ __launch_bounds__(64) void nfc_envelope_kernel(const NfcConfig *__res
    NfcConfig cc;
    nfc_fixed_config(cc);
 
-   nfc_envelope_rewalk(cc, A, A.chunks[listed]);
+   nfc_envelope_rewalk_wave(cc, A, A.chunks[listed], threadIdx.x);
 }

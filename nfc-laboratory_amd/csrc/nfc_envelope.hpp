@@ -138,4 +138,158 @@ NFC_DEV void nfc_envelope_rewalk(const NfcConfig &c, const NfcScanArgs &A, NfcSc
    A.seams[g] = seam; /* (the first walk's record with the tracker's end put right, or untouched after a merge) */
 }
 
+#ifdef NFC_ENVELOPE_WAVE
+/* The same walk by a whole wavefront (round 5; the form the GPU runs). The tracker is a recurrence: one lane's worth of
+ * arithmetic per sample, whatever is done about it. What a lane per chunk cannot do is fetch its samples well - sixty-four
+ * lanes of a wave read sixty-four chunks, a cache line each per load (profiles/r04/ab_envelope: slower than the scan kernel
+ * for the long lists of a large submission) -, and what the scan kernel's row machinery cannot do is walk fast: 64 row
+ * fetches, 64 transposed LDS stores and a barrier per 64-sample step (0.27 us per sample: a round costs the walk of one
+ * chunk, 9 ms for the headline's 32768 samples, however few chunks are on its list). Here the wave is the chunk: lane j
+ * loads sample j of the tile at hand (one coalesced load a tile, two tiles ahead, the magnitudes formed 64 at a time), then
+ * every lane walks the same 64 steps on the samples handed round with v_readlane - the decoder's own nfc_envelope_step,
+ * values every lane holds alike -, lane 0 writes what nfc_envelope_rewalk writes. A dozen dependent instructions per sample
+ * instead of the row machinery's several hundred cycles; eight and more waves per SIMD fit.
+ * NFC_ENVELOPE_READLANE_F(v, j): the value lane j holds. */
+NFC_DEV void nfc_envelope_rewalk_wave(const NfcConfig &c, const NfcScanArgs &A, NfcScanChunk ch, uint32_t lane)
+{
+   ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
+
+   const NfcScanJob *job = A.jobs + ch.job;
+   const uint32_t g = job->firstChunk + ch.index;
+   const uint32_t count = job->count;
+   const uint32_t L = A.params.chunkSamples;
+   const uint32_t start = ch.index * L;
+   const uint32_t end = start + L < count ? start + L : count;
+
+   if (start >= end)
+      return;
+
+   const uint8_t *data = job->data;
+   const uint32_t stride = A.stride;
+
+   NfcScanSeam seam = A.seams[g];
+
+   uint32_t clock = A.states[job->slot].clock + start;
+   float env = seam.start.env;
+   uint32_t pulseFilter = seam.start.pulseFilter;
+
+   if ((start % NFC_SCAN_POINT) == 0 && lane == 0u)
+   {
+      NfcScanPoint &first = A.points[job->firstPoint + start / NFC_SCAN_POINT];
+      first.env = seam.start.env;
+      first.pulseFilter = seam.start.pulseFilter;
+   }
+
+   /* this lane's sample of the tile at hand and of the two after it (what lies beyond the chunk is fetched and not walked) */
+   const uint32_t last = end - 1u;
+   float x0 = NFC_SAMPLE_AT(data, stride, start + lane < last ? start + lane : last);
+   float x1 = NFC_SAMPLE_AT(data, stride, start + NFC_SCAN_TILE + lane < last ? start + NFC_SCAN_TILE + lane : last);
+
+   for (uint32_t pos = start; pos < end; pos += NFC_SCAN_TILE)
+   {
+      const uint32_t n = end - pos < NFC_SCAN_TILE ? end - pos : NFC_SCAN_TILE;
+      const uint32_t ahead = pos + 2u * NFC_SCAN_TILE + lane;
+      const float x2 = NFC_SAMPLE_AT(data, stride, ahead < last ? ahead : last);
+
+      if (pos > start && (pos % NFC_SCAN_POINT) == 0)
+      {
+         NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
+
+         if (nfc_envelope_bits(stored.env) == nfc_envelope_bits(env) && stored.pulseFilter == pulseFilter)
+         {
+            seam.end = A.seams[g].end;
+            break;
+         }
+
+         if (lane == 0u)
+         {
+            stored.env = env;
+            stored.pulseFilter = pulseFilter;
+         }
+      }
+
+      float lo = NFC_ENVELOPE_BIG, hi = -NFC_ENVELOPE_BIG;
+      bool walked = false;
+
+      /* A whole tile past the stream's first symbol (where the tracker may still take the sample itself): the tracker's common
+       * path, without a branch. nfc_envelope_step decides |x - env| / env < 0.05 without the division whenever the envelope is
+       * positive and the deviation is clearly on one side of the limit (below 0.0499 env: yes; above 0.0501 env: no) - the
+       * tile is walked on that assumption, a dozen vector instructions a sample with selects where the statement has
+       * branches, and noting whether any sample was in neither case; only then (the envelope at zero, a ratio within 0.2 % of
+       * the limit, a NaN) it is walked again by the statement itself. The values are every lane's alike, but written as
+       * vector code on purpose: left to itself the compiler sees that they are uniform and turns every select into a scalar
+       * branch on a vector comparison - four round trips between the two units per sample, ~1000 cycles (measured:
+       * 14 ms per 32768-sample chunk, slower than the row machinery it was to replace). */
+      if (n == NFC_SCAN_TILE && (uint32_t)(clock + 1u) >= (uint32_t)c.etu && (uint32_t)(clock + 1u + NFC_SCAN_TILE) > (uint32_t)(clock + 1u))
+      {
+         float e = env;
+         uint32_t pf = pulseFilter;
+         NFC_ENVELOPE_OPAQUE_F(e);
+         NFC_ENVELOPE_OPAQUE_U(pf);
+         const uint32_t limit = (uint32_t)(c.etu * 10);
+         const float w0 = c.envW0, w1 = c.envW1;
+         bool rare = false;
+         float l = NFC_ENVELOPE_BIG, h = -NFC_ENVELOPE_BIG;
+
+#pragma unroll
+         for (uint32_t j = 0; j < NFC_SCAN_TILE; j++)
+         {
+            const float x = NFC_ENVELOPE_READLANE_F(x0, j);
+            const float dev = nfc_abs(x - e);
+            const bool below = dev < 0.0499f * e;
+            const bool above = dev > 0.0501f * e;
+            rare = rare || !(e > 0.0f && (below || above));
+            const uint32_t pf1 = pf + 1u;
+            const bool update = below || pf1 > limit;
+            const float followed = e * w0 + x * w1;
+            e = update ? followed : e;
+            pf = update ? 0u : pf1;
+            l = e < l ? e : l;
+            h = e > h ? e : h;
+         }
+
+         if (!NFC_ANY(rare))
+         {
+            env = e;
+            pulseFilter = pf;
+            clock += NFC_SCAN_TILE;
+            lo = l;
+            hi = h;
+            walked = true;
+         }
+      }
+
+      if (!walked)
+      {
+         for (uint32_t j = 0; j < n; j++)
+         {
+            const float x = NFC_ENVELOPE_READLANE_F(x0, j);
+            ++clock;
+            ++pulseFilter;
+            nfc_envelope_step(c, clock, pulseFilter, env, x);
+            lo = env < lo ? env : lo;
+            hi = env > hi ? env : hi;
+         }
+      }
+
+      if (lane == 0u)
+      {
+         NfcScanTile &stat = A.tileStats[job->firstTile + pos / NFC_SCAN_TILE];
+         stat.envmin = lo;
+         stat.envmax = hi;
+         stat.bits |= NFC_TILE_REWALKED;
+      }
+
+      seam.end.env = env;
+      seam.end.pulseFilter = pulseFilter;
+
+      x0 = x1;
+      x1 = x2;
+   }
+
+   if (lane == 0u)
+      A.seams[g] = seam;
+}
+#endif
+
 #endif

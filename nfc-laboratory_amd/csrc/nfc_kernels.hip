@@ -496,13 +496,13 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
 {
    const uint32_t lane = threadIdx.x;
    const uint32_t listed = blockIdx.x * NFC_LANES + lane;
-   const bool mine = listed < A.nChunks;
+   const bool mine = listed < A.nChunks + A.nChunksMore;
 
    NfcScanChunk ch;
    ch.job = 0;
    ch.index = 0;
    if (mine)
-      ch = A.chunks[listed];
+      ch = listed < A.nChunks ? A.chunks[listed] : A.chunksMore[listed - A.nChunks];
 
    /* a chunk on the repair list is walked from the true end state of the chunk before, without warm-up */
    const bool repair = (ch.index & NFC_CHUNK_REPAIR) != 0;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
       job.passes = 0;
 
    if (!(job.status & NFC_JOB_INVALID))
-      nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples);
+      nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples, A.repairsEnv, A.repairEnvCount);
 
    A.jobs[j] = job;
 }
@@ -1052,6 +1052,9 @@ __global__ __launch_bounds__(64) void nfc_carry_lanes_kernel(NfcScanArgs A, NfcL
 
       cold.frameHead = 0;
       cold.frameTail = 0;
+      cold.emitOwn = 0; /* (a lane's notes: NfcStreamCold) */
+      cold.waitFlags = 0;
+      cold.waitUsed[0] = cold.waitUsed[1] = cold.waitUsed[2] = cold.waitUsed[3] = 0;
 
       lanes.states[to] = s;
       lanes.cold[to] = cold;
@@ -1290,6 +1293,10 @@ __global__ __launch_bounds__(64) void nfc_finish_kernel(NfcScanArgs A, NfcLaunch
       cold.frameHead = 0;
       cold.frameTail = 0;
       __builtin_memset(cold.boundF, 0, sizeof(cold.boundF)); /* (a lane's notes: nothing of the stream's) */
+      __builtin_memset(cold.waitUsed, 0, sizeof(cold.waitUsed));
+      cold.waitFlags = 0;
+      cold.emitOwn = 0;
+      cold.trackedEnd = 0;
 
       real.states[to] = s;
       real.cold[to] = cold;

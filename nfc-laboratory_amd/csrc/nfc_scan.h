@@ -141,6 +141,8 @@ struct NfcCarry
    float thrF[2];
    uint32_t clearedF[2]; /* result only: the lane's detector started its pulse count over (not compared) */
    uint32_t ownF[2];     /* result only: ... or set the threshold of the last pulse itself (NFC_FBOUND_THR_OWN) */
+   uint32_t emitOwn;     /* result only: the lane has emitted a carrier frame itself (NfcStreamCold::emitOwn) */
+   uint32_t waitOwn;     /* result only: NfcStreamCold::waitFlags as the lane held them (bit 4 + t: it has set protoWaitingTime of t itself) */
    /* The detector records (running sums apart). A lane starts with all of them at rest; one that was tracking something
     * when another technology locked comes back from the lock with its window in the past and stays like that until the
     * next strong pulse (NfcF.cpp:262-283 and the like): a state no amount of warm-up reproduces, so it travels here. */

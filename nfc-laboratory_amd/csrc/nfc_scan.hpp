@@ -282,7 +282,8 @@ NFC_DEV void nfc_scan_resume(NfcScanLane &w, const NfcScanPoint &p, uint32_t edg
  * the guesses achieved. Returns true when the job is waiting for repairs.
  * chunkEdge[k] = edge-tracker time at the start of chunk k (points without a time of their own inherit it). */
 NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *seams, uint32_t *chunkEdge, uint32_t startEdge, NfcScanChunk *repairs,
-                             uint32_t *repairCount, NfcScanPoint *points = nullptr, uint32_t chunkSamples = 0)
+                             uint32_t *repairCount, NfcScanPoint *points = nullptr, uint32_t chunkSamples = 0, NfcScanChunk *repairsEnv = nullptr,
+                             uint32_t *repairEnvCount = nullptr)
 {
    uint32_t edge = startEdge; /* edge time at the start of the chunk at hand, by the records as they are */
    bool pending = false;
@@ -368,7 +369,9 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
             s.start.zone |= NFC_ZONE_EDGE_KNOWN | NFC_ZONE_EDGE_SYNCED;
          }
 
-         NfcScanChunk &r = repairs[NFC_ATOMIC_ADD(repairCount, 1u)];
+         /* (a list of their own for the chunks whose envelope tracker alone is walked again, when the caller keeps one:
+          * nfc_envelope_kernel takes those) */
+         NfcScanChunk &r = (envelopeOnly && repairsEnv) ? repairsEnv[NFC_ATOMIC_ADD(repairEnvCount, 1u)] : repairs[NFC_ATOMIC_ADD(repairCount, 1u)];
          r.job = jobIndex;
          r.index = k | NFC_CHUNK_REPAIR | (envelopeOnly ? NFC_CHUNK_ENVELOPE : 0u);
 
@@ -616,6 +619,8 @@ NFC_DEV void nfc_carry_take(NfcCarry &x, const NfcStreamState &s, const NfcStrea
    x.emitClock = cold.emitClock;
    x.emitValid = cold.emitValid;
    x.edgeTime = s.edgeTime;
+   x.waitOwn = cold.waitFlags;
+   x.emitOwn = cold.emitOwn;
 
    /* only meaningful (and only looked at) for a lane that stopped at rest: the detector records share their storage
     * with the decode registers */
@@ -737,6 +742,25 @@ NFC_DEV bool nfc_fbound_admits(const NfcFBound &b, uint32_t hadPulses, float had
    }
 
    return true;
+}
+
+/* The waiting time of technology t's protocol a lane ran on (`had`: what it assumed at its start, or what it held at the sample
+ * it took over at - then `ownThen`: it had set the value itself by that sample) against what the stream really held there
+ * (`have`). The value reaches the decode through the comparison `clock > waitingEnd` alone (nfc*_listen_*start), and the lane
+ * has noted what its waits on the inherited value required (NfcStreamCold::waitUsed / waitFlags, nfc_wait_ended): none of them
+ * ran out, and all of them were over within `waitUsed` of the sample the waiting time counts from, so any value of at least
+ * that much leaves every one of those comparisons as it was - the lane would have decided, emitted and left the same, up to
+ * the value itself where it never set it (put right in what it hands on: nfc_chain_follow, nfc_final_fixup). `midWait`: the
+ * lane's last state is inside a wait on the inherited value (its waitingEnd is part of what it leaves): not covered. */
+NFC_DEV bool nfc_wait_admits(const NfcStreamCold &cold, uint32_t t, uint32_t had, uint32_t have, bool ownThen, bool midWait)
+{
+   if (had == have)
+      return true;
+
+   if (ownThen || midWait || ((cold.waitFlags >> (8u + t)) & 1u))
+      return false;
+
+   return have >= cold.waitUsed[t];
 }
 
 /* Two carries of lanes meeting at the same sample (`meeting`: their decoders' edge times are compared as they are), or
@@ -1049,12 +1073,19 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
           * hands on what the stream holds */
          const uint32_t used = colds[lane].usedTech;
 
+         const uint32_t waits = colds[lane].waitFlags;
+
          for (int t = 0; t < 4; t++)
          {
             if (!((used >> t) & 1u))
                left.tim[t] = have.tim[t];
-            else if (!((used >> (8 + t)) & 1u))
-               left.tim[t].lastCommand = have.tim[t].lastCommand; /* never changed by the lane: what the stream holds */
+            else
+            {
+               if (!((used >> (8 + t)) & 1u))
+                  left.tim[t].lastCommand = have.tim[t].lastCommand; /* never changed by the lane: what the stream holds */
+               if (!((waits >> (4 + t)) & 1u))
+                  left.tim[t].protoWaitingTime = have.tim[t].protoWaitingTime; /* (the same: a lane that runs on another value than the stream's either passes nfc_wait_admits below or runs again) */
+            }
          }
 
          if (!(used & 1u))
@@ -1095,6 +1126,37 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
                thrPass[i] = nfc_bits(have.thrF[i]) != nfc_bits(had.thrF[i]) ? 1u : 0u;
                hadAdmitted.pulsesF[i] = have.pulsesF[i];
                hadAdmitted.thrF[i] = have.thrF[i];
+            }
+         }
+
+         /* The record of the last carrier frame (NfcStreamCold::emitClock / emitValid) is looked at when a carrier frame is
+          * stamped - it says whether the decoder's edge time has been zeroed since the edge tracker last moved
+          * (nfc_detect_carrier, nfc_wave_edge_time) - and nowhere else: a lane that has emitted no carrier frame did nothing
+          * that depended on the record it was given. It is then held to the carrier state alone (on / off, compared below), and
+          * hands on the record the stream really holds, with the edge time that goes with it where the lane ended. */
+         if (!colds[lane].emitOwn)
+         {
+            hadAdmitted.emitValid = have.emitValid;
+            hadAdmitted.emitClock = have.emitClock;
+            hadAdmitted.edgeTime = have.edgeTime;
+
+            left.emitValid = have.emitValid;
+            left.emitClock = have.emitClock;
+            left.edgeTime = nfc_edge_time(have, colds[lane].trackedEnd);
+         }
+
+         /* a protocol waiting time the lane did run on, but that was as good as the true one (nfc_wait_admits) */
+         {
+            const NfcStreamState &last = lanes[lane];
+            const uint32_t lockedTech = last.lockTech ? last.lockTech - NFC_TECH_A : 4u;
+
+            for (uint32_t t = 0; t < 4u; t++)
+            {
+               const bool midWait = lockedTech == t && ((waits >> t) & 1u) != 0u;
+
+               if (((used >> t) & 1u) && nfc_wait_admits(colds[lane], t, had.tim[t].protoWaitingTime, have.tim[t].protoWaitingTime,
+                                                          handed && ((had.waitOwn >> (4u + t)) & 1u) != 0u, midWait))
+                  hadAdmitted.tim[t].protoWaitingTime = have.tim[t].protoWaitingTime;
             }
          }
 
@@ -1229,12 +1291,25 @@ NFC_DEV void nfc_final_fixup(NfcStreamState &s, NfcStreamCold &cold, const NfcWi
    {
       if (!((used >> t) & 1u))
          cold.tim[t] = have.tim[t];
-      else if (!((used >> (8 + t)) & 1u))
-         cold.tim[t].lastCommand = have.tim[t].lastCommand;
+      else
+      {
+         if (!((used >> (8 + t)) & 1u))
+            cold.tim[t].lastCommand = have.tim[t].lastCommand;
+         if (!((cold.waitFlags >> (4 + t)) & 1u))
+            cold.tim[t].protoWaitingTime = have.tim[t].protoWaitingTime; /* (nfc_wait_admits) */
+      }
    }
 
    if (!(used & 1u))
       s.chainedA = have.chainedA;
+
+   /* the record of the last carrier frame, when the lane has emitted none itself (nfc_chain_follow) */
+   if (!cold.emitOwn)
+   {
+      cold.emitValid = have.emitValid;
+      cold.emitClock = have.emitClock;
+      s.edgeTime = nfc_edge_time(have, cold.trackedEnd);
+   }
 
    /* the detector records are parked while a technology is locked */
    NfcSearchRegs &r = s.lockTech ? cold.parked : s.u.search;

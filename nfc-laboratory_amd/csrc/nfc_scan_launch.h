@@ -28,6 +28,8 @@ struct NfcScanArgs
    uint32_t nJobs;
    const NfcScanChunk *chunks;
    uint32_t nChunks;
+   const NfcScanChunk *chunksMore; /* the scan kernel's list goes on here (a round's two repair lists in one launch) */
+   uint32_t nChunksMore;
    uint32_t stride;            /* floats per sample of every job: 1 magnitude, 2 IQ */
    NfcScanParams params;
    const NfcStreamState *states; /* the streams' own slots (state a submission starts from) */
@@ -45,6 +47,8 @@ struct NfcScanArgs
    uint32_t *rerunCount;       /* jobs that need another decode pass (device counter) */
    NfcScanChunk *repairs;      /* chunks to walk again (nfc_seams_check), at most one per job and round */
    uint32_t *repairCount;
+   NfcScanChunk *repairsEnv;   /* ... those of them whose envelope tracker alone is walked again (NFC_CHUNK_ENVELOPE), when they are listed apart (null: with the others) */
+   uint32_t *repairEnvCount;
    uint32_t *runList;          /* speculative lanes to run in the coming pass (indices into the lane arrays) */
    uint32_t *runCount;         /* entries of runList (device counter) */
    uint32_t *runNext;          /* next entry a persistent wave takes (device counter) */

@@ -74,6 +74,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
    {
       t.guardTime = t.protoGuardTime;
       t.waitingTime = t.protoWaitingTime;
+      nfc_wait_from_proto(mem, 0u);
    }
    else
    {
@@ -90,8 +91,10 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          phase = NFC_PHASE_SELECTION;
          t.lastCommand = b0, nfc_command_written(mem, 0u);
          nfca_default_timing(c, t);
+         nfc_wait_proto_written(mem, 0u);
          t.guardTime = nfc_tu(c, 1024);     /* NFCA_FGT_DEF  */
          t.waitingTime = nfc_tu(c, 128 * 18); /* NFCA_FWT_ATQA */
+         nfc_wait_overridden(mem, 0u);
          s.chainedA = 0;
          done = true;
       }
@@ -110,6 +113,8 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          flags |= NFC_FLAG_CRC;
       t.lastCommand = b0, nfc_command_written(mem, 0u);
       nfca_default_timing(c, t);
+      nfc_wait_proto_written(mem, 0u);
+      nfc_wait_overridden(mem, 0u); /* (no wait follows: the decoder resets) */
       s.chainedA = 0;
       nfca_reset(c, s, mem);
       done = true;
@@ -130,6 +135,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
                t.lastCommand = b0, nfc_command_written(mem, 0u);
                t.guardTime = nfc_tu(c, 1024);
                t.waitingTime = nfc_tu(c, 128 * 18);
+               nfc_wait_overridden(mem, 0u);
             }
          }
          /* RATS */
@@ -142,6 +148,7 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
                t.lastCommand = b0, nfc_command_written(mem, 0u);
                t.maxFrameSize = fsd[fsdi];
                t.waitingTime = nfc_tu(c, 71680); /* NFC_FWT_ACTIVATION */
+               nfc_wait_overridden(mem, 0u);
             }
             else
             {
@@ -169,6 +176,8 @@ NFC_DEV void nfca_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
                   {
                      t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
                   }
+
+                  nfc_wait_proto_written(mem, 0u);
                }
             }
 
@@ -906,6 +915,9 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
       {
          uint32_t pattern = nfca_listen_ask_start(c, s, mem, now, taps);
 
+         if (pattern == A_D || pattern == SYM_TIMEOUT)
+            nfc_wait_ended(mem, s, 0u, pattern == SYM_TIMEOUT && s.clock > s.u.decode.waitingEnd);
+
          if (pattern == A_D)
             s.u.decode.frameStart = s.u.decode.symStart;
          else if (pattern == SYM_TIMEOUT)
@@ -976,6 +988,9 @@ NFC_DEV void nfca_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfca_listen_bpsk_start(c, s, mem, now, taps);
+
+      if (pattern == A_S || pattern == SYM_TIMEOUT)
+         nfc_wait_ended(mem, s, 0u, pattern == SYM_TIMEOUT && s.clock > s.u.decode.waitingEnd);
 
       if (pattern == A_S)
          s.u.decode.frameStart = s.u.decode.symStart;

@@ -46,7 +46,10 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 
    t.guardTime = t.protoGuardTime;
    if (poll)
+   {
       t.waitingTime = t.protoWaitingTime;
+      nfc_wait_from_proto(mem, 1u);
+   }
 
    /* REQB / WUPB and its ATQB */
    if (poll && b0 == 0x05 && len == 5)
@@ -55,8 +58,10 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       t.maxFrameSize = 256;
       t.protoGuardTime = nfc_tu(c, 1024);
       t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
+      nfc_wait_proto_written(mem, 1u);
       t.guardTime = nfc_tu(c, 1024);   /* NFCB_TR0_MIN  */
       t.waitingTime = nfc_tu(c, 7680); /* NFCB_FWT_ATQB */
+      nfc_wait_overridden(mem, 1u);
       phase = NFC_PHASE_SELECTION;
       if (!crcOk)
          flags |= NFC_FLAG_CRC;
@@ -68,6 +73,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 
       t.maxFrameSize = fsd[fsdi];
       t.protoWaitingTime = nfc_tu(c, 4096 << fwi);
+      nfc_wait_proto_written(mem, 1u);
 
       phase = NFC_PHASE_SELECTION;
       if (!crcOk)
@@ -93,6 +99,7 @@ NFC_DEV void nfcb_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
          t.protoGuardTime = nfc_tu(c, tr0min[tr0i]);
 
       t.waitingTime = nfc_tu(c, 71680); /* NFC_FWT_ACTIVATION */
+      nfc_wait_overridden(mem, 1u);
 
       phase = NFC_PHASE_SELECTION;
       if (!crcOk)
@@ -587,6 +594,9 @@ NFC_DEV void nfcb_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfcb_listen_start(c, s, mem, now, taps);
+
+      if (pattern == B_S || pattern == SYM_TIMEOUT)
+         nfc_wait_ended(mem, s, 1u, pattern == SYM_TIMEOUT && s.clock > s.u.decode.waitingEnd);
 
       if (pattern == B_S)
          s.u.decode.frameStart = s.u.decode.symStart;

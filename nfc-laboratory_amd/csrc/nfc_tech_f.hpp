@@ -43,7 +43,10 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 
    t.guardTime = t.protoGuardTime;
    if (poll)
+   {
       t.waitingTime = t.protoWaitingTime;
+      nfc_wait_from_proto(mem, 2u);
+   }
 
    /* REQC (command code 0x00 in the second byte) and its responses */
    if (poll && nfc_byte(data, len, 1) == 0x00)
@@ -55,8 +58,10 @@ NFC_DEV void nfcf_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
       t.maxFrameSize = 256;
       t.protoGuardTime = nfc_tu(c, 1024);
       t.protoWaitingTime = nfc_tu(c, 256 * 16 * 16);
+      nfc_wait_proto_written(mem, 2u);
       t.guardTime = nfc_tu(c, 1024);
       t.waitingTime = (uint32_t)(c.stu * (double)(512 * 64 + (tsn + 1) * 256 * 64)); /* FDT_ATQC + slots */
+      nfc_wait_overridden(mem, 2u);
 
       phase = NFC_PHASE_SELECTION;
       if (!crcOk)
@@ -513,6 +518,9 @@ NFC_DEV void nfcf_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfcf_listen_start(c, s, mem, taps);
+
+      if (pattern == F_S || pattern == SYM_TIMEOUT)
+         nfc_wait_ended(mem, s, 2u, pattern == SYM_TIMEOUT && s.clock > s.u.decode.waitingEnd);
 
       if (pattern == F_S)
          s.u.decode.frameStart = s.u.decode.symStart;

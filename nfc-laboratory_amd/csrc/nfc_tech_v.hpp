@@ -41,7 +41,10 @@ NFC_DEV void nfcv_process(const NfcConfig &c, NfcStreamState &s, const NfcLaneMe
 
    t.guardTime = t.protoGuardTime;
    if (poll)
+   {
       t.waitingTime = t.protoWaitingTime;
+      nfc_wait_from_proto(mem, 3u);
+   }
 
    phase = NFC_PHASE_APPLICATION;
    if (!nfcv_crc_ok(data, len))
@@ -518,6 +521,9 @@ NFC_DEV void nfcv_decode(const NfcConfig &c, NfcStreamState &s, const NfcLaneMem
    if (!s.u.decode.frameStart)
    {
       uint32_t pattern = nfcv_listen_start(c, s, mem, now, taps);
+
+      if (pattern == V_S || pattern == SYM_TIMEOUT)
+         nfc_wait_ended(mem, s, 3u, pattern == SYM_TIMEOUT && s.clock > s.u.decode.waitingEnd);
 
       if (pattern == V_S)
          s.u.decode.frameStart = s.u.decode.symStart;

@@ -280,6 +280,10 @@ struct NfcStreamCold
                            correlation rings hold nothing older than that */
    uint32_t emitClock;  /* clock of the last carrier frame (the decoder zeroes edgeTime when it emits one) */
    uint32_t emitValid;
+   uint32_t emitOwn;    /* a lane's note (time-parallel path): it has emitted a carrier frame itself. One that has not never looked at the
+                           record of the last carrier frame it was given - that record only zeroes the edge time a carrier frame is
+                           stamped with - and hands on the one the stream really holds (nfc_chain_follow) */
+   uint32_t trackedEnd; /* a lane's note: the edge tracker's time where the lane ended (what its edge time is formed from: nfc_edge_time) */
    uint32_t frameHead;  /* chained frame records of this lane in the staging sink: word offset + 1 of the first / last */
    uint32_t frameTail;
    /* Ring phase labels of the seven correlation ring positions (A106 A212 A424 F212 F424 V(p1) V(p0)):
@@ -290,6 +294,19 @@ struct NfcStreamCold
    uint32_t label[7];
    uint32_t clearedF[2]; /* an NFC-F preamble detector cleared its pulse counter since the lane started (NfcCarry::pulsesF) */
    NfcFBound boundF[2];  /* ... and what the evaluations before that require of the pulse memory the lane was given */
+   /* The waiting time of a technology's protocol (NfcTiming::protoWaitingTime: set by an ATS / ATQB, put back by a REQA / HLTA /
+    * REQB / REQC) reaches a lane's decode through one comparison only: `clock > waitingEnd` while the start of an answer is
+    * looked for (nfc*_listen_*start), waitingEnd = end of the poll frame + waiting time. A lane of the time-parallel path that
+    * inherited the value notes what its waits on it required (nfc_wait_*, nfc_core.hpp), so that the chain can tell whether
+    * another value would have made any of those comparisons come out differently (nfc_chain_follow):
+    *   waitUsed[t]  the longest such wait that ended by something else than the time running out - an answer, a modulation too
+    *                deep - counted from the sample the waiting time counts from: any waiting time of at least that much leaves
+    *                every comparison of those waits false, as it was;
+    *   waitFlags    bit t: the wait at hand of technology t runs on the inherited value; bit 4 + t: the lane has set the
+    *                technology's protoWaitingTime itself (what it was given no longer matters from there on); bit 8 + t: a wait
+    *                on the inherited value ran out (only the very same value reproduces that) */
+   uint32_t waitUsed[4];
+   uint32_t waitFlags;
    uint32_t usedTech;    /* bit t: technology t (A B F V) has been locked since the lane started. The protocol timing of a
                             technology is only read when it locks and while its frames are processed, so a lane that never
                             locked it neither depends on what it assumed there nor changes it (nfc_chain_follow).

@@ -227,7 +227,7 @@ NFC_DEV NfcLaneMem nfc_wave_mem(NFC_WAVE_LDS NfcWaveLds *lds, const NfcWaveSink 
 /* the decoder's edge time after the sample at stream position `last`: the edge-peak tracker (NfcTech.cpp:86-104) walked
  * from the stored point at or before it over the filtered plane, then what the decoder's own copy holds (zeroed by the
  * last carrier frame unless the tracker has moved since: nfc_edge_time). Called by every lane. */
-NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t last)
+NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t last, uint32_t *trackerTime = nullptr)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const uint32_t q = last / NFC_SCAN_POINT;
@@ -263,6 +263,9 @@ NFC_DEV uint32_t nfc_wave_edge_time(const NfcConfig &c, const NfcScanArgs &A, co
 
    const bool emitValid = lds->cold.emitValid != 0;
    const uint32_t emitClock = lds->cold.emitClock;
+
+   if (trackerTime)
+      *trackerTime = tracked; /* (the tracker's own time, whatever the last carrier frame has zeroed) */
 
    return (emitValid && (int32_t)(tracked - emitClock) <= 0) ? 0u : tracked;
 }
@@ -1055,9 +1058,9 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
    const bool atEnd = it.startPos + consumed >= it.job->count;
    const bool closing = activate >= it.startPos + it.count;
 
-   uint32_t edgeEnd = 0;
+   uint32_t edgeEnd = 0, trackedEnd = me->tracked; /* (a lane that took no sample: what it started with) */
    if (!atEnd && it.startPos + consumed > 0)
-      edgeEnd = nfc_wave_edge_time(cc, A, it, lds, it.startPos + consumed - 1u);
+      edgeEnd = nfc_wave_edge_time(cc, A, it, lds, it.startPos + consumed - 1u, &trackedEnd);
 
    NFC_WAVE_UNIFORM_BEGIN
    {
@@ -1077,9 +1080,14 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
          s.edgePeak = p.edgePeak;
          s.pulseFilter = p.pulseFilter;
          s.edgeTime = (mem.cold->emitValid && (int32_t)(tracked - mem.cold->emitClock) <= 0) ? 0u : tracked;
+         lds->cold.trackedEnd = tracked;
       }
-      else if (it.startPos + consumed > 0)
-         s.edgeTime = edgeEnd;
+      else
+      {
+         if (it.startPos + consumed > 0)
+            s.edgeTime = edgeEnd;
+         lds->cold.trackedEnd = trackedEnd;
+      }
 
       lds->cold.usedTech = lds->flags;
    }

@@ -174,10 +174,11 @@ struct nfcgpu_ctx
                                        the lanes being what they now are: the bundled captures of 100 k - 200 k samples 25 / 39 / 49 -> 17 / 27 / 37 ms */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    DevBuf wRepairsEnv;             /* the chunks of a round whose envelope tracker alone is walked again (nfc_envelope_kernel) */
-   uint32_t envelopeMax = 64;      /* ... when the round lists at most this many chunks (NFCGPU_ENVELOPE_KERNEL; 0: never). Measured on the MI355X
-                                      (profiles/r04/ab_envelope): a lane that fetches its own chunk is what a short capture wants - its 10 - 20
-                                      rounds of a few 4096-sample chunks 10.2 / 20.4 -> 8.0 / 16.0 ms - and what a large submission does not:
-                                      thousands of lanes reading 32768-sample chunks a cache line each, 79 -> 122 ms per step of the headline */
+   uint32_t envelopeMax = 16384;   /* ... when the round lists at most this many of them (NFCGPU_ENVELOPE_KERNEL; 0: never, one list for the scan kernel).
+                                      Round 5: a wavefront per chunk (nfc_envelope.hpp). Round 4's kernel had a lane per chunk - good for the few
+                                      4096-sample chunks of a short capture's rounds, the wrong shape for the long lists of a large submission
+                                      (thousands of lanes reading 32768-sample chunks a cache line each: 79 -> 122 ms per step of the headline,
+                                      profiles/r04/ab_envelope) - and was given lists of at most 64 */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
    hipEvent_t epoch = nullptr;      /* recorded when the statistics start over: the time base of the launch intervals below */
    std::vector<std::pair<float, float>> waveSpans; /* [start, stop) of every wave decoder launch since, ms after `epoch` */
@@ -882,6 +883,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    A.runList = (uint32_t *)ctx->wRunList.ptr;
    A.repairs = (NfcScanChunk *)ctx->wRepairs.ptr;
    A.repairCount = counters + 7;
+   A.repairsEnv = ctx->envelopeMax ? (NfcScanChunk *)ctx->wRepairsEnv.ptr : nullptr; /* (NFCGPU_ENVELOPE_KERNEL=0: one list, one kernel) */
+   A.repairEnvCount = counters + 9;
 
    /* save area for lanes that run to the end of the submission (nfc_scan_launch.h): a few per stream */
    {
@@ -925,12 +928,15 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    mark("scan");
 
-   /* a first run of the tile tests: how busy is each stream? (routing, nfc_seams_kernel) */
-   hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
-   HIP_TRY(ctx, hipGetLastError());
+   /* a first run of the tile tests: how busy is each stream? Only a small submission is routed by that (below: `small`); a large
+    * one gets its tile flags once, when the envelopes they are formed from are the true ones (3.8 ms for the 67 M tiles of config 5) */
+   if (nJobs < NFC_LANES && !ctx->inBlocks)
+   {
+      hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
+      HIP_TRY(ctx, hipGetLastError());
+   }
 
    /* seams: chunks that did not start from the true state are walked again, a round at a time */
-   std::vector<NfcScanChunk> listed, listedWhole, listedAlone; /* a round's list as the seam check left it, and sorted by what is walked again */
 
    for (uint32_t round = 0;; round++)
    {
@@ -957,20 +963,14 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       }
 
       HIP_TRY(ctx, hipMemsetAsync(counters + 7, 0, 4, ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(counters + 9, 0, 4, ctx->stream));
       hipLaunchKernelGGL(nfc_seams_kernel, dim3((nJobs + 63) / 64), dim3(64), 0, ctx->stream, A, round == 0 ? 1u : 0u);
       HIP_TRY(ctx, hipGetLastError());
 
-      uint32_t word[1] = {0}; /* chunks to walk again */
-      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
-
-      /* (where a short list would go to the envelope kernel - below - its first entries come with the count: one trip to
-       * the host per round instead of two) */
-      const uint32_t early = (sp.chunkSamples <= 4096u && ctx->envelopeMax) ? (ctx->envelopeMax < nChunks ? ctx->envelopeMax : nChunks) : 0u;
-      if (early)
-      {
-         listed.resize(early);
-         HIP_TRY(ctx, hipMemcpyAsync(listed.data(), A.repairs, sizeof(NfcScanChunk) * early, hipMemcpyDeviceToHost, ctx->stream));
-      }
+      /* chunks to walk again: every recurrence of them (A.repairs), the envelope tracker alone (A.repairsEnv: listed apart by
+       * the seam check when the envelope kernel is on) */
+      uint32_t word[3] = {0, 0, 0};
+      HIP_TRY(ctx, hipMemcpyAsync(word, counters + 7, 12, hipMemcpyDeviceToHost, ctx->stream));
 
       /* (a small submission: how busy are its streams? the tile tests have counted) */
       const bool small = round == 0 && nJobs < NFC_LANES && !ctx->inBlocks;
@@ -978,7 +978,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          HIP_TRY(ctx, hipMemcpyAsync(jobs.data(), ctx->wJobs.ptr, sizeof(NfcScanJob) * nJobs, hipMemcpyDeviceToHost, ctx->stream));
 
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      const uint32_t repairs = word[0];
+      const uint32_t whole = word[0], alone = word[2];
+      const uint32_t repairs = whole + alone;
 
       /* A few long busy streams: the passes the chain needs grow with the length of the submission (a frame that changes
        * the protocol timing is learnt one generation per pass), so it is decoded in blocks, each settled before the next.
@@ -1005,57 +1006,43 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (!repairs)
          break;
 
-      /* A short list (a capture, a receiver's block: rounds of a few chunks, and the latency of a round is what the caller waits
-       * for): the chunks whose envelope tracker alone started wrong - from the second round on that is all of them: chains of
-       * chunks that inherit a wrong envelope from each other, a chunk per round - go to a kernel that does nothing else
-       * (nfc_envelope.hpp); the others to the scan kernel, from their true starts. The list is sorted on the host. A long
-       * list, or one of long chunks (what has been measured are the 4096-sample chunks of small submissions), stays with the
-       * scan kernel as it is (its envelope-only branch; see nfcgpu_ctx::envelopeMax). */
-      uint32_t whole = repairs, alone = 0;
-
-      if (repairs <= ctx->envelopeMax && sp.chunkSamples <= 4096u)
-      {
-         listed.resize(repairs); /* (fetched with the count: repairs <= early, the list holds at most one entry per chunk) */
-
-         listedWhole.clear();
-         listedAlone.clear();
-
-         for (const NfcScanChunk &c: listed)
-            ((c.index & NFC_CHUNK_ENVELOPE) ? listedAlone : listedWhole).push_back(c);
-
-         whole = (uint32_t)listedWhole.size();
-         alone = (uint32_t)listedAlone.size();
-
-         /* (both vectors outlive the copies: the next thing that touches them comes after the next round's synchronisation) */
-         if (alone && whole)
-            HIP_TRY(ctx, hipMemcpyAsync((void *)A.repairs, listedWhole.data(), sizeof(NfcScanChunk) * whole, hipMemcpyHostToDevice, ctx->stream));
-         if (alone)
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->wRepairsEnv.ptr, listedAlone.data(), sizeof(NfcScanChunk) * alone, hipMemcpyHostToDevice, ctx->stream));
-      }
-
-      if (debugStages && alone)
+      /* The chunks whose envelope tracker alone started wrong - from the second round on that is all of them: chains of chunks
+       * that inherit a wrong envelope from each other, a chunk per round - go to a kernel that does nothing else, a wavefront
+       * per chunk (nfc_envelope.hpp): a round then costs the tracker's own latency over one chunk instead of the scan kernel's
+       * row machinery over it (9 ms of 32768 samples, however short the list). A list too long for a wave a chunk to pay (the
+       * first round of a large submission: a quarter of its chunks, the scan kernel's 64 chunks per wave are the better use
+       * of the machine) stays with the scan kernel's envelope-only branch (NFCGPU_ENVELOPE_KERNEL: the longest list the
+       * envelope kernel is given). */
+      if (debugStages && alone && alone <= ctx->envelopeMax)
          std::fprintf(stderr, "[nfcgpu]    ... %u of them the envelope tracker's alone, by the envelope kernel\n", alone);
 
       ProfiledLaunch pr {nullptr, nullptr};
       record_span(ctx, ctx->timedScan, pr, true);
 
-      if (whole)
+      const bool byWaves = alone && alone <= ctx->envelopeMax;
+
+      if (whole || (alone && !byWaves))
       {
+         /* the scan kernel: the chunks walked whole, and a list of envelope-only ones too long for a wave each, in one launch */
          NfcScanArgs R = A;
          R.chunks = A.repairs;
          R.nChunks = whole;
+         R.chunksMore = byWaves ? nullptr : A.repairsEnv;
+         R.nChunksMore = byWaves ? 0u : alone;
 
-         hipLaunchKernelGGL(nfc_scan_kernel, dim3((whole + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
+         const uint32_t listedNow = R.nChunks + R.nChunksMore;
+
+         hipLaunchKernelGGL(nfc_scan_kernel, dim3((listedNow + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
          HIP_TRY(ctx, hipGetLastError());
       }
 
-      if (alone)
+      if (byWaves)
       {
          NfcScanArgs R = A;
-         R.chunks = (const NfcScanChunk *)ctx->wRepairsEnv.ptr;
+         R.chunks = A.repairsEnv;
          R.nChunks = alone;
 
-         hipLaunchKernelGGL(nfc_envelope_kernel, dim3((alone + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
+         hipLaunchKernelGGL(nfc_envelope_kernel, dim3(alone), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
          HIP_TRY(ctx, hipGetLastError());
       }
 
@@ -1344,6 +1331,74 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
                std::fprintf(stderr, "[nfcgpu]    lane %3zu: start %8u live from %8u verify %8u stop %8u (%7u samples) retired %u to %3u, rerun %u live %u pub %u\n", i, ws[i].start,
                             ws[i].activate, ws[i].verify, ws[i].stop, ws[i].stop - ws[i].start, ws[i].retired, ws[i].handTo - jb[0].firstWindow, ws[i].rerun, ws[i].live,
                             ws[i].pubState);
+         }
+         if (std::atoi(std::getenv("NFCGPU_WINDOW_DEBUG")) >= 5 && nWindows)
+         {
+            /* why lanes are sent round again: what each lane marked for another run assumed (carry) against what it is told to assume (want) */
+            std::vector<NfcScanJob> jb(nJobs);
+            HIP_TRY(ctx, hipMemcpy(jb.data(), ctx->wJobs.ptr, sizeof(NfcScanJob) * nJobs, hipMemcpyDeviceToHost));
+            uint32_t shown = 0;
+            {
+               /* tally over every lane marked: which fields of its assumption are to change */
+               std::vector<NfcWindow> all(nWindows);
+               HIP_TRY(ctx, hipMemcpy(all.data(), (const NfcWindow *)ctx->wWindows.ptr + firstWindowSlot, sizeof(NfcWindow) * all.size(), hipMemcpyDeviceToHost));
+               uint64_t n[10] = {0}, samples = 0;
+               for (const NfcWindow &w: all)
+               {
+                  if (!w.rerun)
+                     continue;
+                  const NfcCarry &a = w.carry, &b = w.want;
+                  bool tim = false, wait = false;
+                  for (int t = 0; t < 4; t++)
+                  {
+                     tim = tim || a.tim[t].lastCommand != b.tim[t].lastCommand || a.tim[t].maxFrameSize != b.tim[t].maxFrameSize || a.tim[t].protoGuardTime != b.tim[t].protoGuardTime;
+                     wait = wait || a.tim[t].protoWaitingTime != b.tim[t].protoWaitingTime;
+                  }
+                  const bool chained = a.chainedA != b.chainedA, carrier = (a.carrierOn != 0) != (b.carrierOn != 0) || (a.carrierOff != 0) != (b.carrierOff != 0);
+                  const bool emit = a.emitValid != b.emitValid || a.emitClock != b.emitClock;
+                  const bool pulses = a.pulsesF[0] != b.pulsesF[0] || a.pulsesF[1] != b.pulsesF[1] || std::memcmp(a.thrF, b.thrF, 8) != 0;
+                  const bool records = std::memcmp(&a.search, &b.search, sizeof(a.search)) != 0;
+                  n[0]++; n[1] += chained; n[2] += carrier; n[3] += emit; n[4] += tim; n[5] += wait; n[6] += pulses; n[7] += records;
+                  n[8] += !(chained || carrier || emit || tim || wait || pulses || records) ? 1 : 0;
+                  n[9] += (chained && !(carrier || tim || wait || pulses || records)) ? 1 : 0;
+                  samples += w.stop - w.start;
+               }
+               std::fprintf(stderr, "[nfcgpu]    lanes to run again %llu (%llu samples as they last ran): chainedA %llu (and nothing else but the carrier record: %llu), carrier on/off %llu, "
+                                    "carrier record %llu, command / frame size / guard %llu, waiting time %llu, NFC-F pulse memory %llu, detector records %llu, same assumption (sent on past a hand-over) %llu\n",
+                            (unsigned long long)n[0], (unsigned long long)samples, (unsigned long long)n[1], (unsigned long long)n[9], (unsigned long long)n[2], (unsigned long long)n[3],
+                            (unsigned long long)n[4], (unsigned long long)n[5], (unsigned long long)n[6], (unsigned long long)n[7], (unsigned long long)n[8]);
+            }
+            for (uint32_t j = 0; j < nJobs && shown < 24 && pass >= 3; j++)
+            {
+               if (!(jb[j].status & NFC_JOB_RERUN) || !jb[j].windows)
+                  continue;
+               std::vector<NfcWindow> ws(jb[j].windows);
+               HIP_TRY(ctx, hipMemcpy(ws.data(), (const NfcWindow *)ctx->wWindows.ptr + jb[j].firstWindow, sizeof(NfcWindow) * ws.size(), hipMemcpyDeviceToHost));
+               for (size_t i = 0; i < ws.size(); i++)
+               {
+                  const NfcWindow &w = ws[i];
+                  if (!w.rerun)
+                     continue;
+                  shown++;
+                  std::fprintf(stderr, "[nfcgpu]    job %u lane %zu/%zu start %u stop %u retired %u noHand %u handTo %u:", j, i, ws.size(), w.start, w.stop, w.retired, w.noHand, w.handTo);
+                  const NfcCarry &a = w.carry, &b = w.want;
+                  if (a.chainedA != b.chainedA) std::fprintf(stderr, " chainedA %u->%u", a.chainedA, b.chainedA);
+                  if ((a.carrierOn != 0) != (b.carrierOn != 0)) std::fprintf(stderr, " carrierOn %u->%u", a.carrierOn, b.carrierOn);
+                  if ((a.carrierOff != 0) != (b.carrierOff != 0)) std::fprintf(stderr, " carrierOff %u->%u", a.carrierOff, b.carrierOff);
+                  if (a.emitValid != b.emitValid || a.emitClock != b.emitClock) std::fprintf(stderr, " emit %u/%u->%u/%u (tracked %u)", a.emitValid, a.emitClock, b.emitValid, b.emitClock, w.tracked);
+                  for (int t = 0; t < 4; t++)
+                  {
+                     if (a.tim[t].lastCommand != b.tim[t].lastCommand) std::fprintf(stderr, " cmd[%d] %u->%u", t, a.tim[t].lastCommand, b.tim[t].lastCommand);
+                     if (a.tim[t].maxFrameSize != b.tim[t].maxFrameSize) std::fprintf(stderr, " maxFrame[%d] %u->%u", t, a.tim[t].maxFrameSize, b.tim[t].maxFrameSize);
+                     if (a.tim[t].protoGuardTime != b.tim[t].protoGuardTime) std::fprintf(stderr, " guard[%d] %u->%u", t, a.tim[t].protoGuardTime, b.tim[t].protoGuardTime);
+                     if (a.tim[t].protoWaitingTime != b.tim[t].protoWaitingTime) std::fprintf(stderr, " wait[%d] %u->%u", t, a.tim[t].protoWaitingTime, b.tim[t].protoWaitingTime);
+                  }
+                  for (int i2 = 0; i2 < 2; i2++)
+                     if (a.pulsesF[i2] != b.pulsesF[i2] || std::memcmp(&a.thrF[i2], &b.thrF[i2], 4)) std::fprintf(stderr, " F%d pulses %u->%u thr %g->%g", i2, a.pulsesF[i2], b.pulsesF[i2], a.thrF[i2], b.thrF[i2]);
+                  if (std::memcmp(&a.search, &b.search, sizeof(a.search))) std::fprintf(stderr, " records");
+                  std::fprintf(stderr, "\n");
+               }
+            }
          }
          std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled, %.1f ms\n", pass, ls[2],
                       (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again, ms);

@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 #include <atomic>
+#include <memory>
 #include <mutex>
 
 #include <hw/SignalType.h>
@@ -272,10 +273,18 @@ void nfcref_magnitude(const float *iq, uint64_t count, float *out)
 }
 
 /* CPU baseline: `streams` independent decoders (one lab::NfcDecoder each), statically partitioned over `threads`
- * host threads; stream i reads `count` floats at base + i*pitch. Returns total frames; *seconds = wall time of the
- * decode phase only (decoders constructed before the clock starts). */
-long nfcref_decode_many(const float *base, uint64_t pitch_floats, uint32_t streams, uint64_t count, uint32_t sample_rate,
-                        uint32_t chunk, uint32_t threads, double *seconds)
+ * host threads; stream i reads `count` floats at base + i*pitch. Returns total frames.
+ *
+ * What is inside the clock is the decode alone (round 5; VERDICT r04 #7: 128 threads gave 11 x one thread with the round-4
+ * harness, which started its threads and constructed its decoders - 13 modulation records of 8 KiB each, allocated and
+ * cleared - inside the clock of a run of 0.15 s, and had every thread read magnitudes the calling thread had first touched):
+ * every thread first constructs its decoders and takes a copy of its own streams' samples (first touched by the thread
+ * that will read them), then all of them wait at a gate; the clock runs from the moment the gate opens to the moment the
+ * last thread is done. detail (may be null): [0] the seconds of the thread that took longest over its own share, [1] of the
+ * one that took shortest, [2] the sum of all threads' seconds (their ratio to threads x wall seconds says how evenly the
+ * work was spread), [3] seconds spent before the gate opened (set-up, outside the clock). */
+long nfcref_decode_many_detail(const float *base, uint64_t pitch_floats, uint32_t streams, uint64_t count, uint32_t sample_rate,
+                               uint32_t chunk, uint32_t threads, double *seconds, double *detail)
 {
    if (!threads)
       threads = 1;
@@ -283,18 +292,38 @@ long nfcref_decode_many(const float *base, uint64_t pitch_floats, uint32_t strea
       chunk = 65536;
 
    std::atomic<long> total {0};
+   std::atomic<uint32_t> ready {0};
+   std::atomic<int> go {0};
+   std::vector<double> took(threads, 0.0);
    std::vector<std::thread> pool;
 
-   auto t0 = std::chrono::steady_clock::now();
+   const auto tSetup = std::chrono::steady_clock::now();
 
    for (uint32_t t = 0; t < threads; t++)
    {
-      pool.emplace_back([=, &total]() {
-         long frames = 0;
+      pool.emplace_back([=, &total, &ready, &go, &took]() {
+         /* this thread's streams: decoders, and the samples where this thread touches them first */
+         std::vector<std::unique_ptr<lab::NfcDecoder>> decoders;
+         std::vector<std::vector<float>> samples;
+
          for (uint32_t s = t; s < streams; s += threads)
          {
-            lab::NfcDecoder decoder;
+            decoders.emplace_back(new lab::NfcDecoder());
             const float *data = base + (uint64_t)s * pitch_floats;
+            samples.emplace_back(data, data + count);
+         }
+
+         ready.fetch_add(1);
+         while (!go.load(std::memory_order_acquire))
+            std::this_thread::yield();
+
+         const auto t0 = std::chrono::steady_clock::now();
+         long frames = 0;
+
+         for (size_t k = 0; k < decoders.size(); k++)
+         {
+            lab::NfcDecoder &decoder = *decoders[k];
+            const float *data = samples[k].data();
 
             for (uint64_t pos = 0; pos < count; pos += chunk)
             {
@@ -304,17 +333,48 @@ long nfcref_decode_many(const float *base, uint64_t pitch_floats, uint32_t strea
                frames += (long)decoder.nextFrames(buffer).size();
             }
          }
+
+         took[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
          total += frames;
       });
    }
 
+   while (ready.load() < threads)
+      std::this_thread::yield();
+
+   const auto t0 = std::chrono::steady_clock::now();
+   go.store(1, std::memory_order_release);
+
    for (auto &th: pool)
       th.join();
 
+   const auto t1 = std::chrono::steady_clock::now();
+
    if (seconds)
-      *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      *seconds = std::chrono::duration<double>(t1 - t0).count();
+
+   if (detail)
+   {
+      double lo = took[0], hi = took[0], sum = 0.0;
+      for (double v: took)
+      {
+         lo = v < lo ? v : lo;
+         hi = v > hi ? v : hi;
+         sum += v;
+      }
+      detail[0] = hi;
+      detail[1] = lo;
+      detail[2] = sum;
+      detail[3] = std::chrono::duration<double>(t0 - tSetup).count();
+   }
 
    return total.load();
+}
+
+long nfcref_decode_many(const float *base, uint64_t pitch_floats, uint32_t streams, uint64_t count, uint32_t sample_rate,
+                        uint32_t chunk, uint32_t threads, double *seconds)
+{
+   return nfcref_decode_many_detail(base, pitch_floats, streams, count, sample_rate, chunk, threads, seconds, nullptr);
 }
 
 unsigned int nfcref_frame_size()

@@ -323,9 +323,9 @@ void nfc_scan_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 {
    const uint32_t L = A.params.chunkSamples, WU = A.params.warmSamples;
 
-   for (uint32_t listed = 0; listed < A.nChunks; listed++)
+   for (uint32_t listed = 0; listed < A.nChunks + A.nChunksMore; listed++)
    {
-      NfcScanChunk ch = A.chunks[listed];
+      NfcScanChunk ch = listed < A.nChunks ? A.chunks[listed] : A.chunksMore[listed - A.nChunks];
       const bool repair = (ch.index & NFC_CHUNK_REPAIR) != 0;
       const bool envelopeOnly = repair && (ch.index & NFC_CHUNK_ENVELOPE) != 0;
       ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
@@ -521,7 +521,7 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
       if (first)
          job.passes = 0;
       if (!(job.status & NFC_JOB_INVALID))
-         nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples);
+         nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples, A.repairsEnv, A.repairEnvCount);
       A.jobs[j] = job;
    }
 }
@@ -713,6 +713,9 @@ void nfc_carry_lanes_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes, uint
       NfcStreamCold cold = real.cold[job->slot];
       cold.frameHead = 0;
       cold.frameTail = 0;
+      cold.emitOwn = 0; /* (a lane's notes: NfcStreamCold) */
+      cold.waitFlags = 0;
+      cold.waitUsed[0] = cold.waitUsed[1] = cold.waitUsed[2] = cold.waitUsed[3] = 0;
       lanes.states[j] = s;
       lanes.cold[j] = cold;
 
@@ -923,6 +926,10 @@ void nfc_finish_kernel(NfcScanArgs A, NfcLaunch real, NfcLaunch lanes)
       cold.frameHead = 0;
       cold.frameTail = 0;
       std::memset(cold.boundF, 0, sizeof(cold.boundF));
+      std::memset(cold.waitUsed, 0, sizeof(cold.waitUsed));
+      cold.waitFlags = 0;
+      cold.emitOwn = 0;
+      cold.trackedEnd = 0;
       real.states[job->slot] = s;
       real.cold[job->slot] = cold;
    }
