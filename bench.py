@@ -160,14 +160,14 @@ def main():
     ap.add_argument("--check-streams", type=int, default=64, help="streams compared frame-by-frame with the reference")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (BASELINE config 5: one 4096-stream dataset, rank r decodes streams [r*S/N, (r+1)*S/N)); weak: --streams per GPU")
-    ap.add_argument("--require-abi-gather", action="store_true",
-                    help="N > 1: an error when the C ABI's RCCL communicator does not come up on every rank (default: the line is measured with "
-                         "torch.distributed's all_gather instead and says so in config.parallelism and config.gather)")
-    ap.add_argument("--allow-torch-gather", action="store_true", help="(accepted for the command lines of rounds 3-4: it is the default now)")
+    ap.add_argument("--require-abi-gather", action="store_true", help="(accepted for the command lines of rounds 3-4: it is the default again)")
+    ap.add_argument("--allow-torch-gather", action="store_true",
+                    help="N > 1: should the C ABI's RCCL communicator not come up on every rank, measure the line with torch.distributed's "
+                         "all_gather instead (and say so in config.parallelism) rather than fail. Default: the product's gather or an error")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-points", action="store_true", help="headline only")
     ap.add_argument("--points-budget", type=float, default=780.0, help="no new point is started later than this many seconds after the start")
-    ap.add_argument("--points", default="fixtures_single,config5_sparse,config5_idle,share_sparse,share_dense,share_dense_h2d,single_sparse,single_dense,s2_share,saturating")
+    ap.add_argument("--points", default="fixtures_single,config5_sparse,config5_idle,share_sparse,share_dense,share_dense_h2d,single_sparse,single_dense,s2_share,s2_config5,saturating")
     ap.add_argument("--saturating-streams", type=int, default=131072, help="streams of the `saturating` point (8192-sample buffers, sequential kernel)")
     ap.add_argument("--share-streams", type=int, default=512, help="streams one GPU holds when BASELINE's 4096 are spread over 8")
     ap.add_argument("--single-dense-samples", type=int, default=1 << 23)
@@ -261,9 +261,9 @@ def main():
         agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         abi_gather = bool(int(agreed.item()))
-        if not abi_gather and args.require_abi_gather:
+        if not abi_gather and not args.allow_torch_gather:
             raise SystemExit("bench.py: the frame gather behind the C ABI (nfcgpu_comm_init over RCCL) did not come up on every rank "
-                             "(--require-abi-gather)")
+                             "(--allow-torch-gather measures the line with torch.distributed's all_gather instead)")
         if not abi_gather and rank == 0:
             sys.stderr.write("bench.py: nfcgpu_comm_init did not come up on every rank: the frames are gathered with torch.distributed's "
                              "all_gather (RCCL as well; the data path has no collective either way)\n")
@@ -428,13 +428,20 @@ def main():
             cpu_model, cpu_physical, cpu_logical = host_cpu()
             chunk = 65536 if TT >= 65536 else TT  # the reference harness's buffer length (TS/main.cpp:163)
 
-            lib.nfcref_decode_many.restype = ctypes.c_long
-            lib.nfcref_decode_many.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32,
-                                               ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
+            # (oracle/ref_capi.cpp: threads started, decoders constructed and every thread's samples first touched by that thread
+            # before the clock; the clock is the decode alone. detail: slowest / fastest thread, sum over threads, set-up seconds)
+            lib.nfcref_decode_many_detail.restype = ctypes.c_long
+            lib.nfcref_decode_many_detail.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32,
+                                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+            spread = {}
 
             def timed(streams, threads):
                 secs = ctypes.c_double(0)
-                lib.nfcref_decode_many(mags.ctypes.data, TT, streams, TT, FS, chunk, threads, ctypes.byref(secs))
+                detail = (ctypes.c_double * 4)()
+                lib.nfcref_decode_many_detail(mags.ctypes.data, TT, streams, TT, FS, chunk, threads, ctypes.byref(secs), detail)
+                spread[threads] = {"wall_s": round(secs.value, 4), "slowest_thread_s": round(detail[0], 4), "fastest_thread_s": round(detail[1], 4),
+                                   "threads_busy_fraction": round(detail[2] / (threads * secs.value), 3) if secs.value > 0 else None,
+                                   "setup_s_outside_the_clock": round(detail[3], 3)}
                 return streams * TT / secs.value / 1e6, secs.value
 
             n_single = max(1, min(C, int(150e6 // TT)))
@@ -495,6 +502,13 @@ def main():
                 "single_thread_value": round(single, 3),
                 "physical_cores_value": round(multi_phys, 3),
                 "physical_cores_threads": physical,
+                # what the cores would do if every one of them ran like the single thread, and how much of that the threaded run got
+                "ideal_single_thread_x_physical_cores": round(single * physical, 3),
+                "parallel_efficiency": round(multi_phys / (single * physical), 4) if single > 0 and physical else None,
+                "parallel_efficiency_all_threads": round(multi / (single * cores), 4) if single > 0 and cores else None,
+                "thread_spread": {str(k): v for k, v in spread.items()},
+                "harness": "threads started, decoders constructed and each thread's samples first touched by that thread before the clock "
+                           "(oracle/ref_capi.cpp: nfcref_decode_many_detail); the clock is the decode alone",
             }
             # BASELINE configs[0]: the reference's RadioDecoderTask itself (subjects + executor + reference decoder, one stream)
             task = os.path.join(ROOT, "oracle", "_ref", "task-ref")
@@ -526,10 +540,17 @@ def main():
                             dense = synth.magnitude_f32(template, 0, 0, dense_n)
                             TL.write_wav(wav_d, np.clip(np.rint(dense * 32768.0), -32768, 32767).astype(np.int16))
                             env = dict(os.environ, NFCGPU_SHIM_BLOCK=str(1 << 22))
-                            shim = {"block_samples": 1 << 22}
+                            env_auto = dict(os.environ, NFCGPU_SHIM_BLOCK="auto")
+                            env_default = {k: v for k, v in os.environ.items() if k != "NFCGPU_SHIM_BLOCK"}
+                            shim = {"block_samples": 1 << 22,
+                                    "modes": "gpu_task: NFCGPU_SHIM_BLOCK=4194304; gpu_task_auto: NFCGPU_SHIM_BLOCK=auto (the shim grows its block while "
+                                             "the decoder does not keep up with the samples' own duration); gpu_task_default_mode: no variable - every "
+                                             "65536-sample buffer of the task submitted and collected inside its nextFrames() call, frames delivered "
+                                             "by the very call the reference delivers them by"}
                             for label, path, n_w in (("sparse", wav_s, sparse.size), ("dense", wav_d, dense_n)):
                                 row = {"samples": int(n_w)}
-                                for who, exe, e in (("reference_task", task, os.environ), ("gpu_task", task_gpu, env)):
+                                for who, exe, e in (("reference_task", task, os.environ), ("gpu_task", task_gpu, env), ("gpu_task_auto", task_gpu, env_auto),
+                                                    ("gpu_task_default_mode", task_gpu, env_default)):
                                     o = subprocess.run([exe, path], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600, env=e).stdout
                                     dn = [l.split() for l in o.splitlines() if l.startswith("DONE")]
                                     row[who + "_Msamples_per_s"] = round(n_w / float(dn[0][3]) / 1e6, 3) if dn else None
@@ -735,6 +756,9 @@ def main():
                     points[name], _ = run_point(name, 128, args.config5_samples, False, 1, 1, 8, from_host=True)
                 elif name == "s2_share":
                     points[name], _ = run_point(name, args.share_streams, args.config5_samples, False, 1, 1, 64, offgrid=True)
+                elif name == "s2_config5":
+                    # config 5's shape off the capture grid: what 4096 radios deliver (every stream by its carry lane alone)
+                    points[name], _ = run_point(name, args.config5_streams, args.config5_samples, False, 1, 1, 64, offgrid=True)
                 elif name == "saturating":
                     points[name], _ = run_point(name, args.saturating_streams, 8192, False, 6, 2, 64)
                 elif name == "single_dense":

@@ -79,6 +79,7 @@ struct NfcWaveUni
    uint32_t maskValid; /* search bank: the detectors whose gates over the tile at hand (NfcWaveLds::gate) still stand (bit per detector) */
    uint32_t aloneLocked; /* search bank: an NFC-F tracker applied on its own found its preamble complete (the sample is the step's) */
    uint32_t retireLo, retireHi; /* may the lane retire at the boundary before tile 64 m + j of its row? bit j (fetched 64 tiles at a time) */
+   uint32_t darkLo, darkHi;     /* is tile 64 m + j of its row dark (NFC_TILE_DARK: every sample below the power threshold, no carrier event)? bit j */
    /* what the two ring taps of a sample (nfc_wave_taps) are formed from on demand: the correlators as they stood when the
     * values of the tile were formed (sample `from`): ring position and running sum of the sample before, whether the ring
     * entry one sample back is that sum; locked stages (slot 0): ring period, distance of the first tap, ring base, first
@@ -979,12 +980,17 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
             const uint32_t tilesOfRow = (it.count + NFC_SCAN_TILE - 1u) / NFC_SCAN_TILE;
             const uint32_t word = (jobWindows != 0u && first + lane < tilesOfRow) ? it.tiles[first + lane] : 0u;
             const uint64_t retire = NFC_WAVE_BALLOT((word & NFC_TILE_RETIRE_OK) != 0u);
+            /* (tiles of the row that exist, whatever the stream has in the way of windows) */
+            const uint32_t flagsHere = first + lane < tilesOfRow ? it.tiles[first + lane] : 0u;
+            const uint64_t dark = NFC_WAVE_BALLOT((flagsHere & NFC_TILE_DARK) != 0u);
 
             NFC_WAVE_BARRIER();
             NFC_WAVE_UNIFORM_BEGIN
             {
                lds->u.retireLo = (uint32_t)retire;
                lds->u.retireHi = (uint32_t)(retire >> 32);
+               lds->u.darkLo = (uint32_t)dark;
+               lds->u.darkHi = (uint32_t)(dark >> 32);
             }
             NFC_WAVE_UNIFORM_END
          }
@@ -1027,6 +1033,70 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
       if (NFC_WAVE_UNIFORM_U32(lds->u.stopped))
          break;
+
+      /* ---- a searching lane in front of a run of dark tiles ----
+       * In a dark tile (nfc_tile_flags: every sample below the power threshold, no carrier event, on the capture grid) a
+       * searching decoder runs its front end and nothing else: the detector bank is not stepped (NfcDecoder.cpp:394-418: not
+       * armed), sums and correlation rings stand as they are - stale, exactly like the reference's -, the ring positions count
+       * on with the clock. The front end's results are the planes', so the lane goes straight to the last eight dark tiles it
+       * knows of (the flags of 64 tiles at a time): their 512 samples put back every history a detector can look into once
+       * the envelope is above the threshold again (NFC_HIST; the shorter histories hold 256), the clock and the positions
+       * are moved by what was left out. Not across the sample the lane publishes at. (S1's captures begin with the carrier
+       * off: a fifth of what the lanes of a dense stream walk is such tiles.) */
+      if (past && NFC_WAVE_STATE(lds).lockTech == 0u && NFC_WAVE_STATE(lds).unlock == 0u)
+      {
+         const uint64_t dark = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.darkHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.darkLo);
+         const uint64_t from = dark >> tileBit;
+         const uint32_t run = (~from) ? (uint32_t)__builtin_ctzll(~from) : 64u; /* dark tiles in a row from this one (the group's own: bits beyond it are zero) */
+         const uint32_t keep = NFC_HIST / NFC_SCAN_TILE;
+
+         if (run > keep)
+         {
+            uint32_t tilesLeftOut = run - keep;
+
+            if (verifyPos > pos && verifyPos - pos < tilesLeftOut * NFC_SCAN_TILE)
+               tilesLeftOut = (verifyPos - pos) / NFC_SCAN_TILE;
+            while (tilesLeftOut && consumed + tilesLeftOut * NFC_SCAN_TILE + NFC_SCAN_TILE > it.count)
+               tilesLeftOut--;
+
+            /* No carrier frame may fall due on the way (NfcDecoder.cpp:472-523). The scan's carrier zone - the zone the average
+             * was last seen in - does not change inside dark tiles (a change is NFC_TILE_CARRIER), and a decoder whose carrier
+             * state agrees with it has nothing to emit whatever the average does between the thresholds. One that has been
+             * locked while the average crossed has not emitted yet, and does on its first sample here: it is left to walk. */
+            if (tilesLeftOut)
+            {
+               const uint32_t zone = A.points[it.job->firstPoint + (pos + NFC_SCAN_POINT - 1u) / NFC_SCAN_POINT].zone & NFC_ZONE_MASK;
+               const bool agrees = zone == 1u ? NFC_WAVE_STATE(lds).carrierOn != 0u : (zone == 2u ? NFC_WAVE_STATE(lds).carrierOff != 0u : true);
+
+               if (!agrees)
+                  tilesLeftOut = 0u;
+            }
+
+            if (tilesLeftOut)
+            {
+               const uint32_t samples = tilesLeftOut * NFC_SCAN_TILE;
+
+               NFC_WAVE_READ_FENCE();
+               NFC_WAVE_UNIFORM_BEGIN
+               {
+                  NFC_WAVE_LDS NfcStreamState &w = lds->u.s;
+                  w.clock += samples;
+                  w.posA[0] = (w.posA[0] + samples) % cc.a[0].p1;
+                  w.posA[1] = (w.posA[1] + samples) % cc.a[1].p1;
+                  w.posA[2] = (w.posA[2] + samples) % cc.a[2].p1;
+                  w.posF[0] = (w.posF[0] + samples) % cc.f[1].p1;
+                  w.posF[1] = (w.posF[1] + samples) % cc.f[2].p1;
+                  w.posV1 = (w.posV1 + samples) % cc.v.p1;
+                  w.posV0 = (w.posV0 + samples) % cc.v.p0;
+                  lds->u.consumed = consumed + samples;
+               }
+               NFC_WAVE_UNIFORM_END
+
+               fetched = nfc_wave_fetch(it, consumed + samples, stride);
+               continue; /* (the boundary of the tile it lands on is looked at like any other) */
+            }
+         }
+      }
 
       /* ---- the tile ---- */
       const uint32_t left = it.count - consumed;

@@ -118,6 +118,9 @@ struct NfcDecoder::Impl
     * stream: everything is submitted and collected before the call returns. A host that ends a stream on a full buffer
     * has to call nextFrames({}) before cleanup(). */
    size_t blockSamples = 0;
+   bool blockAuto = false; /* NFCGPU_SHIM_BLOCK=auto: the block grows (from 2^17 samples, doubling, up to 2^22) whenever decoding a block took
+                              longer than 0.8 of the time its samples span at their own rate - the decoder is not keeping up with the
+                              receiver, and longer submissions are what the time-parallel path is faster on; it never shrinks */
    std::vector<float> pending;
    unsigned int pendingStride = 1;
    unsigned int pendingRate = 0;
@@ -139,7 +142,15 @@ struct NfcDecoder::Impl
          throw std::runtime_error(std::string("nfcgpu_stream_open failed: ") + nfcgpu_strerror(rc));
 
       if (const char *block = std::getenv("NFCGPU_SHIM_BLOCK"))
-         blockSamples = (size_t)std::strtoull(block, nullptr, 10);
+      {
+         if (std::string(block) == "auto")
+         {
+            blockAuto = true;
+            blockSamples = (size_t)1 << 17;
+         }
+         else
+            blockSamples = (size_t)std::strtoull(block, nullptr, 10);
+      }
       if (const char *ms = std::getenv("NFCGPU_SHIM_BLOCK_MS"))
          blockMillis = std::strtod(ms, nullptr);
    }
@@ -179,9 +190,21 @@ struct NfcDecoder::Impl
 
       backlog.splice(backlog.end(), collect());
 
-      check(nfcgpu_submit(ctx, stream, pending.data(), (uint32_t)(pending.size() / pendingStride), pendingStride, pendingRate), "submit");
+      const size_t count = pending.size() / pendingStride;
+      const auto began = std::chrono::steady_clock::now();
+
+      check(nfcgpu_submit(ctx, stream, pending.data(), (uint32_t)count, pendingStride, pendingRate), "submit");
       submittedStreamTime = (long)params.stream_time;
       pending.clear();
+
+      /* (a submission of host samples returns when it has been decoded: its duration is the decode's) */
+      if (blockAuto && pendingRate && count >= blockSamples && blockSamples < ((size_t)1 << 22))
+      {
+         const double took = std::chrono::duration<double>(std::chrono::steady_clock::now() - began).count();
+
+         if (took > 0.8 * (double)count / (double)pendingRate)
+            blockSamples *= 2;
+      }
    }
 
    void setTech(uint32_t bit, bool enabled)

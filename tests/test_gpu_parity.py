@@ -295,13 +295,14 @@ def test_reference_radio_decoder_task_runs_unchanged_on_the_gpu_decoder(built, t
         assert got[name] == T.load_golden(name), name
 
 
-def test_radio_decoder_task_with_the_shim_in_block_mode(built, tmp_path, monkeypatch):
+@pytest.mark.parametrize("block", ["300000", "auto"])
+def test_radio_decoder_task_with_the_shim_in_block_mode(built, tmp_path, monkeypatch, block):
     """NFCGPU_SHIM_BLOCK: buffers collected into long asynchronous submissions (time-parallel path, pinned double-buffered
     staging), frames of a block handed out when the next block goes in: the task still publishes the golden frames."""
     exe = os.path.join(T.ROOT, "oracle", "_ref", "task-gpu")
     if not os.path.exists(exe):
         pytest.skip("task-gpu not built (needs the reference tree at build time)")
-    monkeypatch.setenv("NFCGPU_SHIM_BLOCK", "300000")
+    monkeypatch.setenv("NFCGPU_SHIM_BLOCK", block)  # ("auto": the shim picks and grows the block itself, host/NfcDecoder.cpp)
     names = ["test_NFC-A_106kbps_001", "test_NFC-B_106kbps_002", "test_NFC-F_212kbps_001", "test_NFC-V_26kbps_001", "test_POLL_ABF_001"]
     for iq in (False, True):
         got = T.run_task_harness(exe, names, tmp_path, iq=iq)

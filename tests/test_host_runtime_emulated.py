@@ -89,14 +89,15 @@ def test_reference_radio_decoder_task_and_shim_on_the_emulated_runtime(emulated,
             assert got[name] == T.load_golden(name), (name, iq)
 
 
-def test_shim_block_mode_on_the_emulated_runtime(emulated, tmp_path, monkeypatch):
+@pytest.mark.parametrize("block", ["300000", "auto"])
+def test_shim_block_mode_on_the_emulated_runtime(emulated, tmp_path, monkeypatch, block):
     """NFCGPU_SHIM_BLOCK: the shim collects the task's 65536-sample buffers into long submissions (time-parallel path) and
     hands a block's frames out when the next one goes in; same frames, same order, magnitude and IQ buffers."""
     exe = os.path.join(T.ROOT, "oracle", "_ref", "task-gpu")
     if not os.path.exists(exe):
         pytest.skip("task-gpu not built (needs the reference tree at build time)")
     monkeypatch.setenv("LD_PRELOAD", emulated)
-    monkeypatch.setenv("NFCGPU_SHIM_BLOCK", "300000")
+    monkeypatch.setenv("NFCGPU_SHIM_BLOCK", block)  # ("auto": the shim picks and grows the block itself, host/NfcDecoder.cpp)
     names = ["test_NFC-A_106kbps_001", "test_NFC-B_106kbps_002", "test_NFC-F_212kbps_001", "test_POLL_ABF_001"]
     for iq in (False, True):
         got = T.run_task_harness(exe, names, tmp_path, iq=iq)
