@@ -1192,9 +1192,13 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
                 * with the same thing from different beginnings): the lane before has to go on past it. The walk goes
                 * on from this lane all the same, on the guess that what it leaves does not depend on the difference:
                 * whatever else is wrong further down is then put right in the same pass */
+               /* (with what it assumed, unless the walk has already found that wrong: then with what it has been told to
+                * assume - round 4 put the old assumption back here, and the lane ran a pass for the hand-over and another
+                * for the assumption: the 545 000-sample lanes of config 5 three times instead of twice) */
                NfcWindow &before = windows[prev];
                before.noHand = lane;
-               before.want = before.carry;
+               if (!before.rerun)
+                  before.want = before.carry;
                before.rerun = 1;
                again = true;
             }
@@ -1228,7 +1232,8 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
          if (y.pubState != 1u || y.pubDigest[0] != x.stopDigest[0] || y.pubDigest[1] != x.stopDigest[1] || y.verify != x.stop)
          {
             x.noHand = x.handTo;
-            x.want = x.carry;
+            if (!x.rerun)
+               x.want = x.carry; /* (a lane already told to assume something else keeps that: see above) */
             x.rerun = 1;
             again = true;
 

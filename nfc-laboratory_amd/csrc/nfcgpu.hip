@@ -1119,7 +1119,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       A.windows = (NfcWindow *)ctx->wWindows.ptr;
       A.works = (NfcWork *)ctx->wWorks.ptr;
-      A.runList = (uint32_t *)ctx->wRunList.ptr;
+         A.runList = (uint32_t *)ctx->wRunList.ptr;
       A.windowRoom = room;
       HIP_TRY(ctx, hipMemsetAsync(counters, 0, 4, ctx->stream));
    }
@@ -1342,7 +1342,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
                /* tally over every lane marked: which fields of its assumption are to change */
                std::vector<NfcWindow> all(nWindows);
                HIP_TRY(ctx, hipMemcpy(all.data(), (const NfcWindow *)ctx->wWindows.ptr + firstWindowSlot, sizeof(NfcWindow) * all.size(), hipMemcpyDeviceToHost));
-               uint64_t n[10] = {0}, samples = 0;
+               uint64_t n[10] = {0}, samples = 0, over[4] = {0, 0, 0, 0};
+               uint32_t longest = 0;
                for (const NfcWindow &w: all)
                {
                   if (!w.rerun)
@@ -1362,7 +1363,23 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
                   n[8] += !(chained || carrier || emit || tim || wait || pulses || records) ? 1 : 0;
                   n[9] += (chained && !(carrier || tim || wait || pulses || records)) ? 1 : 0;
                   samples += w.stop - w.start;
+                  const uint32_t len = w.stop - w.start;
+                  longest = len > longest ? len : longest;
+                  over[0] += len >= 65536u; over[1] += len >= 131072u; over[2] += len >= 196608u; over[3] += len >= 262144u;
                }
+               {
+                  /* the longest of them, and the streams they belong to */
+                  std::vector<const NfcWindow *> byLen;
+                  for (const NfcWindow &w: all)
+                     if (w.rerun)
+                        byLen.push_back(&w);
+                  std::sort(byLen.begin(), byLen.end(), [](const NfcWindow *a, const NfcWindow *b) { return a->stop - a->start > b->stop - b->start; });
+                  for (size_t i = 0; i < byLen.size() && i < 6; i++)
+                     std::fprintf(stderr, "[nfcgpu]    long lane: job %u start %u activate %u stop %u (%u samples) retired %u handTo %u noHand %u\n", byLen[i]->job, byLen[i]->start, byLen[i]->activate,
+                                  byLen[i]->stop, byLen[i]->stop - byLen[i]->start, byLen[i]->retired, byLen[i]->handTo, byLen[i]->noHand);
+               }
+               std::fprintf(stderr, "[nfcgpu]    ... of them %llu ran 65536 samples and more, %llu 131072+, %llu 196608+, %llu 262144+; the longest %u\n",
+                            (unsigned long long)over[0], (unsigned long long)over[1], (unsigned long long)over[2], (unsigned long long)over[3], longest);
                std::fprintf(stderr, "[nfcgpu]    lanes to run again %llu (%llu samples as they last ran): chainedA %llu (and nothing else but the carrier record: %llu), carrier on/off %llu, "
                                     "carrier record %llu, command / frame size / guard %llu, waiting time %llu, NFC-F pulse memory %llu, detector records %llu, same assumption (sent on past a hand-over) %llu\n",
                             (unsigned long long)n[0], (unsigned long long)samples, (unsigned long long)n[1], (unsigned long long)n[9], (unsigned long long)n[2], (unsigned long long)n[3],
