@@ -114,6 +114,21 @@ def host_cpu():
     return model, (len(physical) or None), (logical or None)
 
 
+def host_limits():
+    """what the box lets this process have: the processors it may run on and the processor quota of its control group (a
+    container with a quota of N processors runs 128 threads at N processors' worth, whatever the harness does)"""
+    out = {"sched_affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    for name, path in (("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max"), ("cgroup_v1_cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"),
+                       ("cgroup_v1_cfs_period_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"), ("cgroup_cpuset", "/sys/fs/cgroup/cpuset.cpus.effective"),
+                       ("loadavg", "/proc/loadavg")):
+        try:
+            with open(path) as f:
+                out[name] = f.read().strip()
+        except Exception:
+            out[name] = None
+    return out
+
+
 def clamp_used(cursor, dropped, capacity):
     """valid words of a held sink: the cursor keeps counting past the capacity on overflow (nfc_emit)"""
     limit = capacity - (9 + 128) + 1
@@ -437,11 +452,13 @@ def main():
 
             def timed(streams, threads):
                 secs = ctypes.c_double(0)
-                detail = (ctypes.c_double * 4)()
+                detail = (ctypes.c_double * 5)()
                 lib.nfcref_decode_many_detail(mags.ctypes.data, TT, streams, TT, FS, chunk, threads, ctypes.byref(secs), detail)
                 spread[threads] = {"wall_s": round(secs.value, 4), "slowest_thread_s": round(detail[0], 4), "fastest_thread_s": round(detail[1], 4),
                                    "threads_busy_fraction": round(detail[2] / (threads * secs.value), 3) if secs.value > 0 else None,
-                                   "setup_s_outside_the_clock": round(detail[3], 3)}
+                                   "setup_s_outside_the_clock": round(detail[3], 3),
+                                   # processor seconds the threads got inside the clock / wall seconds: processors really at work
+                                   "processors_at_work": round(detail[4] / secs.value, 2) if secs.value > 0 else None}
                 return streams * TT / secs.value / 1e6, secs.value
 
             n_single = max(1, min(C, int(150e6 // TT)))
@@ -507,6 +524,7 @@ def main():
                 "parallel_efficiency": round(multi_phys / (single * physical), 4) if single > 0 and physical else None,
                 "parallel_efficiency_all_threads": round(multi / (single * cores), 4) if single > 0 and cores else None,
                 "thread_spread": {str(k): v for k, v in spread.items()},
+                "host_limits": host_limits(),
                 "harness": "threads started, decoders constructed and each thread's samples first touched by that thread before the clock "
                            "(oracle/ref_capi.cpp: nfcref_decode_many_detail); the clock is the decode alone",
             }

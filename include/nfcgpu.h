@@ -47,6 +47,7 @@ extern "C" {
 #define NFCGPU_EOVERFLOW (-6) /* frame sink overflowed, frames were dropped */
 #define NFCGPU_EHIP (-7)      /* HIP runtime error, see nfcgpu_last_error */
 #define NFCGPU_EFULL (-8)     /* no free stream slot */
+#define NFCGPU_EIO (-9)       /* a file could not be opened or written (nfcgpu_trace_write*) */
 
 #define NFCGPU_TECH_A 0x1u
 #define NFCGPU_TECH_B 0x2u
@@ -208,7 +209,13 @@ int nfcgpu_pending(nfcgpu_ctx *ctx, uint32_t stream_id, uint32_t *count);
  * range of the "write file" command :211-240); 0, 0 = every frame. *written (may be NULL) = frames in the file.
  *   nfcgpu_trace_write_frames  any frames the caller holds (no context, no device);
  *   nfcgpu_trace_write         the frames the device has decoded for a stream and that wait in its queue (nfcgpu_poll
- *                              order; implies nfcgpu_sync); they stay queued. dateTime = the stream's stream_time + timeStart. */
+ *                              order; implies nfcgpu_sync); they stay queued. dateTime = the stream's stream_time + timeStart.
+ *                              NFCGPU_EINVAL while the sink is held (nfcgpu_sink_hold: nothing is drained into the queues then,
+ *                              the file would come out empty).
+ * One departure from the reference's writer: with a range it keeps the frames that lie inside it with both ends, as the
+ * reference does (timeEnd <= range end); 0, 0 means every frame, where the reference's command always carries a range.
+ * "length" is the number of bytes in frameData (at most the 512 a frame record holds). A file that cannot be opened or
+ * written is NFCGPU_EIO. */
 int nfcgpu_trace_write_frames(const char *path, const nfcgpu_frame *frames, uint32_t count, int64_t stream_time, double range_start, double range_end,
                               uint32_t *written);
 int nfcgpu_trace_write(nfcgpu_ctx *ctx, uint32_t stream_id, const char *path, double range_start, double range_end, uint32_t *written);

@@ -53,26 +53,31 @@ void append_uint(std::string &out, uint64_t v)
    out += buf;
 }
 
-uint32_t crc32_of(const uint8_t *p, size_t n)
+/* the table of CRC-32 (reflected 0xEDB88320), built once: a function-local static of class type is initialised exactly once
+ * whatever threads call first (nfcgpu_trace_write_frames needs no context and may be called from several at a time) */
+struct Crc32Table
 {
-   static uint32_t table[256];
-   static bool ready = false;
+   uint32_t entry[256];
 
-   if (!ready)
+   Crc32Table()
    {
       for (uint32_t i = 0; i < 256; i++)
       {
          uint32_t c = i;
          for (int k = 0; k < 8; k++)
             c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-         table[i] = c;
+         entry[i] = c;
       }
-      ready = true;
    }
+};
+
+uint32_t crc32_of(const uint8_t *p, size_t n)
+{
+   static const Crc32Table table;
 
    uint32_t c = 0xFFFFFFFFu;
    for (size_t i = 0; i < n; i++)
-      c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+      c = table.entry[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
    return c ^ 0xFFFFFFFFu;
 }
 
@@ -111,7 +116,7 @@ int write_gzip_stored(const char *path, const std::vector<uint8_t> &raw)
 {
    std::FILE *f = std::fopen(path, "wb");
    if (!f)
-      return NFCGPU_EINVAL;
+      return NFCGPU_EIO;
 
    const uint8_t head[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 0xFF};
    bool ok = std::fwrite(head, 1, sizeof(head), f) == sizeof(head);
@@ -132,7 +137,7 @@ int write_gzip_stored(const char *path, const std::vector<uint8_t> &raw)
    ok = ok && std::fwrite(tail, 1, 8, f) == 8;
    ok = (std::fclose(f) == 0) && ok;
 
-   return ok ? NFCGPU_OK : NFCGPU_EINVAL;
+   return ok ? NFCGPU_OK : NFCGPU_EIO;
 }
 
 }
@@ -188,7 +193,7 @@ extern "C" int nfcgpu_trace_write_frames(const char *path, const nfcgpu_frame *f
       if (f.length)
       {
          json += ",\"length\":";
-         append_uint(json, f.length);
+         append_uint(json, f.length < sizeof(f.data) ? f.length : (uint32_t)sizeof(f.data)); /* (the bytes frameData holds) */
       }
       json += ",\"sampleEnd\":";
       append_uint(json, f.sample_end - offset);

@@ -182,6 +182,7 @@ struct nfcgpu_ctx
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
    hipEvent_t epoch = nullptr;      /* recorded when the statistics start over: the time base of the launch intervals below */
    std::vector<std::pair<float, float>> waveSpans; /* [start, stop) of every wave decoder launch since, ms after `epoch` */
+   double waveBusyMs = 0.0;         /* ... and the union of those that have been folded away (fold_wave_spans) */
 
    /* ---- frame gather over RCCL (nfcgpu_comm_*) ---- */
    void *comm = nullptr;
@@ -506,6 +507,12 @@ int grow(nfcgpu_ctx *ctx, nfcgpu_ctx::DevBuf &b, size_t bytes)
       if (&b == &ctx->wPlanes && bytes > std::strtoull(limit, nullptr, 10))
          return fail(ctx, NFCGPU_ENOMEM, "device allocation for the time-parallel path failed (test limit)");
    }
+   if (const char *limit = std::getenv("NFCGPU_TEST_ALLOC_LIMIT_LANES"))
+   {
+      /* (the same for a buffer that is grown elsewhere in run_windowed: the lanes' decoder states) */
+      if (&b == &ctx->vStates && bytes > std::strtoull(limit, nullptr, 10))
+         return fail(ctx, NFCGPU_ENOMEM, "device allocation for the time-parallel path failed (test limit)");
+   }
 #endif
 
    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -709,6 +716,29 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    const uint32_t nJobs = (uint32_t)items.size();
    const NfcConfig &cfg = ctx->configs[config];
 
+   /* A work buffer the device cannot give (NFCGPU_ENOMEM from grow()) is not the end of a submission as long as nothing of the
+    * streams has been touched - which holds up to the finish: the scan and the lanes only read the streams' state. The
+    * submission is then decoded a quarter of its length at a time (a quarter of every work buffer), and if that does not fit
+    * either by the sequential kernels, which need none. Any other error is the caller's. */
+   auto withoutTheMemory = [&](int code) -> int {
+      if (code != NFCGPU_ENOMEM)
+         return code;
+
+      (void)hipGetLastError();
+
+      uint32_t longest = 0;
+      for (const WindowedItem &it: items)
+         longest = it.count > longest ? it.count : longest;
+
+      const uint32_t quarter = longest / 4u / NFC_SCAN_POINT * NFC_SCAN_POINT;
+
+      if (!ctx->inBlocks && quarter >= 65536u && quarter >= ctx->windowedMinSamples)
+         return run_in_blocks(ctx, config, items, stride, quarter);
+
+      ctx->stats.fallback_streams += nJobs;
+      return launch_sequential(ctx, config, items, stride);
+   };
+
    NfcScanParams sp;
    {
       float corr = 3.0e38f;
@@ -807,7 +837,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
        (rc = grow(ctx, ctx->wTileStats, sizeof(NfcScanTile) * (size_t)tiles)) ||
        (rc = grow(ctx, ctx->wCounters, 256)) || (rc = grow(ctx, ctx->wRepairs, sizeof(NfcScanChunk) * nChunks)) ||
        (rc = grow(ctx, ctx->wRepairsEnv, sizeof(NfcScanChunk) * nChunks)))
-      return rc;
+      return withoutTheMemory(rc);
 
    /* lanes: a first guess (one window per 8192 samples); the window kernel reports what it needs */
    uint32_t room = (uint32_t)(totalSamples / 8192) + 2 * nJobs + 64;
@@ -830,13 +860,19 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    /* is there room already from an earlier, larger submission? */
    {
-      const size_t have = ctx->wWindows.bytes / sizeof(NfcWindow);
+      /* (every lane buffer has to hold them: one that could not be grown last time - NFCGPU_ENOMEM, the submission then taken in
+       * quarters - must not be asked for the room its neighbours got) */
+      size_t have = ctx->wWindows.bytes / sizeof(NfcWindow);
+      have = std::min(have, ctx->wWorks.bytes / sizeof(NfcWork));
+      have = std::min(have, ctx->vStates.bytes / sizeof(NfcStreamState));
+      have = std::min(have, ctx->vCold.bytes / sizeof(NfcStreamCold));
+      have = std::min(have, ctx->wRunList.bytes / 4);
       if (have > (size_t)firstWindowSlot + room)
          room = (uint32_t)(have - firstWindowSlot - NFC_LANES);
    }
 
    if ((rc = growLanes(firstWindowSlot + room)))
-      return rc;
+      return withoutTheMemory(rc);
 
    /* staging sink for the lanes' chained frame records (lanes that turn out not to be live write theirs too): room
     * for four times the frame sink, at least 64 MiB; what does not fit is reported as dropped like any overflow */
@@ -847,7 +883,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       if (staging > 0xFFFFFFF0ull * 4ull)
          staging = 0xFFFFFFF0ull * 4ull;
       if ((rc = grow(ctx, ctx->vSink, staging)) || (rc = grow(ctx, ctx->vSinkCtl, 16)))
-         return rc;
+         return withoutTheMemory(rc);
    }
 
    uint32_t *counters = (uint32_t *)ctx->wCounters.ptr;
@@ -891,7 +927,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       const uint32_t saveRoom = 2 * nJobs + 1024;
       if ((rc = grow(ctx, ctx->vSaveRings, sizeof(float) * (size_t)(kRingBlockFloats / NFC_LANES) * saveRoom)) ||
           (rc = grow(ctx, ctx->vSaveBytes, (size_t)NFC_STREAM_BYTES * saveRoom)))
-         return rc;
+         return withoutTheMemory(rc);
 
       A.saveRings = (float *)ctx->vSaveRings.ptr;
       A.saveBytes = (uint8_t *)ctx->vSaveBytes.ptr;
@@ -1059,26 +1095,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    {
       if ((rc = grow(ctx, ctx->wPlanes, (size_t)tiles * NFC_SCAN_TILE * 16u)) || (rc = grow(ctx, ctx->wPlaneChunks, sizeof(NfcScanChunk) * nChunks)))
       {
-         /* The planes are 16 bytes per sample of the submission (64 GiB for 4096 streams x 2^20): where the device cannot
-          * give that, the submission is decoded a quarter of its length at a time (a quarter of the planes), and if that
-          * does not fit either by the sequential kernels, which need no work buffers. Nothing has been touched yet: the scan
-          * only reads. */
-         if (rc != NFCGPU_ENOMEM)
-            return rc;
-
-         (void)hipGetLastError();
-
-         uint32_t longest = 0;
-         for (const WindowedItem &it: items)
-            longest = it.count > longest ? it.count : longest;
-
-         const uint32_t quarter = longest / 4u / NFC_SCAN_POINT * NFC_SCAN_POINT;
-
-         if (!ctx->inBlocks && quarter >= 65536u && quarter >= ctx->windowedMinSamples)
-            return run_in_blocks(ctx, config, items, stride, quarter);
-
-         ctx->stats.fallback_streams += nJobs;
-         return launch_sequential(ctx, config, items, stride);
+         /* (the planes are 16 bytes per sample of the submission: 64 GiB for 4096 streams x 2^20) */
+         return withoutTheMemory(rc);
       }
 
       std::vector<NfcScanChunk> all(chunks);
@@ -1115,7 +1133,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       room = nWindows + NFC_LANES;
       if ((rc = growLanes(firstWindowSlot + room)))
-         return rc;
+         return withoutTheMemory(rc);
 
       A.windows = (NfcWindow *)ctx->wWindows.ptr;
       A.works = (NfcWork *)ctx->wWorks.ptr;
@@ -1752,6 +1770,45 @@ void release_workspace(nfcgpu_ctx *ctx)
    ctx->side = ctx->stream = nullptr;
 }
 
+/* A profiled service that never resets its statistics must not collect a span per launch for ever: once the list is long, the
+ * spans that end before the most recent ones begin - their union can no longer change - are folded into a running total. */
+void fold_wave_spans(nfcgpu_ctx *ctx)
+{
+   std::vector<std::pair<float, float>> &v = ctx->waveSpans;
+
+   if (v.size() < 4096)
+      return;
+
+   std::sort(v.begin(), v.end());
+
+   /* the list becomes the union of its spans; an interval of that union that ends before the most recent 64 spans begin can
+    * no longer grow (launches of one submission overlap, those of different submissions do not) and goes into the total */
+   const float horizon = v[v.size() - 64].first;
+   std::vector<std::pair<float, float>> open;
+   double busy = 0.0;
+   float lo = v[0].first, hi = v[0].second;
+
+   for (size_t i = 1; i < v.size(); i++)
+   {
+      if (v[i].first > hi)
+      {
+         if (hi < horizon)
+            busy += hi - lo;
+         else
+            open.push_back(std::make_pair(lo, hi));
+         lo = v[i].first;
+         hi = v[i].second;
+      }
+      else if (v[i].second > hi)
+         hi = v[i].second;
+   }
+
+   open.push_back(std::make_pair(lo, hi));
+
+   ctx->waveBusyMs += busy;
+   v.swap(open);
+}
+
 /* HIP-event spans recorded since the last call -> milliseconds in the context's statistics; the events go back to the pool.
  * The streams the events were recorded on must have been waited for. */
 void collect_timings(nfcgpu_ctx *ctx)
@@ -1789,6 +1846,8 @@ void collect_timings(nfcgpu_ctx *ctx)
       }
       into.list->clear();
    }
+
+   fold_wave_spans(ctx);
 }
 
 int run_rows(nfcgpu_ctx *ctx, uint32_t first, uint32_t count, const uint8_t *devBase, uint64_t devPitch, uint32_t n, uint32_t stride);
@@ -2643,6 +2702,10 @@ int nfcgpu_trace_write(nfcgpu_ctx *ctx, uint32_t id, const char *path, double ra
    if (id >= ctx->maxStreams || !ctx->streams[id].open)
       return fail(ctx, NFCGPU_ESTREAM, "unknown stream");
 
+   /* (a held sink is not drained by nfcgpu_sync: the stream's queue would be empty and the file with it) */
+   if (ctx->hold)
+      return fail(ctx, NFCGPU_EINVAL, "nfcgpu_trace_write while the sink is held (nfcgpu_sink_hold): the frames are in the caller's sink, not in the stream's queue");
+
    int rc = nfcgpu_sync(ctx);
    if (rc && rc != NFCGPU_EOVERFLOW)
       return rc;
@@ -2942,7 +3005,7 @@ void close_wave_spans(nfcgpu_ctx *ctx)
    std::vector<std::pair<float, float>> &v = ctx->waveSpans;
    std::sort(v.begin(), v.end());
 
-   double busy = 0.0;
+   double busy = ctx->waveBusyMs; /* (what fold_wave_spans has taken out of the list) */
    float lo = 0, hi = -1.0f;
 
    for (const auto &span: v)
@@ -2993,12 +3056,14 @@ int nfcgpu_stats_reset(nfcgpu_ctx *ctx)
 
    ctx->stats = nfcgpu_stats();
    ctx->waveSpans.clear();
+   ctx->waveBusyMs = 0.0;
 
-   /* the time base of the launch intervals: an event on the context's stream, now */
+   /* the time base of the launch intervals: an event on the context's stream, now (on the context's device: with several
+    * contexts in a process - a rank per GPU - another one may be current) */
+   HIP_TRY(ctx, hipSetDevice(ctx->device));
    if (!ctx->epoch)
-      (void)hipEventCreate(&ctx->epoch);
-   if (ctx->epoch)
-      (void)hipEventRecord(ctx->epoch, ctx->stream);
+      HIP_TRY(ctx, hipEventCreate(&ctx->epoch));
+   HIP_TRY(ctx, hipEventRecord(ctx->epoch, ctx->stream));
 
    return NFCGPU_OK;
 }
@@ -3030,6 +3095,7 @@ const char *nfcgpu_strerror(int code)
       case NFCGPU_EOVERFLOW: return "frame sink overflow, frames dropped";
       case NFCGPU_EHIP: return "HIP runtime error";
       case NFCGPU_EFULL: return "no free stream slot";
+      case NFCGPU_EIO: return "a file could not be opened or written";
       default: return "unknown error";
    }
 }

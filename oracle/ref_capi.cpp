@@ -15,6 +15,7 @@
  * include/nfcgpu.h's nfcgpu_frame.
  */
 #include <cstdint>
+#include <time.h>
 #include <cstring>
 #include <chrono>
 #include <list>
@@ -282,7 +283,8 @@ void nfcref_magnitude(const float *iq, uint64_t count, float *out)
  * that will read them), then all of them wait at a gate; the clock runs from the moment the gate opens to the moment the
  * last thread is done. detail (may be null): [0] the seconds of the thread that took longest over its own share, [1] of the
  * one that took shortest, [2] the sum of all threads' seconds (their ratio to threads x wall seconds says how evenly the
- * work was spread), [3] seconds spent before the gate opened (set-up, outside the clock). */
+ * work was spread), [3] seconds spent before the gate opened (set-up, outside the clock), [4] the sum of the processor
+ * seconds the threads got inside the clock (CLOCK_THREAD_CPUTIME_ID: [4] / wall seconds = processors really at work). */
 long nfcref_decode_many_detail(const float *base, uint64_t pitch_floats, uint32_t streams, uint64_t count, uint32_t sample_rate,
                                uint32_t chunk, uint32_t threads, double *seconds, double *detail)
 {
@@ -294,14 +296,14 @@ long nfcref_decode_many_detail(const float *base, uint64_t pitch_floats, uint32_
    std::atomic<long> total {0};
    std::atomic<uint32_t> ready {0};
    std::atomic<int> go {0};
-   std::vector<double> took(threads, 0.0);
+   std::vector<double> took(threads, 0.0), cpu(threads, 0.0);
    std::vector<std::thread> pool;
 
    const auto tSetup = std::chrono::steady_clock::now();
 
    for (uint32_t t = 0; t < threads; t++)
    {
-      pool.emplace_back([=, &total, &ready, &go, &took]() {
+      pool.emplace_back([=, &total, &ready, &go, &took, &cpu]() {
          /* this thread's streams: decoders, and the samples where this thread touches them first */
          std::vector<std::unique_ptr<lab::NfcDecoder>> decoders;
          std::vector<std::vector<float>> samples;
@@ -316,6 +318,13 @@ long nfcref_decode_many_detail(const float *base, uint64_t pitch_floats, uint32_
          ready.fetch_add(1);
          while (!go.load(std::memory_order_acquire))
             std::this_thread::yield();
+
+         double cpuBefore = 0.0;
+         {
+            struct timespec ts;
+            if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0)
+               cpuBefore = (double)ts.tv_sec + 1.0e-9 * (double)ts.tv_nsec;
+         }
 
          const auto t0 = std::chrono::steady_clock::now();
          long frames = 0;
@@ -335,6 +344,13 @@ long nfcref_decode_many_detail(const float *base, uint64_t pitch_floats, uint32_
          }
 
          took[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+         {
+            /* processor time this thread got (set-up included): next to its wall seconds it tells a decoder that is slow from
+             * one that is not being run - a container's processor quota, more threads than processors */
+            struct timespec ts;
+            if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0)
+               cpu[t] = (double)ts.tv_sec + 1.0e-9 * (double)ts.tv_nsec - cpuBefore;
+         }
          total += frames;
       });
    }
@@ -366,6 +382,9 @@ long nfcref_decode_many_detail(const float *base, uint64_t pitch_floats, uint32_
       detail[1] = lo;
       detail[2] = sum;
       detail[3] = std::chrono::duration<double>(t0 - tSetup).count();
+      detail[4] = 0.0;
+      for (double v: cpu)
+         detail[4] += v;
    }
 
    return total.load();

@@ -142,6 +142,14 @@ def test_planes_that_do_not_fit_the_device_are_not_fatal_emulated(emulated):
     res = _run(["planes"], True, {"NFCGPU_TEST_ALLOC_LIMIT": str(full // 8)})       # nothing fits: sequential kernels
     _check(res, windowed=False)
     assert res[0]["stats"]["windowed"] == 0 and res[0]["stats"]["fallback"] == 4 * 2, res   # (counted per block)
+    # the other work buffers of a submission take the same way out (here: the lanes' decoder states, 364 bytes a lane;
+    # the whole submission wants ~330 lanes, a quarter of it ~230)
+    res = _run(["planes"], True, {"NFCGPU_TEST_ALLOC_LIMIT_LANES": "100000"})        # the quarter fits
+    _check(res)
+    assert res[0]["stats"]["windowed"] == 4 * 2 and res[0]["stats"]["fallback"] == 0, res
+    res = _run(["planes"], True, {"NFCGPU_TEST_ALLOC_LIMIT_LANES": "50000"})         # nothing fits: sequential kernels
+    _check(res, windowed=False)
+    assert res[0]["stats"]["windowed"] == 0 and res[0]["stats"]["fallback"] == 4 * 2, res
 
 
 @needs_reference
