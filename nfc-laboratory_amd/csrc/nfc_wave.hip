@@ -166,11 +166,133 @@ __device__ __forceinline__ float nfc_wave_max(float v)
 #define NFC_WAVE_STAT_ADD(p, v) atomicAdd((p), (v))
 #define NFC_WAVE_STAT_MAX(p, v) atomicMax((p), (v))
 
+#ifdef NFC_WAVE_VERIFY
+/* -DNFC_WAVE_VERIFY (not a product build; one run per round: profiles/tools/r05/wave_verify_device.py): every tile is decoded
+ * twice on the device - with the bulk paths of nfc_wave_fast.hpp and again sample by sample by the step machine alone - and
+ * everything the two leave is compared word for word: decoder state, protocol state, history and correlation rings, frame
+ * bytes, usage marks (what tests/hostsim/emu_wave.cpp does on the CPU build with NFC_EMU_WAVE_VERIFY=1). Tiles verified and
+ * tiles that differ are counted in the submission's counter block (words 12 / 13; 14 / 15: where the first difference was). */
+#include "nfc_scan_launch.h"
+struct NfcWaveLds;
+struct NfcWaveItem;
+struct NfcWaveSink;
+struct NfcWaveFetch;
+__device__ void nfc_wave_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds,
+                                     const NfcWaveSink &sink, uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, const NfcWaveFetch &fetched);
+#define NFC_WAVE_TILE_HOOK nfc_wave_verify_tile
+#endif
+
 #include "nfc_wave.hpp"
+
+#ifdef NFC_WAVE_VERIFY
+__device__ uint32_t *nfcWaveVerifyCounters; /* (set by the kernel from its launch record: NfcLaunch::laneStats + 8) */
+
+__device__ __forceinline__ void nfc_wave_verify_copy(NFC_WAVE_LDS NfcWaveLds *to, const NFC_WAVE_LDS NfcWaveLds *from)
+{
+   NFC_WAVE_LDS uint32_t *t = (NFC_WAVE_LDS uint32_t *)to;
+   const NFC_WAVE_LDS uint32_t *f = (const NFC_WAVE_LDS uint32_t *)from;
+
+   for (uint32_t i = threadIdx.x; i < sizeof(NfcWaveLds) / 4u; i += NFC_LANES)
+      t[i] = f[i];
+}
+
+__device__ void nfc_wave_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &cc, const NfcScanArgs &A, const NfcWaveItem &it, NFC_WAVE_LDS NfcWaveLds *lds,
+                                     const NfcWaveSink &sink, uint32_t n, uint32_t pos, bool carry, uint32_t warmFront, uint32_t warm, const NfcWaveFetch &fetched)
+{
+   __shared__ uint32_t dummy[NFC_FRAME_MAX_WORDS + 16];
+   __shared__ uint32_t dummyCtl[2];
+
+   NFC_WAVE_LDS NfcWaveLds *saved = lds + 1, *fast = lds + 2;
+   const uint32_t lane = threadIdx.x;
+
+   __syncthreads();
+   nfc_wave_verify_copy(saved, lds);
+   __syncthreads();
+
+   nfc_wave_tile(cfgPtr, cc, A, it, lds, sink, n, pos, carry, warmFront, warm, fetched, true);
+
+   __syncthreads();
+   nfc_wave_verify_copy(fast, lds);
+   __syncthreads();
+   nfc_wave_verify_copy(lds, saved);
+   __syncthreads();
+
+   if (lane == 0)
+   {
+      /* (the lane's frame records are chained by their place in the sink: the stepped run's go to a sink of its own) */
+      lds->cold.frameHead = 0;
+      lds->cold.frameTail = 0;
+      dummyCtl[0] = 0;
+      dummyCtl[1] = 0;
+   }
+   __syncthreads();
+
+   NfcWaveSink quiet = sink;
+   quiet.words = (uint32_t *)dummy;
+   quiet.ctl = (uint32_t *)dummyCtl;
+   quiet.capacity = NFC_FRAME_MAX_WORDS + 16;
+
+   nfc_wave_tile(cfgPtr, cc, A, it, lds, quiet, n, pos, carry, warmFront, warm, fetched, false);
+
+   __syncthreads();
+
+   /* word for word: state, where the tile loop stands, protocol state (but the chain of frame records), rings (but the product
+    * ring, written ahead by the bulk paths), frame bytes, usage marks */
+   bool differs = false;
+   {
+      const NFC_WAVE_LDS uint32_t *a = (const NFC_WAVE_LDS uint32_t *)&fast->u.s, *b = (const NFC_WAVE_LDS uint32_t *)&lds->u.s;
+      for (uint32_t i = lane; i < sizeof(NfcStreamState) / 4u; i += NFC_LANES)
+         differs = differs || a[i] != b[i];
+   }
+   {
+      const NFC_WAVE_LDS uint32_t *a = (const NFC_WAVE_LDS uint32_t *)&fast->cold, *b = (const NFC_WAVE_LDS uint32_t *)&lds->cold;
+      const uint32_t head = (uint32_t)offsetof(NfcStreamCold, frameHead) / 4u, tail = (uint32_t)offsetof(NfcStreamCold, frameTail) / 4u;
+      for (uint32_t i = lane; i < sizeof(NfcStreamCold) / 4u; i += NFC_LANES)
+         differs = differs || (i != head && i != tail && a[i] != b[i]);
+   }
+   {
+      const NFC_WAVE_LDS uint32_t *a = (const NFC_WAVE_LDS uint32_t *)fast->ring, *b = (const NFC_WAVE_LDS uint32_t *)lds->ring;
+      for (uint32_t i = lane; i < NFC_R_PROD; i += NFC_LANES)
+         differs = differs || a[i] != b[i];
+      for (uint32_t i = lane; i < NFC_CORR_MAX; i += NFC_LANES)
+         differs = differs || a[NFC_R_CORR + i] != b[NFC_R_CORR + i];
+   }
+   {
+      const NFC_WAVE_LDS uint32_t *a = (const NFC_WAVE_LDS uint32_t *)fast->bytes, *b = (const NFC_WAVE_LDS uint32_t *)lds->bytes;
+      for (uint32_t i = lane; i < NFC_STREAM_BYTES / 4u; i += NFC_LANES)
+         differs = differs || a[i] != b[i];
+   }
+   differs = differs || fast->flags != lds->flags || fast->u.at != lds->u.at;
+
+   const bool any = __ballot(differs) != 0ull;
+
+   if (lane == 0 && nfcWaveVerifyCounters)
+   {
+      atomicAdd(nfcWaveVerifyCounters + 0, 1u);
+      if (any && atomicAdd(nfcWaveVerifyCounters + 1, 1u) == 0u)
+      {
+         nfcWaveVerifyCounters[2] = pos;
+         nfcWaveVerifyCounters[3] = it.w;
+      }
+   }
+
+   /* go on from the first run (its frames are the ones in the sink) */
+   __syncthreads();
+   nfc_wave_verify_copy(lds, fast);
+   __syncthreads();
+}
+#endif
 
 __global__ __launch_bounds__(64) NFC_WAVE_KERNEL_ATTR void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode)
 {
+#ifdef NFC_WAVE_VERIFY
+   __shared__ NfcWaveLds ldsThree[3]; /* the wave's, a copy of it as the tile found it, and what the bulk paths left */
+#define lds ldsThree[0]
+   if (threadIdx.x == 0 && blockIdx.x == 0)
+      nfcWaveVerifyCounters = L.laneStats + 8;
+#else
    __shared__ NfcWaveLds lds;
+#endif
 #ifdef NFC_WAVE_LDS_PAD
    /* experiment: more LDS per wave = fewer waves per CU (how much of the throughput is occupancy?) */
    __shared__ uint32_t pad[NFC_WAVE_LDS_PAD / 4];

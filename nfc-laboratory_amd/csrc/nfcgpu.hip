@@ -1452,6 +1452,19 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    mark("passes");
 
+   /* a library whose wave decoder was built with -DNFC_WAVE_VERIFY (Makefile: libnfcgpu_verify.so) has decoded every tile twice
+    * and counted (csrc/nfc_wave.hip); a product build leaves the words at zero */
+   if (std::getenv("NFCGPU_WAVE_VERIFY_REPORT"))
+   {
+      uint32_t v[4] = {0, 0, 0, 0};
+      HIP_TRY(ctx, hipMemcpyAsync(v, counters + 12, 16, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      std::fprintf(stderr, "[nfcgpu] wave verify: %u tiles decoded twice (bulk paths / step machine alone), %u differ", v[0], v[1]);
+      if (v[1])
+         std::fprintf(stderr, " (the first at stream position %u of lane slot %u)", v[2], v[3]);
+      std::fprintf(stderr, "\n");
+   }
+
    /* The lanes chain their frame records in a staging sink that is sized from an estimate and written by every lane of
     * every pass, live in the end or not. Should it have run full, frames of live lanes may be among the ones that did not
     * fit: nothing of the streams has been touched yet, so the submission is decoded by the sequential kernels instead. */
