@@ -142,6 +142,7 @@ __device__ __forceinline__ float nfc_wave_max(float v)
 /* a word a uniform block hands to the code after it: every lane has computed it (no trip through LDS) */
 #define NFC_WAVE_UNIFORM_LEAVE(slot, value) ((void)0)
 #define NFC_WAVE_UNIFORM_TAKE(slot, value) ((value) = (uint32_t)__builtin_amdgcn_readfirstlane((int)(value)))
+#define NFC_WAVE_UNIFORM_TAKE_BITS(slot, value) ((value) = (uint32_t)__builtin_amdgcn_readfirstlane((int)(value))) /* (the slot is a float) */
 #define NFC_WAVE_SCAN_ADD_F(v) nfc_wave_scan_add(v)
 #define NFC_WAVE_MAX_F(v) nfc_wave_max(v)
 #define NFC_WAVE_PICK_F(reg, array, j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)(reg)), (int)(j)))

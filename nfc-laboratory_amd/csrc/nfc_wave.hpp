@@ -78,8 +78,6 @@ struct NfcWaveUni
    uint32_t whichAt;
    uint32_t maskValid; /* search bank: the detectors whose gates over the tile at hand (NfcWaveLds::gate) still stand (bit per detector) */
    uint32_t aloneLocked; /* search bank: an NFC-F tracker applied on its own found its preamble complete (the sample is the step's) */
-   uint32_t retireLo, retireHi; /* may the lane retire at the boundary before tile 64 m + j of its row? bit j (fetched 64 tiles at a time) */
-   uint32_t darkLo, darkHi;     /* is tile 64 m + j of its row dark (NFC_TILE_DARK: every sample below the power threshold, no carrier event)? bit j */
    /* what the two ring taps of a sample (nfc_wave_taps) are formed from on demand: the correlators as they stood when the
     * values of the tile were formed (sample `from`): ring position and running sum of the sample before, whether the ring
     * entry one sample back is that sum; locked stages (slot 0): ring period, distance of the first tap, ring base, first
@@ -957,9 +955,17 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
    NfcWaveFetch fetched = nfc_wave_fetch(it, 0u, stride);
 
+   /* What a tile boundary needs to know, kept in registers from one boundary to the next (round 5: each used to be a word of the
+    * shared record, an LDS round trip apiece on every boundary - 9 % of the wave's cycles for a boundary at which, nearly
+    * always, nothing happens): where the lane stands, the retire / dark flags of the 64 tiles at hand, the sample from which
+    * on the successor is to be asked. */
+   uint32_t consumedNow = 0;
+   uint64_t retireMask = 0ull, darkMask = 0ull;
+   uint32_t askFrom = 0u; /* (0: not looked up yet) */
+
    for (;;)
    {
-      const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
+      const uint32_t consumed = consumedNow;
 
       if (consumed >= it.count)
          break;
@@ -984,26 +990,25 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
             const uint32_t flagsHere = first + lane < tilesOfRow ? it.tiles[first + lane] : 0u;
             const uint64_t dark = NFC_WAVE_BALLOT((flagsHere & NFC_TILE_DARK) != 0u);
 
-            NFC_WAVE_BARRIER();
-            NFC_WAVE_UNIFORM_BEGIN
-            {
-               lds->u.retireLo = (uint32_t)retire;
-               lds->u.retireHi = (uint32_t)(retire >> 32);
-               lds->u.darkLo = (uint32_t)dark;
-               lds->u.darkHi = (uint32_t)(dark >> 32);
-            }
-            NFC_WAVE_UNIFORM_END
+            retireMask = retire;
+            darkMask = dark;
          }
       }
 
       /* (a stream without windows - NfcScanParams::soloSamples - has nobody to take over from a lane that retires) */
       const uint32_t tileBit = (consumed / NFC_SCAN_TILE) % NFC_LANES;
-      const bool mayRetire = past && jobWindows != 0u && (((tileBit < 32u ? lds->u.retireLo : lds->u.retireHi) >> (tileBit & 31u)) & 1u) != 0u;
+      const bool mayRetire = past && jobWindows != 0u && ((retireMask >> tileBit) & 1ull) != 0ull;
       const bool publishes = pos == verifyPos;
       uint32_t edgeNow = 0;
+      uint32_t stoppedNow = 0u;
 
       if (publishes && pos > 0)
          edgeNow = nfc_wave_edge_time(cc, A, it, lds, pos - 1u); /* a published state carries the decoder's edge time */
+
+      /* (nothing to publish, no leave to retire, the successor not to be asked yet: nothing to look at) */
+      if (publishes || mayRetire || (past && pos >= askFrom))
+      {
+      uint32_t askNext = askFrom;
 
       NFC_WAVE_UNIFORM_BEGIN
       {
@@ -1028,10 +1033,20 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
             lds->u.succ = succ;
             lds->u.succVerify = succ < succEnd ? L.windows[succ].verify : 0xFFFFFFFFu;
          }
+
+         stoppedNow = lds->u.stopped;
+         askNext = lds->u.succVerify;
+         NFC_WAVE_UNIFORM_LEAVE(lds->u.pass[0], __builtin_bit_cast(float, stoppedNow));
+         NFC_WAVE_UNIFORM_LEAVE(lds->u.pass[1], __builtin_bit_cast(float, askNext));
       }
       NFC_WAVE_UNIFORM_END
 
-      if (NFC_WAVE_UNIFORM_U32(lds->u.stopped))
+      NFC_WAVE_UNIFORM_TAKE_BITS(lds->u.pass[0], stoppedNow);
+      NFC_WAVE_UNIFORM_TAKE_BITS(lds->u.pass[1], askNext);
+      askFrom = askNext;
+      }
+
+      if (stoppedNow)
          break;
 
       /* ---- a searching lane in front of a run of dark tiles ----
@@ -1043,10 +1058,9 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
        * the envelope is above the threshold again (NFC_HIST; the shorter histories hold 256), the clock and the positions
        * are moved by what was left out. Not across the sample the lane publishes at. (S1's captures begin with the carrier
        * off: a fifth of what the lanes of a dense stream walk is such tiles.) */
-      if (past && NFC_WAVE_STATE(lds).lockTech == 0u && NFC_WAVE_STATE(lds).unlock == 0u)
+      if (past && ((darkMask >> tileBit) & 1ull) != 0ull && NFC_WAVE_STATE(lds).lockTech == 0u && NFC_WAVE_STATE(lds).unlock == 0u)
       {
-         const uint64_t dark = ((uint64_t)NFC_WAVE_UNIFORM_U32(lds->u.darkHi) << 32) | NFC_WAVE_UNIFORM_U32(lds->u.darkLo);
-         const uint64_t from = dark >> tileBit;
+         const uint64_t from = darkMask >> tileBit;
          const uint32_t run = (~from) ? (uint32_t)__builtin_ctzll(~from) : 64u; /* dark tiles in a row from this one (the group's own: bits beyond it are zero) */
          const uint32_t keep = NFC_HIST / NFC_SCAN_TILE;
 
@@ -1092,6 +1106,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
                }
                NFC_WAVE_UNIFORM_END
 
+               consumedNow = consumed + samples;
                fetched = nfc_wave_fetch(it, consumed + samples, stride);
                continue; /* (the boundary of the tile it lands on is looked at like any other) */
             }
@@ -1112,6 +1127,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 #endif
 
       fetched = ahead;
+      consumedNow = consumed + n;
 
       NFC_WAVE_UNIFORM_BEGIN
       {
@@ -1122,7 +1138,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
 
    /* ---- the lane's result ---- */
    NFC_WAVE_TICK(lds, 7u);
-   const uint32_t consumed = NFC_WAVE_UNIFORM_U32(lds->u.consumed);
+   const uint32_t consumed = consumedNow;
    const uint32_t stopped = NFC_WAVE_UNIFORM_U32(lds->u.stopped);
    const bool ranOut = consumed >= it.count;
    const bool atEnd = it.startPos + consumed >= it.job->count;

@@ -64,6 +64,7 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 #define NFC_WAVE_UNIFORM_U32(x) ((uint32_t)(x))
 #define NFC_WAVE_UNIFORM_LEAVE(slot, value) ((slot) = (value))
 #define NFC_WAVE_UNIFORM_TAKE(slot, value) ((value) = (slot))
+#define NFC_WAVE_UNIFORM_TAKE_BITS(slot, value) ((value) = __builtin_bit_cast(uint32_t, (float)(slot)))
 #define NFC_WAVE_READ_FENCE() wavesim::barrier()
 #define NFC_WAVE_PICK_F(reg, array, j) ((array)[(j)])
 #define NFC_WAVE_PICK_U32(reg, array, j) (wavesim::shfl((reg), (j)))
