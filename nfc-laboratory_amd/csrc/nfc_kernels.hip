@@ -491,7 +491,7 @@ __device__ __forceinline__ void nfc_fixed_runtime_config(const NfcConfig *cfgPtr
 #define NFC_SCAN_PITCH (NFC_SCAN_TILE + 1)
 
 /* S = floats per sample (2 IQ, 1 magnitude) */
-template <uint32_t S, bool PLANES>
+template <uint32_t S>
 __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgPtr, const NfcScanArgs &A, float *tile, uint32_t *rows)
 {
    const uint32_t lane = threadIdx.x;
@@ -506,7 +506,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
 
    /* a chunk on the repair list is walked from the true end state of the chunk before, without warm-up */
    const bool repair = (ch.index & NFC_CHUNK_REPAIR) != 0;
-   const bool envelopeOnly = repair && !PLANES && (ch.index & NFC_CHUNK_ENVELOPE) != 0; /* only the envelope tracker is walked again */
+   const bool envelopeOnly = repair && (ch.index & NFC_CHUNK_ENVELOPE) != 0; /* only the envelope tracker is walked again */
    ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
 
    const NfcScanJob *job = A.jobs + ch.job;
@@ -709,7 +709,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          if (pos == start)
             nfc_scan_point(w, seam.start);
 
-         if (!PLANES && pos >= start && (pos % NFC_SCAN_POINT) == 0)
+         if (pos >= start && (pos % NFC_SCAN_POINT) == 0)
          {
             NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
 
@@ -745,19 +745,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          {
 
          /* (whole tiles - all but the last of a stream - with a fixed trip count) */
-         if (PLANES)
-         {
-            /* second walk, from the verified state: the front end's results per sample, for the wave decoder */
-            float4 *out = reinterpret_cast<float4 *>(A.planes) + ((uint64_t)job->firstTile * NFC_SCAN_TILE + pos);
-
-            for (uint32_t k = 0; k < n; k++)
-            {
-               const float filtered = nfc_scan_sample(cc, w, row[k]);
-               if (pos >= start)
-                  out[k] = make_float4(filtered, w.fe.env, w.fe.mdev, w.fe.avg);
-            }
-         }
-         else if (n == NFC_SCAN_TILE)
+         if (n == NFC_SCAN_TILE)
          {
 #pragma unroll 8
             for (uint32_t k = 0; k < NFC_SCAN_TILE; k++)
@@ -775,7 +763,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
          if (repair)
             stat.bits |= NFC_TILE_REWALKED;
 
-         if (!PLANES && pos >= start)
+         if (pos >= start)
             A.tileStats[job->firstTile + pos / NFC_SCAN_TILE] = stat;
          }
          }
@@ -784,7 +772,7 @@ __device__ __forceinline__ void nfc_scan_body(const NfcConfig *__restrict__ cfgP
       __syncthreads();
    }
 
-   if (mine && !PLANES) /* (the second walk changes nothing the first one established) */
+   if (mine)
    {
       if (envelopeOnly)
       {
@@ -808,21 +796,160 @@ __global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restric
    __shared__ uint32_t rows[NFC_LANES * 4];
 
    if (A.stride == 2)
-      nfc_scan_body<2, false>(cfgPtr, A, tile, rows);
+      nfc_scan_body<2>(cfgPtr, A, tile, rows);
    else
-      nfc_scan_body<1, false>(cfgPtr, A, tile, rows);
+      nfc_scan_body<1>(cfgPtr, A, tile, rows);
 }
 
-/* the same walk over chunks listed for repair (from their verified start states), storing the front-end planes */
+/* The front-end planes (NfcScanArgs::planes: {filtered, envelope, deviation, average} after every sample, 16 B) for the wave
+ * decoder: a walk of the front end alone over every chunk from its verified start state, a lane per chunk, the rows fetched
+ * and transposed like the scan's.
+ * Round 5. Until now this was the scan's body with a store per sample and lane: sixty-four 16-byte pieces per store
+ * instruction, each in a row of its own half a megabyte from the next, which the cache had to piece together into lines
+ * (35 ms for config 5's 69 GB, 2 TB/s; the same stores sent past the cache - nontemporal - took 213 ms: the merging is what
+ * made it bearable). Here four samples of every lane go through LDS and leave as 64-byte pieces - a store instruction writes
+ * sixteen rows' four records each -, and the walk is the decoder's front end and nothing else (the tile extremes, grid test
+ * and edge bookkeeping of nfc_scan_sample are the scan's business). */
+#define NFC_PLANES_GROUP 4u
+
+template <uint32_t S>
+__device__ __forceinline__ void nfc_planes_body(const NfcConfig *__restrict__ cfgPtr, const NfcScanArgs &A, float *tile, float4 *stage, uint64_t *rowOut, uint32_t *rowN)
+{
+   const uint32_t lane = threadIdx.x;
+   const uint32_t listed = blockIdx.x * NFC_LANES + lane;
+   const bool mine = listed < A.nChunks;
+
+   NfcScanChunk ch;
+   ch.job = 0;
+   ch.index = 0;
+   if (mine)
+      ch = A.chunks[listed];
+   ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
+
+   const NfcScanJob *job = A.jobs + ch.job;
+   const uint32_t g = job->firstChunk + ch.index;
+   const uint32_t count = mine ? job->count : 0u;
+   const uint32_t L = A.params.chunkSamples;
+   const uint32_t start = ch.index * L;
+   const uint32_t end = mine ? (start + L < count ? start + L : count) : 0u;
+   const uint32_t mySamples = end > start ? end - start : 0u;
+
+   /* row descriptor (this lane's; the other lanes read it with v_readlane): the chunk's first sample and its length */
+   const uint64_t rowBase = (uint64_t)(mySamples ? job->data : (const uint8_t *)A.tileStats) + (uint64_t)start * (uint64_t)(S * 4u);
+   const uint32_t rowLo = (uint32_t)rowBase, rowHi = (uint32_t)(rowBase >> 32);
+
+   NfcConfig cc;
+   nfc_fixed_runtime_config(cfgPtr, cc);
+
+   NfcScanLane w;
+   __builtin_memset(&w, 0, sizeof(w));
+
+   if (mySamples)
+      nfc_scan_resume(w, A.seams[g].start, A.seams[g].start.edgeTime, A.states[job->slot].clock + start);
+
+   float4 *const outBase = reinterpret_cast<float4 *>(A.planes) + ((uint64_t)job->firstTile * NFC_SCAN_TILE + start);
+
+   float re[NFC_LANES], im[NFC_LANES];
+
+   auto fetch = [&](uint32_t rel) {
+#pragma unroll
+      for (uint32_t q = 0; q < NFC_LANES; q++)
+      {
+         const uint32_t lo = __builtin_amdgcn_readlane(rowLo, q);
+         const uint32_t hi = __builtin_amdgcn_readlane(rowHi, q);
+         const uint32_t endRel = __builtin_amdgcn_readlane(mySamples, q);
+         const bool has = rel < endRel; /* (uniform; the load is issued either way: the 64 of a step in flight together) */
+
+         typedef __attribute__((address_space(1))) const float GlobalFloat;
+         const uint64_t row = ((uint64_t)hi << 32) | lo;
+
+         uint32_t at = rel + lane;
+         at = (has && at >= endRel) ? endRel - 1u : at;
+
+         if (S == 2)
+         {
+            GlobalFloat *p = has ? (GlobalFloat *)row + 2u * at : (GlobalFloat *)A.tileStats;
+            const float vx = p[0], vy = p[1];
+            re[q] = has ? vx : 0.0f;
+            im[q] = has ? vy : 0.0f;
+         }
+         else
+         {
+            GlobalFloat *p = has ? (GlobalFloat *)row + at : (GlobalFloat *)A.tileStats;
+            const float v = *p;
+            re[q] = has ? v : 0.0f;
+            im[q] = 0.0f;
+         }
+      }
+   };
+
+   fetch(0);
+
+   for (uint32_t rel = 0; rel < L; rel += NFC_SCAN_TILE)
+   {
+      if (__ballot(rel < mySamples) == 0ull)
+         break;
+
+#pragma unroll
+      for (uint32_t q = 0; q < NFC_LANES; q++)
+         tile[q * NFC_SCAN_PITCH + lane] = S == 2 ? nfc_iq_magnitude(re[q], im[q]) : re[q];
+
+      /* where this lane's records of the step go, and how many there are (for the lanes that will store them) */
+      const uint32_t n = rel < mySamples ? (mySamples - rel < NFC_SCAN_TILE ? mySamples - rel : NFC_SCAN_TILE) : 0u;
+      rowOut[lane] = n ? (uint64_t)(outBase + rel) : 0ull;
+      rowN[lane] = n;
+
+      __syncthreads();
+
+      if (rel + NFC_SCAN_TILE < L)
+         fetch(rel + NFC_SCAN_TILE);
+
+      const float *row = tile + lane * NFC_SCAN_PITCH;
+
+      for (uint32_t k0 = 0; k0 < NFC_SCAN_TILE; k0 += NFC_PLANES_GROUP)
+      {
+#pragma unroll
+         for (uint32_t j = 0; j < NFC_PLANES_GROUP; j++)
+         {
+            if (k0 + j < n)
+            {
+               ++w.fe.clock;
+               ++w.fe.pulseFilter;
+               const NfcNow now = nfc_front_end_core(cc, w.fe, row[k0 + j]);
+               stage[lane * NFC_PLANES_GROUP + j] = make_float4(now.filt, w.fe.env, w.fe.mdev, w.fe.avg);
+            }
+         }
+
+         __syncthreads();
+
+         /* a store instruction: sixteen rows, the four records of each (64 B contiguous per row) */
+#pragma unroll
+         for (uint32_t i = 0; i < NFC_LANES * NFC_PLANES_GROUP / NFC_LANES; i++)
+         {
+            const uint32_t r = i * (NFC_LANES / NFC_PLANES_GROUP) + lane / NFC_PLANES_GROUP;
+            const uint32_t piece = lane % NFC_PLANES_GROUP;
+            float4 *to = (float4 *)rowOut[r];
+
+            if (to && k0 + piece < rowN[r])
+               to[k0 + piece] = stage[r * NFC_PLANES_GROUP + piece];
+         }
+
+         __syncthreads();
+      }
+   }
+}
+
 __global__ __launch_bounds__(64) void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 {
    __shared__ float tile[NFC_LANES * NFC_SCAN_PITCH];
-   __shared__ uint32_t rows[NFC_LANES * 4];
+   __shared__ float4 stage[NFC_LANES * NFC_PLANES_GROUP];
+   __shared__ uint64_t rowOut[NFC_LANES];
+   __shared__ uint32_t rowN[NFC_LANES];
 
    if (A.stride == 2)
-      nfc_scan_body<2, true>(cfgPtr, A, tile, rows);
+      nfc_planes_body<2>(cfgPtr, A, tile, stage, rowOut, rowN);
    else
-      nfc_scan_body<1, true>(cfgPtr, A, tile, rows);
+      nfc_planes_body<1>(cfgPtr, A, tile, stage, rowOut, rowN);
 }
 
 /* one thread per job: seams, then windows (the two are cheap and sequential per stream) */
@@ -844,24 +971,21 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
    A.jobs[j] = job;
 }
 
-/* one thread per tile: the tile tests */
-__global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t nTilesTotal)
+/* one thread per tile: the tile tests. Grid: x over the jobs, y over the tiles of a job (256 to a block) (round 5; a thread used
+ * to find its job by a binary search of the job table - twelve dependent trips to memory for config 5 - : 3.8 ms for its 67 M
+ * tiles); nTilesMost: tiles of the longest job */
+__global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t nTilesMost)
 {
-   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+   const uint32_t lo = blockIdx.x;
+   const uint32_t inJob = blockIdx.y * blockDim.x + threadIdx.x;
 
-   if (i >= nTilesTotal)
+   if (lo >= A.nJobs || inJob >= nTilesMost)
       return;
 
-   /* the job this tile belongs to: last job whose first tile is <= i */
-   uint32_t lo = 0, hi = A.nJobs;
-   while (hi - lo > 1)
-   {
-      const uint32_t mid = (lo + hi) / 2;
-      if (A.jobs[mid].firstTile <= i)
-         lo = mid;
-      else
-         hi = mid;
-   }
+   if (inJob >= (A.jobs[lo].count + NFC_SCAN_TILE - 1u) / NFC_SCAN_TILE)
+      return;
+
+   const uint32_t i = A.jobs[lo].firstTile + inJob;
 
    NfcConfig cc;
    nfc_fixed_runtime_config(cfgPtr, cc);

@@ -792,7 +792,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    /* job and chunk tables */
    std::vector<NfcScanJob> jobs(nJobs);
    std::vector<NfcScanChunk> chunks;
-   uint32_t tiles = 0, points = 0;
+   uint32_t tiles = 0, points = 0, tilesMost = 0;
    uint64_t totalSamples = 0;
 
    for (uint32_t j = 0; j < nJobs; j++)
@@ -807,6 +807,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       job.firstTile = tiles;
       job.firstPoint = points;
       tiles += (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE;
+      tilesMost = std::max(tilesMost, (job.count + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE);
       points += job.count / NFC_SCAN_POINT + 1;
       totalSamples += job.count;
 
@@ -968,7 +969,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
     * one gets its tile flags once, when the envelopes they are formed from are the true ones (3.8 ms for the 67 M tiles of config 5) */
    if (nJobs < NFC_LANES && !ctx->inBlocks)
    {
-      hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
+      hipLaunchKernelGGL(nfc_tiles_kernel, dim3(nJobs, (tilesMost + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tilesMost);
       HIP_TRY(ctx, hipGetLastError());
    }
 
@@ -1085,7 +1086,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       record_span(ctx, ctx->timedScan, pr, false);
       ctx->stats.scan_repairs += repairs;
    }
-   hipLaunchKernelGGL(nfc_tiles_kernel, dim3((tiles + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tiles);
+   hipLaunchKernelGGL(nfc_tiles_kernel, dim3(nJobs, (tilesMost + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tilesMost);
    HIP_TRY(ctx, hipGetLastError());
 
    mark("seams");
