@@ -22,8 +22,6 @@
 #ifndef NFC_AMD_ENVELOPE_HPP
 #define NFC_AMD_ENVELOPE_HPP
 
-#define NFC_ENVELOPE_GROUP 16u /* samples fetched together (a quarter of a tile) */
-
 #ifndef NFC_ENVELOPE_BIG
 #define NFC_ENVELOPE_BIG 3.0e38f /* (NFC_SCAN_BIG of nfc_scan.hpp) */
 #endif
@@ -35,107 +33,122 @@ NFC_DEV uint32_t nfc_envelope_bits(float v)
    return u;
 }
 
-/* one listed chunk (NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE), c: etu / envW0 / envW1 of the stream's configuration */
+/* One listed chunk (NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE) and the chain behind it; c: etu / envW0 / envW1 of the stream's
+ * configuration. Round 5: the walk does not end with its chunk. Where it arrives at the next chunk with another envelope
+ * than that chunk starts from, it goes on into it - unless somebody else walks that chunk this round (nfc_seams_check:
+ * NFC_ZONE_LISTED / NFC_ZONE_FOLLOWS; a chunk listed like the chunk before it is left to that one's walk) -, until it meets
+ * the trajectory on record: a chain of chunks that inherit a wrong envelope from each other is settled by one walk in one
+ * round - it used to be a round per chunk, ten for a short capture, seven for config 5. This
+ * is the statement (one thread; the emulated runtime runs it); the GPU runs nfc_envelope_rewalk_wave below, the same walk by
+ * a wavefront. */
 NFC_DEV void nfc_envelope_rewalk(const NfcConfig &c, const NfcScanArgs &A, NfcScanChunk ch)
 {
    ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
 
    const NfcScanJob *job = A.jobs + ch.job;
-   const uint32_t g = job->firstChunk + ch.index; /* seam / chunk record */
    const uint32_t count = job->count;
    const uint32_t L = A.params.chunkSamples;
-   const uint32_t start = ch.index * L;
-   const uint32_t end = start + L < count ? start + L : count;
-
-   if (start >= end)
-      return;
-
    const uint8_t *data = job->data;
    const uint32_t stride = A.stride;
 
-   NfcScanSeam seam = A.seams[g];
+   if (A.followChains && (A.seams[job->firstChunk + ch.index].start.zone & NFC_ZONE_FOLLOWS))
+      return; /* (walked with the chunk before it) */
 
-   uint32_t clock = A.states[job->slot].clock + start;
-   float env = seam.start.env;
-   uint32_t pulseFilter = seam.start.pulseFilter;
+   float env = 0.0f;
+   uint32_t pulseFilter = 0;
 
-   /* the point stored where the chunk begins carries the true start too */
-   if ((start % NFC_SCAN_POINT) == 0)
+   const uint32_t walkTo = A.followChains ? job->chunks : ch.index + 1u;
+
+   for (uint32_t index = ch.index; index < walkTo; index++)
    {
-      NfcScanPoint &first = A.points[job->firstPoint + start / NFC_SCAN_POINT];
-      first.env = seam.start.env;
-      first.pulseFilter = seam.start.pulseFilter;
-   }
+      const uint32_t g = job->firstChunk + index; /* seam / chunk record */
+      const uint32_t start = index * L;
+      const uint32_t end = start + L < count ? start + L : count;
 
-   /* the group being walked and the one after it (fetched while this one is walked) */
-   float now[NFC_ENVELOPE_GROUP], ahead[NFC_ENVELOPE_GROUP];
+      if (start >= end)
+         return;
 
-   for (uint32_t k = 0; k < NFC_ENVELOPE_GROUP; k++)
-      now[k] = NFC_SAMPLE_AT(data, stride, start + k < end ? start + k : end - 1u);
+      NfcScanSeam seam = A.seams[g];
 
-   for (uint32_t pos = start; pos < end; pos += NFC_SCAN_TILE)
-   {
-      const uint32_t n = end - pos < NFC_SCAN_TILE ? end - pos : NFC_SCAN_TILE;
-
-      /* has the walk met the first one's trajectory? Then the rest of the chunk, and its end, stand as recorded */
-      if (pos > start && (pos % NFC_SCAN_POINT) == 0)
+      if (index != ch.index)
       {
-         NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
+         /* the next chunk of the chain: somebody else's this round (listed, and not as this one's follower), or one that starts
+          * from the very envelope the walk arrives with (nothing to put right: the trajectory on record is the true one from
+          * here), or one to go on into */
+         const bool others = (seam.start.zone & NFC_ZONE_LISTED) != 0u && (seam.start.zone & NFC_ZONE_FOLLOWS) == 0u;
+         const bool agrees = (seam.start.zone & NFC_ZONE_LISTED) == 0u && nfc_envelope_bits(seam.start.env) == nfc_envelope_bits(env) &&
+                             seam.start.pulseFilter == pulseFilter;
 
-         if (nfc_envelope_bits(stored.env) == nfc_envelope_bits(env) && stored.pulseFilter == pulseFilter)
-         {
-            seam.end = A.seams[g].end;
-            break;
-         }
+         if (others || agrees)
+            return;
 
-         stored.env = env;
-         stored.pulseFilter = pulseFilter;
+         seam.start.env = env;
+         seam.start.pulseFilter = pulseFilter;
       }
 
-      float lo = NFC_ENVELOPE_BIG, hi = -NFC_ENVELOPE_BIG;
+      uint32_t clock = A.states[job->slot].clock + start;
+      env = seam.start.env;
+      pulseFilter = seam.start.pulseFilter;
 
-      for (uint32_t q = 0; q < NFC_SCAN_TILE; q += NFC_ENVELOPE_GROUP)
+      /* the point stored where the chunk begins carries the true start too */
+      if ((start % NFC_SCAN_POINT) == 0)
       {
-         /* the next group (clamped to the chunk: what lies beyond is fetched and not walked) */
-         const uint32_t next = pos + q + NFC_ENVELOPE_GROUP;
+         NfcScanPoint &first = A.points[job->firstPoint + start / NFC_SCAN_POINT];
+         first.env = seam.start.env;
+         first.pulseFilter = seam.start.pulseFilter;
+      }
 
-         if (next + NFC_ENVELOPE_GROUP <= end)
-         {
-            for (uint32_t k = 0; k < NFC_ENVELOPE_GROUP; k++)
-               ahead[k] = NFC_SAMPLE_AT(data, stride, next + k);
-         }
-         else
-         {
-            for (uint32_t k = 0; k < NFC_ENVELOPE_GROUP; k++)
-               ahead[k] = NFC_SAMPLE_AT(data, stride, next + k < end ? next + k : end - 1u);
-         }
+      bool merged = false;
 
-         for (uint32_t k = 0; k < NFC_ENVELOPE_GROUP; k++)
+      for (uint32_t pos = start; pos < end; pos += NFC_SCAN_TILE)
+      {
+         const uint32_t n = end - pos < NFC_SCAN_TILE ? end - pos : NFC_SCAN_TILE;
+
+         /* has the walk met the first one's trajectory? Then the rest of the chunk, and its end, stand as recorded */
+         if (pos > start && (pos % NFC_SCAN_POINT) == 0)
          {
-            if (q + k < n)
+            NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
+
+            if (nfc_envelope_bits(stored.env) == nfc_envelope_bits(env) && stored.pulseFilter == pulseFilter)
             {
-               ++clock;
-               ++pulseFilter;
-               nfc_envelope_step(c, clock, pulseFilter, env, now[k]);
-               lo = env < lo ? env : lo;
-               hi = env > hi ? env : hi;
+               seam.end = A.seams[g].end;
+               merged = true;
+               break;
             }
+
+            stored.env = env;
+            stored.pulseFilter = pulseFilter;
          }
 
-         for (uint32_t k = 0; k < NFC_ENVELOPE_GROUP; k++)
-            now[k] = ahead[k];
+         float lo = NFC_ENVELOPE_BIG, hi = -NFC_ENVELOPE_BIG;
+
+         for (uint32_t k = 0; k < n; k++)
+         {
+            ++clock;
+            ++pulseFilter;
+            nfc_envelope_step(c, clock, pulseFilter, env, NFC_SAMPLE_AT(data, stride, pos + k));
+            lo = env < lo ? env : lo;
+            hi = env > hi ? env : hi;
+         }
+
+         NfcScanTile &stat = A.tileStats[job->firstTile + pos / NFC_SCAN_TILE];
+         stat.envmin = lo;
+         stat.envmax = hi;
+         stat.bits |= NFC_TILE_REWALKED;
+
+         seam.end.env = env;
+         seam.end.pulseFilter = pulseFilter;
       }
 
-      NfcScanTile &stat = A.tileStats[job->firstTile + pos / NFC_SCAN_TILE];
-      stat.envmin = lo;
-      stat.envmax = hi;
-      stat.bits |= NFC_TILE_REWALKED;
+      A.seams[g] = seam; /* (the first walk's record with the tracker's start and end put right, or its end untouched after a merge) */
 
-      seam.end.env = env;
-      seam.end.pulseFilter = pulseFilter;
+      if (merged)
+      {
+         /* from here on the walk would repeat the first one: the chunk ends as recorded */
+         env = seam.end.env;
+         pulseFilter = seam.end.pulseFilter;
+      }
    }
-
-   A.seams[g] = seam; /* (the first walk's record with the tracker's end put right, or untouched after a merge) */
 }
 
 #ifdef NFC_ENVELOPE_WAVE
@@ -155,140 +168,173 @@ NFC_DEV void nfc_envelope_rewalk_wave(const NfcConfig &c, const NfcScanArgs &A, 
    ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
 
    const NfcScanJob *job = A.jobs + ch.job;
-   const uint32_t g = job->firstChunk + ch.index;
    const uint32_t count = job->count;
    const uint32_t L = A.params.chunkSamples;
-   const uint32_t start = ch.index * L;
-   const uint32_t end = start + L < count ? start + L : count;
-
-   if (start >= end)
-      return;
-
    const uint8_t *data = job->data;
    const uint32_t stride = A.stride;
 
-   NfcScanSeam seam = A.seams[g];
+   if (A.followChains && (A.seams[job->firstChunk + ch.index].start.zone & NFC_ZONE_FOLLOWS))
+      return; /* (walked with the chunk before it) */
 
-   uint32_t clock = A.states[job->slot].clock + start;
-   float env = seam.start.env;
-   uint32_t pulseFilter = seam.start.pulseFilter;
+   float env = 0.0f;
+   uint32_t pulseFilter = 0;
 
-   if ((start % NFC_SCAN_POINT) == 0 && lane == 0u)
+   const uint32_t walkTo = A.followChains ? job->chunks : ch.index + 1u;
+
+   for (uint32_t index = ch.index; index < walkTo; index++)
    {
-      NfcScanPoint &first = A.points[job->firstPoint + start / NFC_SCAN_POINT];
-      first.env = seam.start.env;
-      first.pulseFilter = seam.start.pulseFilter;
-   }
+      const uint32_t g = job->firstChunk + index;
+      const uint32_t start = index * L;
+      const uint32_t end = start + L < count ? start + L : count;
 
-   /* this lane's sample of the tile at hand and of the two after it (what lies beyond the chunk is fetched and not walked) */
-   const uint32_t last = end - 1u;
-   float x0 = NFC_SAMPLE_AT(data, stride, start + lane < last ? start + lane : last);
-   float x1 = NFC_SAMPLE_AT(data, stride, start + NFC_SCAN_TILE + lane < last ? start + NFC_SCAN_TILE + lane : last);
+      if (start >= end)
+         return;
 
-   for (uint32_t pos = start; pos < end; pos += NFC_SCAN_TILE)
-   {
-      const uint32_t n = end - pos < NFC_SCAN_TILE ? end - pos : NFC_SCAN_TILE;
-      const uint32_t ahead = pos + 2u * NFC_SCAN_TILE + lane;
-      const float x2 = NFC_SAMPLE_AT(data, stride, ahead < last ? ahead : last);
+      NfcScanSeam seam = A.seams[g];
 
-      if (pos > start && (pos % NFC_SCAN_POINT) == 0)
+      if (index != ch.index)
       {
-         NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
+         const bool others = (seam.start.zone & NFC_ZONE_LISTED) != 0u && (seam.start.zone & NFC_ZONE_FOLLOWS) == 0u;
+         const bool agrees = (seam.start.zone & NFC_ZONE_LISTED) == 0u && nfc_envelope_bits(seam.start.env) == nfc_envelope_bits(env) &&
+                             seam.start.pulseFilter == pulseFilter;
 
-         if (nfc_envelope_bits(stored.env) == nfc_envelope_bits(env) && stored.pulseFilter == pulseFilter)
+         if (others || agrees)
+            return;
+
+         seam.start.env = env;
+         seam.start.pulseFilter = pulseFilter;
+      }
+
+      uint32_t clock = A.states[job->slot].clock + start;
+      env = seam.start.env;
+      pulseFilter = seam.start.pulseFilter;
+
+      if ((start % NFC_SCAN_POINT) == 0 && lane == 0u)
+      {
+         NfcScanPoint &first = A.points[job->firstPoint + start / NFC_SCAN_POINT];
+         first.env = seam.start.env;
+         first.pulseFilter = seam.start.pulseFilter;
+      }
+
+      /* this lane's sample of the tile at hand and of the two after it (what lies beyond the chunk is fetched and not walked) */
+      const uint32_t last = end - 1u;
+      float x0 = NFC_SAMPLE_AT(data, stride, start + lane < last ? start + lane : last);
+      float x1 = NFC_SAMPLE_AT(data, stride, start + NFC_SCAN_TILE + lane < last ? start + NFC_SCAN_TILE + lane : last);
+
+      bool merged = false;
+
+      for (uint32_t pos = start; pos < end; pos += NFC_SCAN_TILE)
+      {
+         const uint32_t n = end - pos < NFC_SCAN_TILE ? end - pos : NFC_SCAN_TILE;
+         const uint32_t ahead = pos + 2u * NFC_SCAN_TILE + lane;
+         const float x2 = NFC_SAMPLE_AT(data, stride, ahead < last ? ahead : last);
+
+         if (pos > start && (pos % NFC_SCAN_POINT) == 0)
          {
-            seam.end = A.seams[g].end;
-            break;
+            NfcScanPoint &stored = A.points[job->firstPoint + pos / NFC_SCAN_POINT];
+
+            if (nfc_envelope_bits(stored.env) == nfc_envelope_bits(env) && stored.pulseFilter == pulseFilter)
+            {
+               seam.end = A.seams[g].end;
+               merged = true;
+               break;
+            }
+
+            if (lane == 0u)
+            {
+               stored.env = env;
+               stored.pulseFilter = pulseFilter;
+            }
+         }
+
+         float lo = NFC_ENVELOPE_BIG, hi = -NFC_ENVELOPE_BIG;
+         bool walked = false;
+
+         /* A whole tile past the stream's first symbol (where the tracker may still take the sample itself): the tracker's common
+          * path, without a branch. nfc_envelope_step decides |x - env| / env < 0.05 without the division whenever the envelope is
+          * positive and the deviation is clearly on one side of the limit (below 0.0499 env: yes; above 0.0501 env: no) - the
+          * tile is walked on that assumption, a dozen vector instructions a sample with selects where the statement has
+          * branches, and noting whether any sample was in neither case; only then (the envelope at zero, a ratio within 0.2 % of
+          * the limit, a NaN) it is walked again by the statement itself. The values are every lane's alike, but written as
+          * vector code on purpose: left to itself the compiler sees that they are uniform and turns every select into a scalar
+          * branch on a vector comparison - four round trips between the two units per sample, ~1000 cycles (measured:
+          * 14 ms per 32768-sample chunk, slower than the row machinery it was to replace). */
+         if (n == NFC_SCAN_TILE && (uint32_t)(clock + 1u) >= (uint32_t)c.etu && (uint32_t)(clock + 1u + NFC_SCAN_TILE) > (uint32_t)(clock + 1u))
+         {
+            float e = env;
+            uint32_t pf = pulseFilter;
+            NFC_ENVELOPE_OPAQUE_F(e);
+            NFC_ENVELOPE_OPAQUE_U(pf);
+            const uint32_t limit = (uint32_t)(c.etu * 10);
+            const float w0 = c.envW0, w1 = c.envW1;
+            bool rare = false;
+            float l = NFC_ENVELOPE_BIG, h = -NFC_ENVELOPE_BIG;
+
+#pragma unroll
+            for (uint32_t j = 0; j < NFC_SCAN_TILE; j++)
+            {
+               const float x = NFC_ENVELOPE_READLANE_F(x0, j);
+               const float dev = nfc_abs(x - e);
+               const bool below = dev < 0.0499f * e;
+               const bool above = dev > 0.0501f * e;
+               rare = rare || !(e > 0.0f && (below || above));
+               const uint32_t pf1 = pf + 1u;
+               const bool update = below || pf1 > limit;
+               const float followed = e * w0 + x * w1;
+               e = update ? followed : e;
+               pf = update ? 0u : pf1;
+               l = e < l ? e : l;
+               h = e > h ? e : h;
+            }
+
+            if (!NFC_ANY(rare))
+            {
+               env = e;
+               pulseFilter = pf;
+               clock += NFC_SCAN_TILE;
+               lo = l;
+               hi = h;
+               walked = true;
+            }
+         }
+
+         if (!walked)
+         {
+            for (uint32_t j = 0; j < n; j++)
+            {
+               const float x = NFC_ENVELOPE_READLANE_F(x0, j);
+               ++clock;
+               ++pulseFilter;
+               nfc_envelope_step(c, clock, pulseFilter, env, x);
+               lo = env < lo ? env : lo;
+               hi = env > hi ? env : hi;
+            }
          }
 
          if (lane == 0u)
          {
-            stored.env = env;
-            stored.pulseFilter = pulseFilter;
-         }
-      }
-
-      float lo = NFC_ENVELOPE_BIG, hi = -NFC_ENVELOPE_BIG;
-      bool walked = false;
-
-      /* A whole tile past the stream's first symbol (where the tracker may still take the sample itself): the tracker's common
-       * path, without a branch. nfc_envelope_step decides |x - env| / env < 0.05 without the division whenever the envelope is
-       * positive and the deviation is clearly on one side of the limit (below 0.0499 env: yes; above 0.0501 env: no) - the
-       * tile is walked on that assumption, a dozen vector instructions a sample with selects where the statement has
-       * branches, and noting whether any sample was in neither case; only then (the envelope at zero, a ratio within 0.2 % of
-       * the limit, a NaN) it is walked again by the statement itself. The values are every lane's alike, but written as
-       * vector code on purpose: left to itself the compiler sees that they are uniform and turns every select into a scalar
-       * branch on a vector comparison - four round trips between the two units per sample, ~1000 cycles (measured:
-       * 14 ms per 32768-sample chunk, slower than the row machinery it was to replace). */
-      if (n == NFC_SCAN_TILE && (uint32_t)(clock + 1u) >= (uint32_t)c.etu && (uint32_t)(clock + 1u + NFC_SCAN_TILE) > (uint32_t)(clock + 1u))
-      {
-         float e = env;
-         uint32_t pf = pulseFilter;
-         NFC_ENVELOPE_OPAQUE_F(e);
-         NFC_ENVELOPE_OPAQUE_U(pf);
-         const uint32_t limit = (uint32_t)(c.etu * 10);
-         const float w0 = c.envW0, w1 = c.envW1;
-         bool rare = false;
-         float l = NFC_ENVELOPE_BIG, h = -NFC_ENVELOPE_BIG;
-
-#pragma unroll
-         for (uint32_t j = 0; j < NFC_SCAN_TILE; j++)
-         {
-            const float x = NFC_ENVELOPE_READLANE_F(x0, j);
-            const float dev = nfc_abs(x - e);
-            const bool below = dev < 0.0499f * e;
-            const bool above = dev > 0.0501f * e;
-            rare = rare || !(e > 0.0f && (below || above));
-            const uint32_t pf1 = pf + 1u;
-            const bool update = below || pf1 > limit;
-            const float followed = e * w0 + x * w1;
-            e = update ? followed : e;
-            pf = update ? 0u : pf1;
-            l = e < l ? e : l;
-            h = e > h ? e : h;
+            NfcScanTile &stat = A.tileStats[job->firstTile + pos / NFC_SCAN_TILE];
+            stat.envmin = lo;
+            stat.envmax = hi;
+            stat.bits |= NFC_TILE_REWALKED;
          }
 
-         if (!NFC_ANY(rare))
-         {
-            env = e;
-            pulseFilter = pf;
-            clock += NFC_SCAN_TILE;
-            lo = l;
-            hi = h;
-            walked = true;
-         }
-      }
+         seam.end.env = env;
+         seam.end.pulseFilter = pulseFilter;
 
-      if (!walked)
-      {
-         for (uint32_t j = 0; j < n; j++)
-         {
-            const float x = NFC_ENVELOPE_READLANE_F(x0, j);
-            ++clock;
-            ++pulseFilter;
-            nfc_envelope_step(c, clock, pulseFilter, env, x);
-            lo = env < lo ? env : lo;
-            hi = env > hi ? env : hi;
-         }
+         x0 = x1;
+         x1 = x2;
       }
 
       if (lane == 0u)
+         A.seams[g] = seam;
+
+      if (merged)
       {
-         NfcScanTile &stat = A.tileStats[job->firstTile + pos / NFC_SCAN_TILE];
-         stat.envmin = lo;
-         stat.envmax = hi;
-         stat.bits |= NFC_TILE_REWALKED;
+         env = seam.end.env;
+         pulseFilter = seam.end.pulseFilter;
       }
-
-      seam.end.env = env;
-      seam.end.pulseFilter = pulseFilter;
-
-      x0 = x1;
-      x1 = x2;
    }
-
-   if (lane == 0u)
-      A.seams[g] = seam;
 }
 #endif
 

@@ -119,6 +119,10 @@ struct NfcScanChunk
    uint32_t index; /* chunk number inside the job; bit 31: walk it again from the true end state of the chunk before (no warm-up) */
 };
 
+#define NFC_ZONE_FOLLOWS 0x400u /* bit of NfcScanSeam::start.zone (beside the carrier zone and the edge-time bits of nfc_scan.hpp): the chunk is listed for
+                                   a second walk of its envelope tracker alone, like the chunk before it; nfc_envelope_kernel walks it in the
+                                   same go as that one (nfc_seams_check, nfc_envelope.hpp) */
+#define NFC_ZONE_LISTED 0x800u  /* ... the chunk is on one of this round's lists at all (whoever walks it owns its records this round) */
 #define NFC_CHUNK_REPAIR 0x80000000u
 #define NFC_CHUNK_ENVELOPE 0x40000000u /* with NFC_CHUNK_REPAIR: only the envelope tracker (envelope, pulse counter) started wrong; the other
                                           recurrences do not depend on it and stand as walked: the second walk is the tracker's alone */

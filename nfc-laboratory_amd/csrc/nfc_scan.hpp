@@ -287,10 +287,12 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
 {
    uint32_t edge = startEdge; /* edge time at the start of the chunk at hand, by the records as they are */
    bool pending = false;
+   bool chain = false; /* the chunk before is listed this round, its envelope tracker alone to be walked again */
 
    for (uint32_t k = 0; k < job.chunks; k++)
    {
       NfcScanSeam &s = seams[job.firstChunk + k];
+      bool listedEnvelope = false;
 
       const bool sound = k == 0 || (nfc_point_same(s.start, seams[job.firstChunk + k - 1].end) &&
                                     (!(s.start.zone & NFC_ZONE_EDGE_KNOWN) || s.start.edgeTime == edge));
@@ -360,6 +362,7 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
          {
             s.start.env = before.env;
             s.start.pulseFilter = before.pulseFilter;
+            listedEnvelope = true;
          }
          else
          {
@@ -377,6 +380,24 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
 
          pending = true;
       }
+
+      /* Chunks inherit a wrong envelope from each other in chains, and a chain used to be walked a chunk per round: the walk of
+       * chunk k ends on another envelope than the one on record, which the NEXT check finds chunk k + 1 not to start from. The
+       * marks let nfc_envelope_kernel settle a chain in one walk: a walk that ends a chunk on another envelope than the next
+       * chunk starts from goes on into that chunk - unless somebody else walks it this round (NFC_ZONE_LISTED: on a list, and
+       * not as the follower of the chunk before it, NFC_ZONE_FOLLOWS) - until it meets the trajectory on record. (The scan
+       * kernel, when it is given the list, walks every listed chunk on its own as before.) */
+      if (listedEnvelope && chain)
+         s.start.zone |= NFC_ZONE_FOLLOWS;
+      else
+         s.start.zone &= ~NFC_ZONE_FOLLOWS;
+
+      if (!soundNow)
+         s.start.zone |= NFC_ZONE_LISTED;
+      else
+         s.start.zone &= ~NFC_ZONE_LISTED;
+
+      chain = listedEnvelope;
 
       /* edge time at the end of the chunk (a chunk about to be walked again may change it: the next round looks again) */
       if (s.end.zone & NFC_ZONE_EDGE_KNOWN)
@@ -1106,6 +1127,9 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
                left.search.detF[i] = have.search.detF[i];
          }
 
+#ifdef NFC_CHAIN_STATS
+         NFC_CHAIN_STATS(x.carry, have, used);
+#endif
          /* kept for the finish: should this be the stream's last lane, what it never looked at is put right in the state
           * it leaves (nfc_final_fixup); a lane that has to run again gets its `want` below */
          x.want = have;

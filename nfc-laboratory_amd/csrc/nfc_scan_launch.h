@@ -49,6 +49,7 @@ struct NfcScanArgs
    uint32_t *repairCount;
    NfcScanChunk *repairsEnv;   /* ... those of them whose envelope tracker alone is walked again (NFC_CHUNK_ENVELOPE), when they are listed apart (null: with the others) */
    uint32_t *repairEnvCount;
+   uint32_t followChains;   /* nfc_envelope_kernel: a walk goes on into the chunks that inherit its chunk's envelope (nfc_envelope.hpp) */
    uint32_t *runList;          /* speculative lanes to run in the coming pass (indices into the lane arrays) */
    uint32_t *runCount;         /* entries of runList (device counter) */
    uint32_t *runNext;          /* next entry a persistent wave takes (device counter) */

@@ -134,7 +134,22 @@ __device__ __forceinline__ float nfc_wave_max(float v)
 }
 
 #define NFC_WAVE_LANE() (threadIdx.x)
+/* A workgroup is one wavefront, and a wavefront's LDS instructions are carried out in the order they were issued: what one lane
+ * has written another lane reads after it without waiting for anything. __syncthreads() would also wait for every global
+ * access in flight - the next tile's samples and planes, fetched ahead on purpose - and for the LDS queue to drain, at each of
+ * the dozen points per tile where the lanes hand values to each other. What is needed there is that the compiler keeps the
+ * order of the accesses: a fence at wavefront scope. (-DNFC_WAVE_HARD_BARRIER: the workgroup barrier, as until round 4) */
+#ifdef NFC_WAVE_HARD_BARRIER
 #define NFC_WAVE_BARRIER() __syncthreads()
+#else
+#define NFC_WAVE_BARRIER()                                          \
+   do                                                               \
+   {                                                                \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+      __builtin_amdgcn_wave_barrier();                              \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+   } while (0)
+#endif
 #define NFC_WAVE_BALLOT(p) ((uint64_t)__ballot(p))
 #define NFC_WAVE_UNIFORM_BEGIN {
 #define NFC_WAVE_UNIFORM_END }

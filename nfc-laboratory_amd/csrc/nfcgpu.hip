@@ -179,6 +179,10 @@ struct nfcgpu_ctx
                                       4096-sample chunks of a short capture's rounds, the wrong shape for the long lists of a large submission
                                       (thousands of lanes reading 32768-sample chunks a cache line each: 79 -> 122 ms per step of the headline,
                                       profiles/r04/ab_envelope) - and was given lists of at most 64 */
+   uint32_t envelopeFollowMax = 1024; /* ... and a walk goes on through the chain of chunks that inherit its chunk's envelope when the round lists at
+                                         most this many (NFCGPU_ENVELOPE_FOLLOW): the tail of rounds with a few chunks each becomes one or two rounds
+                                         (a short capture: ten rounds -> three, 3.9 -> 2.6 ms; config 5: seven -> five). Not for the long lists: a
+                                         chain is then one wavefront's serial work while the rest of the device waits (seams 40 -> 46 ms with it) */
    std::vector<ProfiledLaunch> timedScan, timedWindow, timedWave, timedPlanes;
    hipEvent_t epoch = nullptr;      /* recorded when the statistics start over: the time base of the launch intervals below */
    std::vector<std::pair<float, float>> waveSpans; /* [start, stop) of every wave decoder launch since, ms after `epoch` */
@@ -1078,6 +1082,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          NfcScanArgs R = A;
          R.chunks = A.repairsEnv;
          R.nChunks = alone;
+         R.followChains = alone <= ctx->envelopeFollowMax ? 1u : 0u;
 
          hipLaunchKernelGGL(nfc_envelope_kernel, dim3(alone), dim3(NFC_LANES), 0, ctx->stream, dCfg, R);
          HIP_TRY(ctx, hipGetLastError());
@@ -1936,6 +1941,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->lanesWanted = knob("NFCGPU_LANES_WANTED", ctx->lanesWanted);
    ctx->longFirst = knob("NFCGPU_LONG_FIRST", ctx->longFirst);
    ctx->envelopeMax = knob("NFCGPU_ENVELOPE_KERNEL", ctx->envelopeMax);
+   ctx->envelopeFollowMax = knob("NFCGPU_ENVELOPE_FOLLOW", ctx->envelopeFollowMax);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;

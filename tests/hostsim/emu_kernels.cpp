@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <algorithm>
 #include <vector>
@@ -53,6 +54,29 @@ static void emu_chain_trace(uint32_t lane, const NfcCarry &assumed, const NfcCar
    std::fprintf(stderr, "\n");
 }
 #define NFC_CHAIN_TRACE(lane, a, b, c) emu_chain_trace((lane), (a), (b), (c))
+/* NFC_EMU_CHAIN_STATS=1: how often the NFC-F pulse memory a lane meets is what it assumed / is clear */
+static unsigned long emuChainStats[8];
+static void emu_chain_stats(const NfcCarry &assumed, const NfcCarry &have, uint32_t used)
+{
+   static const bool on = std::getenv("NFC_EMU_CHAIN_STATS") != nullptr;
+   if (!on)
+      return;
+   for (int i = 0; i < 2; i++)
+   {
+      const bool same = assumed.pulsesF[i] == have.pulsesF[i] && std::memcmp(&assumed.thrF[i], &have.thrF[i], 4) == 0;
+      const bool clear = have.pulsesF[i] == 0 && have.thrF[i] == 0.0f;
+      emuChainStats[0]++;
+      emuChainStats[1] += same;
+      emuChainStats[2] += clear;
+      emuChainStats[3] += ((used >> (12 + i)) & 1u) ? 1 : 0;
+      emuChainStats[4] += (((used >> (12 + i)) & 1u) && same) ? 1 : 0;
+      emuChainStats[5] += (((used >> (12 + i)) & 1u) && clear) ? 1 : 0;
+   }
+   if ((emuChainStats[0] % 2000) == 0)
+      std::fprintf(stderr, "[emu chain stats] lane x detector meetings %lu: memory as assumed %lu, clear %lu; of %lu that looked at it: as assumed %lu, clear %lu\n", emuChainStats[0],
+                   emuChainStats[1], emuChainStats[2], emuChainStats[3], emuChainStats[4], emuChainStats[5]);
+}
+#define NFC_CHAIN_STATS(a, b, u) emu_chain_stats((a), (b), (u))
 static void emu_seam_debug(uint32_t k, const NfcScanPoint &start, const NfcScanPoint &end, uint32_t edge)
 {
    if (!std::getenv("NFC_EMU_SEAM_DEBUG"))

@@ -1,7 +1,7 @@
 """Driver of tests/test_parity_at_size.py. Parity at size, on the GPU: S streams x L samples x K submissions of the sparse /
 dense synthetic set through the C ABI (IQ resident in HBM), EVERY stream compared frame by frame with the reference
 decoder (oracle/_ref, one decoder per stream, a pool of host threads). Prints one JSON object.
-usage: python tests/parity_sweep_driver.py sparse|dense S L K   (NFCGPU_* knobs apply; the test sets none)"""
+usage: python tests/parity_sweep_driver.py sparse|dense|offgrid S L K   (NFCGPU_* knobs apply; the test sets none)"""
 import json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +21,18 @@ if kind == "sparse":
     synth.fill_sparse_iq_torch(data, template_dev, synth.sparse_segments(template), first_stream=0, chunk_streams=max(1, min(256, (1 << 26) // T)))
 else:
     synth.fill_iq_torch(data, template_dev, first_stream=0, chunk_streams=max(1, min(1024, (1 << 26) // T)))
+if kind == "offgrid":
+    # set S2: the dense S1 magnitudes on a random phase per stream plus white noise of sigma 0.002 on both components,
+    # fp32 IQ - what a radio delivers, off the capture grid (the generator of bench.py's s2 points)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20260927)
+    for s0 in range(0, S, 64):
+        s1 = min(S, s0 + 64)
+        m = torch.sqrt(data[s0:s1, :, 0] ** 2 + data[s0:s1, :, 1] ** 2)
+        phi = torch.rand((s1 - s0, 1), device=dev, generator=gen) * 6.283185307179586
+        data[s0:s1, :, 0] = m * torch.cos(phi) + torch.randn(m.shape, device=dev, generator=gen) * 0.002
+        data[s0:s1, :, 1] = m * torch.sin(phi) + torch.randn(m.shape, device=dev, generator=gen) * 0.002
+        del m
 sink_words = 128 << 20
 sink = torch.zeros(sink_words, dtype=torch.int32, device=dev)
 ctl = torch.zeros(4, dtype=torch.int32, device=dev)

@@ -61,3 +61,13 @@ def test_config5_dense_every_stream_matches_the_reference(built):
     to 131072 samples apart: another lane geometry than the 512-stream case above), default knobs, every stream compared"""
     res = _check(_sweep("dense", 4096, 1 << 20, 1))
     assert res["time_parallel_streams"] + res["sequential_streams"] == 4096 and res["sequential_streams"] <= 32, res
+
+
+@needs_reference
+@pytest.mark.gpu
+def test_off_grid_streams_in_two_submissions_match_the_reference(built):
+    """what a radio delivers - float IQ off the int16 grid of the captures (set S2: the dense set on a random phase
+    per stream plus noise) - at size: 512 streams x 2^20 samples in two submissions, default knobs, EVERY stream compared. Such a
+    stream stays on the time-parallel path (its carry lane decodes it alone, the running sums walked in the reference's order)."""
+    res = _check(_sweep("offgrid", 512, 1 << 19, 2))
+    assert res["time_parallel_streams"] == 1024 and res["sequential_streams"] == 0, res

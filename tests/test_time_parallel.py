@@ -114,8 +114,10 @@ def test_remaining_knobs_at_non_default_values_emulated(emulated, knobs, expect)
 @needs_reference
 def test_envelope_kernel_walks_the_short_lists_of_small_submissions_emulated(emulated):
     """A capture with the default knobs is scanned in chunks of 4096 samples, and after the first round its second walks are the
-    envelope tracker's alone: nfc_envelope_kernel takes them (NFCGPU_ENVELOPE_KERNEL, default 64 chunks per round). Same frames,
-    same chunks walked again, same windows and passes as with the scan kernel's envelope-only branch (knob 0)."""
+    envelope tracker's alone: nfc_envelope_kernel takes them (NFCGPU_ENVELOPE_KERNEL: the longest list it is given). Same frames,
+    same windows and passes as with the scan kernel's envelope-only branch (knob 0) - and fewer chunks on the lists, in fewer
+    rounds: the kernel's walk goes on through a chain of chunks that inherit a wrong envelope from each other, the scan kernel
+    walks a chain a chunk per round."""
     cases = ["fixture:test_NFC-A_424kbps_001", "fixture:test_NFC-B_106kbps_001", "fixture:test_NFC-F_212kbps_004"]
     outs = {}
     for knob in ("64", "0"):
@@ -126,8 +128,12 @@ def test_envelope_kernel_walks_the_short_lists_of_small_submissions_emulated(emu
     for r in outs["64"][0] + outs["0"][0]:
         assert r["mismatching"] == [] and r["frames"] > 0, r
     assert outs["64"][1] > 0 and outs["0"][1] == 0, (outs["64"][1], outs["0"][1])
-    assert [r["stats"] for r in outs["64"][0]] == [r["stats"] for r in outs["0"][0]]
-    assert sum(r["stats"]["repairs"] for r in outs["64"][0]) > 0
+    def but_repairs(stats):
+        return {k: v for k, v in stats.items() if k != "repairs"}
+
+    assert [but_repairs(r["stats"]) for r in outs["64"][0]] == [but_repairs(r["stats"]) for r in outs["0"][0]]
+    listed = [sum(r["stats"]["repairs"] for r in outs[knob][0]) for knob in ("64", "0")]
+    assert 0 < listed[0] <= listed[1], listed
 
 
 @needs_reference
