@@ -827,9 +827,8 @@ __device__ __forceinline__ void nfc_planes_body(const NfcConfig *__restrict__ cf
    ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
 
    const NfcScanJob *job = A.jobs + ch.job;
-   const uint32_t g = job->firstChunk + ch.index;
    const uint32_t count = mine ? job->count : 0u;
-   const uint32_t L = A.params.chunkSamples;
+   const uint32_t L = A.planesPiece ? A.planesPiece : A.params.chunkSamples;
    const uint32_t start = ch.index * L;
    const uint32_t end = mine ? (start + L < count ? start + L : count) : 0u;
    const uint32_t mySamples = end > start ? end - start : 0u;
@@ -844,8 +843,13 @@ __device__ __forceinline__ void nfc_planes_body(const NfcConfig *__restrict__ cf
    NfcScanLane w;
    __builtin_memset(&w, 0, sizeof(w));
 
+   /* from the chunk's verified start - or, a small submission (NfcScanArgs::planesPiece): from the point stored every 512
+    * samples, which the second walks have left true like the seams: more lanes, each a shorter walk */
    if (mySamples)
-      nfc_scan_resume(w, A.seams[g].start, A.seams[g].start.edgeTime, A.states[job->slot].clock + start);
+   {
+      const NfcScanPoint &from = A.planesPiece ? A.points[job->firstPoint + start / NFC_SCAN_POINT] : A.seams[job->firstChunk + ch.index].start;
+      nfc_scan_resume(w, from, from.edgeTime, A.states[job->slot].clock + start);
+   }
 
    float4 *const outBase = reinterpret_cast<float4 *>(A.planes) + ((uint64_t)job->firstTile * NFC_SCAN_TILE + start);
 

@@ -64,6 +64,8 @@ struct NfcScanArgs
     * decoder's front end leaves them after that sample, written by a second walk of the scan kernel from the verified
     * chunk starts (null: not written). Sample i of a job is record 64 * job.firstTile + i. */
    float *planes;
+   uint32_t planesPiece;       /* the walk that writes them: samples per lane when it goes by the stored points (a multiple of NFC_SCAN_POINT: lane i
+                                  of a job walks [i * planesPiece, ...) from the point stored there); 0: a lane per chunk, from the chunk's start */
 };
 
 #endif

@@ -179,6 +179,7 @@ struct nfcgpu_ctx
                                       4096-sample chunks of a short capture's rounds, the wrong shape for the long lists of a large submission
                                       (thousands of lanes reading 32768-sample chunks a cache line each: 79 -> 122 ms per step of the headline,
                                       profiles/r04/ab_envelope) - and was given lists of at most 64 */
+   uint32_t planesPiece = 512;     /* samples per lane of the walk that writes a small submission's front-end planes (NFCGPU_PLANES_PIECE; 0: a lane per chunk) */
    uint32_t envelopeFollowMax = 1024; /* ... and a walk goes on through the chain of chunks that inherit its chunk's envelope when the round lists at
                                          most this many (NFCGPU_ENVELOPE_FOLLOW): the tail of rounds with a few chunks each becomes one or two rounds
                                          (a short capture: ten rounds -> three, 3.9 -> 2.6 ms; config 5: seven -> five). Not for the long lists: a
@@ -1099,27 +1100,45 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    /* The wave decoder takes the front end's results per sample instead of walking it again: a second walk of every
     * chunk from its verified start state (the repair form of the scan: no warm-up) writes them. */
    {
-      if ((rc = grow(ctx, ctx->wPlanes, (size_t)tiles * NFC_SCAN_TILE * 16u)) || (rc = grow(ctx, ctx->wPlaneChunks, sizeof(NfcScanChunk) * nChunks)))
+      /* A small submission - one a caller waits for - is walked a lane per stored point instead of a lane per chunk: 512 samples
+       * instead of 4096 on the way of everything that follows (NFCGPU_PLANES_PIECE; a short capture: 1.1 -> 0.2 ms) */
+      const uint32_t piece = totalSamples <= (4u << 20) ? ctx->planesPiece / NFC_SCAN_POINT * NFC_SCAN_POINT : 0u;
+
+      std::vector<NfcScanChunk> all;
+
+      if (piece)
+      {
+         for (uint32_t j = 0; j < nJobs; j++)
+            for (uint32_t i = 0; i * piece < jobs[j].count; i++)
+               all.push_back(NfcScanChunk {j, i | NFC_CHUNK_REPAIR});
+      }
+      else
+      {
+         all = chunks;
+         for (NfcScanChunk &c: all)
+            c.index |= NFC_CHUNK_REPAIR;
+      }
+
+      const uint32_t nPlaneLanes = (uint32_t)all.size();
+
+      if ((rc = grow(ctx, ctx->wPlanes, (size_t)tiles * NFC_SCAN_TILE * 16u)) || (rc = grow(ctx, ctx->wPlaneChunks, sizeof(NfcScanChunk) * all.size())))
       {
          /* (the planes are 16 bytes per sample of the submission: 64 GiB for 4096 streams x 2^20) */
          return withoutTheMemory(rc);
       }
 
-      std::vector<NfcScanChunk> all(chunks);
-      for (NfcScanChunk &c: all)
-         c.index |= NFC_CHUNK_REPAIR;
-
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->wPlaneChunks.ptr, all.data(), sizeof(NfcScanChunk) * nChunks, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->wPlaneChunks.ptr, all.data(), sizeof(NfcScanChunk) * all.size(), hipMemcpyHostToDevice, ctx->stream));
 
       A.planes = (float *)ctx->wPlanes.ptr;
 
       NfcScanArgs P = A;
       P.chunks = (const NfcScanChunk *)ctx->wPlaneChunks.ptr;
-      P.nChunks = nChunks;
+      P.nChunks = nPlaneLanes;
+      P.planesPiece = piece;
 
       ProfiledLaunch pp {nullptr, nullptr};
       record_span(ctx, ctx->timedPlanes, pp, true);
-      hipLaunchKernelGGL(nfc_scan_planes_kernel, dim3((nChunks + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, P);
+      hipLaunchKernelGGL(nfc_scan_planes_kernel, dim3((nPlaneLanes + NFC_LANES - 1) / NFC_LANES), dim3(NFC_LANES), 0, ctx->stream, dCfg, P);
       HIP_TRY(ctx, hipGetLastError());
       record_span(ctx, ctx->timedPlanes, pp, false);
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* (the chunk list is a local) */
@@ -1942,6 +1961,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->longFirst = knob("NFCGPU_LONG_FIRST", ctx->longFirst);
    ctx->envelopeMax = knob("NFCGPU_ENVELOPE_KERNEL", ctx->envelopeMax);
    ctx->envelopeFollowMax = knob("NFCGPU_ENVELOPE_FOLLOW", ctx->envelopeFollowMax);
+   ctx->planesPiece = knob("NFCGPU_PLANES_PIECE", ctx->planesPiece);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;

@@ -506,14 +506,13 @@ void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 /* the second walk of the scan (repair form, from the verified chunk starts): front-end planes only */
 void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 {
-   const uint32_t L = A.params.chunkSamples;
+   const uint32_t L = A.planesPiece ? A.planesPiece : A.params.chunkSamples;
 
    for (uint32_t listed = 0; listed < A.nChunks; listed++)
    {
       NfcScanChunk ch = A.chunks[listed];
       ch.index &= ~NFC_CHUNK_REPAIR;
       const NfcScanJob *job = A.jobs + ch.job;
-      const uint32_t g = job->firstChunk + ch.index;
       const uint32_t start = ch.index * L;
       const uint32_t end = start + L < job->count ? start + L : job->count;
       const NfcStreamState *st = A.states + job->slot;
@@ -521,8 +520,11 @@ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
       if (start >= end)
          continue;
 
+      /* (from the chunk's start, or from the stored point: nfc_kernels.hip) */
+      const NfcScanPoint &from = A.planesPiece ? A.points[job->firstPoint + start / NFC_SCAN_POINT] : A.seams[job->firstChunk + ch.index].start;
+
       NfcScanLane w;
-      nfc_scan_resume(w, A.seams[g].start, A.seams[g].start.edgeTime, st->clock + start);
+      nfc_scan_resume(w, from, from.edgeTime, st->clock + start);
 
       float *out = A.planes + 4u * ((uint64_t)job->firstTile * NFC_SCAN_TILE);
 
