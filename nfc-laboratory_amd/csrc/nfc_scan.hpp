@@ -819,10 +819,13 @@ NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, 
 /* Prediction of what a lane will leave when it is run again with `given` instead of `assumed`, from what it `left`
  * last time: every field it left as it had found it is taken to be passed through, every other to be set by the lane
  * whatever it is given. Only used to choose what to run next; results are always checked. */
-NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const NfcCarry &given)
+NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const NfcCarry &given, uint32_t used = 0u)
 {
 #define NFC_CARRY_FIELD(f) left.f = (left.f == assumed.f) ? given.f : left.f
-   NFC_CARRY_FIELD(chainedA);
+   /* (a lane whose first NFC-A frame was REQA / WUPA has written the chaining flags and every field of the technology's
+    * timing itself - `used` bit 22 + t, nfc_finish_frame -: they are its own whatever it is given) */
+   if (!((used >> 22) & 1u))
+      NFC_CARRY_FIELD(chainedA);
 
    /* carrier state: only "set or not" is ever read; a lane that emitted no carrier frame passes everything through */
    if (left.emitClock == assumed.emitClock && left.emitValid == assumed.emitValid)
@@ -835,12 +838,18 @@ NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const Nf
 
    for (int t = 0; t < 4; t++)
    {
-      NFC_CARRY_FIELD(tim[t].lastCommand);
+      /* (what the lane is known to have written itself - `used` bit 8 + t: the last command; NfcCarry::waitOwn bit 4 + t: the
+       * protocol's waiting time - is its own whatever it is given, also where it happens to be what it had assumed) */
+      if ((used >> (22 + t)) & 1u)
+         continue;
+      if (!((used >> (8 + t)) & 1u))
+         NFC_CARRY_FIELD(tim[t].lastCommand);
       NFC_CARRY_FIELD(tim[t].guardTime);
       NFC_CARRY_FIELD(tim[t].waitingTime);
       NFC_CARRY_FIELD(tim[t].maxFrameSize);
       NFC_CARRY_FIELD(tim[t].protoGuardTime);
-      NFC_CARRY_FIELD(tim[t].protoWaitingTime);
+      if (!((left.waitOwn >> (4 + t)) & 1u) || used == 0u)
+         NFC_CARRY_FIELD(tim[t].protoWaitingTime);
    }
 
    for (int i = 0; i < 2; i++)
@@ -848,7 +857,8 @@ NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const Nf
       /* the pulse counter is counted on: a lane adds what it added before, unless it cleared the counter on the way */
       if (!left.clearedF[i])
          left.pulsesF[i] = given.pulsesF[i] + (left.pulsesF[i] - assumed.pulsesF[i]);
-      left.thrF[i] = nfc_bits(left.thrF[i]) == nfc_bits(assumed.thrF[i]) ? given.thrF[i] : left.thrF[i];
+      if (!left.ownF[i] || used == 0u)
+         left.thrF[i] = nfc_bits(left.thrF[i]) == nfc_bits(assumed.thrF[i]) ? given.thrF[i] : left.thrF[i];
    }
 
    /* detector records, one by one: left as found -> whatever it is given */
@@ -864,7 +874,14 @@ NFC_DEV void nfc_carry_predict(NfcCarry &left, const NfcCarry &assumed, const Nf
       }
       NFC_CARRY_RECORD(detA[0]) NFC_CARRY_RECORD(detA[1]) NFC_CARRY_RECORD(detA[2])
       NFC_CARRY_RECORD(detB[0]) NFC_CARRY_RECORD(detB[1])
-      NFC_CARRY_RECORD(detF[0]) NFC_CARRY_RECORD(detF[1])
+      /* (round 5: an NFC-F record the lane has reset on its way - `used`: NfcStreamCold::usedTech bit 16 + i, a mark a reset leaves
+       * on a clear record too - is its own whatever it is given. A lane that had found the record at rest and left it at rest was
+       * taken to pass on the one with a window in the past the stream really held: the lane after it was told to assume that
+       * one, wrongly, and a stream of config 5 went through five passes, a link of the chain each, where three will do.) */
+      if (!((used >> 16) & 1u))
+         NFC_CARRY_RECORD(detF[0])
+      if (!((used >> 17) & 1u))
+         NFC_CARRY_RECORD(detF[1])
       NFC_CARRY_RECORD(detV)
 #undef NFC_CARRY_RECORD
    }
@@ -1229,7 +1246,7 @@ NFC_DEV bool nfc_chain_follow(NfcScanJob &job, uint32_t jobIndex, NfcWindow *win
             else
             {
                /* again, and predict what it will leave */
-               nfc_carry_predict(left, x.carry, want);
+               nfc_carry_predict(left, x.carry, want, used);
                x.want = want;
                x.rerun = 1;
                again = true;
