@@ -810,7 +810,7 @@ NFC_DEV bool nfc_carry_same(const NfcCarry &a, const NfcCarry &b, bool meeting, 
 
 #ifdef NFC_CARRY_DEBUG
    if (!same)
-      NFC_CARRY_DEBUG(a, b, meeting, tracked);
+      NFC_CARRY_DEBUG(a, b, meeting, tracked, used);
 #endif
 
    return same;
