@@ -129,6 +129,20 @@ def host_limits():
     return out
 
 
+def processor_quota(limits):
+    """processors' worth of time the control group gives this process (cgroup v2 cpu.max 'quota period', or the v1 pair); None: no quota"""
+    try:
+        v2 = (limits.get("cgroup_cpu_max") or "").split()
+        if len(v2) == 2 and v2[0] != "max":
+            return float(v2[0]) / float(v2[1])
+        q, per = limits.get("cgroup_v1_cfs_quota_us"), limits.get("cgroup_v1_cfs_period_us")
+        if q and per and int(q) > 0:
+            return float(q) / float(per)
+    except Exception:
+        pass
+    return None
+
+
 def clamp_used(cursor, dropped, capacity):
     """valid words of a held sink: the cursor keeps counting past the capacity on overflow (nfc_emit)"""
     limit = capacity - (9 + 128) + 1
@@ -502,6 +516,8 @@ def main():
             # the baseline is the better of the two multi-thread runs (SMT siblings share a core's load ports: on the 2 x 64-core
             # host of the GPU boxes one thread per physical core is the faster run); both are in the object
             best, best_threads = (multi_phys, physical) if multi_phys > multi else (multi, cores)
+            limits = host_limits()
+            quota = processor_quota(limits)
             result["cpu_baseline"] = {
                 "value": round(best, 3),
                 "unit": "Msamples/s",
@@ -524,7 +540,11 @@ def main():
                 "parallel_efficiency": round(multi_phys / (single * physical), 4) if single > 0 and physical else None,
                 "parallel_efficiency_all_threads": round(multi / (single * cores), 4) if single > 0 and cores else None,
                 "thread_spread": {str(k): v for k, v in spread.items()},
-                "host_limits": host_limits(),
+                "host_limits": limits,
+                # the box's control group may give the process fewer processors than it shows (thread_spread.processors_at_work is
+                # what the threads really got): the threaded run against the single thread times that quota
+                "processor_quota": quota,
+                "parallel_efficiency_vs_quota": round(multi_phys / (single * min(quota, physical)), 4) if single > 0 and physical and quota else None,
                 "harness": "threads started, decoders constructed and each thread's samples first touched by that thread before the clock "
                            "(oracle/ref_capi.cpp: nfcref_decode_many_detail); the clock is the decode alone",
             }
