@@ -98,6 +98,9 @@ def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emul
     ({"NFCGPU_LONG_FIRST": "0"}, "windowed"),                                  # the run list of a pass in stream order
     ({"NFCGPU_LONG_FIRST": "2048", "NFCGPU_LANES_WANTED": "0", "NFCGPU_CUT_MAX": "16384"}, "windowed"),  # ... in six classes of length
     ({"NFCGPU_ENVELOPE_KERNEL": "0"}, "windowed"),                             # the envelope tracker's second walks left to the scan kernel
+    ({"NFCGPU_ENVELOPE_FOLLOW": "0"}, "windowed"),                             # ... by the envelope kernel, a round per link of a chain
+    ({"NFCGPU_PLANES_PIECE": "0"}, "windowed"),                                # the planes of a small submission a lane per chunk
+    ({"NFCGPU_PLANES_PIECE": "2048", "NFCGPU_ENVELOPE_FOLLOW": "1000000"}, "windowed"),  # ... a lane per four points; chains followed whatever the list
 ])
 def test_remaining_knobs_at_non_default_values_emulated(emulated, knobs, expect):
     """every knob that is left (INTEGRATION.md lists them) decodes the same frames at a value that is not its
