@@ -168,7 +168,9 @@ struct nfcgpu_ctx
    DevBuf vStates, vCold, vRings, vBytes, vSink, vSinkCtl, vSaveRings, vSaveBytes;
    uint32_t longFirst = 32768;      /* the run list of a pass takes its lanes longest first, by classes of their length down to this one (NFCGPU_LONG_FIRST; 0: as they come) */
    uint32_t lanesWanted = 4096;     /* lanes a large busy submission is cut into, at least (NFCGPU_LANES_WANTED; 0: always NFC_WINDOW_CUT apart). Round 4: 16384 -> 4096: longer lanes need fewer passes (512 dense streams x 2^20: 320 -> 273 ms per step; 4096 streams are at NFCGPU_CUT_MAX either way) */
-   uint32_t cutMax = 1u << 17;      /* ... but never further apart than this (NFCGPU_CUT_MAX) */
+   uint32_t cutMax = 1u << 19;      /* ... but never further apart than this (NFCGPU_CUT_MAX). Round 5: 2^19 instead of 2^17 - config 5 at 2^17, 2^18,
+                                       2^19, 2^20: 458, 456, 452, 452 ms per step (three runs each at 2^17 and 2^19: +-1 ms); 2^16: 500, 2^15: 555. Most
+                                       lanes begin after quiet signal, not at a cut; the fewer cuts, the fewer guesses */
    uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
    uint32_t soloSamples = 1u << 16; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES). Round 4: 2^18 -> 2^16,
                                        the lanes being what they now are: the bundled captures of 100 k - 200 k samples 25 / 39 / 49 -> 17 / 27 / 37 ms */
