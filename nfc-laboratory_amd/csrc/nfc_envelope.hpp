@@ -84,6 +84,9 @@ NFC_DEV void nfc_envelope_rewalk(const NfcConfig &c, const NfcScanArgs &A, NfcSc
 
          seam.start.env = env;
          seam.start.pulseFilter = pulseFilter;
+
+         if (A.planesStale)
+            A.planesStale[g] = 1u; /* (a start state rewritten: NfcScanArgs::planesStale) */
       }
 
       uint32_t clock = A.states[job->slot].clock + start;
@@ -203,6 +206,9 @@ NFC_DEV void nfc_envelope_rewalk_wave(const NfcConfig &c, const NfcScanArgs &A, 
 
          seam.start.env = env;
          seam.start.pulseFilter = pulseFilter;
+
+         if (A.planesStale)
+            A.planesStale[g] = 1u; /* (a start state rewritten: NfcScanArgs::planesStale) */
       }
 
       uint32_t clock = A.states[job->slot].clock + start;

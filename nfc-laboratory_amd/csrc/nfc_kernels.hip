@@ -817,14 +817,19 @@ __device__ __forceinline__ void nfc_planes_body(const NfcConfig *__restrict__ cf
 {
    const uint32_t lane = threadIdx.x;
    const uint32_t listed = blockIdx.x * NFC_LANES + lane;
-   const bool mine = listed < A.nChunks;
+   const uint32_t per = A.planesPerChunk ? A.planesPerChunk : 1u;
+   const bool mine = listed / per < A.nChunks;
 
    NfcScanChunk ch;
    ch.job = 0;
    ch.index = 0;
    if (mine)
-      ch = A.chunks[listed];
+      ch = A.chunks[listed / per];
    ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
+
+   /* (an entry that is a chunk walked by several lanes, a piece each: NfcScanArgs::planesPerChunk) */
+   if (A.planesPerChunk)
+      ch.index = ch.index * per + listed % per;
 
    const NfcScanJob *job = A.jobs + ch.job;
    const uint32_t count = mine ? job->count : 0u;
@@ -956,6 +961,18 @@ __global__ __launch_bounds__(64) void nfc_scan_planes_kernel(const NfcConfig *__
       nfc_planes_body<1>(cfgPtr, A, tile, stage, rowOut, rowN);
 }
 
+/* The chunks whose start state changed after the walk that writes the planes was started (NfcScanArgs::planesStale): listed for
+ * a walk of their own. `all`: the submission's chunk table, chunk after chunk as the seam records lie. */
+__global__ __launch_bounds__(256) void nfc_planes_stale_kernel(NfcScanArgs A, const NfcScanChunk *all, uint32_t nAll, NfcScanChunk *out, uint32_t *count)
+{
+   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+
+   if (g >= nAll || !A.planesStale[g])
+      return;
+
+   out[atomicAdd(count, 1u)] = all[g];
+}
+
 /* one thread per job: seams, then windows (the two are cheap and sequential per stream) */
 __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
 {
@@ -970,7 +987,8 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
       job.passes = 0;
 
    if (!(job.status & NFC_JOB_INVALID))
-      nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples, A.repairsEnv, A.repairEnvCount);
+      nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples, A.repairsEnv, A.repairEnvCount,
+                      A.planesStale);
 
    A.jobs[j] = job;
 }

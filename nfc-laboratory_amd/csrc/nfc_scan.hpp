@@ -283,7 +283,7 @@ NFC_DEV void nfc_scan_resume(NfcScanLane &w, const NfcScanPoint &p, uint32_t edg
  * chunkEdge[k] = edge-tracker time at the start of chunk k (points without a time of their own inherit it). */
 NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *seams, uint32_t *chunkEdge, uint32_t startEdge, NfcScanChunk *repairs,
                              uint32_t *repairCount, NfcScanPoint *points = nullptr, uint32_t chunkSamples = 0, NfcScanChunk *repairsEnv = nullptr,
-                             uint32_t *repairEnvCount = nullptr)
+                             uint32_t *repairEnvCount = nullptr, uint32_t *stale = nullptr)
 {
    uint32_t edge = startEdge; /* edge time at the start of the chunk at hand, by the records as they are */
    bool pending = false;
@@ -377,6 +377,10 @@ NFC_DEV bool nfc_seams_check(NfcScanJob &job, uint32_t jobIndex, NfcScanSeam *se
          NfcScanChunk &r = (envelopeOnly && repairsEnv) ? repairsEnv[NFC_ATOMIC_ADD(repairEnvCount, 1u)] : repairs[NFC_ATOMIC_ADD(repairCount, 1u)];
          r.job = jobIndex;
          r.index = k | NFC_CHUNK_REPAIR | (envelopeOnly ? NFC_CHUNK_ENVELOPE : 0u);
+
+         /* (its start state has just changed: planes written from the old one are written again, NfcScanArgs::planesStale) */
+         if (stale)
+            stale[job.firstChunk + k] = 1u;
 
          pending = true;
       }

@@ -64,6 +64,11 @@ struct NfcScanArgs
     * decoder's front end leaves them after that sample, written by a second walk of the scan kernel from the verified
     * chunk starts (null: not written). Sample i of a job is record 64 * job.firstTile + i. */
    float *planes;
+   uint32_t *planesStale;      /* [chunks] or null: set for a chunk whose start state is rewritten while the walk that writes the planes may
+                                  already have read it (the walk over all chunks runs beside the later rounds of second walks: nfcgpu.hip);
+                                  those chunks' planes are written again when the rounds are over */
+   uint32_t planesPerChunk;    /* ... lanes per entry of the walk's list: entry e is a chunk, lane e * planesPerChunk + i walks its piece i of planesPiece
+                                  samples (0: an entry is a lane's own piece or chunk) */
    uint32_t planesPiece;       /* the walk that writes them: samples per lane when it goes by the stored points (a multiple of NFC_SCAN_POINT: lane i
                                   of a job walks [i * planesPiece, ...) from the point stored there); 0: a lane per chunk, from the chunk's start */
 };

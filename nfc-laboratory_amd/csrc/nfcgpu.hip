@@ -51,6 +51,7 @@ __global__ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, flo
 __global__ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode);
+__global__ void nfc_planes_stale_kernel(NfcScanArgs A, const NfcScanChunk *all, uint32_t nAll, NfcScanChunk *out, uint32_t *count);
 
 namespace {
 
@@ -103,6 +104,7 @@ struct nfcgpu_ctx
    hipStream_t side = nullptr;       /* the carry lanes of a windowed pass run beside the speculative ones */
    uint32_t sideMode = 2;            /* NFCGPU_SIDE_STREAM: 0 one stream, 1 two fixed events, 2 events per pass */
    hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
+   hipStream_t low = nullptr;        /* lowest priority: the walk that writes the planes beside the rounds of second walks */
    uint32_t maxStreams = 0;
    uint32_t blocks = 0;
 
@@ -181,6 +183,11 @@ struct nfcgpu_ctx
                                       4096-sample chunks of a short capture's rounds, the wrong shape for the long lists of a large submission
                                       (thousands of lanes reading 32768-sample chunks a cache line each: 79 -> 122 ms per step of the headline,
                                       profiles/r04/ab_envelope) - and was given lists of at most 64 */
+   DevBuf wPlanesStale;            /* NfcScanArgs::planesStale */
+   uint32_t planesBeside = 1;      /* the walk that writes a large submission's planes runs on the side stream beside the rounds of second walks that follow the
+                                      first (NFCGPU_PLANES_BESIDE; 0: after them, as until round 5) */
+   uint32_t planesBesidePiece = 2048; /* ... samples per lane of that walk, from the stored points (NFCGPU_PLANES_BESIDE_PIECE; 0: a lane per chunk, from its start).
+                                      Config 5, ms per step: after the rounds 452.7; beside them a lane per chunk 442.8, per 8192 / 2048 / 512 samples 438.5 / 436.7 / 437.6 */
    uint32_t planesPiece = 512;     /* samples per lane of the walk that writes a small submission's front-end planes (NFCGPU_PLANES_PIECE; 0: a lane per chunk) */
    uint32_t envelopeFollowMax = 1024; /* ... and a walk goes on through the chain of chunks that inherit its chunk's envelope when the round lists at
                                          most this many (NFCGPU_ENVELOPE_FOLLOW): the tail of rounds with a few chunks each becomes one or two rounds
@@ -980,6 +987,35 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       HIP_TRY(ctx, hipGetLastError());
    }
 
+   /* The front-end planes (below) are a walk of every chunk from its verified start state: 69 GB of stores for config 5, 32 ms
+    * of a device that the rounds of second walks after the first leave nearly idle (a few thousand chunks each, as long as
+    * their longest chain). Round 5: for a large submission that walk is started on a stream of its own (lowest priority) as soon as the first round's
+    * second walks are queued - by then nine chunks in ten start from their true state -, the seam check and the envelope
+    * walks note every start state they rewrite from then on (NfcScanArgs::planesStale), and those chunks' planes are written
+    * again when the rounds are over. */
+   const bool planesBeside = ctx->planesBeside && ctx->low != nullptr && totalSamples > (4u << 20);
+   bool planesStarted = false;
+
+   struct PlanesGuard
+   {
+      nfcgpu_ctx *ctx;
+      bool running;
+      ~PlanesGuard()
+      {
+         if (running)
+            (void)hipStreamSynchronize(ctx->low); /* (whatever way the function is left: nobody reuses what the walk reads or writes while it runs) */
+      }
+   } planesGuard {ctx, false};
+
+   if (planesBeside)
+   {
+      if ((rc = grow(ctx, ctx->wPlanes, (size_t)tiles * NFC_SCAN_TILE * 16u)) || (rc = grow(ctx, ctx->wPlaneChunks, sizeof(NfcScanChunk) * nChunks)) ||
+          (rc = grow(ctx, ctx->wPlanesStale, 4u * (size_t)nChunks)))
+         return withoutTheMemory(rc);
+
+      HIP_TRY(ctx, hipMemsetAsync(ctx->wPlanesStale.ptr, 0, 4u * (size_t)nChunks, ctx->stream));
+   }
+
    /* seams: chunks that did not start from the true state are walked again, a round at a time */
 
    for (uint32_t round = 0;; round++)
@@ -1093,6 +1129,35 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       record_span(ctx, ctx->timedScan, pr, false);
       ctx->stats.scan_repairs += repairs;
+
+      if (planesBeside && round == 0)
+      {
+         /* the planes of every chunk, beside the rounds to come */
+         HIP_TRY(ctx, hipEventRecord(ctx->forkEvent, ctx->stream));
+         HIP_TRY(ctx, hipStreamWaitEvent(ctx->low, ctx->forkEvent, 0));
+         planesGuard.running = true;
+
+         NfcScanArgs P = A;
+         P.planes = (float *)ctx->wPlanes.ptr;
+         P.chunks = (const NfcScanChunk *)ctx->wChunks.ptr; /* (the submission's chunk table as it is: the walk takes no notice of the repair marks) */
+         P.nChunks = nChunks;
+         P.planesPiece = ctx->planesBesidePiece / NFC_SCAN_POINT * NFC_SCAN_POINT;
+         P.planesPerChunk = P.planesPiece ? sp.chunkSamples / P.planesPiece : 0u;
+         if (P.planesPerChunk == 0u)
+            P.planesPiece = 0u;
+
+         const uint64_t lanesOfIt = (uint64_t)nChunks * (P.planesPerChunk ? P.planesPerChunk : 1u);
+
+         ProfiledLaunch pp {nullptr, nullptr};
+         record_span(ctx, ctx->timedPlanes, pp, true, ctx->low);
+         hipLaunchKernelGGL(nfc_scan_planes_kernel, dim3((uint32_t)((lanesOfIt + NFC_LANES - 1) / NFC_LANES)), dim3(NFC_LANES), 0, ctx->low, dCfg, P);
+         HIP_TRY(ctx, hipGetLastError());
+         record_span(ctx, ctx->timedPlanes, pp, false, ctx->low);
+         HIP_TRY(ctx, hipEventRecord(ctx->joinEvent, ctx->low));
+
+         planesStarted = true;
+         A.planesStale = (uint32_t *)ctx->wPlanesStale.ptr; /* from the next round on */
+      }
    }
    hipLaunchKernelGGL(nfc_tiles_kernel, dim3(nJobs, (tilesMost + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tilesMost);
    HIP_TRY(ctx, hipGetLastError());
@@ -1101,6 +1166,47 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    /* The wave decoder takes the front end's results per sample instead of walking it again: a second walk of every
     * chunk from its verified start state (the repair form of the scan: no warm-up) writes them. */
+   if (planesStarted)
+   {
+      /* the walk over all chunks has run beside the rounds: the chunks whose start state changed under it, again */
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->joinEvent, 0));
+      planesGuard.running = false; /* (the main stream now waits for it) */
+
+      HIP_TRY(ctx, hipMemsetAsync(counters + 11, 0, 4, ctx->stream));
+      hipLaunchKernelGGL(nfc_planes_stale_kernel, dim3((nChunks + 255) / 256), dim3(256), 0, ctx->stream, A, (const NfcScanChunk *)ctx->wChunks.ptr, nChunks,
+                         (NfcScanChunk *)ctx->wPlaneChunks.ptr, counters + 11);
+      HIP_TRY(ctx, hipGetLastError());
+
+      uint32_t again = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(&again, counters + 11, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+      A.planes = (float *)ctx->wPlanes.ptr;
+      A.planesStale = nullptr;
+
+      if (debugStages)
+         std::fprintf(stderr, "[nfcgpu]    planes written beside the rounds; %u chunks of %u again\n", again, nChunks);
+
+      if (again)
+      {
+         NfcScanArgs P = A;
+         /* (a stored point per lane - 512 samples, from the points the rounds have left true -: a few thousand chunks a lane each
+          * would take as long as one chunk's walk, 12 ms, with the device all but idle) */
+         P.chunks = (const NfcScanChunk *)ctx->wPlaneChunks.ptr;
+         P.nChunks = again;
+         P.planesPiece = NFC_SCAN_POINT;
+         P.planesPerChunk = sp.chunkSamples / NFC_SCAN_POINT;
+
+         ProfiledLaunch pp {nullptr, nullptr};
+         record_span(ctx, ctx->timedPlanes, pp, true);
+         hipLaunchKernelGGL(nfc_scan_planes_kernel, dim3((uint32_t)(((uint64_t)again * P.planesPerChunk + NFC_LANES - 1) / NFC_LANES)), dim3(NFC_LANES), 0, ctx->stream, dCfg, P);
+         HIP_TRY(ctx, hipGetLastError());
+         record_span(ctx, ctx->timedPlanes, pp, false);
+      }
+
+      mark("planes");
+   }
+   else
    {
       /* A small submission - one a caller waits for - is walked a lane per stored point instead of a lane per chunk: 512 samples
        * instead of 4096 on the way of everything that follows (NFCGPU_PLANES_PIECE; a short capture: 1.1 -> 0.2 ms) */
@@ -1771,6 +1877,8 @@ void release_workspace(nfcgpu_ctx *ctx)
       (void)hipStreamSynchronize(ctx->stream);
    if (ctx->side)
       (void)hipStreamSynchronize(ctx->side);
+   if (ctx->low)
+      (void)hipStreamSynchronize(ctx->low);
 
    for (auto *list: {&ctx->timed, &ctx->timedScan, &ctx->timedWindow, &ctx->timedWave, &ctx->timedPlanes})
    {
@@ -1804,6 +1912,9 @@ void release_workspace(nfcgpu_ctx *ctx)
       (void)hipEventDestroy(ctx->joinEvent);
    if (ctx->side)
       (void)hipStreamDestroy(ctx->side);
+   if (ctx->low)
+      (void)hipStreamDestroy(ctx->low);
+   ctx->low = nullptr;
    if (ctx->stream)
       (void)hipStreamDestroy(ctx->stream);
    ctx->forkEvent = ctx->joinEvent = nullptr;
@@ -1964,6 +2075,8 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->envelopeMax = knob("NFCGPU_ENVELOPE_KERNEL", ctx->envelopeMax);
    ctx->envelopeFollowMax = knob("NFCGPU_ENVELOPE_FOLLOW", ctx->envelopeFollowMax);
    ctx->planesPiece = knob("NFCGPU_PLANES_PIECE", ctx->planesPiece);
+   ctx->planesBeside = knob("NFCGPU_PLANES_BESIDE", ctx->planesBeside);
+   ctx->planesBesidePiece = knob("NFCGPU_PLANES_BESIDE_PIECE", ctx->planesBesidePiece);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;
@@ -1993,6 +2106,13 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
 
    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
    ok = ok && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
+   {
+      /* (the stream of the walk that writes the planes beside the rounds of second walks: whatever those rounds launch goes first) */
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
+         least = 0;
+      ok = ok && hipStreamCreateWithPriority(&ctx->low, hipStreamNonBlocking, least) == hipSuccess;
+   }
    ok = ok && hipEventCreateWithFlags(&ctx->forkEvent, hipEventDisableTiming) == hipSuccess;
    ok = ok && hipEventCreateWithFlags(&ctx->joinEvent, hipEventDisableTiming) == hipSuccess;
 

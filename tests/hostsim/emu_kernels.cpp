@@ -561,10 +561,14 @@ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 {
    const uint32_t L = A.planesPiece ? A.planesPiece : A.params.chunkSamples;
 
-   for (uint32_t listed = 0; listed < A.nChunks; listed++)
+   const uint32_t per = A.planesPerChunk ? A.planesPerChunk : 1u;
+
+   for (uint32_t listed = 0; listed < A.nChunks * per; listed++)
    {
-      NfcScanChunk ch = A.chunks[listed];
-      ch.index &= ~NFC_CHUNK_REPAIR;
+      NfcScanChunk ch = A.chunks[listed / per];
+      ch.index &= ~(NFC_CHUNK_REPAIR | NFC_CHUNK_ENVELOPE);
+      if (A.planesPerChunk)
+         ch.index = ch.index * per + listed % per; /* (an entry that is a chunk walked a piece per lane: nfc_kernels.hip) */
       const NfcScanJob *job = A.jobs + ch.job;
       const uint32_t start = ch.index * L;
       const uint32_t end = start + L < job->count ? start + L : job->count;
@@ -592,6 +596,13 @@ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
    }
 }
 
+void nfc_planes_stale_kernel(NfcScanArgs A, const NfcScanChunk *all, uint32_t nAll, NfcScanChunk *out, uint32_t *count)
+{
+   for (uint32_t g = 0; g < nAll; g++)
+      if (A.planesStale[g])
+         out[emu_add(count, 1u)] = all[g];
+}
+
 void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
 {
    for (uint32_t j = 0; j < A.nJobs; j++)
@@ -600,7 +611,8 @@ void nfc_seams_kernel(NfcScanArgs A, uint32_t first)
       if (first)
          job.passes = 0;
       if (!(job.status & NFC_JOB_INVALID))
-         nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples, A.repairsEnv, A.repairEnvCount);
+         nfc_seams_check(job, j, A.seams, A.chunkEdge, A.states[job.slot].edgeTime, A.repairs, A.repairCount, A.points, A.params.chunkSamples, A.repairsEnv, A.repairEnvCount,
+                         A.planesStale);
       A.jobs[j] = job;
    }
 }

@@ -100,6 +100,9 @@ def test_a_full_staging_sink_sends_the_submission_to_the_sequential_kernels_emul
     ({"NFCGPU_ENVELOPE_KERNEL": "0"}, "windowed"),                             # the envelope tracker's second walks left to the scan kernel
     ({"NFCGPU_ENVELOPE_FOLLOW": "0"}, "windowed"),                             # ... by the envelope kernel, a round per link of a chain
     ({"NFCGPU_PLANES_PIECE": "0"}, "windowed"),                                # the planes of a small submission a lane per chunk
+    ({"NFCGPU_PLANES_BESIDE": "0"}, "windowed"),                               # a large submission's planes after the rounds of second walks
+    ({"NFCGPU_PLANES_BESIDE_PIECE": "0"}, "windowed"),                         # ... beside them, a lane per chunk
+    ({"NFCGPU_PLANES_BESIDE_PIECE": "512"}, "windowed"),                       # ... a lane per stored point
     ({"NFCGPU_PLANES_PIECE": "2048", "NFCGPU_ENVELOPE_FOLLOW": "1000000"}, "windowed"),  # ... a lane per four points; chains followed whatever the list
 ])
 def test_remaining_knobs_at_non_default_values_emulated(emulated, knobs, expect):
@@ -137,6 +140,25 @@ def test_envelope_kernel_walks_the_short_lists_of_small_submissions_emulated(emu
     assert [but_repairs(r["stats"]) for r in outs["64"][0]] == [but_repairs(r["stats"]) for r in outs["0"][0]]
     listed = [sum(r["stats"]["repairs"] for r in outs[knob][0]) for knob in ("64", "0")]
     assert 0 < listed[0] <= listed[1], listed
+
+
+@needs_reference
+@pytest.mark.parametrize("knobs, beside", [({}, True), ({"NFCGPU_PLANES_BESIDE_PIECE": "0"}, True), ({"NFCGPU_PLANES_BESIDE_PIECE": "512"}, True),
+                                           ({"NFCGPU_PLANES_BESIDE": "0"}, False)])
+def test_planes_written_beside_the_rounds_of_second_walks_emulated(emulated, knobs, beside):
+    """Round 5: a large submission's front-end planes are written by a walk that starts when the first round's second walks are
+    queued; the seam check and the envelope walks note every start state they rewrite from then on, and those chunks' planes are
+    written again (a lane per stored point) when the rounds are over. Five dense streams x 2^20 (more than 4 Mi samples) with the
+    default piece of that walk, a lane per chunk, a lane per point, and with the walk after the rounds: the reference's frames."""
+    env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOW_DEBUG="1")
+    env.update(knobs)
+    run = subprocess.run([sys.executable, DRIVER, "beside"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
+    assert run.returncode == 0, run.stderr[-3000:]
+    res = json.loads(run.stdout.strip().splitlines()[-1])
+    for r in res:
+        assert r["mismatching"] == [] and r["frames"] > 0 and r["stats"]["fallback"] == 0, r
+    again = [int(l.split(";")[1].split()[0]) for l in run.stderr.splitlines() if "planes written beside the rounds" in l]
+    assert (len(again) == 1 and again[0] > 0) if beside else again == [], (again, run.stderr[-2000:])
 
 
 @needs_reference

@@ -108,6 +108,11 @@ def main():
         streams = [synth.magnitude_f32(template, s, 0, 3 << 16) for s in (29, 5)]
         out.append(case("2 dense synthetic streams x 3 * 2^16 in 3 buffers", streams, buffers=3))
 
+    if "beside" in which:
+        # (tests/test_time_parallel.py: a submission of more than 4 Mi samples - its planes are written beside the rounds of second walks)
+        streams = [synth.magnitude_f32(template, 90 + 7 * s, 0, 1 << 20) for s in range(5)]
+        out.append(case("5 dense synthetic streams x 2^20", streams))
+
     if "planes" in which:
         # (tests/test_time_parallel.py: the front-end planes - 16 bytes per sample - do not fit the device)
         streams = [synth.magnitude_f32(template, 60 + s, 0, 1 << 19) for s in range(2)]
