@@ -999,32 +999,33 @@ __global__ __launch_bounds__(64) void nfc_seams_kernel(NfcScanArgs A, uint32_t f
 __global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A, uint32_t nTilesMost)
 {
    const uint32_t lo = blockIdx.x;
-   const uint32_t inJob = blockIdx.y * blockDim.x + threadIdx.x;
 
-   if (lo >= A.nJobs || inJob >= nTilesMost)
+   if (lo >= A.nJobs)
       return;
-
-   if (inJob >= (A.jobs[lo].count + NFC_SCAN_TILE - 1u) / NFC_SCAN_TILE)
-      return;
-
-   const uint32_t i = A.jobs[lo].firstTile + inJob;
 
    NfcConfig cc;
    nfc_fixed_runtime_config(cfgPtr, cc);
 
    const uint32_t first = A.jobs[lo].firstTile;
-   const uint32_t flags = nfc_tile_flags(cc, A.params, A.tileStats + first, i - first);
+   const uint32_t nTiles = (A.jobs[lo].count + NFC_SCAN_TILE - 1u) / NFC_SCAN_TILE;
 
-   A.tiles[i] = flags;
+   /* (the host keeps grid.y inside the 65535 blocks a grid may have in y: a job of more than 2^24 tiles strides) */
+   for (uint32_t inJob = blockIdx.y * blockDim.x + threadIdx.x; inJob < nTiles && inJob < nTilesMost; inJob += gridDim.y * blockDim.x)
+   {
+      const uint32_t i = first + inJob;
+      const uint32_t flags = nfc_tile_flags(cc, A.params, A.tileStats + first, inJob);
 
-   /* Off the capture grid a running sum depends on everything that was ever added to it: no lane that starts inside the
-    * stream can be in the decoder's state. The carry lane is (it continues the stream's own sums), so it decodes such a
-    * stream alone; the lane-per-window kernels have no way of walking the sums and leave it to the sequential ones. */
-   if (flags & NFC_TILE_OFFGRID)
-      atomicOr(&A.jobs[lo].status, A.params.offGridAlone ? (NFC_JOB_ALONE | NFC_JOB_OFFGRID_SEEN) : NFC_JOB_OFFGRID);
+      A.tiles[i] = flags;
 
-   if ((flags & NFC_TILE_BUSY) && !(flags & NFC_TILE_DARK))
-      atomicAdd(&A.jobs[lo].busyTiles, 1u);
+      /* Off the capture grid a running sum depends on everything that was ever added to it: no lane that starts inside the
+       * stream can be in the decoder's state. The carry lane is (it continues the stream's own sums), so it decodes such a
+       * stream alone; the lane-per-window kernels have no way of walking the sums and leave it to the sequential ones. */
+      if (flags & NFC_TILE_OFFGRID)
+         atomicOr(&A.jobs[lo].status, A.params.offGridAlone ? (NFC_JOB_ALONE | NFC_JOB_OFFGRID_SEEN) : NFC_JOB_OFFGRID);
+
+      if ((flags & NFC_TILE_BUSY) && !(flags & NFC_TILE_DARK))
+         atomicAdd(&A.jobs[lo].busyTiles, 1u);
+   }
 }
 
 /* One wave per job: retire / dark marks and the windows, 64 tiles per step (nfc_scan.hpp: nfc_group_*). Every lane of

@@ -299,7 +299,12 @@ __device__ void nfc_wave_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &c
 }
 #endif
 
-__global__ __launch_bounds__(64) NFC_WAVE_KERNEL_ATTR void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode)
+/* the same text is compiled twice (nfc_wave_lone.hip): NFC_WAVE_KERNEL_NAME names the second build */
+#ifndef NFC_WAVE_KERNEL_NAME
+#define NFC_WAVE_KERNEL_NAME nfc_wave_kernel
+#endif
+
+__global__ __launch_bounds__(64) NFC_WAVE_KERNEL_ATTR void NFC_WAVE_KERNEL_NAME(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode)
 {
 #ifdef NFC_WAVE_VERIFY
    __shared__ NfcWaveLds ldsThree[3]; /* the wave's, a copy of it as the tile found it, and what the bulk paths left */

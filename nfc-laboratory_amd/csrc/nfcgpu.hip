@@ -51,6 +51,11 @@ __global__ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, flo
 __global__ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode);
+#ifdef NFCGPU_EMULATED_TEST_BUILD
+#define nfc_wave_lone_kernel nfc_wave_kernel /* (one twin on the CPU: the two device builds are the same text) */
+#else
+__global__ void nfc_wave_lone_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode);
+#endif
 __global__ void nfc_planes_stale_kernel(NfcScanArgs A, const NfcScanChunk *all, uint32_t nAll, NfcScanChunk *out, uint32_t *count);
 
 namespace {
@@ -173,6 +178,8 @@ struct nfcgpu_ctx
    uint32_t cutMax = 1u << 19;      /* ... but never further apart than this (NFCGPU_CUT_MAX). Round 5: 2^19 instead of 2^17 - config 5 at 2^17, 2^18,
                                        2^19, 2^20: 458, 456, 452, 452 ms per step (three runs each at 2^17 and 2^19: +-1 ms); 2^16: 500, 2^15: 555. Most
                                        lanes begin after quiet signal, not at a cut; the fewer cuts, the fewer guesses */
+   uint32_t loneLanes = 1024u;     /* a launch of the wave decoder with at most this many lanes of work runs the build for one wave per SIMD (nfc_wave_lone.hip:
+                                       no scratch memory on the critical path of a wavefront that has its SIMD to itself; NFCGPU_LONE_LANES, 0: never) */
    uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
    uint32_t soloSamples = 1u << 16; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES). Round 4: 2^18 -> 2^16,
                                        the lanes being what they now are: the bundled captures of 100 k - 200 k samples 25 / 39 / 49 -> 17 / 27 / 37 ms */
@@ -979,11 +986,14 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    mark("scan");
 
+   /* (a grid has at most 65535 blocks in y: beyond 2^24 tiles in one job the kernel strides) */
+   const uint32_t tilesGridY = (tilesMost + 255) / 256 > 65535u ? 65535u : (tilesMost + 255) / 256;
+
    /* a first run of the tile tests: how busy is each stream? Only a small submission is routed by that (below: `small`); a large
     * one gets its tile flags once, when the envelopes they are formed from are the true ones (3.8 ms for the 67 M tiles of config 5) */
    if (nJobs < NFC_LANES && !ctx->inBlocks)
    {
-      hipLaunchKernelGGL(nfc_tiles_kernel, dim3(nJobs, (tilesMost + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tilesMost);
+      hipLaunchKernelGGL(nfc_tiles_kernel, dim3(nJobs, tilesGridY), dim3(256), 0, ctx->stream, dCfg, A, tilesMost);
       HIP_TRY(ctx, hipGetLastError());
    }
 
@@ -1141,10 +1151,19 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          P.planes = (float *)ctx->wPlanes.ptr;
          P.chunks = (const NfcScanChunk *)ctx->wChunks.ptr; /* (the submission's chunk table as it is: the walk takes no notice of the repair marks) */
          P.nChunks = nChunks;
+         /* a lane per piece, and the pieces of a chunk have to tile it: the largest multiple of the distance of the stored
+          * points (every lane starts from one) that is no longer than NFCGPU_PLANES_BESIDE_PIECE and divides the chunk. (Until
+          * round 6 the quotient was truncated: with a chunk that is no multiple of the piece - the default sizing gives any
+          * multiple of 512 for totals between 2^28 and 2^30 samples - the tail of every chunk that was not walked again got no
+          * planes at all.) A chunk is a multiple of the points' distance, so that distance always does. */
          P.planesPiece = ctx->planesBesidePiece / NFC_SCAN_POINT * NFC_SCAN_POINT;
+         if (P.planesPiece > sp.chunkSamples)
+            P.planesPiece = sp.chunkSamples / NFC_SCAN_POINT * NFC_SCAN_POINT;
+         while (P.planesPiece > NFC_SCAN_POINT && sp.chunkSamples % P.planesPiece != 0u)
+            P.planesPiece -= NFC_SCAN_POINT;
+         if (P.planesPiece && sp.chunkSamples % P.planesPiece != 0u)
+            P.planesPiece = 0u; /* (a chunk that is no multiple of the points' distance: a lane per chunk, from its start) */
          P.planesPerChunk = P.planesPiece ? sp.chunkSamples / P.planesPiece : 0u;
-         if (P.planesPerChunk == 0u)
-            P.planesPiece = 0u;
 
          const uint64_t lanesOfIt = (uint64_t)nChunks * (P.planesPerChunk ? P.planesPerChunk : 1u);
 
@@ -1159,7 +1178,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          A.planesStale = (uint32_t *)ctx->wPlanesStale.ptr; /* from the next round on */
       }
    }
-   hipLaunchKernelGGL(nfc_tiles_kernel, dim3(nJobs, (tilesMost + 255) / 256), dim3(256), 0, ctx->stream, dCfg, A, tilesMost);
+   hipLaunchKernelGGL(nfc_tiles_kernel, dim3(nJobs, tilesGridY), dim3(256), 0, ctx->stream, dCfg, A, tilesMost);
    HIP_TRY(ctx, hipGetLastError());
 
    mark("seams");
@@ -1317,7 +1336,10 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       ProfiledLaunch wl {nullptr, nullptr};
       record_span(ctx, ctx->timedWave, wl, true, on);
-      hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
+      if (slotCount <= ctx->loneLanes)
+         hipLaunchKernelGGL(nfc_wave_lone_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u);
+      else
+         hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
       record_span(ctx, ctx->timedWave, wl, false, on);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
@@ -1325,14 +1347,17 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    };
 
    /* the speculative windows on the run list: persistent waves */
-   auto decodeWindows = [&]() -> int {
+   auto decodeWindows = [&](uint32_t runLanes) -> int {
       NfcLaunch L = lanes;
       L.warmFront = NFC_WINDOW_WARM_FRONT;
       L.warmCorr = NFC_WINDOW_WARM_CORR;
 
       ProfiledLaunch wl {nullptr, nullptr};
       record_span(ctx, ctx->timedWave, wl, true);
-      hipLaunchKernelGGL(nfc_wave_kernel, dim3(nWindows), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
+      if (runLanes <= ctx->loneLanes)
+         hipLaunchKernelGGL(nfc_wave_lone_kernel, dim3(runLanes), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u);
+      else
+         hipLaunchKernelGGL(nfc_wave_kernel, dim3(runLanes), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
       record_span(ctx, ctx->timedWave, wl, false);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
@@ -1395,6 +1420,17 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
          }
       }
 
+      /* how many lanes the list holds: the later passes of a submission list a few thousand, then a few dozen, of its windows -
+       * launches of that size go to the wave decoder's build for few lanes (nfc_wave_lone.hip), with a grid of the list's length */
+      uint32_t runLanes = 0;
+      if (nWindows)
+      {
+         HIP_TRY(ctx, hipMemcpyAsync(&runLanes, counters + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+         if (runLanes > nWindows)
+            runLanes = nWindows;
+      }
+
       /* the carry lanes (later passes: those the chain kernel sent on): from the stream's own state, which has not
        * been touched */
       if (pass > 0)
@@ -1405,12 +1441,12 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       /* carry lanes and speculative lanes side by side: no lane looks at what another one is doing while it runs
        * (nfc_lane_handover), and the longest lane of either kind can be most of the submission */
-      if (ctx->sideMode == 0 || nWindows == 0)
+      if (ctx->sideMode == 0 || nWindows == 0 || runLanes == 0)
       {
          /* nothing to run beside (or NFCGPU_SIDE_STREAM=0): one stream */
          if ((rc = decodeSlots(true, 0, nJobs, ctx->stream)))
             return rc;
-         if (nWindows && (rc = decodeWindows()))
+         if (nWindows && runLanes && (rc = decodeWindows(runLanes)))
             return rc;
       }
       else
@@ -1434,7 +1470,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
          HIP_TRY(ctx, hipEventRecord(join, ctx->side));
 
-         if ((rc = decodeWindows()))
+         if (runLanes && (rc = decodeWindows(runLanes)))
             return rc;
 
          HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, join, 0));
@@ -2078,6 +2114,7 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->planesBeside = knob("NFCGPU_PLANES_BESIDE", ctx->planesBeside);
    ctx->planesBesidePiece = knob("NFCGPU_PLANES_BESIDE_PIECE", ctx->planesBesidePiece);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
+   ctx->loneLanes = knob("NFCGPU_LONE_LANES", ctx->loneLanes);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);

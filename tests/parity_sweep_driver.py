@@ -55,12 +55,17 @@ assert lib is not None, "oracle/_ref not available"
 
 def check(s0):
     bad, frames = [], 0
-    mags = torch.sqrt(data[s0:s0 + 64, :, 0] ** 2 + data[s0:s0 + 64, :, 1] ** 2).cpu().numpy().astype(np.float32)
-    for i in range(mags.shape[0]):
-        fr, _ = TL.reference_decode(mags[i], sample_rate=FS, chunk=65536, keep_carrier=True, cap=1 << 17, defined_storage=True)
-        frames += len(fr)
-        if got.get(first + s0 + i, []) != fr:
-            bad.append(s0 + i)
+    # the oracle's input is the reference's own IQ -> magnitude step (RadioDeviceTask.cpp:626-642, the scalar formula compiled with
+    # the reference's flags: oracle/ref_capi.cpp nfcref_magnitude), not a root taken on the device
+    for s1 in range(s0, min(S, s0 + 64), 8):  # (eight streams of IQ on the host at a time per worker)
+        iq = np.ascontiguousarray(data[s1:s1 + 8].cpu().numpy())
+        for i in range(iq.shape[0]):
+            mag = np.empty(iq.shape[1], dtype=np.float32)
+            lib.nfcref_magnitude(iq[i].ctypes.data, iq.shape[1], mag.ctypes.data)
+            fr, _ = TL.reference_decode(mag, sample_rate=FS, chunk=65536, keep_carrier=True, cap=1 << 17, defined_storage=True)
+            frames += len(fr)
+            if got.get(first + s1 + i, []) != fr:
+                bad.append(s1 + i)
     return bad, frames
 
 bad, ref_frames = [], 0
