@@ -221,14 +221,24 @@ def main():
               "--nproc-per-node %d bench.py --gpus %d for the multi-GPU figure" % (args.gpus, world, world, args.gpus, args.gpus),
               file=sys.stderr)
 
+    # NFC_BENCH_DRY_CPU=1: a rehearsal of this script's control flow on a box without GPUs (tests/test_bench_multi_rank_dry.py): tensors
+    # on the host, gloo between the ranks, the library under NFCGPU_LIB the emulated test build with its stand-in for RCCL
+    # (tests/hostsim). Not a measurement: the line it prints says so.
+    dry = os.environ.get("NFC_BENCH_DRY_CPU") == "1"
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if dry else "nccl", rank=rank, world_size=world)
 
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if dry:
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None
+        torch.cuda.empty_cache = lambda *a, **k: None
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
 
     import __graft_entry__
     if rank == 0:
@@ -368,9 +378,10 @@ def main():
     achieved_busy = bytes_per_launch / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
 
     # the measured denominator: streaming read of this very buffer with 16-byte loads
-    read_peak = gpu.read_bandwidth(data.data_ptr(), min(data.numel() * 4, 32 << 30), repeats=5)
+    read_peak = 0.0 if dry else gpu.read_bandwidth(data.data_ptr(), min(data.numel() * 4, 32 << 30), repeats=5)
 
     traffic, traffic_source = stored_traffic(dominant, S, L)
+    traffic_step, traffic_step_source = stored_traffic("step", S, L)  # every kernel of a step, not only the dominant one
 
     result = {
         "metric": "IQ Msamples/s demodulated",
@@ -384,7 +395,7 @@ def main():
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not dry else "synthetic - DRY RUN on the emulated runtime (NFC_BENCH_DRY_CPU=1): a rehearsal of the script, not a measurement",
         "config": {
             "workload": "BASELINE config 5: %d independent 10 MS/s IQ streams (set S1: fixture-derived synthetic float2 IQ resident in HBM, "
                         "dense traffic - the bundled captures tiled end to end), %d per GPU, all four tech decoders (NFC-A/B/F/V) enabled, "
@@ -412,6 +423,11 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic,
             "traffic_source": traffic_source,
+            # HBM bytes of a WHOLE step by the same counters: scan, second walks, planes, tile tests, windows, every pass of the wave
+            # decoder, chain and finish summed (profiles/tools/r06/make_traffic.py); `traffic` above is the dominant kernel's alone
+            "traffic_step": traffic_step,
+            "traffic_step_source": traffic_step_source,
+            "traffic_step_over_algorithmic": round(traffic_step / bytes_per_launch, 3) if traffic_step else None,
             "kernel": dominant,
             "kernel_ms_avg": round(kernel_ms, 4),
             "kernel_ms_is": "sum over all launches of the kernel in one step (HIP events on the launching streams; launches on the "

@@ -810,7 +810,9 @@ __global__ __launch_bounds__(64) void nfc_scan_kernel(const NfcConfig *__restric
  * made it bearable). Here four samples of every lane go through LDS and leave as 64-byte pieces - a store instruction writes
  * sixteen rows' four records each -, and the walk is the decoder's front end and nothing else (the tile extremes, grid test
  * and edge bookkeeping of nfc_scan_sample are the scan's business). */
+#ifndef NFC_PLANES_GROUP
 #define NFC_PLANES_GROUP 4u
+#endif
 
 template <uint32_t S>
 __device__ __forceinline__ void nfc_planes_body(const NfcConfig *__restrict__ cfgPtr, const NfcScanArgs &A, float *tile, float4 *stage, uint64_t *rowOut, uint32_t *rowN)

@@ -299,7 +299,8 @@ __device__ void nfc_wave_verify_tile(const NfcConfig *cfgPtr, const NfcConfig &c
 }
 #endif
 
-/* the same text is compiled twice (nfc_wave_lone.hip): NFC_WAVE_KERNEL_NAME names the second build */
+/* (experiments compile this text a second time under another name: NFC_WAVE_KERNEL_NAME, e.g. profiles/r06/NOTES.md "a build
+ * for few lanes") */
 #ifndef NFC_WAVE_KERNEL_NAME
 #define NFC_WAVE_KERNEL_NAME nfc_wave_kernel
 #endif

@@ -223,16 +223,16 @@ NFC_DEV uint32_t nfc_wave_stage(const NfcStreamState &s, bool upkeep)
  * record as it stands - the state is that of the sample before the run)? Each restates the early exits of its detector
  * (nfca_detect_decide, nfcb_track, nfcf_detect_decide, nfcv_detect_decide). A gate that is up where nothing would have
  * changed only costs a step; one that is down where something would have is an error. */
+/* (num: the correlation of this lane's sample, S0 - S1 - the taps of a tile's samples are formed once per call of nfc_wave_fast
+ * and kept by the lanes: NfcSearchTaps) */
 template <int I>
-NFC_DEV bool nfc_wave_gate_a(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env)
+NFC_DEV bool nfc_wave_gate_a(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env, float num)
 {
    /* nfca_detect_rate past its first exit: a correlation beyond the threshold only changes the record when it is a new
     * extreme of the pause being tracked (or, on the way down, a new deepest modulation) */
-   const uint32_t lane = NFC_WAVE_LANE();
    const NfcDetA &m = NFC_WAVE_STATE(lds).u.search.detA[I];
    const NfcRate &rt = c.a[I];
    const float limit = env * c.corrThreshold[0];
-   const float num = nfc_wave_search_num(c, lds, I, lane);
    const bool timeout = m.peakTime && t > m.peakTime + rt.p1;
    bool moves = false;
 
@@ -270,16 +270,14 @@ NFC_DEV bool nfc_wave_gate_b(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, c
  * looked: the detector gets as far as looking at its record (a correlation that may exceed the threshold with the window
  * open): when the record is one the lane inherited, that leaves a mark too (NfcStreamCold::usedTech, bit 14 + I) */
 template <int I>
-NFC_DEV bool nfc_wave_gate_f(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env, bool &asked, bool &looked)
+NFC_DEV bool nfc_wave_gate_f(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env, float num, bool &asked, bool &looked)
 {
-   const uint32_t lane = NFC_WAVE_LANE();
    const NfcDetF &m = NFC_WAVE_STATE(lds).u.search.detF[I];
    const NfcRate &rt = c.f[I + 1];
    const float limit = env * c.corrThreshold[2];
    const float deep = lds->ring[NFC_R_DEPTH + (t & NFC_FMASK)];
    /* nfcf_detect_rate / nfcf_track_preamble: a correlation above the threshold only changes the record when it is the
     * largest of the pulse so far */
-   const float num = nfc_wave_search_num(c, lds, 3 + I, lane);
    const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.sync | m.peakTime | nfc_bits(m.peak)) == 0u;
    bool moves = false;
 
@@ -296,15 +294,12 @@ NFC_DEV bool nfc_wave_gate_f(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    return (asked && !clear) || (t >= m.winStart && (moves || t == m.sync || t == m.winEnd));
 }
 
-NFC_DEV bool nfc_wave_gate_v(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env)
+NFC_DEV bool nfc_wave_gate_v(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t t, float env, float num /* c2 - sum */)
 {
-   const uint32_t lane = NFC_WAVE_LANE();
    const NfcDetV &m = NFC_WAVE_STATE(lds).u.search.detV;
    const float limit = env * c.corrThreshold[3];
    /* nfcv_detect: a pulse correlation above the threshold only changes the record when it is the largest so far or comes
     * with a deeper modulation */
-   float num, unused;
-   nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 5u, lane, num, unused); /* c2 - sum */
    const bool timeout = m.peakTime && t > m.peakTime + c.v.p0;
    bool moves = false;
 
@@ -325,7 +320,45 @@ NFC_DEV bool nfc_wave_gate_v(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
 /* (bits 0 .. 7: the detectors are shown their records where their gates are up, in place: nfc_wave_fast) */
 #define NFC_WAVE_GATE_OTHER 0x1000u /* bit 12: the bank is not armed at this sample, or a carrier frame is due */
 
-NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t valid, uint32_t w)
+/* What the six box-sum correlators of the search bank hold for this lane's sample of the tile: the differences the detectors
+ * look at (nfc_wave_s0s1), formed once per call of nfc_wave_fast where the call first needs a correlator's - the first
+ * evaluation of a gate, a detector shown its record - and kept by the lanes until the call returns (round 6: every gate
+ * evaluated again after a detector had been shown its record formed its taps again, two ring reads and a dozen words of
+ * the shared record a time: a seventh of the wave's cycles). They are functions of the tile's running sums and of the rings as
+ * the tile found them: nothing a call does to the records changes them. The value at a sample the wave is about (uniform) is
+ * the value the lane of that sample holds. */
+struct NfcSearchTaps
+{
+   float numA[3];  /* NFC-A: S0 - S1 */
+   float s0F[2];   /* NFC-F: S0 ... */
+   float numF[2];  /* ... and S0 - S1 */
+   float numV;     /* NFC-V: c2 - sum */
+   uint32_t have;  /* bit per correlator (0..2 NFC-A, 3..4 NFC-F, 5 NFC-V): formed in this call (uniform) */
+};
+
+NFC_DEV void nfc_wave_search_tap(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, NfcSearchTaps &taps, uint32_t slot)
+{
+   if ((taps.have >> slot) & 1u)
+      return;
+
+   const uint32_t lane = NFC_WAVE_LANE();
+   float s0, s1;
+   nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, slot, lane, s0, s1);
+
+   if (slot < 3u)
+      taps.numA[slot] = s0 - s1;
+   else if (slot < 5u)
+   {
+      taps.s0F[slot - 3u] = s0;
+      taps.numF[slot - 3u] = s0 - s1;
+   }
+   else
+      taps.numV = s0;
+
+   taps.have |= 1u << slot;
+}
+
+NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uint32_t clock0, uint32_t valid, uint32_t w, NfcSearchTaps &taps)
 {
    const uint32_t lane = NFC_WAVE_LANE();
    const uint32_t t = nfc_wave_clock_of(clock0);
@@ -334,11 +367,20 @@ NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLd
    if (c.enabled & 1u)
    {
       if (!(valid & 1u))
-         w = (w & ~1u) | (nfc_wave_gate_a<0>(c, lds, t, env) ? 1u : 0u);
+      {
+         nfc_wave_search_tap(c, lds, taps, 0u);
+         w = (w & ~1u) | (nfc_wave_gate_a<0>(c, lds, t, env, taps.numA[0]) ? 1u : 0u);
+      }
       if (!(valid & 2u))
-         w = (w & ~2u) | (nfc_wave_gate_a<1>(c, lds, t, env) ? 2u : 0u);
+      {
+         nfc_wave_search_tap(c, lds, taps, 1u);
+         w = (w & ~2u) | (nfc_wave_gate_a<1>(c, lds, t, env, taps.numA[1]) ? 2u : 0u);
+      }
       if (!(valid & 4u))
-         w = (w & ~4u) | (nfc_wave_gate_a<2>(c, lds, t, env) ? 4u : 0u);
+      {
+         nfc_wave_search_tap(c, lds, taps, 2u);
+         w = (w & ~4u) | (nfc_wave_gate_a<2>(c, lds, t, env, taps.numA[2]) ? 4u : 0u);
+      }
    }
 
    if (c.enabled & 2u)
@@ -360,13 +402,15 @@ NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLd
       if (!(valid & 32u))
       {
          bool asked, looked;
-         const bool gate = nfc_wave_gate_f<0>(c, lds, t, env, asked, looked);
+         nfc_wave_search_tap(c, lds, taps, 3u);
+         const bool gate = nfc_wave_gate_f<0>(c, lds, t, env, taps.numF[0], asked, looked);
          w = (w & ~0x520u) | (gate ? 0x20u : 0u) | (asked ? 0x100u : 0u) | (looked ? 0x400u : 0u);
       }
       if (!(valid & 64u))
       {
          bool asked, looked;
-         const bool gate = nfc_wave_gate_f<1>(c, lds, t, env, asked, looked);
+         nfc_wave_search_tap(c, lds, taps, 4u);
+         const bool gate = nfc_wave_gate_f<1>(c, lds, t, env, taps.numF[1], asked, looked);
          w = (w & ~0xA40u) | (gate ? 0x40u : 0u) | (asked ? 0x200u : 0u) | (looked ? 0x800u : 0u);
       }
    }
@@ -374,7 +418,10 @@ NFC_DEV uint32_t nfc_wave_search_bits(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLd
    if (c.enabled & 8u)
    {
       if (!(valid & 128u))
-         w = (w & ~128u) | (nfc_wave_gate_v(c, lds, t, env) ? 128u : 0u);
+      {
+         nfc_wave_search_tap(c, lds, taps, 5u);
+         w = (w & ~128u) | (nfc_wave_gate_v(c, lds, t, env, taps.numV) ? 128u : 0u);
+      }
    }
 
    return w;
@@ -928,7 +975,12 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
       /* The detectors' gates are kept per sample while their records stand. A sample only NFC-B detectors still looking
        * for their first or second edge react to is taken in the run: it cannot lock, the records of the two rates are all
        * it touches (nfcb_track), and in a busy signal of the other technologies every pause is a falling edge to them. */
-      bits = nfc_wave_search_bits(c, lds, clock0, formed ? 0u : NFC_WAVE_UNIFORM_U32(lds->u.maskValid), formed ? 0u : lds->gate[lane]);
+      NfcSearchTaps taps;
+      taps.numA[0] = taps.numA[1] = taps.numA[2] = 0.0f;
+      taps.s0F[0] = taps.s0F[1] = taps.numF[0] = taps.numF[1] = taps.numV = 0.0f;
+      taps.have = 0u;
+
+      bits = nfc_wave_search_bits(c, lds, clock0, formed ? 0u : NFC_WAVE_UNIFORM_U32(lds->u.maskValid), formed ? 0u : lds->gate[lane], taps);
       bits = (bits & ~NFC_WAVE_GATE_OTHER) | ((!armed || carrier) ? NFC_WAVE_GATE_OTHER : 0u);
 
       /* Only a sample at which the bank is not armed, or a carrier frame is due, is the step machine's from the start. Where a
@@ -959,6 +1011,29 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
           * in the order the step machine would: the tracker below may reset a record */
          const uint32_t before = (onF0 || onF1) ? nfc_wave_f_marks(lds, bits, marksFrom, g) : 0u;
 
+         /* the correlations at the sample the detectors are shown: what the lane of that sample holds (the taps of the detectors'
+          * correlators formed now if the gates that brought the wave here were kept from an earlier call) */
+         if (c.enabled & 1u)
+         {
+            if (here & 1u)
+               nfc_wave_search_tap(c, lds, taps, 0u);
+            if (here & 2u)
+               nfc_wave_search_tap(c, lds, taps, 1u);
+            if (here & 4u)
+               nfc_wave_search_tap(c, lds, taps, 2u);
+         }
+         if ((c.enabled & 4u) && onF0)
+            nfc_wave_search_tap(c, lds, taps, 3u);
+         if ((c.enabled & 4u) && onF1)
+            nfc_wave_search_tap(c, lds, taps, 4u);
+         if ((c.enabled & 8u) && (here & 128u))
+            nfc_wave_search_tap(c, lds, taps, 5u);
+
+         const float numA0 = NFC_WAVE_SHFL_F(taps.numA[0], g), numA1 = NFC_WAVE_SHFL_F(taps.numA[1], g), numA2 = NFC_WAVE_SHFL_F(taps.numA[2], g);
+         const float s0F0 = NFC_WAVE_SHFL_F(taps.s0F[0], g), s0F1 = NFC_WAVE_SHFL_F(taps.s0F[1], g);
+         const float numF0 = NFC_WAVE_SHFL_F(taps.numF[0], g), numF1 = NFC_WAVE_SHFL_F(taps.numF[1], g);
+         const float numV = NFC_WAVE_SHFL_F(taps.numV, g);
+
          NFC_WAVE_READ_FENCE(); /* (the records are about to change) */
 
          NFC_WAVE_TICK(lds, 10u);
@@ -984,16 +1059,16 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
             {
                const float limit = envAt * c.corrThreshold[0];
 
-#define NFC_WAVE_A_ALONE(R)                                                                                                              \
+#define NFC_WAVE_A_ALONE(R, NUM)                                                                                                         \
                if (!locks && ((here >> R) & 1u))                                                                                         \
                {                                                                                                                         \
                   shown.u.search.detA[R] = *(const NfcDetA *)&lds->u.s.u.search.detA[R];                                                 \
-                  locks = nfca_detect_decide<R>(c, shown, mem, nfc_wave_search_num(c, lds, R, g),                                        \
+                  locks = nfca_detect_decide<R>(c, shown, mem, NUM,                                                                      \
                                                 lds->ring[NFC_R_DEPTH + ((clk - c.a[R].delay - c.a[R].p8) & NFC_FMASK)], limit, c.minDepth[0]); \
                }
-               NFC_WAVE_A_ALONE(0)
-               NFC_WAVE_A_ALONE(1)
-               NFC_WAVE_A_ALONE(2)
+               NFC_WAVE_A_ALONE(0, numA0)
+               NFC_WAVE_A_ALONE(1, numA1)
+               NFC_WAVE_A_ALONE(2, numA2)
 #undef NFC_WAVE_A_ALONE
             }
 
@@ -1033,27 +1108,21 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
 
                if (onF0)
                {
-                  float f0, f1;
-                  nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 3u, g, f0, f1);
                   shown.u.search.detF[0] = *(const NfcDetF *)&lds->u.s.u.search.detF[0];
-                  locks = nfcf_detect_decide<1>(c, shown, mem, f0, f0 - f1, deep, limit);
+                  locks = nfcf_detect_decide<1>(c, shown, mem, s0F0, numF0, deep, limit);
                }
 
                if (!locks && onF1)
                {
-                  float f0, f1;
-                  nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 4u, g, f0, f1);
                   shown.u.search.detF[1] = *(const NfcDetF *)&lds->u.s.u.search.detF[1];
-                  locks = nfcf_detect_decide<2>(c, shown, mem, f0, f0 - f1, deep, limit);
+                  locks = nfcf_detect_decide<2>(c, shown, mem, s0F1, numF1, deep, limit);
                }
             }
 
             if (!locks && (c.enabled & 8u) && ((here >> 7) & 1u))
             {
-               float v0, v1;
-               nfc_wave_s0s1(c, lds, NFC_FK_SEARCH, 5u, g, v0, v1);
                shown.u.search.detV = *(const NfcDetV *)&lds->u.s.u.search.detV;
-               locks = nfcv_detect_decide(c, shown, mem, v0, lds->ring[NFC_R_X + ((clk - c.v.delay) & NFC_HMASK)]);
+               locks = nfcv_detect_decide(c, shown, mem, numV, lds->ring[NFC_R_X + ((clk - c.v.delay) & NFC_HMASK)]);
             }
 
             /* every record that was shown, or none (the step decides about all of them again) */
@@ -1105,11 +1174,11 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
             if (c.enabled & 1u)
             {
                if (here & 1u)
-                  bits = (bits & ~1u) | (nfc_wave_gate_a<0>(c, lds, t, env) ? 1u : 0u);
+                  bits = (bits & ~1u) | (nfc_wave_gate_a<0>(c, lds, t, env, taps.numA[0]) ? 1u : 0u);
                if (here & 2u)
-                  bits = (bits & ~2u) | (nfc_wave_gate_a<1>(c, lds, t, env) ? 2u : 0u);
+                  bits = (bits & ~2u) | (nfc_wave_gate_a<1>(c, lds, t, env, taps.numA[1]) ? 2u : 0u);
                if (here & 4u)
-                  bits = (bits & ~4u) | (nfc_wave_gate_a<2>(c, lds, t, env) ? 4u : 0u);
+                  bits = (bits & ~4u) | (nfc_wave_gate_a<2>(c, lds, t, env, taps.numA[2]) ? 4u : 0u);
             }
             if (c.enabled & 2u)
             {
@@ -1127,17 +1196,17 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
             if ((c.enabled & 4u) && onF0)
             {
                bool asked, looked;
-               const bool gate = nfc_wave_gate_f<0>(c, lds, t, env, asked, looked);
+               const bool gate = nfc_wave_gate_f<0>(c, lds, t, env, taps.numF[0], asked, looked);
                bits = (bits & ~0x520u) | (gate ? 0x20u : 0u) | (asked ? 0x100u : 0u) | (looked ? 0x400u : 0u);
             }
             if ((c.enabled & 4u) && onF1)
             {
                bool asked, looked;
-               const bool gate = nfc_wave_gate_f<1>(c, lds, t, env, asked, looked);
+               const bool gate = nfc_wave_gate_f<1>(c, lds, t, env, taps.numF[1], asked, looked);
                bits = (bits & ~0xA40u) | (gate ? 0x40u : 0u) | (asked ? 0x200u : 0u) | (looked ? 0x800u : 0u);
             }
             if ((c.enabled & 8u) && (here & 128u))
-               bits = (bits & ~128u) | (nfc_wave_gate_v(c, lds, t, env) ? 128u : 0u);
+               bits = (bits & ~128u) | (nfc_wave_gate_v(c, lds, t, env, taps.numV) ? 128u : 0u);
          }
 
          if (onF0 || onF1)

@@ -51,11 +51,6 @@ __global__ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, flo
 __global__ void nfc_scan_planes_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A);
 __global__ void nfc_wave_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode);
-#ifdef NFCGPU_EMULATED_TEST_BUILD
-#define nfc_wave_lone_kernel nfc_wave_kernel /* (one twin on the CPU: the two device builds are the same text) */
-#else
-__global__ void nfc_wave_lone_kernel(const NfcConfig *__restrict__ cfgPtr, NfcLaunch L, NfcScanArgs A, uint32_t mode);
-#endif
 __global__ void nfc_planes_stale_kernel(NfcScanArgs A, const NfcScanChunk *all, uint32_t nAll, NfcScanChunk *out, uint32_t *count);
 
 namespace {
@@ -178,11 +173,13 @@ struct nfcgpu_ctx
    uint32_t cutMax = 1u << 19;      /* ... but never further apart than this (NFCGPU_CUT_MAX). Round 5: 2^19 instead of 2^17 - config 5 at 2^17, 2^18,
                                        2^19, 2^20: 458, 456, 452, 452 ms per step (three runs each at 2^17 and 2^19: +-1 ms); 2^16: 500, 2^15: 555. Most
                                        lanes begin after quiet signal, not at a cut; the fewer cuts, the fewer guesses */
-   uint32_t loneLanes = 1024u;     /* a launch of the wave decoder with at most this many lanes of work runs the build for one wave per SIMD (nfc_wave_lone.hip:
-                                       no scratch memory on the critical path of a wavefront that has its SIMD to itself; NFCGPU_LONE_LANES, 0: never) */
    uint32_t stagingWords = 0;       /* NFCGPU_STAGING_WORDS: cap on the lanes' staging sink (0: none) */
-   uint32_t soloSamples = 1u << 16; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES). Round 4: 2^18 -> 2^16,
-                                       the lanes being what they now are: the bundled captures of 100 k - 200 k samples 25 / 39 / 49 -> 17 / 27 / 37 ms */
+   uint32_t soloSamples = 1u << 15; /* streams this short are decoded by their carry lane alone, in one pass (NFCGPU_SOLO_SAMPLES). Round 4: 2^18 -> 2^16,
+                                       the lanes being what they now are: the bundled captures of 100 k - 200 k samples 25 / 39 / 49 -> 17 / 27 / 37 ms.
+                                       Round 6: 2^16 -> 2^15. A 65536-sample buffer is what the reference's task hands the decoder per call
+                                       (TS/main.cpp:163-165, RadioDecoderTask.cpp:377-401), and a lane without windows can retire to nobody: it walked
+                                       all 1024 tiles of a buffer with nothing in it (7 ms). The task on the shim in its default mode, dense / sparse
+                                       WAV: 4.9 / 6.4 -> 8.3 / 15.1 MS/s (profiles/r06/shim_default_mode.txt) */
    DevBuf wPlanes, wPlaneChunks;   /* front-end planes (NfcScanArgs::planes) and the chunk list of the walk that writes them */
    DevBuf wRepairsEnv;             /* the chunks of a round whose envelope tracker alone is walked again (nfc_envelope_kernel) */
    uint32_t envelopeMax = 16384;   /* ... when the round lists at most this many of them (NFCGPU_ENVELOPE_KERNEL; 0: never, one list for the scan kernel).
@@ -1336,10 +1333,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       ProfiledLaunch wl {nullptr, nullptr};
       record_span(ctx, ctx->timedWave, wl, true, on);
-      if (slotCount <= ctx->loneLanes)
-         hipLaunchKernelGGL(nfc_wave_lone_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u);
-      else
-         hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
+      hipLaunchKernelGGL(nfc_wave_kernel, dim3(slotCount), dim3(NFC_LANES), 0, on, dCfg, L, A, carry ? 0u : 2u); /* a wave per lane */
       record_span(ctx, ctx->timedWave, wl, false, on);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
@@ -1354,10 +1348,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       ProfiledLaunch wl {nullptr, nullptr};
       record_span(ctx, ctx->timedWave, wl, true);
-      if (runLanes <= ctx->loneLanes)
-         hipLaunchKernelGGL(nfc_wave_lone_kernel, dim3(runLanes), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u);
-      else
-         hipLaunchKernelGGL(nfc_wave_kernel, dim3(runLanes), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
+      hipLaunchKernelGGL(nfc_wave_kernel, dim3(runLanes), dim3(NFC_LANES), 0, ctx->stream, dCfg, L, A, 1u); /* a wave per run-list entry */
       record_span(ctx, ctx->timedWave, wl, false);
       HIP_TRY(ctx, hipGetLastError());
       ctx->stats.launches++;
@@ -1421,7 +1412,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       }
 
       /* how many lanes the list holds: the later passes of a submission list a few thousand, then a few dozen, of its windows -
-       * launches of that size go to the wave decoder's build for few lanes (nfc_wave_lone.hip), with a grid of the list's length */
+       * the launch gets a grid of the list's length, not of the submission's window count */
       uint32_t runLanes = 0;
       if (nWindows)
       {
@@ -2114,7 +2105,6 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    ctx->planesBeside = knob("NFCGPU_PLANES_BESIDE", ctx->planesBeside);
    ctx->planesBesidePiece = knob("NFCGPU_PLANES_BESIDE_PIECE", ctx->planesBesidePiece);
    ctx->cutMax = knob("NFCGPU_CUT_MAX", ctx->cutMax);
-   ctx->loneLanes = knob("NFCGPU_LONE_LANES", ctx->loneLanes);
    if (ctx->cutMax < NFC_WINDOW_CUT)
       ctx->cutMax = NFC_WINDOW_CUT;
    ctx->sideMode = knob("NFCGPU_SIDE_STREAM", ctx->sideMode);
@@ -3051,6 +3041,7 @@ int nfcgpu_comm_destroy(nfcgpu_ctx *ctx)
 
    if (ctx->comm && r)
    {
+      (void)hipSetDevice(ctx->device);
       (void)hipStreamSynchronize(ctx->stream);
       (void)r->commDestroy(ctx->comm);
    }

@@ -97,6 +97,7 @@ static void emu_carry_debug(const NfcCarry &a, const NfcCarry &b, bool meeting, 
 namespace fakehip {
 dim3 launchGrid, launchBlock;
 std::recursive_mutex launchMutex;
+thread_local int currentDevice = -1;
 }
 
 /* NFC_EMU_CARRY_TALLY=1: which part of an assumption was wrong where nfc_carry_same fails (printed when the library is unloaded) */
@@ -1041,4 +1042,10 @@ void nfc_read_kernel(const float4 *__restrict__ data, uint64_t n, float *__restr
       acc += data[i].x;
    if (acc == 12345.678f)
       out[0] = acc;
+}
+
+/* (test hook: the device the calling thread's last C-ABI call left current) */
+extern "C" int nfcgpu_emulated_current_device()
+{
+   return fakehip::currentDevice;
 }

@@ -60,6 +60,176 @@ size_t width(int type)
 
 }
 
+/* ---- NFCGPU_FAKE_RCCL=shm (round 6): the ranks are PROCESSES, as they are under torch.distributed.run ----
+ * The world is a POSIX shared-memory object named by the unique id: a header with a sense-reversing barrier on atomics and one
+ * slot per rank through which a collective's bytes travel (pointers mean nothing across processes). Whoever joins first creates
+ * it, the last to leave unlinks it. tests/test_bench_multi_rank_dry.py runs `bench.py --gpus 8` on it with eight processes. */
+#include <atomic>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+constexpr int kShmMaxRanks = 16;
+constexpr size_t kShmSlot = 8u << 20;
+
+struct ShmHeader
+{
+   std::atomic<uint32_t> ready;   /* 1 once n has been set by the creator */
+   std::atomic<uint32_t> arrived;
+   std::atomic<uint32_t> generation;
+   std::atomic<uint32_t> attached;
+   uint32_t n;
+   uint32_t pad[11];
+};
+
+struct ShmComm
+{
+   ShmHeader *h;
+   char *slots;
+   size_t bytes;
+   int rank;
+   char name[64];
+};
+
+bool shm_mode()
+{
+   const char *v = std::getenv("NFCGPU_FAKE_RCCL");
+   return v && std::strcmp(v, "shm") == 0;
+}
+
+void shm_rendezvous(ShmHeader *h)
+{
+   const uint32_t mine = h->generation.load(std::memory_order_acquire);
+
+   if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == h->n)
+   {
+      h->arrived.store(0, std::memory_order_relaxed);
+      h->generation.fetch_add(1, std::memory_order_acq_rel);
+   }
+   else
+   {
+      /* (ranks may outnumber the processors: yield, then sleep) */
+      for (uint32_t spins = 0; h->generation.load(std::memory_order_acquire) == mine; spins++)
+      {
+         if (spins < 64)
+            sched_yield();
+         else
+            usleep(200);
+      }
+   }
+}
+
+int shm_init(void **comm, int nRanks, uint64_t key, int rank)
+{
+   if (nRanks < 1 || nRanks > kShmMaxRanks || rank < 0 || rank >= nRanks)
+      return 1;
+
+   ShmComm *c = new ShmComm();
+   std::snprintf(c->name, sizeof(c->name), "/nfcfake_%016llx", (unsigned long long)key);
+   c->bytes = sizeof(ShmHeader) + (size_t)kShmMaxRanks * kShmSlot;
+   c->rank = rank;
+
+   bool creator = true;
+   int fd = shm_open(c->name, O_RDWR | O_CREAT | O_EXCL, 0600);
+   if (fd < 0 && errno == EEXIST)
+   {
+      creator = false;
+      fd = shm_open(c->name, O_RDWR, 0600);
+   }
+   if (fd < 0)
+   {
+      delete c;
+      return 1;
+   }
+   if (creator && ftruncate(fd, (off_t)c->bytes) != 0)
+   {
+      close(fd);
+      shm_unlink(c->name);
+      delete c;
+      return 1;
+   }
+   if (!creator)
+   {
+      /* (the creator may not have sized it yet) */
+      struct stat st;
+      for (int tries = 0; tries < 20000; tries++)
+      {
+         if (fstat(fd, &st) == 0 && (size_t)st.st_size >= c->bytes)
+            break;
+         usleep(500);
+      }
+   }
+
+   void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+   close(fd);
+   if (p == MAP_FAILED)
+   {
+      delete c;
+      return 1;
+   }
+
+   c->h = (ShmHeader *)p;
+   c->slots = (char *)p + sizeof(ShmHeader);
+
+   if (creator)
+   {
+      c->h->n = (uint32_t)nRanks;
+      c->h->ready.store(1, std::memory_order_release);
+   }
+   else
+   {
+      while (c->h->ready.load(std::memory_order_acquire) == 0)
+         usleep(200);
+      if (c->h->n != (uint32_t)nRanks)
+      {
+         munmap(p, c->bytes);
+         delete c;
+         return 1;
+      }
+   }
+
+   c->h->attached.fetch_add(1, std::memory_order_acq_rel);
+   *comm = c;
+   shm_rendezvous(c->h); /* like the real call: returns once every rank has joined */
+   return 0;
+}
+
+/* moves `bytes` from every rank (or from `root` only) through the slots, a slot's worth at a time */
+void shm_exchange(ShmComm *c, const void *send, void *recv, size_t bytes, int root)
+{
+   const uint32_t n = c->h->n;
+
+   for (size_t done = 0; done < bytes || (bytes == 0 && done == 0); done += kShmSlot)
+   {
+      const size_t part = bytes - done < kShmSlot ? bytes - done : kShmSlot;
+
+      if (root < 0 || c->rank == root)
+         std::memcpy(c->slots + (size_t)c->rank * kShmSlot, (const char *)send + done, part);
+      shm_rendezvous(c->h);
+      if (root < 0)
+      {
+         for (uint32_t i = 0; i < n; i++)
+            std::memcpy((char *)recv + (size_t)i * bytes + done, c->slots + (size_t)i * kShmSlot, part);
+      }
+      else
+         std::memcpy((char *)recv + done, c->slots + (size_t)root * kShmSlot, part);
+      shm_rendezvous(c->h);
+
+      if (bytes == 0)
+         break;
+   }
+}
+
+}
+
 extern "C" {
 
 struct FakeNcclId
@@ -69,6 +239,17 @@ struct FakeNcclId
 
 int fake_ncclGetUniqueId(void *id)
 {
+   if (shm_mode())
+   {
+      std::memset(id, 0, 128);
+      struct timespec ts;
+      clock_gettime(CLOCK_REALTIME, &ts);
+      static std::atomic<uint32_t> serial {0};
+      const uint64_t v = ((uint64_t)getpid() << 40) ^ ((uint64_t)ts.tv_sec << 20) ^ (uint64_t)ts.tv_nsec ^ ((uint64_t)serial.fetch_add(1) << 56) ^ 0x5a5a000000000001ull;
+      std::memcpy(id, &v, 8);
+      return 0;
+   }
+
    std::lock_guard<std::mutex> lock(registryMutex);
    std::memset(id, 0, 128);
    const uint64_t v = nextId++;
@@ -80,6 +261,9 @@ int fake_ncclCommInitRank(void **comm, int nRanks, FakeNcclId id, int rank)
 {
    uint64_t key = 0;
    std::memcpy(&key, id.internal, 8);
+
+   if (shm_mode())
+      return shm_init(comm, nRanks, key, rank);
 
    std::shared_ptr<World> world;
    {
@@ -104,12 +288,29 @@ int fake_ncclCommInitRank(void **comm, int nRanks, FakeNcclId id, int rank)
 
 int fake_ncclCommDestroy(void *comm)
 {
+   if (shm_mode())
+   {
+      ShmComm *c = (ShmComm *)comm;
+      const bool last = c->h->attached.fetch_sub(1, std::memory_order_acq_rel) == 1;
+      munmap((void *)c->h, c->bytes);
+      if (last)
+         shm_unlink(c->name);
+      delete c;
+      return 0;
+   }
+
    delete (Comm *)comm;
    return 0;
 }
 
 int fake_ncclAllGather(const void *send, void *recv, size_t count, int type, void *comm, void *)
 {
+   if (shm_mode())
+   {
+      shm_exchange((ShmComm *)comm, send, recv, count * width(type), -1);
+      return 0;
+   }
+
    Comm *c = (Comm *)comm;
    World &w = *c->world;
    const size_t bytes = count * width(type);
@@ -124,6 +325,12 @@ int fake_ncclAllGather(const void *send, void *recv, size_t count, int type, voi
 
 int fake_ncclBroadcast(const void *send, void *recv, size_t count, int type, int root, void *comm, void *)
 {
+   if (shm_mode())
+   {
+      shm_exchange((ShmComm *)comm, send, recv, count * width(type), root);
+      return 0;
+   }
+
    Comm *c = (Comm *)comm;
    World &w = *c->world;
 

@@ -50,12 +50,21 @@ extern dim3 launchGrid, launchBlock;
 /* the CPU twins keep their working storage in statics (one wave's LDS, the fibres of a wave): one launch at a time,
  * whatever host thread it comes from (the shards of nfcgpu.hip launch from threads of their own) */
 extern std::recursive_mutex launchMutex;
+/* the device the calling thread last made current (hipSetDevice): every entry point of the C ABI has to set its context's own
+ * before it touches the runtime - a host with a context per GPU calls them in any order (tests/test_bench_multi_rank_dry.py) */
+extern thread_local int currentDevice;
 }
 
 static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *count) { *count = 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+/* (NFCGPU_FAKE_DEVICES: how many devices the stand-in shows - a rehearsal of one process per GPU asks for device LOCAL_RANK) */
+static inline hipError_t hipGetDeviceCount(int *count)
+{
+   const char *v = std::getenv("NFCGPU_FAKE_DEVICES");
+   *count = v && v[0] ? std::atoi(v) : 1;
+   return hipSuccess;
+}
+static inline hipError_t hipSetDevice(int device) { fakehip::currentDevice = device; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)std::malloc(1); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)std::malloc(1); return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }

@@ -65,10 +65,11 @@ def test_stepping_alone_decodes_the_same_frames(emulated):
 
 @needs_reference
 def test_short_streams_are_decoded_by_their_carry_lane_alone(emulated):
-    """the default (NFCGPU_SOLO_SAMPLES = 2^16 since round 4, 2^18 before): a stream of up to 2^16 samples gets no speculative
-    windows - one lane, one pass; a longer one does (every bundled capture is longer: the short ones are their first samples)"""
+    """the default (NFCGPU_SOLO_SAMPLES = 2^15 since round 6, 2^16 in rounds 4-5, 2^18 before): a stream of up to 2^15 samples gets no
+    speculative windows - one lane, one pass; a longer one does (every bundled capture is longer: the short ones are their first
+    samples) - the 65536-sample buffers of the reference's task among them"""
     env = dict(os.environ, NFCGPU_LIB=EMU, NFCGPU_NO_TORCH="1", NFCGPU_WINDOWED_MIN="4096")
-    run = subprocess.run([sys.executable, DRIVER, "fixture:test_NFC-A_106kbps_002@61000", "fixture:test_NFC-B_106kbps_001@65536", "fixture:test_NFC-A_106kbps_002"],
+    run = subprocess.run([sys.executable, DRIVER, "fixture:test_NFC-A_106kbps_002@30000", "fixture:test_NFC-B_106kbps_001@32768", "fixture:test_NFC-A_106kbps_002@65536"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
     results = json.loads(run.stdout.strip().splitlines()[-1])
