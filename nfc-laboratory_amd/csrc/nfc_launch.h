@@ -39,7 +39,8 @@ struct NfcLaunch
    uint32_t warmCorr;   /* ... then samples that also keep the search correlators up, before the decoder goes live */
    struct NfcWindow *windows; /* windowed launches: per-slot records (stop / retired are written back) */
    const struct NfcScanJob *jobs; /* windowed launches: the submission's streams */
-   uint32_t *laneStats; /* windowed launches: [0] tiles stepped by all lanes, [1] most tiles stepped by one lane, [2] lanes run */
+   uint32_t *laneStats; /* windowed launches: [0] samples stepped one by one by all lanes (in tiles' worth), [1] most by one lane, [2] lanes run,
+                           [6] tiles the lanes took (what a pass decodes) */
    uint32_t launchSeq;  /* non-zero, distinct for every demodulation launch of a context (see NfcStreamState::served) */
    uint32_t forceExact; /* the host launches only the exact-modulo kernel: it takes every block, whatever the clocks say */
 };

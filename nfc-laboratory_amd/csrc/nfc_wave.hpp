@@ -1246,6 +1246,7 @@ NFC_DEV void nfc_wave_run(const NfcConfig *cfgPtr, const NfcConfig &cc, const Nf
       NFC_WAVE_STAT_ADD(L.laneStats, tilesStepped);
       NFC_WAVE_STAT_MAX(L.laneStats + 1, tilesStepped);
       NFC_WAVE_STAT_ADD(L.laneStats + 2, 1u);
+      NFC_WAVE_STAT_ADD(L.laneStats + 6, (consumed + NFC_SCAN_TILE - 1u) / NFC_SCAN_TILE); /* tiles the lane took (warm-up and jumped dark tiles included) */
 
 #ifdef NFC_WAVE_PROFILE
       NFC_WAVE_TICK(lds, 7u);

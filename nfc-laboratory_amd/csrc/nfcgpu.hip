@@ -1478,9 +1478,11 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
       if (debugPasses)
       {
-         uint32_t ls[3] = {0, 0, 0};
+         uint32_t ls[3] = {0, 0, 0}, tilesTaken = 0;
          HIP_TRY(ctx, hipMemcpy(ls, counters + 4, 12, hipMemcpyDeviceToHost));
+         HIP_TRY(ctx, hipMemcpy(&tilesTaken, counters + 10, 4, hipMemcpyDeviceToHost));
          HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, 12, ctx->stream));
+         HIP_TRY(ctx, hipMemsetAsync(counters + 10, 0, 4, ctx->stream));
          HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
          const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - passBegan).count();
          {
@@ -1595,7 +1597,9 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
                }
             }
          }
-         std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled, %.1f ms\n", pass, ls[2],
+         /* (lane-steps: samples handled one by one by the step machine; tiles: what the lanes took in all, warm-ups included) */
+         std::fprintf(stderr, "[nfcgpu] windowed pass %u: %u lanes, %u tiles of %llu (%.1f tiles per us), %llu lane-steps (%.2f per sample), longest lane %u steps, %u streams unsettled, %.1f ms\n",
+                      pass, ls[2], tilesTaken, (unsigned long long)((totalSamples + NFC_SCAN_TILE - 1) / NFC_SCAN_TILE), ms > 0.0 ? (double)tilesTaken / (ms * 1000.0) : 0.0,
                       (unsigned long long)ls[0] * NFC_SCAN_TILE, (double)ls[0] * NFC_SCAN_TILE / (double)totalSamples, ls[1] * NFC_SCAN_TILE, again, ms);
       }
 
@@ -2079,15 +2083,25 @@ int nfcgpu_init(int device, const nfcgpu_options *options, nfcgpu_ctx **out)
    const char *generic = std::getenv("NFCGPU_GENERIC_KERNELS");
    ctx->genericOnly = generic && generic[0] == '1';
 
-   /* knobs of the time-parallel path (testing and tuning; the defaults are what DESIGN.md describes) */
-   auto knob = [](const char *name, uint32_t fallback) -> uint32_t {
-      const char *v = std::getenv(name);
+   /* Tuning switches of the time-parallel path. They are experiment switches, not configuration (round 6: the product library
+    * used to read all nineteen from the environment): libnfcgpu.so runs on the defaults of nfcgpu_ctx and does not look at them.
+    * A build of this file with -DNFCGPU_TUNING_KNOBS (`make tuning`: libnfcgpu_tuning.so, the same kernels; and the emulated test
+    * build) takes them from the environment - what the tests use to force every path on small inputs and what the sweeps under
+    * profiles/ were made with. What the product reads: NFCGPU_WINDOW_DEBUG (stage log on stderr), NFCGPU_GENERIC_KERNELS (the
+    * any-rate kernels at the compiled-in rate too) and, in the shim, NFCGPU_DEVICE / NFCGPU_MAX_STREAMS / NFCGPU_SHIM_BLOCK(_MS). */
+#if defined(NFCGPU_TUNING_KNOBS) || defined(NFCGPU_EMULATED_TEST_BUILD)
+   auto tuning = [](const char *name) -> const char * { return std::getenv(name); };
+#else
+   auto tuning = [](const char *) -> const char * { return nullptr; };
+#endif
+   auto knob = [&](const char *name, uint32_t fallback) -> uint32_t {
+      const char *v = tuning(name);
       return v && v[0] ? (uint32_t)std::strtoul(v, nullptr, 10) : fallback;
    };
 
    ctx->windowed = knob("NFCGPU_WINDOWED", 1) != 0;
    ctx->windowedMinSamples = knob("NFCGPU_WINDOWED_MIN", ctx->windowedMinSamples);
-   ctx->scanChunkFixed = std::getenv("NFCGPU_SCAN_CHUNK") != nullptr && std::getenv("NFCGPU_SCAN_CHUNK")[0] != 0;
+   ctx->scanChunkFixed = tuning("NFCGPU_SCAN_CHUNK") != nullptr && tuning("NFCGPU_SCAN_CHUNK")[0] != 0;
    ctx->scanChunk = knob("NFCGPU_SCAN_CHUNK", ctx->scanChunk) / NFC_SCAN_POINT * NFC_SCAN_POINT;
    ctx->scanLanes = knob("NFCGPU_SCAN_LANES", ctx->scanLanes);
    if (ctx->scanLanes == 0u)

@@ -79,3 +79,23 @@ def test_decoder_shim_refuses_loudly_without_gpu(built, tmp_path):
     assert run.returncode != 0
     assert "PASS" not in run.stdout
     assert "no usable HIP device" in run.stdout
+
+
+def _env_names(path):
+    data = open(path, "rb").read()
+    return sorted(set(m.decode() for m in re.findall(rb"NFCGPU_[A-Z][A-Z_]+(?=\x00)", data)))
+
+
+def test_product_library_reads_no_tuning_switches(built):
+    """the tuning switches of the time-parallel path are experiment switches. The product library knows three
+    diagnostic variables and nothing else (the shim's own - device, stream count, block mode - are in host/NfcDecoder.cpp); the
+    tuning build of the same kernels (`make tuning`: libnfcgpu_tuning.so, what the tests force paths with) reads the rest."""
+    pkg = os.path.join(T.ROOT, "nfc-laboratory_amd")
+    product = [n for n in _env_names(os.path.join(pkg, "libnfcgpu.so")) if not n.startswith("NFCGPU_E") and n != "NFCGPU_OK"]
+    assert product == ["NFCGPU_GENERIC_KERNELS", "NFCGPU_WAVE_VERIFY_REPORT", "NFCGPU_WINDOW_DEBUG"], product
+    tuning = _env_names(os.path.join(pkg, "libnfcgpu_tuning.so"))
+    for name in ("NFCGPU_WINDOWED", "NFCGPU_WINDOWED_MIN", "NFCGPU_SCAN_CHUNK", "NFCGPU_SCAN_LANES", "NFCGPU_SOLO_SAMPLES", "NFCGPU_CUT_MAX", "NFCGPU_PLANES_BESIDE"):
+        assert name in tuning, (name, tuning)
+    lib = ctypes.CDLL(os.path.join(pkg, "libnfcgpu_tuning.so"))
+    for name in declared_functions():
+        assert hasattr(lib, name), name

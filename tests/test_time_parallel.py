@@ -14,6 +14,7 @@ import nfc_testlib as T
 
 DRIVER = os.path.join(T.ROOT, "tests", "time_parallel_driver.py")
 EMU = os.path.join(T.ROOT, "tests", "hostsim", "libnfcgpu_emulated.so")
+TUNING = os.path.join(T.ROOT, "nfc-laboratory_amd", "libnfcgpu_tuning.so")
 
 needs_reference = pytest.mark.skipif(T.reference_lib() is None, reason="oracle/_ref not built")
 
@@ -25,6 +26,9 @@ def _run(cases, emulated, extra=None):
     if emulated:
         env["NFCGPU_LIB"] = EMU
         env["NFCGPU_NO_TORCH"] = "1"
+    else:
+        # (the product library does not read the tuning switches: the same kernels behind a host runtime that does - `make tuning`)
+        env["NFCGPU_LIB"] = TUNING
     env.update(extra or {})
     run = subprocess.run([sys.executable, DRIVER] + cases, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
     assert run.returncode == 0, run.stderr[-3000:]
