@@ -83,7 +83,8 @@ def main():
     by_kernel = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "dispatches": 0})
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for (_, k, g, n, v) in counters(os.path.join(out, "pmc_" + c)):
-            if n != c or not k.startswith("nfc_"):
+            # (nfc_read_kernel is bench.py's bandwidth probe, nfc_init_kernel the opening of the streams: neither is part of a step)
+            if n != c or not k.startswith("nfc_") or k in ("nfc_read_kernel", "nfc_init_kernel"):
                 continue
             by_kernel[k][c] += v
             if c == "FETCH_SIZE":
