@@ -246,12 +246,11 @@ NFC_DEV bool nfc_wave_gate_a(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, u
    return timeout || (t >= m.winStart && (moves || t == m.winEnd));
 }
 
-/* (the record `m` given: the bulk path steps this detector on its own, nfc_wave_fast) */
+/* (the record `m` given: the bulk path steps this detector on its own, nfc_wave_fast; edge / deep: the DC-removed signal and
+ * the modulation depth at the detector's decode point of this lane's sample) */
 template <int I>
-NFC_DEV bool nfc_wave_gate_b(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, const NfcDetB &m, uint32_t t, float env)
+NFC_DEV bool nfc_wave_gate_b_at(const NfcConfig &c, const NfcDetB &m, uint32_t t, float env, float edge, float deep)
 {
-   const uint32_t slot = (t - c.b[I].delay) & NFC_FMASK;
-   const float edge = lds->ring[NFC_R_FILT + slot], deep = lds->ring[NFC_R_DEPTH + slot];
    const bool clear = (m.symStart | m.symEnd | m.winStart | m.winEnd | m.auxTime | nfc_bits(m.aux)) == 0u;
    const bool reset = (deep > c.maxDepth[1] || (m.auxTime && t > m.auxTime + c.b[I].p1)) && !clear;
    bool hit;
@@ -264,6 +263,13 @@ NFC_DEV bool nfc_wave_gate_b(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, c
       hit = t < m.winStart ? edge < -m.thr : ((edge < -m.thr && m.aux > edge) || t == m.winEnd);
 
    return reset || hit;
+}
+
+template <int I>
+NFC_DEV bool nfc_wave_gate_b(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, const NfcDetB &m, uint32_t t, float env)
+{
+   const uint32_t slot = (t - c.b[I].delay) & NFC_FMASK;
+   return nfc_wave_gate_b_at<I>(c, m, t, env, lds->ring[NFC_R_FILT + slot], lds->ring[NFC_R_DEPTH + slot]);
 }
 
 /* asked: the detector is told to reset; on a clear record that only leaves its mark (folded into the commit).
@@ -995,6 +1001,21 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
       uint64_t soft = NFC_WAVE_BALLOT((bits & 0xFFu) != 0u) & range;
       uint32_t at = from, g = n;
 
+      /* The NFC-B detectors alone (round 6). In a busy signal of the other technologies every pause is a falling edge to them -
+       * two or three samples of a new minimum, the end of the window a quarter symbol later, the rising edge that clears the
+       * record again: three samples in five at which the wave is brought to a record are theirs, two in five theirs alone -, and
+       * all they touch is their own record of seven words (nfcb_track). For those samples the two records are kept in registers
+       * from the first such sample of the call on, with what every lane's sample shows the detectors (the DC-removed signal and
+       * the modulation depth at their decode points): the tracker - the decoder's own function - runs on the registers, the
+       * gates of the rest of the tile are evaluated from them, the record goes back to the shared state without anybody
+       * waiting for it. A visit used to be three round trips to LDS (the record, the two ring entries, the record again for
+       * the gates) and the copying of a state for the detector to be shown. */
+      bool heldB = false; /* (uniform: the registers below hold the records as they stand) */
+      NfcDetB recB0, recB1;
+      float edgeB0 = 0.0f, deepB0 = 0.0f, edgeB1 = 0.0f, deepB1 = 0.0f;
+      __builtin_memset(&recB0, 0, sizeof(recB0));
+      __builtin_memset(&recB1, 0, sizeof(recB1));
+
       for (;;)
       {
          const uint64_t rest = at < 64u ? (hard | soft) >> at : 0ull;
@@ -1005,6 +1026,76 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
             break;
 
          const uint32_t here = NFC_WAVE_PICK_U32(bits, lds->gate, g);
+
+#ifndef NFC_WAVE_NO_B_ALONE
+         if ((here & 0xE7u) == 0u && (c.enabled & 2u))
+         {
+            if (!heldB)
+            {
+               const uint32_t slot0 = (t - c.b[0].delay) & NFC_FMASK, slot1 = (t - c.b[1].delay) & NFC_FMASK;
+
+               recB0 = *(const NfcDetB *)&lds->u.s.u.search.detB[0];
+               recB1 = *(const NfcDetB *)&lds->u.s.u.search.detB[1];
+               edgeB0 = lds->ring[NFC_R_FILT + slot0];
+               deepB0 = lds->ring[NFC_R_DEPTH + slot0];
+               edgeB1 = lds->ring[NFC_R_FILT + slot1];
+               deepB1 = lds->ring[NFC_R_DEPTH + slot1];
+               heldB = true;
+            }
+
+            const uint32_t clk = clock0 + 1u + g;
+            const float envAt = NFC_WAVE_SHFL_F(env, g);
+            const float e0 = NFC_WAVE_SHFL_F(edgeB0, g), d0 = NFC_WAVE_SHFL_F(deepB0, g);
+            const float e1 = NFC_WAVE_SHFL_F(edgeB1, g), d1 = NFC_WAVE_SHFL_F(deepB1, g);
+
+            /* (the order of nfcb_detect: the second rate is not asked when the first has left the loop of the rates) */
+            NfcDetB new0 = recB0, new1 = recB1;
+            int r0 = 0, r1 = 0;
+
+            if (here & 8u)
+               r0 = nfcb_track<0>(c, new0, clk, envAt, e0, d0);
+            if (r0 == 0 && (here & 16u))
+               r1 = nfcb_track<1>(c, new1, clk, envAt, e1, d1);
+
+            if (r0 == 1 || r1 == 1)
+               break; /* a start of frame: the sample is the search step's (nothing has been moved) */
+
+            NFC_WAVE_READ_FENCE(); /* (the records are about to change) */
+
+            recB0 = new0;
+            recB1 = new1;
+
+            NFC_WAVE_UNIFORM_BEGIN
+            {
+               if (here & 8u)
+                  *(NfcDetB *)&lds->u.s.u.search.detB[0] = new0;
+               if (r0 == 0 && (here & 16u))
+                  *(NfcDetB *)&lds->u.s.u.search.detB[1] = new1;
+            }
+            NFC_WAVE_UNIFORM_END
+
+            NFC_WAVE_COUNT(44u, 0u, 1u); /* detectors shown their records in place */
+#ifdef NFC_WAVE_COUNT_VISITS
+            NFC_WAVE_COUNT(59u, 0u, 1u); /* NFC-B only */
+#endif
+
+            if (lane > g)
+            {
+               if (here & 8u)
+                  bits = (bits & ~8u) | (nfc_wave_gate_b_at<0>(c, recB0, t, env, edgeB0, deepB0) ? 8u : 0u);
+               if (here & 16u)
+                  bits = (bits & ~16u) | (nfc_wave_gate_b_at<1>(c, recB1, t, env, edgeB1, deepB1) ? 16u : 0u);
+            }
+
+            soft = NFC_WAVE_BALLOT((bits & 0xFFu) != 0u) & range;
+            at = g + 1u;
+            continue;
+         }
+
+         /* (the visit below may move the NFC-B records where they lie) */
+         if (here & 0x18u)
+            heldB = false;
+#endif
          const bool onF0 = (here & 0x20u) != 0u, onF1 = (here & 0x40u) != 0u;
 
          /* the marks of the samples before it (NFC-F: what its detectors leave where nothing else happens) are left first,
@@ -1080,6 +1171,9 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
                if ((here >> 3) & 1u)
                {
                   shown.u.search.detB[0] = *(const NfcDetB *)&lds->u.s.u.search.detB[0];
+#ifdef NFC_WAVE_COUNT_B
+                  NFC_WAVE_COUNT_B(c, shown.u.search.detB[0], 0, clk, envAt, lds->ring[NFC_R_FILT + slot0], lds->ring[NFC_R_DEPTH + slot0]);
+#endif
                   r0 = nfcb_detect_decide<0>(c, shown, mem, lds->ring[NFC_R_FILT + slot0], lds->ring[NFC_R_DEPTH + slot0]);
                }
 
@@ -1166,6 +1260,9 @@ NFC_DEV bool nfc_wave_fast(const NfcConfig &c, NFC_WAVE_LDS NfcWaveLds *lds, uin
                NFC_WAVE_COUNT(51u + kk, 0u, 1u);
          if ((here & 0xFFu & ~0x18u) == 0u)
             NFC_WAVE_COUNT(59u, 0u, 1u); /* NFC-B only */
+#ifdef NFC_WAVE_COUNT_RUN
+         NFC_WAVE_COUNT_RUN(clock0 + 1u + g, here & 0xFFu);
+#endif
 #endif
 
          /* their gates over the rest of the tile, for the records as they now stand */

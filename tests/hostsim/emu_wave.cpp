@@ -115,6 +115,20 @@ static bool emu_counting = true;
 static uint32_t emu_trace_clock;
 #define NFC_WAVE_COUNT_DETECTORS(b) do { emu_wave_counts[32 + (b)][0]++; if (std::getenv("NFC_EMU_TRACE_SEARCH")) std::fprintf(stderr, "[trace] %u %u\n", clock0 + 1u + from, (unsigned)(b)); } while (0)
 #define NFC_WAVE_COUNT_NOT_TAKEN(key, grid) do { if (wavesim::lane() == 0 && std::getenv("NFC_EMU_TRACE_NOT_TAKEN")) std::fprintf(stderr, "[not taken] key %u grid %d clock %u\n", (unsigned)(key), (int)(grid), clock0 + 1u + from); } while (0)
+/* (diagnostic, -DNFC_WAVE_COUNT_VISITS: what brings the wave to the NFC-B 106k detector's record) */
+extern uint64_t emu_b_counts[16];
+#define NFC_WAVE_COUNT_B(c, m, I, clk, env, edge, deep) do { if (wavesim::lane() == 0 && emu_counting) { \
+   const bool reset_ = (deep) > (c).maxDepth[1] || ((m).auxTime && (clk) > (m).auxTime + (c).b[I].p1); \
+   const int stage_ = !(m).symStart ? 0 : (!(m).symEnd ? 1 : 2); \
+   int why_ = reset_ ? 0 : ((clk) == (m).winEnd ? 1 : (stage_ && (clk) < (m).winStart ? 2 : 3)); \
+   emu_b_counts[stage_ * 4 + why_]++; } } while (0)
+/* (diagnostic, -DNFC_WAVE_COUNT_VISITS: visits of one detector alone at consecutive samples) */
+static uint32_t emu_run_clock, emu_run_here;
+extern uint64_t emu_run_counts[9][2];
+uint64_t emu_b_counts[16];
+#define NFC_WAVE_COUNT_RUN(clk, here) do { if (wavesim::lane() == 0 && emu_counting) { const uint32_t h_ = (here); const bool single_ = h_ && !(h_ & (h_ - 1u)); \
+   if (single_) { const int b_ = __builtin_ctz(h_); emu_run_counts[b_][0]++; if (emu_run_here == h_ && emu_run_clock + 1u == (clk)) emu_run_counts[b_][1]++; } \
+   emu_run_clock = (clk); emu_run_here = h_; } } while (0)
 #define NFC_WAVE_COUNT(key, which, count) do { if (wavesim::lane() == 0 && emu_counting) emu_wave_counts[(key) & 63u][(which)] += (count); } while (0)
 
 #define NFC_WAVE_DEBUG_FETCH(f, clock) do { if (std::getenv("NFC_EMU_DEBUG_FETCH") && (wavesim::lane() < 2) && (clock) >= 131071u && (clock) < 131300u) std::fprintf(stderr, "[fetch] lane %u clock %u &f %p env %g x %g\n", wavesim::lane(), (unsigned)(clock), (const void *)&(f), (f).env, (f).x); } while (0)
@@ -144,6 +158,7 @@ static int emu_verify_mode()
    return mode;
 }
 
+uint64_t emu_run_counts[9][2];
 uint64_t emu_wave_counts[64][2]; /* per stage key: samples committed in bulk, samples stepped */
 
 namespace {
@@ -162,6 +177,12 @@ struct CountPrinter
       std::fprintf(stderr, "[emu wave] NFC-B detectors stepped on their own %llu, steps in the wake of another %llu, bulk paths not taken %llu, unarmed / carrier steps %llu\n",
                    (unsigned long long)emu_wave_counts[44][0], (unsigned long long)emu_wave_counts[45][0], (unsigned long long)emu_wave_counts[46][0],
                    (unsigned long long)emu_wave_counts[47][0]);
+      for (uint32_t k = 0; k < 12; k++)
+         if (emu_b_counts[k])
+            std::fprintf(stderr, "[emu wave] B106 shown its record in stage %u because of %s: %llu\n", k / 4, (k % 4) == 0 ? "a reset" : ((k % 4) == 1 ? "the window's end" : ((k % 4) == 2 ? "an edge before the window" : "a new extreme")), (unsigned long long)emu_b_counts[k]);
+      for (uint32_t k = 0; k < 8; k++)
+         if (emu_run_counts[k][0])
+            std::fprintf(stderr, "[emu wave] visits of %-5s alone %10llu, of them right after a visit of the same alone %10llu\n", det[k], (unsigned long long)emu_run_counts[k][0], (unsigned long long)emu_run_counts[k][1]);
       for (uint32_t k = 0; k < 9; k++)
          if (emu_wave_counts[51 + k][0])
             std::fprintf(stderr, "[emu wave] shown in place: %-5s %10llu\n", k < 8 ? det[k] : "B only", (unsigned long long)emu_wave_counts[51 + k][0]);
