@@ -1476,6 +1476,26 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
       HIP_TRY(ctx, hipMemcpyAsync(&again, counters + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
+#if defined(NFCGPU_TUNING_KNOBS) || defined(NFCGPU_EMULATED_TEST_BUILD)
+      /* (the tuning build: NFCGPU_DUMP_WINDOWS=<file> - the pieces of the first pass as they ended, five words each: job, start,
+       * sample from which the piece was live, first sample not consumed, how it ended; profiles/tools/r06/item5_pieces_ab.py) */
+      if (pass == 0 && nWindows)
+         if (const char *dumpTo = std::getenv("NFCGPU_DUMP_WINDOWS"))
+         {
+            std::vector<NfcWindow> ws(nWindows);
+            HIP_TRY(ctx, hipMemcpy(ws.data(), (const NfcWindow *)ctx->wWindows.ptr + firstWindowSlot, sizeof(NfcWindow) * ws.size(), hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(dumpTo, "ab"))
+            {
+               for (const NfcWindow &w: ws)
+               {
+                  const uint32_t rec[5] = {w.job, w.start, w.activate, w.stop, w.retired};
+                  std::fwrite(rec, 4, 5, f);
+               }
+               std::fclose(f);
+            }
+         }
+#endif
+
       if (debugPasses)
       {
          uint32_t ls[3] = {0, 0, 0}, tilesTaken = 0;
