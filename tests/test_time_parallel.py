@@ -152,7 +152,11 @@ def test_envelope_kernel_walks_the_short_lists_of_small_submissions_emulated(emu
                                            # chunks that are no multiple of the walk's default piece of 2048 samples (the default
                                            # sizing gives any multiple of 512 for totals of 2^28 .. 2^30 samples; here 9216 = 4.5 pieces):
                                            # the pieces have to tile the chunk, or the tail of every chunk gets no planes
-                                           ({"NFCGPU_SCAN_CHUNK": "9216"}, True), ({"NFCGPU_SCAN_CHUNK": "9216", "NFCGPU_PLANES_BESIDE_PIECE": "4096"}, True)])
+                                           ({"NFCGPU_SCAN_CHUNK": "9216"}, True), ({"NFCGPU_SCAN_CHUNK": "9216", "NFCGPU_PLANES_BESIDE_PIECE": "4096"}, True),
+                                           # the emulated runtime ran the low-priority stream's walk at its launch, i.e. always
+                                           # before the rounds; NFC_EMU_DEFER_LOW keeps that stream's launches until somebody waits for it
+                                           # (tests/hostsim/fakehip): the walk then runs after every rewrite of the rounds - the other order
+                                           ({"NFC_EMU_DEFER_LOW": "1"}, True), ({"NFC_EMU_DEFER_LOW": "1", "NFCGPU_SCAN_CHUNK": "9216"}, True)])
 def test_planes_written_beside_the_rounds_of_second_walks_emulated(emulated, knobs, beside):
     """Round 5: a large submission's front-end planes are written by a walk that starts when the first round's second walks are
     queued; the seam check and the envelope walks note every start state they rewrite from then on, and those chunks' planes are
