@@ -1047,6 +1047,10 @@ NFC_DEV bool nfc_lane_handover(NfcWindow *windows, NfcWindow &me, uint32_t &succ
    while (succ < succEnd && (windows[succ].verify < pos || succ <= me.noHand))
       succ++;
 
+#ifdef NFC_HANDOVER_TALLY
+   if (succ < succEnd && windows[succ].verify == pos)
+      NFC_HANDOVER_TALLY(s, cold, pos - me.start);
+#endif
    if (succ >= succEnd || windows[succ].verify != pos || !nfc_lane_comparable(s, cold))
       return false;
 

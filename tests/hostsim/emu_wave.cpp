@@ -54,7 +54,18 @@ static inline float emu_sample_at(const uint8_t *data, uint32_t stride, uint32_t
 }
 #define NFC_SAMPLE_AT(data, stride, index) emu_sample_at((data), (stride), (index))
 #define NFC_FENCE() ((void)0)
+/* (diagnostic: at the samples at which a piece may hand over - its successors' verify samples - why it does not; printed with
+ * NFC_EMU_WAVE_STATS) */
+extern uint64_t emu_handover_counts[8][4];
+static inline void emu_handover_tally(const NfcStreamState &s, const NfcStreamCold &cold, uint32_t ran);
+#define NFC_HANDOVER_TALLY(s, cold, ran) emu_handover_tally((s), (cold), (ran))
 #include "../../nfc-laboratory_amd/csrc/nfc_scan.hpp"
+static inline void emu_handover_tally(const NfcStreamState &s, const NfcStreamCold &cold, uint32_t ran)
+{
+   const int why = s.lockTech ? 1 + (int)(((s.lockTech & 0xFFu) - 1u) & 3u)
+                              : (s.unlock ? 5 : (s.bankClock != s.clock ? 6 : ((uint32_t)(s.clock - cold.bankRun) < NFC_WINDOW_STEADY ? 7 : 0)));
+   emu_handover_counts[why][ran < 40000u ? 0 : (ran < 100000u ? 1 : (ran < 250000u ? 2 : 3))]++;
+}
 
 #define NFC_WAVE_LANE() (wavesim::lane())
 #define NFC_WAVE_BARRIER() wavesim::barrier()
@@ -126,6 +137,7 @@ extern uint64_t emu_b_counts[16];
 static uint32_t emu_run_clock, emu_run_here;
 extern uint64_t emu_run_counts[9][2];
 uint64_t emu_b_counts[16];
+uint64_t emu_handover_counts[8][4];
 #define NFC_WAVE_COUNT_RUN(clk, here) do { if (wavesim::lane() == 0 && emu_counting) { const uint32_t h_ = (here); const bool single_ = h_ && !(h_ & (h_ - 1u)); \
    if (single_) { const int b_ = __builtin_ctz(h_); emu_run_counts[b_][0]++; if (emu_run_here == h_ && emu_run_clock + 1u == (clk)) emu_run_counts[b_][1]++; } \
    emu_run_clock = (clk); emu_run_here = h_; } } while (0)
@@ -177,6 +189,13 @@ struct CountPrinter
       std::fprintf(stderr, "[emu wave] NFC-B detectors stepped on their own %llu, steps in the wake of another %llu, bulk paths not taken %llu, unarmed / carrier steps %llu\n",
                    (unsigned long long)emu_wave_counts[44][0], (unsigned long long)emu_wave_counts[45][0], (unsigned long long)emu_wave_counts[46][0],
                    (unsigned long long)emu_wave_counts[47][0]);
+      {
+         static const char *why[] = {"hands over", "locked NFC-A", "locked NFC-B", "locked NFC-F", "locked NFC-V", "unlock pending", "bank not stepped", "steady run too short"};
+         for (uint32_t k = 0; k < 8; k++)
+            if (emu_handover_counts[k][0] | emu_handover_counts[k][1] | emu_handover_counts[k][2] | emu_handover_counts[k][3])
+               std::fprintf(stderr, "[emu wave] at a successor's verify sample, %-22s pieces that had run < 40 k: %6llu, < 100 k: %6llu, < 250 k: %6llu, longer: %6llu\n", why[k],
+                            (unsigned long long)emu_handover_counts[k][0], (unsigned long long)emu_handover_counts[k][1], (unsigned long long)emu_handover_counts[k][2], (unsigned long long)emu_handover_counts[k][3]);
+      }
       for (uint32_t k = 0; k < 12; k++)
          if (emu_b_counts[k])
             std::fprintf(stderr, "[emu wave] B106 shown its record in stage %u because of %s: %llu\n", k / 4, (k % 4) == 0 ? "a reset" : ((k % 4) == 1 ? "the window's end" : ((k % 4) == 2 ? "an edge before the window" : "a new extreme")), (unsigned long long)emu_b_counts[k]);
