@@ -44,12 +44,58 @@ __device__ __forceinline__ float nfc_envelope_sample_at(const uint8_t *data, uin
 #define NFC_ENVELOPE_OPAQUE_F(v) asm volatile("" : "+v"(v))
 #define NFC_ENVELOPE_OPAQUE_U(v) asm volatile("" : "+v"(v))
 
+#define NFC_ENVELOPE_BALLOT(p) ((uint64_t)__ballot(p))
+/* (a value every lane holds alike: is it positive? as a uniform condition) */
+#define NFC_ENVELOPE_UNIFORM_POSITIVE(v) (__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (v)))) > 0.0f)
+
+#ifdef NFC_ENVELOPE_VERIFY_BUILD
+/* -DNFC_ENVELOPE_VERIFY_BUILD (not a product build): every tile the groups have walked is walked again sample by sample by the
+ * statement (nfc_envelope_step) from the same state and the two results compared bit for bit; every launch says what the launches
+ * before it have found (stdout: "[envelope verify] tiles differing") */
+static __device__ uint32_t nfcEnvelopeVerifyTiles, nfcEnvelopeVerifyDiffering;
+
+__device__ __forceinline__ void nfc_envelope_verify(const NfcConfig &c, float env, uint32_t pulseFilter, float x0, float e, uint32_t pf, float l, float h)
+{
+   float ve = env, vl = 3.0e38f, vh = -3.0e38f;
+   uint32_t vpf = pulseFilter;
+   uint32_t clock = 1u << 20; /* (past the stream's first symbol, as the tile is) */
+
+   for (uint32_t j = 0; j < 64u; j++)
+   {
+      const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), (int)j));
+      ++clock;
+      ++vpf;
+      nfc_envelope_step(c, clock, vpf, ve, x);
+      vl = ve < vl ? ve : vl;
+      vh = ve > vh ? ve : vh;
+   }
+
+   if (threadIdx.x == 0)
+   {
+      atomicAdd(&nfcEnvelopeVerifyTiles, 1u);
+      if (__builtin_bit_cast(uint32_t, ve) != __builtin_bit_cast(uint32_t, e) || vpf != pf || __builtin_bit_cast(uint32_t, vl) != __builtin_bit_cast(uint32_t, l) ||
+          __builtin_bit_cast(uint32_t, vh) != __builtin_bit_cast(uint32_t, h))
+      {
+         if (atomicAdd(&nfcEnvelopeVerifyDiffering, 1u) < 8u)
+            printf("[envelope verify] differs: env %a -> %a / %a, counter %u -> %u / %u, min %a / %a, max %a / %a\n", (double)env, (double)e, (double)ve, pulseFilter, pf, vpf,
+                   (double)l, (double)vl, (double)h, (double)vh);
+      }
+   }
+}
+#define NFC_ENVELOPE_VERIFY(c, env, pf0, x0, limit, e, pf, l, h) nfc_envelope_verify((c), (env), (pf0), (x0), (e), (pf), (l), (h))
+#endif
+
 #include "nfc_envelope.hpp"
 
 /* one wavefront per listed chunk (nfc_envelope_rewalk_wave) */
 __global__ __launch_bounds__(64) void nfc_envelope_kernel(const NfcConfig *__restrict__ cfgPtr, NfcScanArgs A)
 {
    const uint32_t listed = blockIdx.x;
+
+#ifdef NFC_ENVELOPE_VERIFY_BUILD
+   if (listed == 0u && threadIdx.x == 0u)
+      printf("[envelope verify] %u %u\n", nfcEnvelopeVerifyTiles, nfcEnvelopeVerifyDiffering);
+#endif
 
    if (listed >= A.nChunks)
       return;

@@ -267,12 +267,100 @@ NFC_DEV void nfc_envelope_rewalk_wave(const NfcConfig &c, const NfcScanArgs &A, 
           * 14 ms per 32768-sample chunk, slower than the row machinery it was to replace). */
          if (n == NFC_SCAN_TILE && (uint32_t)(clock + 1u) >= (uint32_t)c.etu && (uint32_t)(clock + 1u + NFC_SCAN_TILE) > (uint32_t)(clock + 1u))
          {
+            const uint32_t limit = (uint32_t)(c.etu * 10);
+            const float w0 = c.envW0, w1 = c.envW1;
+
+#ifndef NFC_ENVELOPE_NO_GROUPS
+            /* Round 6: sixteen samples at a time, which of them the tracker follows decided for all sixteen at once. Inside a
+             * group every update moves the envelope by less than 0.0501 w1 of itself (a sample it follows is within 5 % of it, and
+             * the group is only taken when no sample can be followed for the counter's sake: counter + 16 <= ten symbols), so by
+             * less than `drift` = 16 x 0.0506 w1 in all (0.8 % at this rate): a sample whose deviation from the envelope the
+             * group begins with is below (0.0499 (1 - drift) - drift) of it is below 0.0499 of the envelope as it stands when the
+             * sample's turn comes - the statement's own shortcut, nfc_envelope_step: followed -, one above (0.0501 (1 + drift) +
+             * drift) is above 0.0501 of it - not followed. A group with a sample in neither case (the flank of an edge passing
+             * through 4.1 - 5.9 %), an envelope that is not positive or a counter near its limit sends the whole tile to the walk
+             * below, sample by sample. What is left of a group is e <- e a + b per sample with (a, b) = (w0, x w1) where the
+             * sample is followed and (1, 0) where it is not - the same multiplication, the same addition, the same roundings as
+             * the statement's e w0 + x w1 (and e 1 + 0 = e) -, two dependent operations instead of nine, and a group nothing of
+             * which is followed (a pause, a modulated stretch) is a dozen instructions for its sixteen samples. */
+            {
+               const float drift = 16.0f * 0.0506f * w1;
+               const float kBelow = 0.0499f * (1.0f - drift) - drift;
+               const float kAbove = 0.0501f * (1.0f + drift) + drift;
+
+               float e = env;
+               uint32_t pf = pulseFilter;
+               NFC_ENVELOPE_OPAQUE_F(e);
+               float l = NFC_ENVELOPE_BIG, h = -NFC_ENVELOPE_BIG;
+               bool ok = kBelow > 0.0f;
+               const float xw = x0 * w1;
+
+#pragma unroll
+               for (uint32_t grp = 0; grp < NFC_SCAN_TILE / 16u; grp++)
+               {
+                  if (ok)
+                  {
+                     const bool inGroup = (lane >> 4) == grp;
+                     const float dev = nfc_abs(x0 - e);
+                     const bool below = dev < kBelow * e;
+                     const bool above = dev > kAbove * e;
+                     const uint64_t clear = NFC_ENVELOPE_BALLOT(inGroup && (below || above));
+                     const uint64_t followed = NFC_ENVELOPE_BALLOT(inGroup && below);
+
+                     ok = NFC_ENVELOPE_UNIFORM_POSITIVE(e) && clear == (0xFFFFull << (16u * grp)) && pf + 16u <= limit;
+
+                     if (ok)
+                     {
+                        if (followed == 0ull)
+                        {
+                           /* (held throughout: the value the group's samples leave is the one it found) */
+                           l = e < l ? e : l;
+                           h = e > h ? e : h;
+                           pf += 16u;
+                        }
+                        else
+                        {
+                           const float a = below ? w0 : 1.0f;
+                           const float b = below ? xw : 0.0f;
+
+#pragma unroll
+                           for (uint32_t k = 0; k < 16u; k++)
+                           {
+                              const uint32_t j = 16u * grp + k;
+                              e = e * NFC_ENVELOPE_READLANE_F(a, j) + NFC_ENVELOPE_READLANE_F(b, j);
+                              l = e < l ? e : l;
+                              h = e > h ? e : h;
+                           }
+
+                           /* the counter: samples since the last one followed */
+                           const uint32_t lastFollowed = 63u - (uint32_t)__builtin_clzll(followed);
+                           pf = 16u * grp + 15u - lastFollowed;
+                        }
+                     }
+                  }
+               }
+
+               if (ok)
+               {
+#ifdef NFC_ENVELOPE_VERIFY
+                  NFC_ENVELOPE_VERIFY(c, env, pulseFilter, x0, limit, e, pf, l, h);
+#endif
+                  env = e;
+                  pulseFilter = pf;
+                  clock += NFC_SCAN_TILE;
+                  lo = l;
+                  hi = h;
+                  walked = true;
+               }
+            }
+
+            if (!walked)
+#endif
+            {
             float e = env;
             uint32_t pf = pulseFilter;
             NFC_ENVELOPE_OPAQUE_F(e);
             NFC_ENVELOPE_OPAQUE_U(pf);
-            const uint32_t limit = (uint32_t)(c.etu * 10);
-            const float w0 = c.envW0, w1 = c.envW1;
             bool rare = false;
             float l = NFC_ENVELOPE_BIG, h = -NFC_ENVELOPE_BIG;
 
@@ -301,6 +389,7 @@ NFC_DEV void nfc_envelope_rewalk_wave(const NfcConfig &c, const NfcScanArgs &A, 
                lo = l;
                hi = h;
                walked = true;
+            }
             }
          }
 
