@@ -41,6 +41,18 @@ __device__ __forceinline__ float nfc_sample_at(const uint8_t *data, uint32_t str
 
 #define NFC_SAMPLE_AT(data, stride, index) nfc_sample_at((data), (stride), (index))
 #define NFC_FENCE() __threadfence()
+/* a window record written by the 64 lanes of the wave that builds a stream's windows (nfc_windows_kernel; every lane is there with
+ * the same values): lane d + 64 k writes word d + 64 k - the record's first four words are the ones that are not zero */
+#define NFC_WINDOW_STORE(w, job_, start_, activate_, verify_)                                                                   \
+   do                                                                                                                           \
+   {                                                                                                                            \
+      static_assert(offsetof(NfcWindow, job) == 0 && offsetof(NfcWindow, start) == 4 && offsetof(NfcWindow, activate) == 8 &&  \
+                       offsetof(NfcWindow, verify) == 12 && sizeof(NfcWindow) % 4 == 0,                                         \
+                    "NFC_WINDOW_STORE writes the first four words of NfcWindow by position");                                   \
+      uint32_t *words_ = (uint32_t *)&(w);                                                                                      \
+      for (uint32_t d_ = threadIdx.x; d_ < sizeof(NfcWindow) / 4u; d_ += NFC_LANES)                                             \
+         words_[d_] = d_ == 0u ? (uint32_t)(job_) : (d_ == 1u ? (uint32_t)(start_) : (d_ == 2u ? (uint32_t)(activate_) : (d_ == 3u ? (uint32_t)(verify_) : 0u))); \
+   } while (0)
 #include "nfc_scan.hpp"
 #include "nfc_launch.h"
 #include "nfc_scan_launch.h"
@@ -1031,7 +1043,7 @@ __global__ __launch_bounds__(256) void nfc_tiles_kernel(const NfcConfig *__restr
 }
 
 /* One wave per job: retire / dark marks and the windows, 64 tiles per step (nfc_scan.hpp: nfc_group_*). Every lane of
- * the wave holds the same masks and the same placer state; lane 0 writes the windows. */
+ * the wave holds the same masks and the same placer state; the lanes share the stores of a window record (NFC_WINDOW_STORE). */
 __device__ __forceinline__ uint32_t nfc_windows_place(const NfcScanJob &job, uint32_t j, const uint32_t *__restrict__ t, uint32_t nTiles, NfcWindow *out,
                                                       uint32_t room, bool write)
 {
@@ -1062,13 +1074,13 @@ __device__ __forceinline__ uint32_t nfc_windows_place(const NfcScanJob &job, uin
          const uint64_t cut = __ballot(exists && !(f[k] & (NFC_TILE_RETIRE_OK | NFC_TILE_DARK)) && nfc_tile_may_cut(i, job.count));
 
          if (cluster | cut)
-            nfc_group_place(placer, job, j, out, room, g, cluster, cut, write && lane == 0u);
+            nfc_group_place(placer, job, j, out, room, g, cluster, cut, write);
 
          busyBefore = busy;
       }
    }
 
-   nfc_windows_close(placer, job, j, out, room, write && lane == 0u);
+   nfc_windows_close(placer, job, j, out, room, write);
    return placer.n;
 }
 

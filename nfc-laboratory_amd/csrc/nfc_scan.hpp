@@ -565,6 +565,21 @@ NFC_DEV bool nfc_tile_may_cut(uint32_t i, uint32_t count)
    return nfc_tile_may_start(i, count) && i * NFC_SCAN_TILE + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= count;
 }
 
+/* a window record as the builder leaves it: everything zero but these four words. (The includer may have the lanes of a wave
+ * share the stores - nfc_kernels.hip: the record is 1.4 KB, and one lane cleared it a word at a time, 180 000 records a step of
+ * the headline.) */
+#ifndef NFC_WINDOW_STORE
+#define NFC_WINDOW_STORE(w, job_, start_, activate_, verify_) \
+   do                                                        \
+   {                                                         \
+      __builtin_memset(&(w), 0, sizeof(w));                  \
+      (w).job = (job_);                                      \
+      (w).start = (start_);                                  \
+      (w).activate = (activate_);                            \
+      (w).verify = (verify_);                                \
+   } while (0)
+#endif
+
 struct NfcWindowPlacer
 {
    uint32_t lastAct; /* activation of the most recent window (the carry lane goes live at 0) */
@@ -575,12 +590,8 @@ NFC_DEV void nfc_window_put(NfcWindowPlacer &p, const NfcScanJob &job, uint32_t 
 {
    if (write && p.n < room)
    {
-      NfcWindow &w = out[p.n];
-      __builtin_memset(&w, 0, sizeof(w));
-      w.job = jobIndex;
-      w.start = start;
-      w.activate = activate;
-      w.verify = activate + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= job.count ? activate + NFC_WINDOW_VERIFY : 0xFFFFFFFFu;
+      const uint32_t verify = activate + NFC_WINDOW_VERIFY + NFC_SCAN_TILE <= job.count ? activate + NFC_WINDOW_VERIFY : 0xFFFFFFFFu;
+      NFC_WINDOW_STORE(out[p.n], jobIndex, start, activate, verify);
    }
    p.n++;
 }
