@@ -731,6 +731,7 @@ int run_in_blocks(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIt
  * int16 grid, a seam that did not verify, no settled chain) are then decoded sequentially from their untouched state. */
 int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedItem> &items, uint32_t stride)
 {
+   const auto entered = std::chrono::steady_clock::now(); /* (the stage log counts the host's tables from here) */
    const uint32_t nJobs = (uint32_t)items.size();
    const NfcConfig &cfg = ctx->configs[config];
 
@@ -958,7 +959,7 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
 
    /* NFCGPU_WINDOW_DEBUG: where the time of a submission goes (synchronises at every mark) */
    const bool debugStages = std::getenv("NFCGPU_WINDOW_DEBUG") != nullptr;
-   auto stageBegan = std::chrono::steady_clock::now();
+   auto stageBegan = entered;
    auto mark = [&](const char *what) {
       if (!debugStages)
          return;
@@ -1720,6 +1721,8 @@ int run_windowed(nfcgpu_ctx *ctx, uint32_t config, const std::vector<WindowedIte
    }
 
    ctx->stats.fallback_streams += fallback.size();
+
+   mark("return");
 
    if (!fallback.empty())
    {
