@@ -59,9 +59,15 @@ def main():
                 per[kern][c] = {"dispatches": len(full), "grid": biggest, "last_KiB": full[-1], "mean_KiB": sum(full) / len(full)}
 
     try:
-        git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip() or None
+        git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.strip() or None
     except Exception:
         git = None
+    if not git:
+        # (the GPU box has no repository: the commit the libraries were built from, left beside them by __graft_entry__.build())
+        try:
+            git = open(os.path.join(ROOT, "nfc-laboratory_amd", "build", "git_head.txt")).read().strip() or None
+        except Exception:
+            git = None
     sys.path.insert(0, ROOT)
     import bench
     digest = bench.sources_digest()
