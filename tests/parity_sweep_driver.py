@@ -11,6 +11,7 @@ import nfclab_amd, synth, frames as framelib
 import nfc_testlib as TL
 
 kind, S, L, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+FIRST = int(os.environ.get("PARITY_FIRST_STREAM", "0"))  # (another draw of the synthetic set: streams FIRST .. FIRST + S - 1)
 FS = 10000000
 dev = torch.device("cuda", 0)
 template = synth.load_template(os.path.join(ROOT, "tests", "golden"))
@@ -18,9 +19,9 @@ template_dev = torch.from_numpy(template.astype(np.int16)).to(dev)
 T = K * L
 data = torch.empty((S, T, 2), dtype=torch.float32, device=dev)
 if kind == "sparse":
-    synth.fill_sparse_iq_torch(data, template_dev, synth.sparse_segments(template), first_stream=0, chunk_streams=max(1, min(256, (1 << 26) // T)))
+    synth.fill_sparse_iq_torch(data, template_dev, synth.sparse_segments(template), first_stream=FIRST, chunk_streams=max(1, min(256, (1 << 26) // T)))
 else:
-    synth.fill_iq_torch(data, template_dev, first_stream=0, chunk_streams=max(1, min(1024, (1 << 26) // T)))
+    synth.fill_iq_torch(data, template_dev, first_stream=FIRST, chunk_streams=max(1, min(1024, (1 << 26) // T)))
 if kind == "offgrid":
     # set S2: the dense S1 magnitudes on a random phase per stream plus white noise of sigma 0.002 on both components,
     # fp32 IQ - what a radio delivers, off the capture grid (the generator of bench.py's s2 points)
